@@ -1,0 +1,260 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+ctypes front-end of oracle/zvdb_oracle.c (a C restatement of the reference's
+src/hnsw.zig hot path).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this package; nothing under zvdb_amd/ does.
+
+Parity-pin status: pinned by the known answers of the reference's own tests
+(src/test_hnsw.zig, see tests/test_oracle_pins.py).  Exact-tie pop order and
+every extension without a reference symbol (brute force, ef mode, dot/cosine,
+bf16) are "parity unpinned" -- see oracle/zvdb_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libzvdb_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (strict fp32).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "zvdb_oracle.c")
+    hdr = os.path.join(_HERE, "zvdb_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(
+            ["gcc", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11",
+             "-shared", "-o", _LIB_PATH, src])
+    return _LIB_PATH
+
+
+class Counters(C.Structure):
+    _fields_ = [("search_dist_evals", C.c_uint64), ("search_pops", C.c_uint64),
+                ("sort_dist_evals", C.c_uint64), ("insert_dist_evals", C.c_uint64),
+                ("shrink_dist_evals", C.c_uint64)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    f32p, u64p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    L.orc_distance_f32.restype = C.c_float
+    L.orc_distance_f32.argtypes = [f32p, f32p, C.c_size_t]
+    L.orc_distance_f64.restype = C.c_double
+    L.orc_distance_f64.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
+    L.orc_distance_i32.restype = C.c_int32
+    L.orc_distance_i32.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t]
+    L.orc_mix64.restype = C.c_uint64
+    L.orc_mix64.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_fill_uniform.restype = None
+    L.orc_fill_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, f32p]
+    L.orc_bf16_round.restype = C.c_float
+    L.orc_bf16_round.argtypes = [C.c_float]
+    L.orc_hnsw_create.restype = C.c_void_p
+    L.orc_hnsw_create.argtypes = [C.c_size_t, C.c_size_t, C.c_uint64]
+    L.orc_hnsw_destroy.restype = None
+    L.orc_hnsw_destroy.argtypes = [C.c_void_p]
+    L.orc_hnsw_insert.restype = C.c_int
+    L.orc_hnsw_insert.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_int]
+    L.orc_hnsw_search.restype = C.c_size_t
+    L.orc_hnsw_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, u64p, f32p]
+    L.orc_hnsw_search_ef.restype = C.c_size_t
+    L.orc_hnsw_search_ef.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p]
+    L.orc_hnsw_count.restype = C.c_size_t
+    L.orc_hnsw_count.argtypes = [C.c_void_p]
+    L.orc_hnsw_dim.restype = C.c_size_t
+    L.orc_hnsw_dim.argtypes = [C.c_void_p]
+    L.orc_hnsw_max_level.restype = C.c_size_t
+    L.orc_hnsw_max_level.argtypes = [C.c_void_p]
+    L.orc_hnsw_node_level.restype = C.c_int
+    L.orc_hnsw_node_level.argtypes = [C.c_void_p, C.c_size_t]
+    L.orc_hnsw_neighbors.restype = C.c_size_t
+    L.orc_hnsw_neighbors.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, u64p, C.c_size_t]
+    L.orc_hnsw_point.restype = f32p
+    L.orc_hnsw_point.argtypes = [C.c_void_p, C.c_size_t]
+    L.orc_hnsw_set_neighbors.restype = C.c_int
+    L.orc_hnsw_set_neighbors.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, u64p, C.c_size_t]
+    L.orc_hnsw_counters.restype = None
+    L.orc_hnsw_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    L.orc_hnsw_reset_counters.restype = None
+    L.orc_hnsw_reset_counters.argtypes = [C.c_void_p]
+    L.orc_bruteforce_topk.restype = None
+    L.orc_bruteforce_topk.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
+                                      C.c_size_t, C.c_int, u64p, f32p, u32p]
+    L.orc_merge_topk.restype = None
+    L.orc_merge_topk.argtypes = [u64p, f32p, u32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p, u32p]
+    _lib = L
+    return L
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def distance(a, b) -> np.float32:
+    a, b = _f32(a), _f32(b)
+    assert a.shape == b.shape and a.ndim == 1
+    return np.float32(lib().orc_distance_f32(_p(a, C.c_float), _p(b, C.c_float), a.size))
+
+
+def distance_f64(a, b) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return float(lib().orc_distance_f64(_p(a, C.c_double), _p(b, C.c_double), a.size))
+
+
+def distance_i32(a, b) -> int:
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    return int(lib().orc_distance_i32(_p(a, C.c_int32), _p(b, C.c_int32), a.size))
+
+
+def fill_uniform(seed: int, first_elem: int, count: int) -> np.ndarray:
+    out = np.empty(count, dtype=np.float32)
+    lib().orc_fill_uniform(seed, first_elem, count, _p(out, C.c_float))
+    return out
+
+
+def uniform_rows(seed: int, first_row: int, nrows: int, dim: int) -> np.ndarray:
+    """Rows [first_row, first_row+nrows) of the synthetic U[0,1) corpus `seed`."""
+    return fill_uniform(seed, first_row * dim, nrows * dim).reshape(nrows, dim)
+
+
+def bf16_round(a) -> np.ndarray:
+    a = _f32(a)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(a.shape)
+
+
+class HNSW:
+    """Oracle mirror of HNSW(f32) (src/hnsw.zig:8-247)."""
+
+    def __init__(self, m: int = 16, ef_construction: int = 200, level_seed: int = 1):
+        self._L = lib()
+        self._h = self._L.orc_hnsw_create(m, ef_construction, level_seed)
+        if not self._h:
+            raise MemoryError
+        self.m = m
+        self.ef_construction = ef_construction
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.orc_hnsw_destroy(h)
+
+    def insert(self, point, level: int = -1) -> None:
+        p = _f32(point)
+        rc = self._L.orc_hnsw_insert(self._h, _p(p, C.c_float), p.size, level)
+        if rc == -2:
+            raise ValueError("Mismatched dimensions in distance calculation")
+        if rc:
+            raise RuntimeError(f"oracle insert failed rc={rc}")
+
+    def search(self, query, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _f32(query)
+        ids = np.zeros(max(k, 1), dtype=np.uint64)
+        dist = np.zeros(max(k, 1), dtype=np.float32)
+        n = self._L.orc_hnsw_search(self._h, _p(q, C.c_float), q.size, k,
+                                    _p(ids, C.c_uint64), _p(dist, C.c_float))
+        return ids[:n].copy(), dist[:n].copy()
+
+    def search_ef(self, query, k: int, ef: int) -> Tuple[np.ndarray, np.ndarray]:
+        q = _f32(query)
+        ids = np.zeros(max(k, 1), dtype=np.uint64)
+        dist = np.zeros(max(k, 1), dtype=np.float32)
+        n = self._L.orc_hnsw_search_ef(self._h, _p(q, C.c_float), q.size, k, ef,
+                                       _p(ids, C.c_uint64), _p(dist, C.c_float))
+        return ids[:n].copy(), dist[:n].copy()
+
+    def count(self) -> int:
+        return int(self._L.orc_hnsw_count(self._h))
+
+    @property
+    def dim(self) -> int:
+        return int(self._L.orc_hnsw_dim(self._h))
+
+    @property
+    def max_level(self) -> int:
+        return int(self._L.orc_hnsw_max_level(self._h))
+
+    def node_level(self, i: int) -> int:
+        return int(self._L.orc_hnsw_node_level(self._h, i))
+
+    def neighbors(self, i: int, layer: int = 0) -> Optional[np.ndarray]:
+        cap = 4096
+        out = np.zeros(cap, dtype=np.uint64)
+        n = self._L.orc_hnsw_neighbors(self._h, i, layer, _p(out, C.c_uint64), cap)
+        if n == C.c_size_t(-1).value:
+            return None
+        return out[:n].copy()
+
+    def set_neighbors(self, i: int, layer: int, ids) -> None:
+        a = np.ascontiguousarray(ids, dtype=np.uint64)
+        rc = self._L.orc_hnsw_set_neighbors(self._h, i, layer, _p(a, C.c_uint64), a.size)
+        if rc:
+            raise KeyError("NodeNotFound")
+
+    def point(self, i: int) -> np.ndarray:
+        p = self._L.orc_hnsw_point(self._h, i)
+        return np.ctypeslib.as_array(p, shape=(self.dim,)).copy()
+
+    def layer0(self, stride: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Fixed-stride layer-0 adjacency (adj[N][stride] u32, deg[N] u32)."""
+        n = self.count()
+        adj = np.zeros((n, stride), dtype=np.uint32)
+        deg = np.zeros(n, dtype=np.uint32)
+        for i in range(n):
+            nb = self.neighbors(i, 0)
+            deg[i] = len(nb)
+            adj[i, :len(nb)] = nb
+        return adj, deg
+
+    def counters(self) -> Counters:
+        c = Counters()
+        self._L.orc_hnsw_counters(self._h, C.byref(c))
+        return c
+
+    def reset_counters(self) -> None:
+        self._L.orc_hnsw_reset_counters(self._h)
+
+
+def bruteforce_topk(V, Q, k: int, metric: int = 0):
+    V, Q = _f32(V), _f32(Q)
+    N, d = V.shape
+    nq = Q.shape[0]
+    ids = np.zeros((nq, k), dtype=np.uint64)
+    dist = np.zeros((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    lib().orc_bruteforce_topk(_p(V, C.c_float), N, d, d, _p(Q, C.c_float), nq, k, metric,
+                              _p(ids, C.c_uint64), _p(dist, C.c_float), _p(cnt, C.c_uint32))
+    return ids, dist, cnt
+
+
+def merge_topk(ids, dist, count, k: int):
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    dist = _f32(dist)
+    count = np.ascontiguousarray(count, dtype=np.uint32)
+    G, nq, kk = ids.shape
+    assert kk == k
+    oi = np.zeros((nq, k), dtype=np.uint64)
+    od = np.zeros((nq, k), dtype=np.float32)
+    oc = np.zeros(nq, dtype=np.uint32)
+    lib().orc_merge_topk(_p(ids, C.c_uint64), _p(dist, C.c_float), _p(count, C.c_uint32), G, nq, k,
+                         _p(oi, C.c_uint64), _p(od, C.c_float), _p(oc, C.c_uint32))
+    return oi, od, oc
