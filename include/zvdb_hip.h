@@ -1,0 +1,192 @@
+/*
+ * zvdb_hip.h -- C ABI of libzvdb_hip.so: the MI355X (gfx950) distance /
+ * neighbour-scan / top-k engine behind zvdb's HNSW(T) insert/search API.
+ *
+ * The reference (allisoneer/zvdb) has no FFI: its boundary is the Zig generic
+ * type re-exported at src/zvdb.zig:1 (HNSW(T), src/hnsw.zig:8).  These entry
+ * points are what a thin `hnsw_hip.zig` wrapper binds with `extern "c"` (see
+ * INTEGRATION.md) -- host-side graph bookkeeping (ids, adjacency lists, level
+ * draw, mutex, Node copies) stays on the host; every distance evaluation,
+ * neighbour-list scan and top-k selection runs in hand-written HIP kernels.
+ *
+ * Conventions
+ *   - every call returns an int status (ZVDB_OK = 0); zvdb_hip_last_error()
+ *     returns a thread-local message for the last failing call;
+ *   - the caller owns every in/out buffer; no callbacks; plain pointers/sizes;
+ *   - ids cross the ABI as uint64_t (Zig usize, hnsw.zig:13) and are u32 on
+ *     the device;
+ *   - a handle carries its own mutex: calls may come from any thread
+ *     (mirrors the global mutex of hnsw.zig:74-75,:195-196);
+ *   - "host" entry points take host pointers and synchronise before returning;
+ *     "_dev" entry points take DEVICE pointers + a hipStream_t (as void*) and
+ *     only enqueue work (no allocation, no sync): they are what bench.py and
+ *     the multi-GPU path call with torch-owned device memory;
+ *   - without a HIP device every entry point that needs one fails with
+ *     ZVDB_ERR_NO_DEVICE.  There is no CPU fallback.
+ */
+#ifndef ZVDB_HIP_H
+#define ZVDB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZVDB_HIP_ABI_VERSION 1
+
+enum zvdb_status {
+    ZVDB_OK = 0,
+    ZVDB_ERR_INVALID = 1,        /* bad argument */
+    ZVDB_ERR_DIM_MISMATCH = 2,   /* reference @panic, hnsw.zig:183-185 */
+    ZVDB_ERR_OOM = 3,            /* error.OutOfMemory */
+    ZVDB_ERR_NODE_NOT_FOUND = 4, /* error.NodeNotFound, hnsw.zig:120-121 */
+    ZVDB_ERR_HIP = 5,            /* HIP runtime failure */
+    ZVDB_ERR_UNSUPPORTED = 6,
+    ZVDB_ERR_NO_DEVICE = 7
+};
+
+enum zvdb_metric {
+    ZVDB_METRIC_L2SQ = 0,  /* hnsw.zig:182-192 (the only reference metric) */
+    ZVDB_METRIC_DOT = 1,   /* extension: rank by -q.v (parity unpinned) */
+    ZVDB_METRIC_COSINE = 2 /* extension: rows normalised at add; rank by -q.v */
+};
+
+/* brute-force contraction modes (a10; no reference symbol) */
+enum zvdb_bf_mode {
+    ZVDB_BF_F32 = 0,  /* fp32 MFMA (v_mfma_f32_32x32x2_f32) screen + exact fp32 re-rank */
+    ZVDB_BF_BF16 = 1  /* bf16 MFMA screen over the bf16 mirror + exact fp32 re-rank */
+};
+
+typedef struct zvdb_hip_index zvdb_hip_index; /* opaque */
+
+typedef struct zvdb_hip_config {
+    uint32_t abi_version;     /* ZVDB_HIP_ABI_VERSION */
+    uint32_t dim;             /* 0 = take from the first add (hnsw.zig:52 declares none) */
+    uint32_t metric;          /* enum zvdb_metric */
+    uint32_t m;               /* hnsw.zig:48: cap of EVERY layer's list incl. layer 0 (:146) */
+    uint32_t ef_construction; /* hnsw.zig:49: stored, never read by the reference */
+    int32_t device;           /* HIP device ordinal; -1 = current device */
+    uint32_t flags;           /* ZVDB_FLAG_* */
+    uint32_t graph_stride;    /* layer-0 adjacency stride on device; 0 = m */
+    uint64_t capacity;        /* rows to reserve up front (0 = grow geometrically) */
+} zvdb_hip_config;
+
+#define ZVDB_FLAG_BF16_MIRROR 1u /* keep a bf16 copy of the rows for ZVDB_BF_BF16 */
+
+typedef struct zvdb_hip_search_stats {
+    uint64_t dist_evals; /* E of SURVEY 8d: hnsw.zig:208 + :219 evaluations */
+    uint64_t pops;       /* P: hnsw.zig:212 */
+} zvdb_hip_search_stats;
+
+/* ---- library ------------------------------------------------------------ */
+const char *zvdb_hip_last_error(void);
+int zvdb_hip_abi_version(void);
+int zvdb_hip_device_count(int *out_count);
+
+/* ---- lifecycle: HNSW(T).init / deinit (hnsw.zig:52-62, :64-71) ----------- */
+int zvdb_hip_create(const zvdb_hip_config *cfg, zvdb_hip_index **out);
+void zvdb_hip_destroy(zvdb_hip_index *h);
+
+/* nodes.count() (hnsw.zig:77, test_hnsw.zig:198) and the implied dimension */
+int zvdb_hip_count(zvdb_hip_index *h, uint64_t *out_count);
+int zvdb_hip_dim(zvdb_hip_index *h, uint32_t *out_dim);
+
+/* ---- rows: the vector copy of Node.init (hnsw.zig:24-26) ----------------- */
+/* Append n rows of `dim` floats (host memory); ids are dense from count()
+ * (hnsw.zig:77).  *first_id receives the id of rows[0].  dim must match
+ * (ZVDB_ERR_DIM_MISMATCH mirrors the @panic of hnsw.zig:183-185). */
+int zvdb_hip_add(zvdb_hip_index *h, const float *rows, uint64_t n, uint32_t dim, uint64_t *first_id);
+/* Same with rows already in device memory (row-major, stride dim floats). */
+int zvdb_hip_add_dev(zvdb_hip_index *h, const void *d_rows, uint64_t n, uint32_t dim,
+                     void *stream, uint64_t *first_id);
+/* Append n rows of the build's seeded synthetic U[0,1) stream (distribution of
+ * shared_benchmarks.zig:53-59), generated on the device: element e of the
+ * stream is (mix64(seed, e) >> 40) * 2^-24, rows [first_row, first_row+n). */
+int zvdb_hip_add_synthetic(zvdb_hip_index *h, uint64_t n, uint32_t dim, uint64_t seed,
+                           uint64_t first_row, uint64_t *first_id);
+/* Fill a DEVICE buffer with rows of the same stream (queries for bench). */
+int zvdb_hip_fill_synthetic_dev(void *d_out, uint64_t nrows, uint32_t dim, uint64_t seed,
+                                uint64_t first_row, void *stream);
+/* Copy row `id` back (Node.point readers: test_hnsw.zig:40,:67,:98,:306). */
+int zvdb_hip_get_vector(zvdb_hip_index *h, uint64_t id, float *out, uint32_t dim);
+
+/* ---- graph mirror: connections[0] of every node (hnsw.zig:15,:216) -------- */
+/* Replace layer-0 list of `node` (host bookkeeping -> device mirror).  Only
+ * layer 0 is mirrored: search reads nothing else (hnsw.zig:216). */
+int zvdb_hip_set_neighbors(zvdb_hip_index *h, uint64_t node, const uint64_t *ids, uint32_t n);
+/* Bulk upload: adj[n][stride] u32 + deg[n] u32 for nodes [0,n). */
+int zvdb_hip_upload_graph(zvdb_hip_index *h, const uint32_t *adj, const uint32_t *deg,
+                          uint64_t n, uint32_t stride);
+int zvdb_hip_get_neighbors(zvdb_hip_index *h, uint64_t node, uint64_t *out_ids, uint32_t cap,
+                           uint32_t *out_n);
+
+/* ---- a1/a2/a3 seam: distance(query, rows[ids]) (hnsw.zig:86,:96,:160-161) -- */
+/* out[i] = distance(query, row ids[i]) in EXACT reference arithmetic (strict
+ * sequential fp32 sub/mul/add, no FMA).  `query` is host memory of dim floats. */
+int zvdb_hip_distances(zvdb_hip_index *h, const float *query, uint32_t dim,
+                       const uint64_t *ids, uint32_t n, float *out);
+/* Same with the query being row `owner` of the index (insert's new point,
+ * shrinkConnections' owner). */
+int zvdb_hip_distances_from(zvdb_hip_index *h, uint64_t owner, const uint64_t *ids, uint32_t n,
+                            float *out);
+/* a2: the whole layer-0 greedy descent of insert (hnsw.zig:88-104 at layer 0)
+ * for query row `owner`, starting at (*ep, *ep_dist); returns the final pair
+ * and the number of distance evaluations. */
+int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, float *ep_dist,
+                           uint64_t *out_evals);
+
+/* ---- a5/a6/a7: search (hnsw.zig:194-236) ---------------------------------- */
+/* Batched graph search over the device mirror of layer 0, entry point = node
+ * `entry` (the reference never moves it off node 0: hnsw.zig:84,:110-112).
+ *   ef == 0 : reference-compat mode -- first k pops of a best-first frontier,
+ *             then stable sort (bit-exact ids/distances vs the oracle);
+ *   ef  > 0 : ef-mode beam search (extension; spec in oracle/zvdb_oracle.h).
+ * Outputs: out_ids[nq*k], out_dist[nq*k], out_count[nq] (count may be < k:
+ * test_hnsw.zig:122-125; unused slots are id = UINT64_MAX, dist = +inf).
+ * stats may be NULL. */
+int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, uint32_t dim,
+                          uint32_t k, uint32_t ef, uint64_t entry,
+                          uint64_t *out_ids, float *out_dist, uint32_t *out_count,
+                          zvdb_hip_search_stats *stats);
+
+/* ---- a10: brute-force Q x V^T + fused top-k (no reference symbol) --------- */
+/* For each query the k smallest distances over all rows, ascending, ties by
+ * lower id; final distances are recomputed in exact reference arithmetic. */
+int zvdb_hip_search_bruteforce(zvdb_hip_index *h, const float *queries, uint32_t nq, uint32_t dim,
+                               uint32_t k, uint32_t mode,
+                               uint64_t *out_ids, float *out_dist, uint32_t *out_count);
+
+/* ---- device-pointer variants (bench / multi-GPU; enqueue only) ------------ */
+/* Workspace sizing for the _dev calls (bytes); allocate once, reuse. */
+int zvdb_hip_bruteforce_workspace(zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t mode,
+                                  uint64_t *out_bytes);
+/* d_queries: nq x dim fp32 row-major; outputs on device: d_ids u64[nq*k] (ids
+ * already offset by id_offset: the shard's first global id), d_dist f32[nq*k],
+ * d_count u32[nq]. */
+int zvdb_hip_search_bruteforce_dev(zvdb_hip_index *h, const void *d_queries, uint32_t nq,
+                                   uint32_t dim, uint32_t k, uint32_t mode, uint64_t id_offset,
+                                   void *d_workspace, uint64_t workspace_bytes,
+                                   void *d_ids, void *d_dist, void *d_count, void *stream);
+int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t nq, uint32_t dim,
+                              uint32_t k, uint32_t ef, uint64_t entry, uint64_t id_offset,
+                              void *d_ids, void *d_dist, void *d_count, void *d_stats,
+                              void *stream);
+/* C1 consumer: merge G all-gathered per-shard lists ([G][nq][k] ids/dist,
+ * [G][nq] counts, device memory) into the global top-k by (dist, id). */
+int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d_count,
+                            uint32_t G, uint32_t nq, uint32_t k,
+                            void *d_out_ids, void *d_out_dist, void *d_out_count, void *stream);
+
+/* Kernel timing hook for bench.py's roofline object: the library records HIP
+ * events around the dominant kernel of the last *_dev brute-force/graph call
+ * on the stream it was launched on; this returns the elapsed ms of the last
+ * `n` recorded launches (synchronises on the events). */
+int zvdb_hip_timing_enable(zvdb_hip_index *h, int enable);
+int zvdb_hip_timing_read(zvdb_hip_index *h, double *out_total_ms, uint32_t *out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZVDB_HIP_H */

@@ -1,0 +1,682 @@
+// api.hip -- extern "C" entry points of libzvdb_hip.so (declared in include/zvdb_hip.h)
+// plus the host-side plumbing they share: error string, staging buffers, capacity growth.
+#include <cstdarg>
+#include <cstring>
+#include <algorithm>
+
+#include "common.h"
+
+namespace zvdb {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ensure_pin(zvdb_hip_index *h, size_t bytes) {
+    if (h->pin.bytes >= bytes) return ZVDB_OK;
+    if (h->pin.ptr) {
+        ZV_HIP(hipStreamSynchronize(h->stream));
+        ZV_HIP(hipHostFree(h->pin.ptr));
+        h->pin.ptr = nullptr;
+        h->pin.bytes = 0;
+    }
+    const size_t nb = std::max<size_t>(round_up64(bytes, 4096), 1 << 16);
+    ZV_HIP(hipHostMalloc(&h->pin.ptr, nb, hipHostMallocDefault));
+    h->pin.bytes = nb;
+    return ZVDB_OK;
+}
+
+int ensure_scratch(zvdb_hip_index *h, size_t bytes) {
+    if (h->scratch_bytes >= bytes) return ZVDB_OK;
+    if (h->scratch) {
+        ZV_HIP(hipStreamSynchronize(h->stream));
+        ZV_HIP(hipFree(h->scratch));
+        h->scratch = nullptr;
+        h->scratch_bytes = 0;
+    }
+    const size_t nb = std::max<size_t>(round_up64(bytes, 4096), 1 << 16);
+    ZV_HIP(hipMalloc(&h->scratch, nb));
+    h->scratch_bytes = nb;
+    return ZVDB_OK;
+}
+
+template <typename T>
+static int regrow(T **p, uint64_t old_elems, uint64_t new_elems, hipStream_t s) {
+    T *np = nullptr;
+    ZV_HIP(hipMalloc(reinterpret_cast<void **>(&np), new_elems * sizeof(T)));
+    ZV_HIP(hipMemsetAsync(np, 0, new_elems * sizeof(T), s));
+    if (*p && old_elems)
+        ZV_HIP(hipMemcpyAsync(np, *p, old_elems * sizeof(T), hipMemcpyDeviceToDevice, s));
+    ZV_HIP(hipStreamSynchronize(s));
+    if (*p) ZV_HIP(hipFree(*p));
+    *p = np;
+    return ZVDB_OK;
+}
+
+int ensure_capacity(zvdb_hip_index *h, uint64_t want) {
+    if (want <= h->cap) return ZVDB_OK;
+    if (want > 0xFFFFFFF0ull) {
+        set_error("more than 2^32 rows per shard are not supported (ids are u32 on device)");
+        return ZVDB_ERR_UNSUPPORTED;
+    }
+    const uint64_t ncap = std::max<uint64_t>({want, h->cap * 2, 1024});
+    ZV_CHECK(regrow(&h->rows, h->count * h->ld, ncap * h->ld, h->stream));
+    ZV_CHECK(regrow(&h->norm, h->count, ncap, h->stream));
+    if (h->flags & ZVDB_FLAG_BF16_MIRROR) {
+        ZV_CHECK(regrow(&h->rows_h, h->count * h->ldh, ncap * h->ldh, h->stream));
+        ZV_CHECK(regrow(&h->norm_h, h->count, ncap, h->stream));
+    }
+    ZV_CHECK(regrow(&h->adj, h->count * h->gstride, ncap * h->gstride, h->stream));
+    ZV_CHECK(regrow(&h->deg, h->count, ncap, h->stream));
+    h->cap = ncap;
+    return ZVDB_OK;
+}
+
+void timing_begin(zvdb_hip_index *h, hipStream_t s) {
+    if (!h->timing) return;
+    if (h->events_used == h->events.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        h->events.emplace_back(a, b);
+    }
+    (void)hipEventRecord(h->events[h->events_used].first, s);
+}
+
+void timing_end(zvdb_hip_index *h, hipStream_t s) {
+    if (!h->timing || h->events_used >= h->events.size()) return;
+    (void)hipEventRecord(h->events[h->events_used].second, s);
+    h->events_used += 1;
+}
+
+static int set_dim(zvdb_hip_index *h, uint32_t dim) {
+    if (dim == 0) {
+        set_error("dimension 0");
+        return ZVDB_ERR_INVALID;
+    }
+    if (h->dim == 0) {
+        h->dim = dim;
+        h->ld = round_up(dim, 32);
+        h->ldh = round_up(dim, 64);
+    } else if (h->dim != dim) {
+        set_error("Mismatched dimensions in distance calculation (index %u, got %u)", h->dim, dim);
+        return ZVDB_ERR_DIM_MISMATCH;
+    }
+    return ZVDB_OK;
+}
+
+static int use_device(zvdb_hip_index *h) {
+    ZV_HIP(hipSetDevice(h->device));
+    return ZVDB_OK;
+}
+
+// rows [first, first+n) are in place in h->rows: normalise (cosine), norms, bf16 mirror
+static int finish_rows(zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s) {
+    if (h->metric == ZVDB_METRIC_COSINE)
+        ZV_CHECK(launch_normalize_rows(h->rows + first * h->ld, h->dim, h->ld, n, s));
+    ZV_CHECK(launch_finalize_rows(h, first, n, s));
+    return ZVDB_OK;
+}
+
+static int stage_queries(zvdb_hip_index *h, const float *queries, uint32_t nq, float *d_q) {
+    const size_t qb = (size_t)nq * h->dim * sizeof(float);
+    ZV_CHECK(ensure_pin(h, qb));
+    std::memcpy(h->pin.ptr, queries, qb);
+    ZV_HIP(hipMemcpyAsync(d_q, h->pin.ptr, qb, hipMemcpyHostToDevice, h->stream));
+    return ZVDB_OK;
+}
+
+}  // namespace zvdb
+
+using namespace zvdb;
+
+#define ZV_ARG(cond, msg)              \
+    do {                               \
+        if (!(cond)) {                 \
+            zvdb::set_error("%s", msg); \
+            return ZVDB_ERR_INVALID;   \
+        }                              \
+    } while (0)
+
+extern "C" {
+
+const char *zvdb_hip_last_error(void) { return g_err; }
+int zvdb_hip_abi_version(void) { return ZVDB_HIP_ABI_VERSION; }
+
+int zvdb_hip_device_count(int *out_count) {
+    ZV_ARG(out_count, "null out_count");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *out_count = n;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_create(const zvdb_hip_config *cfg, zvdb_hip_index **out) {
+    ZV_ARG(cfg && out, "null argument");
+    ZV_ARG(cfg->abi_version == ZVDB_HIP_ABI_VERSION, "ABI version mismatch");
+    ZV_ARG(cfg->metric <= ZVDB_METRIC_COSINE, "unknown metric");
+    ZV_ARG(cfg->m >= 1 && cfg->m <= 4096, "m out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: libzvdb_hip has no CPU fallback");
+        return ZVDB_ERR_NO_DEVICE;
+    }
+    int dev = cfg->device;
+    if (dev < 0) ZV_HIP(hipGetDevice(&dev));
+    ZV_ARG(dev < ndev, "device ordinal out of range");
+    ZV_HIP(hipSetDevice(dev));
+    zvdb_hip_index *h = new (std::nothrow) zvdb_hip_index();
+    if (!h) return ZVDB_ERR_OOM;
+    h->device = dev;
+    h->metric = cfg->metric;
+    h->m = cfg->m;
+    h->ef_construction = cfg->ef_construction;
+    h->gstride = cfg->graph_stride ? cfg->graph_stride : cfg->m;
+    h->flags = cfg->flags;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        delete h;
+        return ZVDB_ERR_HIP;
+    }
+    if (cfg->dim) {
+        int rc = set_dim(h, cfg->dim);
+        if (rc == ZVDB_OK && cfg->capacity) rc = ensure_capacity(h, cfg->capacity);
+        if (rc != ZVDB_OK) {
+            zvdb_hip_destroy(h);
+            return rc;
+        }
+    }
+    *out = h;
+    return ZVDB_OK;
+}
+
+void zvdb_hip_destroy(zvdb_hip_index *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->rows);
+    (void)hipFree(h->rows_h);
+    (void)hipFree(h->norm);
+    (void)hipFree(h->norm_h);
+    (void)hipFree(h->adj);
+    (void)hipFree(h->deg);
+    (void)hipFree(h->scratch);
+    if (h->pin.ptr) (void)hipHostFree(h->pin.ptr);
+    for (auto &e : h->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int zvdb_hip_count(zvdb_hip_index *h, uint64_t *out_count) {
+    ZV_ARG(h && out_count, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    *out_count = h->count;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_dim(zvdb_hip_index *h, uint32_t *out_dim) {
+    ZV_ARG(h && out_dim, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    *out_dim = h->dim;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_add(zvdb_hip_index *h, const float *rows, uint64_t n, uint32_t dim, uint64_t *first_id) {
+    ZV_ARG(h && (rows || n == 0), "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(set_dim(h, dim));
+    if (first_id) *first_id = h->count;
+    if (n == 0) return ZVDB_OK;
+    ZV_CHECK(ensure_capacity(h, h->count + n));
+    float *dst = h->rows + h->count * h->ld;
+    // chunked through the pinned buffer so the copy is a real async DMA
+    const uint64_t chunk_rows = std::max<uint64_t>(1, (8u << 20) / (dim * sizeof(float)));
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const uint64_t nr = std::min(chunk_rows, n - r0);
+        const size_t bytes = nr * dim * sizeof(float);
+        ZV_CHECK(ensure_pin(h, bytes));
+        std::memcpy(h->pin.ptr, rows + r0 * dim, bytes);
+        ZV_HIP(hipMemcpy2DAsync(dst + r0 * h->ld, h->ld * sizeof(float), h->pin.ptr, dim * sizeof(float),
+                                dim * sizeof(float), nr, hipMemcpyHostToDevice, h->stream));
+        ZV_HIP(hipStreamSynchronize(h->stream));
+    }
+    ZV_CHECK(finish_rows(h, h->count, n, h->stream));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    h->count += n;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_add_dev(zvdb_hip_index *h, const void *d_rows, uint64_t n, uint32_t dim, void *stream,
+                     uint64_t *first_id) {
+    ZV_ARG(h && (d_rows || n == 0), "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(set_dim(h, dim));
+    if (first_id) *first_id = h->count;
+    if (n == 0) return ZVDB_OK;
+    ZV_CHECK(ensure_capacity(h, h->count + n));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ZV_CHECK(launch_pack_rows(static_cast<const float *>(d_rows), dim, h->rows + h->count * h->ld, h->ld,
+                              n, s));
+    ZV_CHECK(finish_rows(h, h->count, n, s));
+    ZV_HIP(hipStreamSynchronize(s));
+    h->count += n;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_add_synthetic(zvdb_hip_index *h, uint64_t n, uint32_t dim, uint64_t seed,
+                           uint64_t first_row, uint64_t *first_id) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(set_dim(h, dim));
+    if (first_id) *first_id = h->count;
+    if (n == 0) return ZVDB_OK;
+    ZV_CHECK(ensure_capacity(h, h->count + n));
+    ZV_CHECK(launch_fill_synthetic(h->rows + h->count * h->ld, n, dim, h->ld, seed, first_row, h->stream));
+    ZV_CHECK(finish_rows(h, h->count, n, h->stream));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    h->count += n;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_fill_synthetic_dev(void *d_out, uint64_t nrows, uint32_t dim, uint64_t seed,
+                                uint64_t first_row, void *stream) {
+    ZV_ARG(d_out || nrows == 0, "null argument");
+    ZV_ARG(dim % 4 == 0, "fill_synthetic_dev needs dim % 4 == 0 (dense float4 rows)");
+    return launch_fill_synthetic(static_cast<float *>(d_out), nrows, dim, dim, seed, first_row,
+                                 static_cast<hipStream_t>(stream));
+}
+
+int zvdb_hip_get_vector(zvdb_hip_index *h, uint64_t id, float *out, uint32_t dim) {
+    ZV_ARG(h && out, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    if (id >= h->count) {
+        set_error("NodeNotFound: id %llu >= count %llu", (unsigned long long)id,
+                  (unsigned long long)h->count);
+        return ZVDB_ERR_NODE_NOT_FOUND;
+    }
+    if (dim != h->dim) {
+        set_error("Mismatched dimensions (index %u, got %u)", h->dim, dim);
+        return ZVDB_ERR_DIM_MISMATCH;
+    }
+    ZV_HIP(hipMemcpyAsync(out, h->rows + id * h->ld, dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    return ZVDB_OK;
+}
+
+int zvdb_hip_set_neighbors(zvdb_hip_index *h, uint64_t node, const uint64_t *ids, uint32_t n) {
+    ZV_ARG(h && (ids || n == 0), "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    if (node >= h->count) {
+        set_error("NodeNotFound: node %llu", (unsigned long long)node);
+        return ZVDB_ERR_NODE_NOT_FOUND;
+    }
+    if (n > h->gstride) {
+        set_error("neighbour list of %u exceeds the device stride %u", n, h->gstride);
+        return ZVDB_ERR_INVALID;
+    }
+    ZV_CHECK(ensure_pin(h, (h->gstride + 1) * sizeof(uint32_t)));
+    uint32_t *p = static_cast<uint32_t *>(h->pin.ptr);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ids[i] >= h->count) {
+            set_error("NodeNotFound: neighbour %llu", (unsigned long long)ids[i]);
+            return ZVDB_ERR_NODE_NOT_FOUND;
+        }
+        p[i] = (uint32_t)ids[i];
+    }
+    p[h->gstride] = n;
+    if (n)
+        ZV_HIP(hipMemcpyAsync(h->adj + node * h->gstride, p, n * sizeof(uint32_t), hipMemcpyHostToDevice,
+                              h->stream));
+    ZV_HIP(hipMemcpyAsync(h->deg + node, p + h->gstride, sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    return ZVDB_OK;
+}
+
+int zvdb_hip_upload_graph(zvdb_hip_index *h, const uint32_t *adj, const uint32_t *deg, uint64_t n,
+                          uint32_t stride) {
+    ZV_ARG(h && adj && deg, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_ARG(n <= h->count, "graph has more nodes than the index has rows");
+    ZV_ARG(stride <= h->gstride, "graph stride exceeds the device stride");
+    for (uint64_t i = 0; i < n; ++i) {
+        ZV_ARG(deg[i] <= stride, "degree exceeds stride");
+        for (uint32_t j = 0; j < deg[i]; ++j)
+            if (adj[i * stride + j] >= h->count) {
+                set_error("NodeNotFound: neighbour %u of node %llu", adj[i * stride + j],
+                          (unsigned long long)i);
+                return ZVDB_ERR_NODE_NOT_FOUND;
+            }
+    }
+    ZV_HIP(hipMemcpy2D(h->adj, h->gstride * sizeof(uint32_t), adj, stride * sizeof(uint32_t),
+                       stride * sizeof(uint32_t), n, hipMemcpyHostToDevice));
+    ZV_HIP(hipMemcpy(h->deg, deg, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return ZVDB_OK;
+}
+
+int zvdb_hip_get_neighbors(zvdb_hip_index *h, uint64_t node, uint64_t *out_ids, uint32_t cap,
+                           uint32_t *out_n) {
+    ZV_ARG(h && out_n, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    if (node >= h->count) {
+        set_error("NodeNotFound: node %llu", (unsigned long long)node);
+        return ZVDB_ERR_NODE_NOT_FOUND;
+    }
+    std::vector<uint32_t> tmp(h->gstride + 1);
+    ZV_HIP(hipMemcpy(tmp.data(), h->adj + node * h->gstride, h->gstride * sizeof(uint32_t),
+                     hipMemcpyDeviceToHost));
+    ZV_HIP(hipMemcpy(&tmp[h->gstride], h->deg + node, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t n = tmp[h->gstride];
+    *out_n = n;
+    for (uint32_t i = 0; i < n && i < cap; ++i) out_ids[i] = tmp[i];
+    return ZVDB_OK;
+}
+
+// shared body of distances / distances_from
+static int distances_impl(zvdb_hip_index *h, const float *host_query, uint64_t owner,
+                          const uint64_t *ids, uint32_t n, float *out) {
+    if (n == 0) return ZVDB_OK;
+    const size_t qb = (size_t)h->ld * sizeof(float);
+    const size_t need = qb + (size_t)n * 8;
+    ZV_CHECK(ensure_scratch(h, need));
+    ZV_CHECK(ensure_pin(h, need));
+    unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr);
+    unsigned char *scr = static_cast<unsigned char *>(h->scratch);
+    uint32_t *p_ids = reinterpret_cast<uint32_t *>(pin + qb);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ids[i] >= h->count) {
+            set_error("NodeNotFound: id %llu", (unsigned long long)ids[i]);
+            return ZVDB_ERR_NODE_NOT_FOUND;
+        }
+        p_ids[i] = (uint32_t)ids[i];
+    }
+    const float *d_query;
+    size_t h2d_off = qb, h2d_bytes = (size_t)n * 4;
+    if (host_query) {
+        std::memset(pin, 0, qb);
+        std::memcpy(pin, host_query, h->dim * sizeof(float));
+        d_query = reinterpret_cast<const float *>(scr);
+        h2d_off = 0;
+        h2d_bytes += qb;
+    } else {
+        d_query = h->rows + owner * h->ld;
+    }
+    ZV_HIP(hipMemcpyAsync(scr + h2d_off, pin + h2d_off, h2d_bytes, hipMemcpyHostToDevice, h->stream));
+    uint32_t *d_ids = reinterpret_cast<uint32_t *>(scr + qb);
+    float *d_out = reinterpret_cast<float *>(scr + qb + (size_t)n * 4);
+    ZV_CHECK(launch_exact_distances(h, d_query, d_ids, n, d_out, h->stream));
+    float *p_out = reinterpret_cast<float *>(pin + qb + (size_t)n * 4);
+    ZV_HIP(hipMemcpyAsync(p_out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    std::memcpy(out, p_out, (size_t)n * 4);
+    return ZVDB_OK;
+}
+
+int zvdb_hip_distances(zvdb_hip_index *h, const float *query, uint32_t dim, const uint64_t *ids,
+                       uint32_t n, float *out) {
+    ZV_ARG(h && query && (ids || n == 0) && (out || n == 0), "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    if (dim != h->dim) {
+        set_error("Mismatched dimensions in distance calculation (index %u, got %u)", h->dim, dim);
+        return ZVDB_ERR_DIM_MISMATCH;
+    }
+    return distances_impl(h, query, 0, ids, n, out);
+}
+
+int zvdb_hip_distances_from(zvdb_hip_index *h, uint64_t owner, const uint64_t *ids, uint32_t n,
+                            float *out) {
+    ZV_ARG(h && (ids || n == 0) && (out || n == 0), "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    if (owner >= h->count) {
+        set_error("NodeNotFound: owner %llu", (unsigned long long)owner);
+        return ZVDB_ERR_NODE_NOT_FOUND;
+    }
+    return distances_impl(h, nullptr, owner, ids, n, out);
+}
+
+int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, float *ep_dist,
+                           uint64_t *out_evals) {
+    ZV_ARG(h && ep && ep_dist, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    if (owner >= h->count || *ep >= h->count) {
+        set_error("NodeNotFound: owner %llu / ep %llu", (unsigned long long)owner, (unsigned long long)*ep);
+        return ZVDB_ERR_NODE_NOT_FOUND;
+    }
+    ZV_CHECK(ensure_scratch(h, 64));
+    ZV_CHECK(ensure_pin(h, 64));
+    struct Io { uint32_t ep; float dist; unsigned long long evals; };
+    Io *p = static_cast<Io *>(h->pin.ptr);
+    p->ep = (uint32_t)*ep;
+    p->dist = *ep_dist;
+    p->evals = 0;
+    Io *d = static_cast<Io *>(h->scratch);
+    ZV_HIP(hipMemcpyAsync(d, p, sizeof(Io), hipMemcpyHostToDevice, h->stream));
+    ZV_CHECK(launch_greedy_layer0(h, (uint32_t)owner, &d->ep, &d->dist, &d->evals, h->stream));
+    ZV_HIP(hipMemcpyAsync(p, d, sizeof(Io), hipMemcpyDeviceToHost, h->stream));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    *ep = p->ep;
+    *ep_dist = p->dist;
+    if (out_evals) *out_evals = p->evals;
+    return ZVDB_OK;
+}
+
+static int check_query_args(zvdb_hip_index *h, uint32_t dim, uint32_t k) {
+    if (h->count > 0 && dim != h->dim) {
+        set_error("Mismatched dimensions in distance calculation (index %u, got %u)", h->dim, dim);
+        return ZVDB_ERR_DIM_MISMATCH;
+    }
+    if (k > (1u << 20)) {
+        set_error("k too large");
+        return ZVDB_ERR_INVALID;
+    }
+    return ZVDB_OK;
+}
+
+static void fill_empty(uint32_t nq, uint32_t k, uint64_t *ids, float *dist, uint32_t *cnt) {
+    for (size_t i = 0; i < (size_t)nq * k; ++i) {
+        ids[i] = ~0ull;
+        dist[i] = __builtin_inff();
+    }
+    for (uint32_t i = 0; i < nq; ++i) cnt[i] = 0;
+}
+
+int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t nq, uint32_t dim,
+                              uint32_t k, uint32_t ef, uint64_t entry, uint64_t id_offset,
+                              void *d_ids, void *d_dist, void *d_count, void *d_stats, void *stream) {
+    ZV_ARG(h && d_queries && d_ids && d_dist && d_count, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(check_query_args(h, dim, k));
+    ZV_ARG(h->count > 0 && k > 0, "search_graph_dev needs a non-empty index and k > 0");
+    if (entry >= h->count) {
+        set_error("NodeNotFound: entry %llu", (unsigned long long)entry);
+        return ZVDB_ERR_NODE_NOT_FOUND;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    timing_begin(h, s);
+    int rc;
+    if (ef == 0)
+        rc = launch_search_compat(h, static_cast<const float *>(d_queries), nq, k, (uint32_t)entry,
+                                  id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
+                                  static_cast<uint32_t *>(d_count),
+                                  static_cast<unsigned long long *>(d_stats), s);
+    else
+        rc = launch_search_ef(h, static_cast<const float *>(d_queries), nq, k, ef, (uint32_t)entry,
+                              id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
+                              static_cast<uint32_t *>(d_count),
+                              static_cast<unsigned long long *>(d_stats), s);
+    timing_end(h, s);
+    return rc;
+}
+
+int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, uint32_t dim,
+                          uint32_t k, uint32_t ef, uint64_t entry, uint64_t *out_ids, float *out_dist,
+                          uint32_t *out_count, zvdb_hip_search_stats *stats) {
+    ZV_ARG(h && (queries || nq == 0) && out_ids && out_dist && out_count, "null argument");
+    if (stats) stats->dist_evals = stats->pops = 0;
+    if (nq == 0) return ZVDB_OK;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        ZV_CHECK(use_device(h));
+        ZV_CHECK(check_query_args(h, dim, k));
+        if (h->count == 0 || k == 0) {  // hnsw.zig:201: no entry point -> empty result, no error
+            fill_empty(nq, k, out_ids, out_dist, out_count);
+            return ZVDB_OK;
+        }
+        const size_t qb = round_up64((size_t)nq * dim * 4, 256);
+        const size_t ib = round_up64((size_t)nq * k * 8, 256);
+        const size_t db = round_up64((size_t)nq * k * 4, 256);
+        const size_t cb = round_up64((size_t)nq * 4, 256);
+        const size_t total = qb + ib + db + cb + 64;
+        ZV_CHECK(ensure_scratch(h, total));
+        ZV_CHECK(ensure_pin(h, total));
+        unsigned char *scr = static_cast<unsigned char *>(h->scratch);
+        ZV_CHECK(stage_queries(h, queries, nq, reinterpret_cast<float *>(scr)));
+        ZV_HIP(hipMemsetAsync(scr + qb + ib + db + cb, 0, 64, h->stream));
+        // unlock-free inner call: we already hold the mutex, so call the launchers directly
+        if (entry >= h->count) {
+            set_error("NodeNotFound: entry %llu", (unsigned long long)entry);
+            return ZVDB_ERR_NODE_NOT_FOUND;
+        }
+        uint64_t *d_ids = reinterpret_cast<uint64_t *>(scr + qb);
+        float *d_dist = reinterpret_cast<float *>(scr + qb + ib);
+        uint32_t *d_cnt = reinterpret_cast<uint32_t *>(scr + qb + ib + db);
+        unsigned long long *d_st = reinterpret_cast<unsigned long long *>(scr + qb + ib + db + cb);
+        int rc = ef == 0 ? launch_search_compat(h, reinterpret_cast<float *>(scr), nq, k, (uint32_t)entry, 0,
+                                                d_ids, d_dist, d_cnt, d_st, h->stream)
+                         : launch_search_ef(h, reinterpret_cast<float *>(scr), nq, k, ef, (uint32_t)entry,
+                                            0, d_ids, d_dist, d_cnt, d_st, h->stream);
+        ZV_CHECK(rc);
+        unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr);
+        ZV_HIP(hipMemcpyAsync(pin + qb, scr + qb, ib + db + cb + 64, hipMemcpyDeviceToHost, h->stream));
+        ZV_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(out_ids, pin + qb, (size_t)nq * k * 8);
+        std::memcpy(out_dist, pin + qb + ib, (size_t)nq * k * 4);
+        std::memcpy(out_count, pin + qb + ib + db, (size_t)nq * 4);
+        const unsigned long long *st = reinterpret_cast<const unsigned long long *>(pin + qb + ib + db + cb);
+        if (stats) {
+            stats->dist_evals = st[0];
+            stats->pops = st[1];
+        }
+        if (st[2] != 0) {
+            set_error("ef-mode visited set exhausted for %llu queries (ef*stride too large for LDS)", st[2]);
+            return ZVDB_ERR_UNSUPPORTED;
+        }
+    }
+    return ZVDB_OK;
+}
+
+int zvdb_hip_bruteforce_workspace(zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t mode,
+                                  uint64_t *out_bytes) {
+    ZV_ARG(h && out_bytes, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_ARG(mode <= ZVDB_BF_BF16, "unknown brute-force mode");
+    *out_bytes = bruteforce_workspace_bytes(h, nq, k, mode);
+    return ZVDB_OK;
+}
+
+int zvdb_hip_search_bruteforce_dev(zvdb_hip_index *h, const void *d_queries, uint32_t nq, uint32_t dim,
+                                   uint32_t k, uint32_t mode, uint64_t id_offset, void *d_workspace,
+                                   uint64_t workspace_bytes, void *d_ids, void *d_dist, void *d_count,
+                                   void *stream) {
+    ZV_ARG(h && d_queries && d_ids && d_dist && d_count && d_workspace, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(check_query_args(h, dim, k));
+    ZV_ARG(mode <= ZVDB_BF_BF16, "unknown brute-force mode");
+    ZV_ARG(h->count > 0 && k > 0, "search_bruteforce_dev needs a non-empty index and k > 0");
+    return launch_bruteforce(h, static_cast<const float *>(d_queries), nq, k, mode, id_offset, d_workspace,
+                             workspace_bytes, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
+                             static_cast<uint32_t *>(d_count), static_cast<hipStream_t>(stream));
+}
+
+int zvdb_hip_search_bruteforce(zvdb_hip_index *h, const float *queries, uint32_t nq, uint32_t dim,
+                               uint32_t k, uint32_t mode, uint64_t *out_ids, float *out_dist,
+                               uint32_t *out_count) {
+    ZV_ARG(h && (queries || nq == 0) && out_ids && out_dist && out_count, "null argument");
+    if (nq == 0) return ZVDB_OK;
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(check_query_args(h, dim, k));
+    ZV_ARG(mode <= ZVDB_BF_BF16, "unknown brute-force mode");
+    if (h->count == 0 || k == 0) {
+        fill_empty(nq, k, out_ids, out_dist, out_count);
+        return ZVDB_OK;
+    }
+    const size_t qb = round_up64((size_t)nq * dim * 4, 256);
+    const size_t ib = round_up64((size_t)nq * k * 8, 256);
+    const size_t db = round_up64((size_t)nq * k * 4, 256);
+    const size_t cb = round_up64((size_t)nq * 4, 256);
+    const uint64_t wsb = bruteforce_workspace_bytes(h, nq, k, mode);
+    const size_t total = qb + ib + db + cb + wsb;
+    ZV_CHECK(ensure_scratch(h, total));
+    ZV_CHECK(ensure_pin(h, qb + ib + db + cb));
+    unsigned char *scr = static_cast<unsigned char *>(h->scratch);
+    ZV_CHECK(stage_queries(h, queries, nq, reinterpret_cast<float *>(scr)));
+    uint64_t *d_ids = reinterpret_cast<uint64_t *>(scr + qb);
+    float *d_dist = reinterpret_cast<float *>(scr + qb + ib);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(scr + qb + ib + db);
+    ZV_CHECK(launch_bruteforce(h, reinterpret_cast<float *>(scr), nq, k, mode, 0, scr + qb + ib + db + cb, wsb,
+                               d_ids, d_dist, d_cnt, h->stream));
+    unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr);
+    ZV_HIP(hipMemcpyAsync(pin + qb, scr + qb, ib + db + cb, hipMemcpyDeviceToHost, h->stream));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    std::memcpy(out_ids, pin + qb, (size_t)nq * k * 8);
+    std::memcpy(out_dist, pin + qb + ib, (size_t)nq * k * 4);
+    std::memcpy(out_count, pin + qb + ib + db, (size_t)nq * 4);
+    return ZVDB_OK;
+}
+
+int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d_count, uint32_t G,
+                            uint32_t nq, uint32_t k, void *d_out_ids, void *d_out_dist,
+                            void *d_out_count, void *stream) {
+    ZV_ARG(d_ids && d_dist && d_count && d_out_ids && d_out_dist && d_out_count, "null argument");
+    ZV_ARG(G >= 1, "G must be >= 1");
+    return launch_merge_topk(static_cast<const uint64_t *>(d_ids), static_cast<const float *>(d_dist),
+                             static_cast<const uint32_t *>(d_count), G, nq, k,
+                             static_cast<uint64_t *>(d_out_ids), static_cast<float *>(d_out_dist),
+                             static_cast<uint32_t *>(d_out_count), static_cast<hipStream_t>(stream));
+}
+
+int zvdb_hip_timing_enable(zvdb_hip_index *h, int enable) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    h->timing = enable != 0;
+    h->events_used = 0;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_timing_read(zvdb_hip_index *h, double *out_total_ms, uint32_t *out_launches) {
+    ZV_ARG(h && out_total_ms && out_launches, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    double tot = 0.0;
+    for (size_t i = 0; i < h->events_used; ++i) {
+        ZV_HIP(hipEventSynchronize(h->events[i].second));
+        float ms = 0.0f;
+        ZV_HIP(hipEventElapsedTime(&ms, h->events[i].first, h->events[i].second));
+        tot += ms;
+    }
+    *out_total_ms = tot;
+    *out_launches = (uint32_t)h->events_used;
+    h->events_used = 0;
+    return ZVDB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// common.h -- internal declarations shared by the translation units of libzvdb_hip.so.
+// gfx950 only; wave64 is assumed everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/zvdb_hip.h"
+
+namespace zvdb {
+
+constexpr int kWave = 64;
+
+void set_error(const char *fmt, ...);
+
+#define ZV_HIP(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            zvdb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                            __FILE__, __LINE__);                                      \
+            return _e == hipErrorOutOfMemory ? ZVDB_ERR_OOM : ZVDB_ERR_HIP;           \
+        }                                                                             \
+    } while (0)
+
+#define ZV_CHECK(expr)                 \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != ZVDB_OK) return _rc; \
+    } while (0)
+
+inline uint32_t round_up(uint32_t x, uint32_t a) { return (x + a - 1) / a * a; }
+inline uint64_t round_up64(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// splitmix-style counter hash shared with oracle/zvdb_oracle.c:orc_mix64
+__host__ __device__ inline uint64_t mix64(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// monotone map of an fp32 (any sign) onto u32: a < b  <=>  key(a) < key(b)
+__host__ __device__ inline uint32_t f32_key(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    __builtin_memcpy(&u, &f, 4);
+#endif
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float f32_unkey(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+struct PinnedBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace zvdb
+
+// Device-resident index.  Layout (DESIGN.md "Data layout in HBM"):
+//   rows   : fp32 [cap][ld]   row-major, ld = round_up(dim, 32), zero padded
+//   rows_h : bf16 [cap][ldh]  row-major mirror, ldh = round_up(dim, 64) (optional)
+//   norm   : fp32 [cap]       sum v^2 over the fp32 row   (MFMA screen only)
+//   norm_h : fp32 [cap]       sum v^2 over the bf16 row
+//   adj    : u32  [cap][gstride]  layer-0 lists, deg : u32 [cap]
+struct zvdb_hip_index {
+    std::mutex mu;
+    int device = 0;
+    uint32_t dim = 0, ld = 0, ldh = 0;
+    uint32_t metric = 0, m = 16, ef_construction = 200, gstride = 16, flags = 0;
+    uint64_t count = 0, cap = 0;
+    float *rows = nullptr;
+    uint16_t *rows_h = nullptr;
+    float *norm = nullptr;
+    float *norm_h = nullptr;
+    uint32_t *adj = nullptr;
+    uint32_t *deg = nullptr;
+    hipStream_t stream = nullptr;
+    // pinned host staging + device scratch for the host-pointer entry points
+    zvdb::PinnedBuf pin;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // timing hook (zvdb_hip_timing_*)
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+};
+
+namespace zvdb {
+
+int ensure_pin(zvdb_hip_index *h, size_t bytes);
+int ensure_scratch(zvdb_hip_index *h, size_t bytes);
+int ensure_capacity(zvdb_hip_index *h, uint64_t want);
+void timing_begin(zvdb_hip_index *h, hipStream_t s);
+void timing_end(zvdb_hip_index *h, hipStream_t s);
+
+// ---- exact_kernels.hip (compiled with -ffp-contract=off) -------------------
+int launch_exact_distances(const zvdb_hip_index *h, const float *d_query, const uint32_t *d_ids,
+                           uint32_t n, float *d_out, hipStream_t s);
+int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep_io,
+                         float *d_dist_io, unsigned long long *d_evals, hipStream_t s);
+int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
+                         uint32_t entry, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
+                         uint32_t *d_count, unsigned long long *d_stats, hipStream_t s);
+int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
+                     uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
+                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s);
+// exact re-rank of candidate lists: cand[nq][kc] u32 (0xFFFFFFFF = empty) -> top-k by (dist,id)
+int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, const uint32_t *d_cand,
+                  uint32_t kc, uint32_t k, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
+                  uint32_t *d_count, hipStream_t s);
+
+// ---- data_kernels.hip -------------------------------------------------------
+int launch_fill_synthetic(float *d_out, uint64_t nrows, uint32_t dim, uint32_t ld, uint64_t seed,
+                          uint64_t first_row, hipStream_t s);
+int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld, uint64_t n,
+                     hipStream_t s);
+int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
+int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
+int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,
+                      uint32_t G, uint32_t nq, uint32_t k, uint64_t *o_ids, float *o_dist,
+                      uint32_t *o_count, hipStream_t s);
+
+// ---- bruteforce.hip ---------------------------------------------------------
+uint64_t bruteforce_workspace_bytes(const zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t mode);
+int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
+                      uint32_t mode, uint64_t id_offset, void *d_ws, uint64_t ws_bytes,
+                      uint64_t *d_ids, float *d_dist, uint32_t *d_count, hipStream_t s);
+
+}  // namespace zvdb

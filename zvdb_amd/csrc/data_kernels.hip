@@ -1,0 +1,215 @@
+// data_kernels.hip -- row ingestion (pack / synthetic / normalise / norms + bf16 mirror)
+// and the k-way merge that consumes the RCCL all-gather of per-shard top-k lists.
+#include "common.h"
+
+namespace zvdb {
+
+// Synthetic U[0,1) rows (distribution of benchmarks/shared_benchmarks.zig:53-59; the
+// stream definition is shared with oracle/zvdb_oracle.c:orc_fill_uniform).
+__global__ __launch_bounds__(256) void k_fill_synthetic(float *__restrict__ out, uint64_t nrows,
+                                                        uint32_t dim, uint32_t ld, uint64_t seed,
+                                                        uint64_t first_row) {
+    const uint32_t ld4 = ld >> 2;
+    const uint64_t total = nrows * ld4;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / ld4;
+        const uint32_t c = (uint32_t)(t - r * ld4) * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t cc = c + j;
+            if (cc < dim) {
+                const uint64_t z = mix64(seed, (first_row + r) * dim + cc);
+                v[j] = (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+            } else {
+                v[j] = 0.0f;
+            }
+        }
+        *reinterpret_cast<float4 *>(out + r * ld + c) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+int launch_fill_synthetic(float *d_out, uint64_t nrows, uint32_t dim, uint32_t ld, uint64_t seed,
+                          uint64_t first_row, hipStream_t s) {
+    if (nrows == 0) return ZVDB_OK;
+    const uint64_t total = nrows * (ld / 4);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_fill_synthetic, dim3(grid), dim3(256), 0, s, d_out, nrows, dim, ld, seed,
+                       first_row);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+// dense [n][dim] -> padded [n][ld]
+__global__ __launch_bounds__(256) void k_pack_rows(const float *__restrict__ src, uint32_t dim,
+                                                   float *__restrict__ dst, uint32_t ld, uint64_t n) {
+    const uint64_t total = n * ld;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = t / ld;
+        const uint32_t c = (uint32_t)(t - r * ld);
+        dst[t] = c < dim ? src[r * dim + c] : 0.0f;
+    }
+}
+
+int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld, uint64_t n,
+                     hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n * ld + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, s, d_src, dim, d_dst, ld, n);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+// cosine metric: v <- v / sqrt(sum v^2) with the sum taken strictly left to right in fp32
+// (one lane per row, so the arithmetic is reproducible on the CPU).
+__global__ __launch_bounds__(256) void k_normalize_rows(float *__restrict__ rows, uint32_t dim,
+                                                        uint32_t ld, uint64_t n) {
+#pragma clang fp contract(off)
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float *v = rows + r * ld;
+    float s = 0.0f;
+    for (uint32_t i = 0; i < dim; ++i) {
+        const float t = v[i] * v[i];
+        s = s + t;
+    }
+    const float nrm = __fsqrt_rn(s);
+    if (nrm > 0.0f)
+        for (uint32_t i = 0; i < dim; ++i) v[i] = __fdiv_rn(v[i], nrm);
+}
+
+int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    hipLaunchKernelGGL(k_normalize_rows, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, d_rows,
+                       dim, ld, n);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0x007FFFFFu) ? 0x40u : 0u));
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// per row: norm = sum v^2 (fp32), bf16 mirror row + its own norm.  One wave per row.
+__global__ __launch_bounds__(256) void k_finalize_rows(const float *__restrict__ rows, uint32_t dim,
+                                                       uint32_t ld, uint16_t *__restrict__ rows_h,
+                                                       uint32_t ldh, float *__restrict__ norm,
+                                                       float *__restrict__ norm_h, uint64_t first,
+                                                       uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = first + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= first + n) return;
+    const float *v = rows + r * ld;
+    float s = 0.0f, sh = 0.0f;
+    for (uint32_t c = lane * 4; c < ld; c += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(v + c);
+        s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        if (rows_h) {
+            const uint16_t b0 = f32_to_bf16_rne(x.x), b1 = f32_to_bf16_rne(x.y);
+            const uint16_t b2 = f32_to_bf16_rne(x.z), b3 = f32_to_bf16_rne(x.w);
+            const float f0 = __uint_as_float((uint32_t)b0 << 16), f1 = __uint_as_float((uint32_t)b1 << 16);
+            const float f2 = __uint_as_float((uint32_t)b2 << 16), f3 = __uint_as_float((uint32_t)b3 << 16);
+            sh += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
+            uint2 pk;
+            pk.x = (uint32_t)b0 | ((uint32_t)b1 << 16);
+            pk.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
+            *reinterpret_cast<uint2 *>(rows_h + r * ldh + c) = pk;
+        }
+    }
+    if (rows_h)
+        for (uint32_t c = ld + lane * 4; c < ldh; c += 256)
+            *reinterpret_cast<uint2 *>(rows_h + r * ldh + c) = make_uint2(0, 0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        sh += __shfl_xor(sh, off);
+    }
+    if (lane == 0) {
+        norm[r] = s;
+        if (norm_h) norm_h[r] = sh;
+    }
+}
+
+int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    hipLaunchKernelGGL(k_finalize_rows, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
+                       h->ld, h->rows_h, h->ldh, h->norm, h->norm_h, first, n);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+// C1 consumer: global top-k of G all-gathered shard lists, order (dist, id).  One wave per
+// query; rank by counting over the <= G*k live candidates held in LDS.
+__global__ __launch_bounds__(64) void k_merge_topk(const uint64_t *__restrict__ ids,
+                                                   const float *__restrict__ dist,
+                                                   const uint32_t *__restrict__ count, uint32_t G,
+                                                   uint32_t nq, uint32_t k,
+                                                   uint64_t *__restrict__ o_ids,
+                                                   float *__restrict__ o_dist,
+                                                   uint32_t *__restrict__ o_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t *ci = reinterpret_cast<uint64_t *>(smem);
+    float *cd = reinterpret_cast<float *>(ci + (size_t)G * k);
+    const int lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const uint32_t tot = G * k;
+    for (uint32_t t = lane; t < tot; t += kWave) {
+        const uint32_t g = t / k, j = t - g * k;
+        const bool live = j < count[(size_t)g * nq + qi];
+        const size_t src = ((size_t)g * nq + qi) * k + j;
+        ci[t] = live ? ids[src] : ~0ull;
+        cd[t] = live ? dist[src] : __builtin_inff();
+    }
+    __syncthreads();
+    uint32_t total = 0;
+    for (uint32_t base = 0; base < tot; base += kWave) {
+        const uint32_t t = base + lane;
+        const bool valid = t < tot && ci[t] != ~0ull;
+        if (valid) {
+            const float dt = cd[t];
+            const uint64_t it = ci[t];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < tot; ++j) {
+                const uint64_t ij = ci[j];
+                const float dj = cd[j];
+                if (ij != ~0ull && (dj < dt || (dj == dt && (ij < it || (ij == it && j < t))))) ++rank;
+            }
+            if (rank < k) {
+                o_ids[(size_t)qi * k + rank] = it;
+                o_dist[(size_t)qi * k + rank] = dt;
+            }
+        }
+        total += (uint32_t)__popcll(__ballot(valid));
+    }
+    const uint32_t nres = total < k ? total : k;
+    for (uint32_t i = nres + lane; i < k; i += kWave) {
+        o_ids[(size_t)qi * k + i] = ~0ull;
+        o_dist[(size_t)qi * k + i] = __builtin_inff();
+    }
+    if (lane == 0) o_count[qi] = nres;
+}
+
+int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,
+                      uint32_t G, uint32_t nq, uint32_t k, uint64_t *o_ids, float *o_dist,
+                      uint32_t *o_count, hipStream_t s) {
+    if (nq == 0 || k == 0) return ZVDB_OK;
+    const size_t lds = (size_t)G * k * 12;
+    if (lds > 160 * 1024) {
+        set_error("merge_topk: G*k = %u candidates exceed LDS", G * k);
+        return ZVDB_ERR_UNSUPPORTED;
+    }
+    if (lds > 48 * 1024)
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_merge_topk),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(64), lds, s, d_ids, d_dist, d_count, G, nq, k,
+                       o_ids, o_dist, o_count);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+}  // namespace zvdb
