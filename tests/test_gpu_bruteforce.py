@@ -1,0 +1,105 @@
+"""GPU parity tests of the brute-force path (a10; no reference symbol -- pinned to the oracle's
+exact (distance, id) top-k): MFMA screen (fp32 / bf16) + fused threshold top-k' + exact re-rank.
+Bit-exact ids AND distances (the re-rank recomputes the reference arithmetic)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvdb_amd
+    assert zvdb_amd.device_count() > 0
+    return zvdb_amd
+
+
+def _index(zv, V, **kw):
+    idx = zv.Index(flags=zv.FLAG_BF16_MIRROR, **kw)
+    idx.add(V)
+    return idx
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(400, 64, 8, 10), (5000, 128, 300, 10), (20000, 96, 130, 32),
+                                      (3000, 3, 64, 5), (9000, 40, 17, 64), (100, 128, 5, 10),
+                                      (1, 16, 3, 4), (129, 256, 1, 1)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_bruteforce_bit_exact_vs_oracle(zv, oracle, n, d, nq, k, mode):
+    V = oracle.uniform_rows(1000 + n, 0, n, d)
+    Q = oracle.uniform_rows(2000 + n, 0, nq, d)
+    idx = _index(zv, V)
+    ids, dist, cnt = idx.search_bruteforce(Q, k, zv.BF_F32 if mode == "f32" else zv.BF_BF16)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
+    assert np.array_equal(cnt, rc)
+    for qi in range(nq):
+        c = int(rc[qi])
+        assert np.array_equal(ids[qi, :c], ri[qi, :c]), (qi, ids[qi], ri[qi])
+        assert np.array_equal(dist[qi, :c], rd[qi, :c])
+        assert np.all(ids[qi, c:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_bruteforce_ties_by_lower_id(zv, oracle, mode):
+    """Duplicated rows and grid data: exactly equal distances must come back lowest id first."""
+    rng = np.random.default_rng(4)
+    base = rng.integers(0, 4, size=(300, 8)).astype(np.float32)
+    V = np.concatenate([base, base, base[:100]], axis=0)  # every row appears 2-3 times
+    Q = rng.integers(0, 4, size=(40, 8)).astype(np.float32)
+    idx = _index(zv, V)
+    ids, dist, cnt = idx.search_bruteforce(Q, 20, zv.BF_F32 if mode == "f32" else zv.BF_BF16)
+    ri, rd, _ = oracle.bruteforce_topk(V, Q, 20)
+    assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
+
+
+def test_bruteforce_adversarial_order_forces_prunes(zv, oracle):
+    """Rows sorted by DEcreasing distance to the query: every row passes the running threshold,
+    so the in-kernel prune runs every tile (a rare data-dependent path, tested on purpose)."""
+    V = oracle.uniform_rows(77, 0, 6000, 32)
+    q = oracle.uniform_rows(78, 0, 1, 32)[0]
+    d = np.array([oracle.distance(q, v) for v in V])
+    V = V[np.argsort(-d, kind="stable")]
+    Q = np.stack([q, V[0], V[-1]])
+    idx = _index(zv, V)
+    for mode in (zv.BF_F32, zv.BF_BF16):
+        ids, dist, _ = idx.search_bruteforce(Q, 10, mode)
+        ri, rd, _ = oracle.bruteforce_topk(V, Q, 10)
+        assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
+
+
+def test_bruteforce_large_self_consistency(zv, oracle):
+    """BASELINE config 2 shape scaled to test size (200k x 128, batch 256): the bf16 screen and the
+    fp32 screen must agree on every id (recall 1.0 against each other), distances exact, sorted."""
+    idx = zv.Index(flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(200_000, 128, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, 256, 128)
+    i32, d32, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)
+    i16, d16, _ = idx.search_bruteforce(Q, 10, zv.BF_BF16)
+    assert np.array_equal(i32, i16) and np.array_equal(d32, d16)
+    assert np.all(np.diff(d32, axis=1) >= 0)
+    # spot-check 8 queries against the oracle on the same synthetic stream
+    V = oracle.uniform_rows(0x5EED, 0, 200_000, 128)
+    assert np.array_equal(idx.get_vector(123_456), V[123_456])
+    ri, rd, _ = oracle.bruteforce_topk(V, Q[:8], 10)
+    assert np.array_equal(i32[:8], ri) and np.array_equal(d32[:8], rd)
+
+
+def test_bruteforce_dot_metric(zv, oracle):
+    V = oracle.uniform_rows(5, 0, 3000, 64) - 0.5
+    Q = oracle.uniform_rows(6, 0, 32, 64) - 0.5
+    idx = zv.Index(metric=zv.METRIC_DOT)
+    idx.add(V)
+    ids, dist, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)
+    ri, rd, _ = oracle.bruteforce_topk(V, Q, 10, metric=1)
+    assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
+
+
+def test_bruteforce_limits(zv, oracle):
+    idx = zv.Index()
+    idx.add(oracle.uniform_rows(1, 0, 10, 8))
+    with pytest.raises(zv.ZvdbError):
+        idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 65)        # k > k'
+    with pytest.raises(zv.ZvdbError):
+        idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 5, zv.BF_BF16)  # no mirror
+    empty = zv.Index(dim=8)
+    ids, dist, cnt = empty.search_bruteforce(oracle.uniform_rows(2, 0, 2, 8), 5)
+    assert np.all(cnt == 0)
