@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the zvdb hot path on MI355X.
+
+Metric (BASELINE.json): QPS at recall@10 >= 0.95, 10M x 768 fp32 corpus, batch = 1024 queries,
+1/2/4/8 MI355X.  One "step" = one batch of 1024 synthetic queries answered end to end (k = 10)
+by the recall-guaranteed route: bf16-MFMA screen over the bf16 mirror of the corpus with a
+fused running-threshold top-64, per-stream merge, then an EXACT fp32 re-rank in the reference's
+arithmetic (hnsw.zig:182-192).  Recall@10 is measured in the same run against the fp32-MFMA
+route (whose ids/distances are parity-tested against the CPU oracle).
+
+N > 1 (one process per GPU, torch.distributed over RCCL): the corpus is sharded by vector-id
+range, every rank answers every query on its shard, ONE all-gather of the per-shard top-k
+(nq*k*(8+4) B + counts per rank) and a local k-way merge.  Total corpus is fixed => "strong".
+
+Prints ONE JSON line (rank 0).  Inputs are resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CORPUS_SEED = 0x5EED
+QUERY_SEED = 0xC0FFEE
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--mode", choices=["bf16", "f32"], default="bf16",
+                    help="screen arithmetic (final distances are exact fp32 either way)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, gpu_ids, gpu_dist, q_host):
+    """The oracle's exact brute-force top-k (a port: scalar strict-fp32 C, 1 thread) timed on a
+    BOUNDED sample of the same workload, scaled to the metric's unit; also used as a checker:
+    no sampled row may beat the GPU's k-th result unless it is in the result."""
+    import numpy as np
+
+    import oracle
+
+    ns = min(args.cpu_sample_rows, args.rows)
+    nqs = min(args.cpu_sample_queries, args.batch)
+    V = oracle.uniform_rows(CORPUS_SEED, 0, ns, args.dim)  # same stream as the GPU corpus
+    Q = np.ascontiguousarray(q_host[:nqs])
+    t0 = time.perf_counter()
+    ids, dist, _ = oracle.bruteforce_topk(V, Q, args.k)
+    dt = time.perf_counter() - t0
+    # checker (not timed): GPU distances are bit-exact for the rows it returned, and consistent
+    # with the exact top-k of the sample
+    ok = True
+    for qi in range(nqs):
+        for j in range(args.k):
+            gid = int(gpu_ids[qi, j])
+            row = oracle.uniform_rows(CORPUS_SEED, gid, 1, args.dim)[0]
+            if oracle.distance(Q[qi], row) != gpu_dist[qi, j]:
+                ok = False
+        kth = gpu_dist[qi, args.k - 1]
+        res = set(int(x) for x in gpu_ids[qi])
+        for j in range(args.k):
+            if dist[qi, j] < kth and int(ids[qi, j]) not in res:
+                ok = False
+    qps_sample = nqs / dt
+    return {
+        "value": qps_sample * (ns / args.rows),
+        "unit": "QPS",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"oracle exact brute-force top-{args.k} (strict sequential fp32, 1 thread) over the first "
+                   f"{ns} of {args.rows} rows x {nqs} queries in {dt:.2f} s; value = sample QPS x {ns}/{args.rows}"),
+        "host_cores_available": os.cpu_count(),
+        "gpu_result_check": "ok" if ok else "MISMATCH",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    import zvdb_amd as zv
+    from zvdb_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available() or zv.device_count() == 0:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, D, B, K = args.rows, args.dim, args.batch, args.k
+    lo = rank * N // world
+    hi = (rank + 1) * N // world
+    n_local = hi - lo
+    mode = zv.BF_BF16 if args.mode == "bf16" else zv.BF_F32
+
+    # ---- resident inputs -------------------------------------------------------------------
+    idx = zv.Index(dim=D, capacity=n_local, device=local_rank, flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(n_local, D, CORPUS_SEED, first_row=lo)  # rows [lo, hi) of the global stream
+    total_steps = args.warmup + args.steps
+    queries = torch.empty((total_steps + 1, B, D), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    zv.fill_synthetic_dev(queries.data_ptr(), (total_steps + 1) * B, D, QUERY_SEED, 0, stream)
+
+    ws_bytes = max(idx.bruteforce_workspace(B, K, zv.BF_BF16), idx.bruteforce_workspace(B, K, zv.BF_F32))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    l_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
+    l_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
+    l_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    if dist_on:
+        g_ids = torch.empty((world, B, K), dtype=torch.int64, device=dev)
+        g_dist = torch.empty((world, B, K), dtype=torch.float32, device=dev)
+        g_cnt = torch.empty((world, B), dtype=torch.int32, device=dev)
+    o_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
+    o_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
+    o_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+
+    def step(q, m):
+        idx.search_bruteforce_dev(q.data_ptr(), B, D, K, m, lo, ws.data_ptr(), ws_bytes, l_ids.data_ptr(),
+                                  l_dist.data_ptr(), l_cnt.data_ptr(), stream)
+        if dist_on:
+            dist.all_gather_into_tensor(g_ids, l_ids)
+            dist.all_gather_into_tensor(g_dist, l_dist)
+            dist.all_gather_into_tensor(g_cnt, l_cnt)
+            zv.merge_topk_dev(g_ids.data_ptr(), g_dist.data_ptr(), g_cnt.data_ptr(), world, B, K,
+                              o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), stream)
+            return o_ids, o_dist
+        return l_ids, l_dist
+
+    def sync():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- ground truth for recall: fp32-MFMA route on the last query batch (untimed) ------------
+    gt_ids, _ = step(queries[total_steps], zv.BF_F32)
+    gt_ids = gt_ids.clone()
+    got_ids, got_dist = step(queries[total_steps], mode)
+    torch.cuda.synchronize()
+    a = got_ids.cpu().numpy()
+    b = gt_ids.cpu().numpy()
+    recall = float(np.mean([len(set(a[i]) & set(b[i])) / K for i in range(B)]))
+    chk_ids = a.astype(np.uint64)
+    chk_dist = got_dist.cpu().numpy().copy()
+    chk_q = queries[total_steps].cpu().numpy()
+
+    # ---- timed region ----------------------------------------------------------------------------
+    for i in range(args.warmup):
+        step(queries[i], mode)
+    sync()
+    idx.timing_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(queries[args.warmup + i], mode)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kern_ms, kern_n = idx.timing_read()
+    idx.timing_enable(False)
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        qps = B * args.steps / elapsed
+        flops = 2.0 * B * n_local * D  # algorithmic flops of one scan launch on this rank
+        kavg = kern_ms / max(kern_n, 1) * 1e-3
+        achieved = flops / kavg / 1e12 if kavg > 0 else 0.0
+        peak = PEAK_TFLOPS[args.mode]
+        out = {
+            "metric": "QPS at recall@10>=0.95, 10Mx768 fp32, batch=1024",
+            "value": qps,
+            "unit": "QPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.mode,
+            "data": "synthetic",
+            "recall_at_10": recall,
+            "config": {
+                "workload": (f"{N}x{D} fp32 corpus (U[0,1) seeded), batch={B}, k={K}: brute-force "
+                             f"{args.mode}-MFMA screen + fused top-64 + exact fp32 re-rank"),
+                "rows": N, "dim": D, "batch": B, "k": K,
+                "parallelism": f"id-range shards x{world}, all-gather top-k" if world > 1 else "1 GPU",
+                "recall_ground_truth": "fp32-MFMA route + exact re-rank (oracle-parity-tested)",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "k_bf_scan<bf16>" if args.mode == "bf16" else "k_bf_scan<f32>",
+                "achieved": achieved,
+                "peak": peak,
+                "unit": "TFLOP/s",
+                "frac": achieved / peak,
+                "traffic": None,
+                "kernel_ms_avg": kavg * 1e3,
+                "launches": kern_n,
+                "algorithmic_flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": float(n_local) * D * (2 if args.mode == "bf16" else 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, chk_ids, chk_dist, chk_q)
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

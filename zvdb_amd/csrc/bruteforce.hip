@@ -355,8 +355,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                       uint32_t mode, uint64_t id_offset, void *d_ws, uint64_t ws_bytes,
                       uint64_t *d_ids, float *d_dist, uint32_t *d_count, hipStream_t s) {
     if (nq == 0) return ZVDB_OK;
-    if (k > (uint32_t)KP) {
-        set_error("brute force supports k <= %d (k' = %d candidates are re-ranked exactly)", KP, KP);
+    // the screen keeps k' = 64 candidates per query; the exact re-rank needs a margin over k to
+    // absorb the screen's rounding (bf16 inputs: wider margin).  TODO(next round): 2 keys/lane.
+    const uint32_t kmax = mode == ZVDB_BF_BF16 ? KP - 16 : KP - 8;
+    if (k > kmax) {
+        set_error("brute force supports k <= %u in this mode (k' = %d candidates are re-ranked exactly)", kmax, KP);
         return ZVDB_ERR_UNSUPPORTED;
     }
     if (mode == ZVDB_BF_BF16 && !(h->flags & ZVDB_FLAG_BF16_MIRROR)) {
