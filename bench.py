@@ -134,9 +134,9 @@ def main():
     l_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
     l_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     if dist_on:
-        g_ids = torch.empty((world, B, K), dtype=torch.int64, device=dev)
-        g_dist = torch.empty((world, B, K), dtype=torch.float32, device=dev)
-        g_cnt = torch.empty((world, B), dtype=torch.int32, device=dev)
+        g_ids = torch.empty((world * B, K), dtype=torch.int64, device=dev)   # == [G][B][K] row-major
+        g_dist = torch.empty((world * B, K), dtype=torch.float32, device=dev)
+        g_cnt = torch.empty((world * B,), dtype=torch.int32, device=dev)
     o_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
     o_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
     o_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
