@@ -43,8 +43,8 @@ def parse_args():
     ap.add_argument("--mode", choices=["bf16", "f32"], default="bf16",
                     help="screen arithmetic (final distances are exact fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=400_000)
-    ap.add_argument("--cpu-sample-queries", type=int, default=8)
+    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=16)
     return ap.parse_args()
 
 

@@ -1,0 +1,20 @@
+"""Runs the C++ restatement of the reference's src/test_hnsw.zig (tests/cpp/test_hnsw_host.cpp)
+against the C++ host mirror + C ABI on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_host_mirror_passes_reference_tests():
+    from zvdb_amd import _build
+    exe = _build.build_cpp_tests()
+    assert os.path.exists(exe)
+    out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL OK" in out.stdout
+    for name in ("basic_functionality", "empty_index", "single_point", "edge_cases", "large_dataset",
+                 "consistency", "concurrent_access", "stress", "memory_leaks"):
+        assert f"ok {name}" in out.stdout
