@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 
 CORPUS_SEED = 0x5EED
 QUERY_SEED = 0xC0FFEE
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "i8": 5000.0}  # dense MFMA peaks (i8 = 2x bf16 per clock), MI355X_MICROARCH.md
 
 
 def parse_args():
@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--mode", choices=["bf16", "f32"], default="bf16",
+    ap.add_argument("--mode", choices=["bf16", "f32", "i8"], default="bf16",
                     help="screen arithmetic (final distances are exact fp32 either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
@@ -118,7 +118,7 @@ def main():
     lo = rank * N // world
     hi = (rank + 1) * N // world
     n_local = hi - lo
-    mode = zv.BF_BF16 if args.mode == "bf16" else zv.BF_F32
+    mode = {"bf16": zv.BF_BF16, "f32": zv.BF_F32, "i8": zv.BF_I8}[args.mode]
 
     # ---- resident inputs -------------------------------------------------------------------
     idx = zv.Index(dim=D, capacity=n_local, device=local_rank, flags=zv.FLAG_BF16_MIRROR)
@@ -128,7 +128,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     zv.fill_synthetic_dev(queries.data_ptr(), (total_steps + 1) * B, D, QUERY_SEED, 0, stream)
 
-    ws_bytes = max(idx.bruteforce_workspace(B, K, zv.BF_BF16), idx.bruteforce_workspace(B, K, zv.BF_F32))
+    ws_bytes = max(idx.bruteforce_workspace(B, K, m) for m in (zv.BF_BF16, zv.BF_F32, zv.BF_I8))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     l_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
     l_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
@@ -216,16 +216,16 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_bf_scan<bf16>" if args.mode == "bf16" else "k_bf_scan<f32>",
+                "kernel": f"k_bf_scan2<{args.mode}>",
                 "achieved": achieved,
                 "peak": peak,
-                "unit": "TFLOP/s",
+                "unit": "TFLOP/s" if args.mode != "i8" else "TOP/s",
                 "frac": achieved / peak,
                 "traffic": None,
                 "kernel_ms_avg": kavg * 1e3,
                 "launches": kern_n,
                 "algorithmic_flops_per_launch": flops,
-                "algorithmic_bytes_per_launch": float(n_local) * D * (2 if args.mode == "bf16" else 4),
+                "algorithmic_bytes_per_launch": float(n_local) * D * {"bf16": 2, "f32": 4, "i8": 1}[args.mode],
             },
         }
         if world == 1 and not args.no_cpu_baseline:

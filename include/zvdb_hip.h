@@ -56,7 +56,10 @@ enum zvdb_metric {
 /* brute-force contraction modes (a10; no reference symbol) */
 enum zvdb_bf_mode {
     ZVDB_BF_F32 = 0,  /* fp32 MFMA (v_mfma_f32_32x32x2_f32) screen + exact fp32 re-rank */
-    ZVDB_BF_BF16 = 1  /* bf16 MFMA screen over the bf16 mirror + exact fp32 re-rank */
+    ZVDB_BF_BF16 = 1, /* bf16 MFMA screen over the bf16 mirror + exact fp32 re-rank */
+    ZVDB_BF_I8 = 2    /* int8 MFMA (v_mfma_i32_32x32x32_i8) screen over a scalar-quantised mirror
+                         (global affine range for L2, symmetric for dot/cosine; built lazily from
+                         the fp32 rows) + exact fp32 re-rank */
 };
 
 typedef struct zvdb_hip_index zvdb_hip_index; /* opaque */

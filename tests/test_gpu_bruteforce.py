@@ -14,6 +14,10 @@ def zv():
     return zvdb_amd
 
 
+def MODES(zv):
+    return {"f32": zv.BF_F32, "bf16": zv.BF_BF16, "i8": zv.BF_I8}
+
+
 def _index(zv, V, **kw):
     idx = zv.Index(flags=zv.FLAG_BF16_MIRROR, **kw)
     idx.add(V)
@@ -23,12 +27,12 @@ def _index(zv, V, **kw):
 @pytest.mark.parametrize("n,d,nq,k", [(400, 64, 8, 10), (5000, 128, 300, 10), (20000, 96, 130, 32),
                                       (3000, 3, 64, 5), (9000, 40, 17, 48), (100, 128, 5, 10),
                                       (1, 16, 3, 4), (129, 256, 1, 1)])
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "i8"])
 def test_bruteforce_bit_exact_vs_oracle(zv, oracle, n, d, nq, k, mode):
     V = oracle.uniform_rows(1000 + n, 0, n, d)
     Q = oracle.uniform_rows(2000 + n, 0, nq, d)
     idx = _index(zv, V)
-    ids, dist, cnt = idx.search_bruteforce(Q, k, zv.BF_F32 if mode == "f32" else zv.BF_BF16)
+    ids, dist, cnt = idx.search_bruteforce(Q, k, MODES(zv)[mode])
     ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
     assert np.array_equal(cnt, rc)
     for qi in range(nq):
@@ -38,7 +42,7 @@ def test_bruteforce_bit_exact_vs_oracle(zv, oracle, n, d, nq, k, mode):
         assert np.all(ids[qi, c:] == np.uint64(0xFFFFFFFFFFFFFFFF))
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "i8"])
 def test_bruteforce_ties_by_lower_id(zv, oracle, mode):
     """Duplicated rows and grid data: exactly equal distances must come back lowest id first."""
     rng = np.random.default_rng(4)
@@ -46,7 +50,7 @@ def test_bruteforce_ties_by_lower_id(zv, oracle, mode):
     V = np.concatenate([base, base, base[:100]], axis=0)  # every row appears 2-3 times
     Q = rng.integers(0, 4, size=(40, 8)).astype(np.float32)
     idx = _index(zv, V)
-    ids, dist, cnt = idx.search_bruteforce(Q, 20, zv.BF_F32 if mode == "f32" else zv.BF_BF16)
+    ids, dist, cnt = idx.search_bruteforce(Q, 20, MODES(zv)[mode])
     ri, rd, _ = oracle.bruteforce_topk(V, Q, 20)
     assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
 
@@ -60,7 +64,7 @@ def test_bruteforce_adversarial_order_forces_prunes(zv, oracle):
     V = V[np.argsort(-d, kind="stable")]
     Q = np.stack([q, V[0], V[-1]])
     idx = _index(zv, V)
-    for mode in (zv.BF_F32, zv.BF_BF16):
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
         ids, dist, _ = idx.search_bruteforce(Q, 10, mode)
         ri, rd, _ = oracle.bruteforce_topk(V, Q, 10)
         assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
@@ -75,6 +79,8 @@ def test_bruteforce_large_self_consistency(zv, oracle):
     i32, d32, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)
     i16, d16, _ = idx.search_bruteforce(Q, 10, zv.BF_BF16)
     assert np.array_equal(i32, i16) and np.array_equal(d32, d16)
+    i8, d8, _ = idx.search_bruteforce(Q, 10, zv.BF_I8)
+    assert np.array_equal(i32, i8) and np.array_equal(d32, d8)
     assert np.all(np.diff(d32, axis=1) >= 0)
     # spot-check 8 queries against the oracle on the same synthetic stream
     V = oracle.uniform_rows(0x5EED, 0, 200_000, 128)
@@ -88,9 +94,28 @@ def test_bruteforce_dot_metric(zv, oracle):
     Q = oracle.uniform_rows(6, 0, 32, 64) - 0.5
     idx = zv.Index(metric=zv.METRIC_DOT)
     idx.add(V)
-    ids, dist, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)
     ri, rd, _ = oracle.bruteforce_topk(V, Q, 10, metric=1)
-    assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
+    for mode in (zv.BF_F32, zv.BF_I8):
+        ids, dist, _ = idx.search_bruteforce(Q, 10, mode)
+        assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
+
+
+def test_bruteforce_v1_kernel_still_correct(zv, oracle):
+    """The first-generation 128x128 register-staged scan is kept for A/B (ZVDB_BF_KERNEL=v1)."""
+    import subprocess, sys, os
+    code = (
+        "import numpy as np, oracle, zvdb_amd as zv\n"
+        "V = oracle.uniform_rows(3, 0, 5000, 96); Q = oracle.uniform_rows(4, 0, 70, 96)\n"
+        "idx = zv.Index(flags=zv.FLAG_BF16_MIRROR); idx.add(V)\n"
+        "ri, rd, _ = oracle.bruteforce_topk(V, Q, 10)\n"
+        "for m in (zv.BF_F32, zv.BF_BF16):\n"
+        "    i, d, _ = idx.search_bruteforce(Q, 10, m)\n"
+        "    assert np.array_equal(i, ri) and np.array_equal(d, rd)\n"
+        "print('v1 ok')\n")
+    env = dict(os.environ, ZVDB_BF_KERNEL="v1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True)
+    assert out.returncode == 0 and "v1 ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_bruteforce_limits(zv, oracle):

@@ -76,9 +76,11 @@ __device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
 }
 
 // Reduce row `row`'s candidate buffer to its exact best KP (sorted, at the front).
+// INTKEY: tau holds an int32 screen value (i8 path) instead of an fp32 one.
+template <int CAPV = CAP, bool INTKEY = false>
 __device__ __forceinline__ uint64_t prune_row(uint64_t *__restrict__ buf, uint32_t *cnt, uint32_t *nsorted,
-                                              float *tau, int row, int lane) {
-    const uint32_t n = min(cnt[row], (uint32_t)CAP);
+                                              float *tau, int row, int lane, uint32_t *tau_g = nullptr) {
+    const uint32_t n = min(cnt[row], (uint32_t)CAPV);
     const uint32_t ns = nsorted[row];
     uint64_t best = ~0ull;
     for (uint32_t base = 0; base < n; base += kWave) {
@@ -93,7 +95,17 @@ __device__ __forceinline__ uint64_t prune_row(uint64_t *__restrict__ buf, uint32
     if (lane == 0) {
         cnt[row] = kept;
         nsorted[row] = kept == KP ? KP : 0;  // a short list is re-sorted next time (it is cheap)
-        tau[row] = kept == KP ? f32_unkey((uint32_t)(last >> 32)) : __builtin_inff();
+        // never loosen a bound already tightened from the shared threshold
+        if (INTKEY) {
+            int32_t *ti = reinterpret_cast<int32_t *>(tau);
+            const int32_t nt = kept == KP ? (int32_t)((uint32_t)(last >> 32) ^ 0x80000000u) : 0x7FFFFFFF;
+            if (nt < ti[row]) ti[row] = nt;
+        } else {
+            const float nt = kept == KP ? f32_unkey((uint32_t)(last >> 32)) : __builtin_inff();
+            if (nt < tau[row]) tau[row] = nt;
+        }
+        // publish: this stream's 64th best bounds the global 64th best from above
+        if (tau_g && kept == KP) atomicMin(tau_g, (uint32_t)(last >> 32));
     }
     return best;
 }
@@ -275,13 +287,786 @@ __global__ __launch_bounds__(256, 2) void k_bf_scan(
     }
 }
 
+
+// =====================================================================================
+// (v2, superseded) 256 x 256 output tile, 8 waves as 2(M) x 4(N), 128 x 64 per wave = 4 x 2 MFMA
+// 32x32 fragments (128 accumulator VGPRs), operands staged by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), two 64 KiB stages, the
+// next 128-byte K slice (or the next tile's first slice) in flight behind every slice's MFMAs
+// and behind the epilogue.  One workgroup per CU.  Bytes per flop are half the 128 x 128
+// tile's: 64 KiB of operands per 8.4 MFLOP (bf16) / 16.8 MOP (i8) slice.
+//
+// LDS-DMA writes wave-uniform base + lane*16, i.e. 8 whole 128-B rows per wave-instruction, so
+// the XOR swizzle of the LDS image is applied to the per-lane SOURCE chunk: the lane that fills
+// (row r, slot c') fetches chunk c' ^ ((r>>1)&7) of row r.
+// MODE: 0 = fp32 (32x32x2 f32), 1 = bf16 (32x32x16), 2 = int8 (32x32x32, i32 accumulate).
+// =====================================================================================
+constexpr int T2 = 256;                      // tile edge (queries and corpus rows)
+constexpr int CAP2 = HW + T2;                // per-row candidate buffer of the v2 scan
+constexpr int STAGE2 = 2 * T2 * KB;          // A + B = 64 KiB per stage
+constexpr int LDS2 = 2 * STAGE2 + 3 * T2 * 4;
+
+using i32x16 = __attribute__((ext_vector_type(16))) int;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int MODE> struct AccT { using type = f32x16; };
+template <> struct AccT<2> { using type = i32x16; };
+
+// =====================================================================================
+// v3 scan: the v2 tile (256 x 256, 8 waves 2x4, LDS-DMA) with a DEEPER operand pipeline.
+// K is walked in 64-byte row slices; four 32 KiB LDS stages form a ring with three slices
+// (96 KiB) in flight behind the one being multiplied, so an L2/HBM round trip (1-2 us under
+// load) is covered by ~3 slices of MFMA work instead of one.  Hand-off uses a COUNTED
+// s_waitcnt vmcnt(8) (this wave's 2 youngest slices may still be in flight) + a raw s_barrier;
+// nothing in the steady-state loop drains the VMEM queue: |v|^2 of the tile's 256 columns also
+// arrives by LDS-DMA, and the epilogue's appends are plain stores.  The DMA stream runs past
+// the end of the block's work (dummy re-reads) so the wait count is the same for every slice.
+// LDS image per operand and stage: [256 rows][64 B], 16-B chunk c of row r stored at slot
+// c ^ ((r>>2)&3) (conflict-free ds_read_b128: 16 consecutive rows hit 16 distinct slots);
+// the swizzle is applied to the per-lane SOURCE chunk (LDS-DMA writes lane-linear).
+// =====================================================================================
+constexpr int KB3 = 64;                       // bytes of every row per slice
+constexpr int STAGE3 = 2 * T2 * KB3;          // A + B = 32 KiB
+constexpr int NSTAGE3 = 4;
+constexpr int LDS3_VN = NSTAGE3 * STAGE3;     // vn[4][256] fp32/int32: the DMA runs up to 3 tiles ahead
+constexpr int LDS3_TG = LDS3_VN + 4 * T2 * 4;      // tg[4][256]: shared-threshold keys, DMA'd per tile
+constexpr int LDS3_STATE = LDS3_TG + 4 * T2 * 4;
+constexpr int LDS3 = LDS3_STATE + 3 * T2 * 4 + 16;  // tau, cnt, nsorted, prune flag
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_bf_scan3(
+    const unsigned char *__restrict__ A, const unsigned char *__restrict__ B, uint32_t row_bytes,
+    uint32_t KT /* 64-B slices per row */, const void *__restrict__ vnorm, uint32_t N, uint32_t nq,
+    int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
+    uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g, uint32_t t_first, uint32_t list_base,
+    uint32_t Stot, uint32_t dbg) {
+    using acc_t = typename AccT<MODE>::type;
+    constexpr bool INT = MODE == 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS3_VN);   // [4][T2]
+    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS3_TG);   // [4][T2]
+    float *tau = reinterpret_cast<float *>(smem + LDS3_STATE);          // [T2]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(tau + T2);             // [T2]
+    uint32_t *nsorted = cnt + T2;                                       // [T2]
+    uint32_t *pflag = nsorted + T2;                                     // [1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const uint32_t b = blockIdx.x;
+    const uint32_t x = b & 7, jb = b >> 3;
+    const uint32_t qt = jb % QT;
+    const uint32_t s = (jb / QT) * 8 + x;
+    const uint32_t per = (NT + S - 1) / S;
+    // this launch covers tiles [t_first, t_first + NT) of the corpus (NT = tiles of this pass)
+    const uint32_t t_begin = t_first + min(s * per, NT), t_end = min(t_begin + per, t_first + NT);
+    const uint32_t ntiles = t_end - t_begin;
+
+    uint64_t *mybuf = cand + (size_t)b * T2 * CAP2;
+    if (tid < T2) {
+        const bool live = (qt * T2 + tid) < nq;
+        if (INT) reinterpret_cast<int32_t *>(tau)[tid] = live ? 0x7FFFFFFF : (int32_t)0x80000000;
+        else tau[tid] = live ? __builtin_inff() : -__builtin_inff();
+        cnt[tid] = 0;
+        nsorted[tid] = 0;
+    }
+    if (tid == 0) pflag[0] = 0;
+
+    // ---- DMA issue side -------------------------------------------------------------
+    // per slice and operand 16 pieces of 16 rows x 64 B; wave w issues pieces 2w, 2w+1
+    const unsigned char *a_base = A + (size_t)qt * T2 * row_bytes;
+    const uint32_t prow = 32 * wave + (lane >> 2);  // + 16*i : LDS row this lane fills
+    uint32_t a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t r = prow + 16 * i;
+        a_off[i] = r * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
+    }
+    uint32_t it = t_begin, ikt = 0;      // next slice to issue (tile, k slice)
+    auto issue_slice = [&](uint32_t stage_idx) {
+        const uint32_t tcl = min(it, t_end - 1);               // past the end: dummy re-read
+        const uint32_t col0 = tcl * T2;
+        if (ikt == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t r = prow + 16 * i;
+                const uint32_t rc = min(r, N - 1 - col0);       // rows past N: clamp (masked later)
+                b_off[i] = rc * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
+            }
+            if (tau_g && wave >= 4 && it < t_end) {             // shared thresholds of my 256 queries
+                // sc1: served from L2, never from a stale L1 line (other CUs publish with atomics)
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)(tau_g + (size_t)qt * T2 + 64 * (wave - 4) + lane),
+                    (lptr_t)(reinterpret_cast<unsigned char *>(tg_lds) + ((it - t_begin) & 3) * T2 * 4 + (wave - 4) * 256),
+                    4, 0, 16);
+            }
+            if (vnorm && wave < 4 && it < t_end) {              // |v|^2 of the tile's 256 columns
+                const uint32_t c = min(col0 + 64 * wave + lane, N - 1);
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)(reinterpret_cast<const unsigned char *>(vnorm) + (size_t)c * 4),
+                    (lptr_t)(reinterpret_cast<unsigned char *>(vn_lds) + ((it - t_begin) & 3) * T2 * 4 + wave * 256), 4, 0, 0);
+            }
+        }
+        unsigned char *dst = smem + stage_idx * STAGE3;
+        const unsigned char *ap = a_base + (size_t)ikt * KB3;
+        const unsigned char *bp = B + (size_t)col0 * row_bytes + (size_t)ikt * KB3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ap + a_off[i]),
+                                             (lptr_t)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(bp + b_off[i]),
+                                             (lptr_t)(dst + T2 * KB3 + (2 * wave + i) * 1024), 16, 0, 0);
+        }
+        if (++ikt == KT) {
+            ikt = 0;
+            if (it < t_end) ++it;
+        }
+    };
+
+    // fragment reads: lane -> row (l&31), chunk 2*cc + (l>>5) of the 4 chunks, swizzled
+    const uint32_t fr = lane & 31, fh = lane >> 5;
+    uint32_t f_off[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) f_off[cc] = fr * KB3 + ((((uint32_t)(2 * cc) + fh) ^ ((fr >> 2) & 3)) << 4);
+
+    if (ntiles > 0) {
+        issue_slice(0);
+        issue_slice(1);
+        issue_slice(2);
+    }
+    uint32_t islice = 0;  // slice being consumed (ring stage = islice & 3)
+
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        const uint32_t col0 = t * T2;
+        const uint32_t *vn_t = vn_lds + ((t - t_begin) & 3) * T2;
+        acc_t acc[4][2];
+
+        for (uint32_t kt = 0; kt < KT; ++kt, ++islice) {
+            // slice `islice` has landed once at most this wave's 8 youngest VMEM ops are pending
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt == 0) {  // tile start: a buffer crossed its high-water mark last tile?
+                if (pflag[0] != 0) {
+                    // rare path: every wave's appends must be complete (and the flag read) before
+                    // any wave reads the buffers
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (tid == 0) pflag[0] = 0;
+                    for (int row = wave; row < T2; row += 8)
+                        if (cnt[row] > (uint32_t)HW) {
+                            if ((dbg & 16) && lane == 0) atomicAdd(&partial[2], 1ull);
+                            prune_row<CAP2, INT>(mybuf + (size_t)row * CAP2, cnt, nsorted, tau, row, lane,
+                                                 tau_g ? tau_g + (size_t)qt * T2 + row : nullptr);
+                        }
+                    __syncthreads();
+                }
+                // fold the shared threshold into the local bound: pass <=> d < min(tau_local, next_up(tau_G))
+                // (non-strict on tau_G: an equal distance in ANOTHER stream may carry a lower id).
+                // Benign race with other waves' epilogue reads: both old and new are valid bounds.
+                if (tau_g && tid < T2) {
+                    const uint32_t g = tg_lds[((t - t_begin) & 3) * T2 + tid];
+                    if (g != 0xFFFFFFFFu) {
+                        uint32_t nb;
+                        bool tighter;
+                        if (INT) {
+                            const int32_t gv = (int32_t)(g ^ 0x80000000u);
+                            const int32_t bv = gv == 0x7FFFFFFF ? gv : gv + 1;
+                            tighter = bv < reinterpret_cast<int32_t *>(tau)[tid];
+                            nb = (uint32_t)bv;
+                        } else {
+                            const float bv = f32_unkey(g + 1);
+                            tighter = bv < tau[tid];
+                            nb = __float_as_uint(bv);
+                        }
+                        if (tighter) {
+                            const uint32_t addr = (uint32_t)(size_t)(lptr_t)(tau + tid);
+                            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(nb) : "memory");
+                        }
+                    }
+                }
+                // accumulator init.  fp modes: acc starts at -|v|^2/2 of its column (|v|^2 arrived by
+                // LDS-DMA with this tile's first slice), so the finished accumulator is q.v - |v|^2/2 =
+                // -d'/2 and the selection test is ONE compare per element: acc > -tau/2.  Columns past
+                // N start at -inf and can never pass.
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const uint32_t cl = wn * 64 + ni * 32 + fr;
+                    acc_t init;
+                    if constexpr (INT) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) init[r] = 0;
+                    } else {
+                        const float v0 = (col0 + cl) < N ? (vnorm ? -0.5f * __uint_as_float(vn_t[cl]) : 0.0f)
+                                                         : -__builtin_inff();
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) init[r] = v0;
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = init;
+                }
+            }
+            issue_slice((islice + 3) & 3);
+            const unsigned char *st = smem + (islice & 3) * STAGE3;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                u32x4 fa[4], fb[2];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    fa[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[cc]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    fb[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[cc]);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if constexpr (MODE == 1) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
+                                acc[mi][ni], 0, 0, 0);
+                        } else if constexpr (MODE == 2) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                __builtin_bit_cast(i32x4, fa[mi]), __builtin_bit_cast(i32x4, fb[ni]),
+                                acc[mi][ni], 0, 0, 0);
+                        } else {
+                            const f32x4 xa = __builtin_bit_cast(f32x4, fa[mi]);
+                            const f32x4 xb = __builtin_bit_cast(f32x4, fb[ni]);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc[mi][ni], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+
+        // ---- fused selection epilogue (three slices of the next tile are in flight) -----------
+        // Phase A is branch-free: one compare per element (fp) and an OR of the lane masks; phase B
+        // (the appends) only runs when some lane of the wave passed something in this tile.
+        if (!(dbg & 1)) {
+            const uint32_t qb = wm * 128 + 4 * fh;
+            const uint32_t cnt_lds_addr = (uint32_t)(size_t)(lptr_t)cnt;
+            const uint32_t pflag_lds_addr = (uint32_t)(size_t)(lptr_t)pflag;
+            // fp: scale = alpha/2 * -2 ... the finished accumulator a = q.v - |v|^2/2 (L2, alpha = -2)
+            // or a = q.v (dot, alpha = -1): d' = fscale * a with fscale = -2 or -1; pass <=> a > tau / fscale
+            const float fscale = (float)alpha_i;
+            const float finv = 1.0f / fscale;  // -0.5 or -1: exact
+            int vni[2];
+            bool colok[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const uint32_t cl = wn * 64 + ni * 32 + fr;
+                colok[ni] = (col0 + cl) < N;
+                vni[ni] = (INT && vnorm) ? (int)vn_t[cl] : 0;
+            }
+            unsigned long long any = 0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4 *>(tau + qb + mi * 32 + 8 * g);
+#pragma unroll
+                    for (int j2 = 0; j2 < 4; ++j2) {
+                        const int r = 4 * g + j2;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            bool pass;
+                            if constexpr (INT) pass = colok[ni] && (vni[ni] + alpha_i * acc[mi][ni][r]) < (int)t4[j2];
+                            else pass = acc[mi][ni][r] > __uint_as_float(t4[j2]) * finv;
+                            any |= __ballot(pass);
+                        }
+                    }
+                }
+            }
+            if (dbg & 16) { if (lane == 0) { atomicAdd(&partial[0], 1ull); if (any) atomicAdd(&partial[1], 1ull); } }
+            if (any && !(dbg & 4)) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x4 t4 = *reinterpret_cast<const u32x4 *>(tau + qb + mi * 32 + 8 * g);
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) {
+                            const int r = 4 * g + j2;
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                bool pass;
+                                uint32_t keyhi;
+                                if constexpr (INT) {
+                                    const int d = vni[ni] + alpha_i * acc[mi][ni][r];
+                                    pass = colok[ni] && d < (int)t4[j2];
+                                    keyhi = (uint32_t)d ^ 0x80000000u;
+                                } else {
+                                    pass = acc[mi][ni][r] > __uint_as_float(t4[j2]) * finv;
+                                    keyhi = __float_as_uint(acc[mi][ni][r] * fscale);
+                                }
+                                if (pass) {
+                                    uint32_t qrow = qb + mi * 32 + 8 * g + j2;
+                                    asm volatile("" : "+v"(qrow));
+                                    if constexpr (!INT) keyhi = f32_key(__uint_as_float(keyhi));
+                                    const uint32_t col = col0 + wn * 64 + ni * 32 + fr;
+                                    uint32_t slot;
+                                    {
+                                        const uint32_t addr = cnt_lds_addr + qrow * 4, one = 1;
+                                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                                     : "=&v"(slot) : "v"(addr), "v"(one) : "memory");
+                                    }
+                                    if (dbg & 16) atomicAdd(&partial[3], 1ull);
+                                    if (slot < (uint32_t)CAP2)
+                                        mybuf[(size_t)qrow * CAP2 + slot] = ((uint64_t)keyhi << 32) | col;
+                                    if (slot >= (uint32_t)HW) {
+                                        const uint32_t one = 1;
+                                        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                                                     :: "v"(pflag_lds_addr), "v"(one) : "memory");
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // drain the DMA ring (dummy slices included) before the LDS is released / state is read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (dbg & 16) return;  // counting run: partial[0..3] hold {wave-tiles, wave-tiles with a pass, prunes, appends}
+    for (int row = wave; row < T2; row += 8) {
+        const uint32_t q = qt * T2 + row;
+        if (q >= nq) continue;
+        uint64_t best = ~0ull;
+        if (cnt[row] > 0) best = prune_row<CAP2, INT>(mybuf + (size_t)row * CAP2, cnt, nsorted, tau, row, lane);
+        partial[((size_t)q * Stot + list_base + s) * KP + lane] = best;
+    }
+}
+
+
+// =====================================================================================
+// v4 scan (default): v3's operand pipeline with the roles of the MFMA operands SWAPPED so that
+// a lane owns QUERIES, not corpus rows: A = corpus tile (rows -> accumulator registers),
+// B = query tile (columns -> lanes).  Each lane then serves exactly 2 queries for the whole
+// stream, so the selection state of the hot path lives in REGISTERS:
+//   * thr[2]   the pass bound of the lane's 2 queries (re-read from LDS once per tile);
+//   * cnt[2]   fill of the lane's 2 PRIVATE sub-buffers (4 lanes = 2 waves x 2 lane halves
+//              serve one query; each appends to its own 128-entry sub-buffer: no atomics, no
+//              LDS traffic, no waits -- an append is one predicated 8-byte store);
+//   * the epilogue's phase A is one v_cmp per accumulator element + a mask OR.
+// When a sub-buffer passes 64 entries the block prunes that query at the next tile start: one
+// wave merges the query's kept list with its 4 sub-buffers (bitonic sort/merge of 64-bit keys),
+// keeps the exact best k' (32 or 64), tightens tau and publishes it to the shared threshold.
+// =====================================================================================
+constexpr int SUBCAP = 256, SUBHW = 64, SUBURG = 192, NSUB = 4;  // capacity, soft mark, must-prune mark
+constexpr int PTHRESH = 32;  // start a prune round once this many sub-buffers crossed the soft mark
+constexpr int LDS4_VN = NSTAGE3 * STAGE3;        // vn[4][256]
+constexpr int LDS4_TG = LDS4_VN + 4 * T2 * 4;    // tg[4][256]
+constexpr int LDS4_TAU = LDS4_TG + 4 * T2 * 4;   // tau[256]
+constexpr int LDS4_NK = LDS4_TAU + T2 * 4;       // nkept[256]
+constexpr int LDS4_SC = LDS4_NK + T2 * 4;        // subcnt[256][4]
+constexpr int LDS4_FLAG = LDS4_SC + T2 * NSUB * 4;
+constexpr int LDS4 = LDS4_FLAG + 16;
+constexpr size_t BLK4_KEPT = (size_t)T2 * KP;                 // u64 entries
+constexpr size_t BLK4_ENTRIES = BLK4_KEPT + (size_t)T2 * NSUB * SUBCAP;
+
+// merge query q's kept list with its sub-buffers -> exact best kp, sorted; resets the sub-buffers
+template <bool INTKEY>
+__device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, const uint64_t *__restrict__ sub,
+                                                float *tau, uint32_t *nkept, uint32_t *subcnt, int q, int lane,
+                                                uint32_t kp, uint32_t *tau_g) {
+    const uint32_t n0 = min(subcnt[q * NSUB + 0], (uint32_t)SUBCAP), n1 = min(subcnt[q * NSUB + 1], (uint32_t)SUBCAP);
+    const uint32_t n2 = min(subcnt[q * NSUB + 2], (uint32_t)SUBCAP), n3 = min(subcnt[q * NSUB + 3], (uint32_t)SUBCAP);
+    const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, total = p3 + n3;
+    const uint32_t nk = nkept[q];
+    uint64_t best = (uint32_t)lane < nk ? kept[(size_t)q * KP + lane] : ~0ull;
+    for (uint32_t base = 0; base < total; base += kWave) {
+        const uint32_t i = base + lane;
+        uint64_t key = ~0ull;
+        if (i < total) {
+            const uint32_t si = (i >= p1) + (i >= p2) + (i >= p3);
+            const uint32_t off = i - (si == 0 ? 0u : si == 1 ? p1 : si == 2 ? p2 : p3);
+            key = sub[((size_t)q * NSUB + si) * SUBCAP + off];
+        }
+        key = wave_sort64(key, lane);
+        best = wave_merge64(best, key, lane);
+    }
+    if ((uint32_t)lane >= kp) best = ~0ull;
+    kept[(size_t)q * KP + lane] = best;
+    const uint32_t nkn = (uint32_t)__popcll(__ballot(best != ~0ull));
+    const uint64_t last = shfl64(best, (int)kp - 1);
+    if (lane == 0) {
+        nkept[q] = nkn;
+        subcnt[q * NSUB + 0] = 0; subcnt[q * NSUB + 1] = 0; subcnt[q * NSUB + 2] = 0; subcnt[q * NSUB + 3] = 0;
+        if (nkn == kp) {
+            if (INTKEY) {
+                int32_t *ti = reinterpret_cast<int32_t *>(tau);
+                const int32_t nt = (int32_t)((uint32_t)(last >> 32) ^ 0x80000000u);
+                if (nt < ti[q]) ti[q] = nt;
+            } else {
+                const float nt = f32_unkey((uint32_t)(last >> 32));
+                if (nt < tau[q]) tau[q] = nt;
+            }
+            if (tau_g) atomicMin(tau_g + q, (uint32_t)(last >> 32));
+        }
+    }
+    return best;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_bf_scan4(
+    const unsigned char *__restrict__ Q /* query operand */, const unsigned char *__restrict__ V /* corpus operand */,
+    uint32_t row_bytes, uint32_t KT /* 64-B slices per row */, const void *__restrict__ vnorm, uint32_t N,
+    uint32_t nq, int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
+    uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
+    uint32_t list_base, uint32_t Stot, uint32_t dbg, unsigned long long *__restrict__ dbgbuf) {
+    using acc_t = typename AccT<MODE>::type;
+    constexpr bool INT = MODE == 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS4_VN);
+    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS4_TG);
+    float *tau = reinterpret_cast<float *>(smem + LDS4_TAU);
+    uint32_t *nkept = reinterpret_cast<uint32_t *>(smem + LDS4_NK);
+    uint32_t *subcnt = reinterpret_cast<uint32_t *>(smem + LDS4_SC);
+    uint32_t *pflag = reinterpret_cast<uint32_t *>(smem + LDS4_FLAG);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;   // wm: corpus half of the tile, wn: query quarter
+
+    const uint32_t b = blockIdx.x;
+    const uint32_t x = b & 7, jb = b >> 3;
+    const uint32_t qt = jb % QT;
+    const uint32_t s = (jb / QT) * 8 + x;
+    const uint32_t per = (NT + S - 1) / S;
+    // this launch covers tiles [t_first, t_first + NT) of the corpus (NT = tiles of this pass)
+    const uint32_t t_begin = t_first + min(s * per, NT), t_end = min(t_begin + per, t_first + NT);
+    const uint32_t ntiles = t_end - t_begin;
+    uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
+
+    uint64_t *kept = cand + (size_t)b * BLK4_ENTRIES;
+    uint64_t *subs = kept + BLK4_KEPT;
+    if (tid < T2) {
+        const bool live = (qt * T2 + tid) < nq;
+        // screen key of (query, row) = -(q.v - |v|^2/2) = d'/2 (L2) or -q.v (dot): tau lives in that domain.
+        // int: live rows satisfy acc >= -2^29 (dim <= 16384), rows past N start at -2^30: tau0 = 0x30000000
+        // lets every live row pass and no padded one.
+        // start from the shared threshold of the previous pass (if any): pass <=> key < next_up(tau_G)
+        const uint32_t g = (tau_g && live) ? __hip_atomic_load(tau_g + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0xFFFFFFFFu;
+        if (INT) {
+            int32_t t0 = live ? 0x30000000 : -0x7FFFFFFF;
+            if (g != 0xFFFFFFFFu) { const int32_t gv = (int32_t)(g ^ 0x80000000u); t0 = min(t0, gv == 0x7FFFFFFF ? gv : gv + 1); }
+            reinterpret_cast<int32_t *>(tau)[tid] = t0;
+        } else {
+            float t0 = live ? __builtin_inff() : -__builtin_inff();
+            if (g != 0xFFFFFFFFu) t0 = fminf(t0, f32_unkey(g + 1));
+            tau[tid] = t0;
+        }
+        nkept[tid] = 0;
+    }
+    for (int i = tid; i < T2 * NSUB; i += 512) subcnt[i] = 0;
+    if (tid == 0) { pflag[0] = 0; pflag[1] = 0; }
+
+    // ---- DMA issue side: A region <- corpus tile, B region <- my query tile ------------------
+    const unsigned char *q_base = Q + (size_t)qt * T2 * row_bytes;
+    const uint32_t prow = 32 * wave + (lane >> 2);  // + 16*i : LDS row this lane fills
+    uint32_t q_off[2], c_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t r = prow + 16 * i;
+        q_off[i] = r * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
+    }
+    uint32_t it = t_begin, ikt = 0;
+    auto issue_slice = [&](uint32_t stage_idx) {
+        const uint32_t tcl = min(it, t_end - 1);
+        const uint32_t col0 = tcl * T2;
+        if (ikt == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t r = prow + 16 * i;
+                const uint32_t rc = min(r, N - 1 - col0);
+                c_off[i] = rc * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
+            }
+            if (tau_g && wave >= 4 && it < t_end) {
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)(tau_g + 64 * (wave - 4) + lane),
+                    (lptr_t)(reinterpret_cast<unsigned char *>(tg_lds) + ((it - t_begin) & 3) * T2 * 4 + (wave - 4) * 256),
+                    4, 0, 16);
+            }
+            if (vnorm && wave < 4 && it < t_end) {
+                const uint32_t c = min(col0 + 64 * wave + lane, N - 1);
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)(reinterpret_cast<const unsigned char *>(vnorm) + (size_t)c * 4),
+                    (lptr_t)(reinterpret_cast<unsigned char *>(vn_lds) + ((it - t_begin) & 3) * T2 * 4 + wave * 256), 4, 0, 0);
+            }
+        }
+        unsigned char *dst = smem + stage_idx * STAGE3;
+        const unsigned char *cp = V + (size_t)col0 * row_bytes + (size_t)ikt * KB3;
+        const unsigned char *qp = q_base + (size_t)ikt * KB3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(cp + c_off[i]),
+                                             (lptr_t)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(qp + q_off[i]),
+                                             (lptr_t)(dst + T2 * KB3 + (2 * wave + i) * 1024), 16, 0, 0);
+        }
+        if (++ikt == KT) {
+            ikt = 0;
+            if (it < t_end) ++it;
+        }
+    };
+
+    const uint32_t fr = lane & 31, fh = lane >> 5;
+    uint32_t f_off[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) f_off[cc] = fr * KB3 + ((((uint32_t)(2 * cc) + fh) ^ ((fr >> 2) & 3)) << 4);
+
+    // the lane's two queries and its private sub-buffers
+    const uint32_t sub_id = wm * 2 + fh;
+    uint32_t ql[2];
+    uint64_t *sbuf[2];
+    uint32_t sc_addr[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        ql[ni] = wn * 64 + ni * 32 + fr;
+        sbuf[ni] = subs + ((size_t)ql[ni] * NSUB + sub_id) * SUBCAP;
+        sc_addr[ni] = (uint32_t)(size_t)(lptr_t)(subcnt + ql[ni] * NSUB + sub_id);
+    }
+    const uint32_t rbase = wm * 128 + 4 * fh;  // corpus row of accumulator register (mi, r): rbase + mi*32 + (r&3) + 8*(r>>2)
+    const uint32_t pflag_lds_addr = (uint32_t)(size_t)(lptr_t)pflag;
+
+    if (ntiles > 0) {
+        issue_slice(0);
+        issue_slice(1);
+        issue_slice(2);
+    }
+    __syncthreads();  // state arrays initialised (plain LDS stores) before anyone reads them
+    uint32_t islice = 0;
+    unsigned long long tk0 = 0, t_round = 0, t_phb = 0, t_pha = 0, n_round = 0;
+    if (dbg & 32) tk0 = __builtin_amdgcn_s_memtime();
+
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        const uint32_t col0 = t * T2;
+        const uint32_t *vn_t = vn_lds + ((t - t_begin) & 3) * T2;
+        acc_t acc[4][2];
+        uint32_t thr[2];   // fp: bits of the accumulator bound; int: tau
+        uint32_t cntr[2], cnt0[2];
+
+        for (uint32_t kt = 0; kt < KT; ++kt, ++islice) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt == 0) {
+                // prune ROUND: batched so that all 8 waves have queries to merge (a round stalls the
+                    // whole pipeline); started when enough sub-buffers crossed the soft mark or one is
+                    // close to its capacity (a tile adds at most 64 entries to a sub-buffer)
+                if (pflag[0] != 0 || pflag[1] >= (uint32_t)PTHRESH) {
+                    unsigned long long ts = 0;
+                    if (dbg & 32) ts = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everyone's appends are complete
+                    __builtin_amdgcn_s_barrier();                     // ... and everyone has read the flags
+                    if (tid == 0) { pflag[0] = 0; pflag[1] = 0; }
+                    for (int q = wave; q < T2; q += 8) {
+                        const u32x4 c4 = *reinterpret_cast<const u32x4 *>(subcnt + q * NSUB);
+                        if (max(max(c4.x, c4.y), max(c4.z, c4.w)) > (uint32_t)SUBHW) {
+                            if ((dbg & 16) && lane == 0) atomicAdd(&dbgbuf[2], 1ull);
+                            prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g);
+                        }
+                    }
+                    __syncthreads();
+                    if (dbg & 32) { t_round += __builtin_amdgcn_s_memtime() - ts; n_round += 1; }
+                }
+                if (tau_g && tid < T2) {  // fold the shared threshold (see v3)
+                    const uint32_t g = tg_lds[((t - t_begin) & 3) * T2 + tid];
+                    if (g != 0xFFFFFFFFu) {
+                        uint32_t nb;
+                        bool tighter;
+                        if (INT) {
+                            const int32_t gv = (int32_t)(g ^ 0x80000000u);
+                            const int32_t bv = gv == 0x7FFFFFFF ? gv : gv + 1;
+                            tighter = bv < reinterpret_cast<int32_t *>(tau)[tid];
+                            nb = (uint32_t)bv;
+                        } else {
+                            const float bv = f32_unkey(g + 1);
+                            tighter = bv < tau[tid];
+                            nb = __float_as_uint(bv);
+                        }
+                        if (tighter) {
+                            const uint32_t addr = (uint32_t)(size_t)(lptr_t)(tau + tid);
+                            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(nb) : "memory");
+                        }
+                    }
+                }
+                // per-lane selection state for this tile
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    cntr[ni] = subcnt[ql[ni] * NSUB + sub_id];
+                    cnt0[ni] = cntr[ni];
+                    // pass <=> key < tau <=> acc > -tau
+                    if constexpr (INT) thr[ni] = (uint32_t)(-reinterpret_cast<const int32_t *>(tau)[ql[ni]]);
+                    else thr[ni] = __float_as_uint(-tau[ql[ni]]);
+                }
+                // accumulator init = -|v|^2/2 of the register's corpus row (fp) / -(|v|^2 >> 1) (int; the
+                // dropped parity bit perturbs the int screen by < 1 unit and equally for equal rows);
+                // rows past N start at -inf / -2^30 and can never pass.  The finished accumulator IS the
+                // negated screen key, so the selection test is one compare per element.
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    acc_t init;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t rl = rbase + mi * 32 + 8 * g;
+                        u32x4 v4 = {0, 0, 0, 0};
+                        if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rl);
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) {
+                            const bool ok = (col0 + rl + j2) < N;
+                            if constexpr (INT) init[4 * g + j2] = ok ? -((int)v4[j2] >> 1) : -0x40000000;
+                            else init[4 * g + j2] = ok ? -0.5f * __uint_as_float(v4[j2]) : -__builtin_inff();
+                        }
+                    }
+                    acc[mi][0] = init;
+                    acc[mi][1] = init;
+                }
+            }
+            issue_slice((islice + 3) & 3);
+            const unsigned char *st = smem + (islice & 3) * STAGE3;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                u32x4 fa[4], fb[2];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    fa[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[cc]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    fb[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[cc]);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if constexpr (MODE == 1) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
+                                acc[mi][ni], 0, 0, 0);
+                        } else if constexpr (MODE == 2) {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
+                                __builtin_bit_cast(i32x4, fa[mi]), __builtin_bit_cast(i32x4, fb[ni]),
+                                acc[mi][ni], 0, 0, 0);
+                        } else {
+                            const f32x4 xa = __builtin_bit_cast(f32x4, fa[mi]);
+                            const f32x4 xb = __builtin_bit_cast(f32x4, fb[ni]);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc[mi][ni], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+
+        // ---- fused selection epilogue: registers only on the common path -----------------------
+        if (!(dbg & 1)) {
+            unsigned long long te0 = 0;
+            if (dbg & 32) te0 = __builtin_amdgcn_s_memtime();
+            // Phase A: per 32x32 fragment, the lane's maximum over its 16 accumulator registers
+            // (v_max3) against the lane's bound: 8 compares + 8 mask tests per tile on the common path.
+            unsigned long long fany[4][2];
+            unsigned long long any = 0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (INT) {
+                        int m = acc[mi][ni][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) m = max(m, acc[mi][ni][r]);
+                        fany[mi][ni] = __ballot(m > (int)thr[ni]);
+                    } else {
+                        float m = acc[mi][ni][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
+                        fany[mi][ni] = __ballot(m > __uint_as_float(thr[ni]));
+                    }
+                    any |= fany[mi][ni];
+                }
+            if (dbg & 32) { const unsigned long long x2 = __builtin_amdgcn_s_memtime(); t_pha += x2 - te0; te0 = x2; }
+            if (dbg & 16) { if (lane == 0) { atomicAdd(&dbgbuf[0], 1ull); if (any) atomicAdd(&dbgbuf[1], 1ull); } }
+            if (any && !(dbg & 4)) {
+                // Phase B: only fragments in which some lane passed are walked element by element
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if (fany[mi][ni] == 0) continue;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            bool pass;
+                            if constexpr (INT) pass = acc[mi][ni][r] > (int)thr[ni];
+                            else pass = acc[mi][ni][r] > __uint_as_float(thr[ni]);
+                            if (pass) {
+                                uint32_t keyhi;
+                                if constexpr (INT) keyhi = (uint32_t)(-acc[mi][ni][r]) ^ 0x80000000u;
+                                else keyhi = f32_key(-acc[mi][ni][r]);
+                                const uint32_t id = col0 + rbase + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                if (cntr[ni] < (uint32_t)SUBCAP) sbuf[ni][cntr[ni]] = ((uint64_t)keyhi << 32) | id;
+                                cntr[ni] += 1;
+                                if (dbg & 16) atomicAdd(&dbgbuf[3], 1ull);
+                            }
+                        }
+                    }
+                // publish the fills; request a prune when a sub-buffer passed its high-water mark
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    asm volatile("ds_write_b32 %0, %1" :: "v"(sc_addr[ni]), "v"(cntr[ni]) : "memory");
+                const uint32_t ncross = (uint32_t)(cnt0[0] <= (uint32_t)SUBHW && cntr[0] > (uint32_t)SUBHW) +
+                                        (uint32_t)(cnt0[1] <= (uint32_t)SUBHW && cntr[1] > (uint32_t)SUBHW);
+                if (ncross) {
+                    const uint32_t a1 = pflag_lds_addr + 4;
+                    asm volatile("ds_add_u32 %0, %1" :: "v"(a1), "v"(ncross) : "memory");
+                }
+                if (cntr[0] > (uint32_t)SUBURG || cntr[1] > (uint32_t)SUBURG) {
+                    const uint32_t one = 1;
+                    asm volatile("ds_write_b32 %0, %1" :: "v"(pflag_lds_addr), "v"(one) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (dbg & 32) t_phb += __builtin_amdgcn_s_memtime() - te0;
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (dbg & 32) {
+        if (tid == 0) {
+            atomicAdd(&dbgbuf[4], __builtin_amdgcn_s_memtime() - tk0);
+            atomicAdd(&dbgbuf[5], t_round);
+            atomicAdd(&dbgbuf[6], t_pha);
+            atomicAdd(&dbgbuf[7], t_phb);
+            atomicAdd(&dbgbuf[8], n_round);
+        }
+    }
+    for (int q = wave; q < T2; q += 8) {
+        const uint32_t qg = qt * T2 + q;
+        if (qg >= nq) continue;
+        const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr);
+        partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
+    }
+}
+
 // Merge the S sorted per-stream lists of each query into the global best KP (ids only; the
 // exact distances are recomputed by k_rerank).  One wave per query.
-__global__ __launch_bounds__(64) void k_bf_merge(const uint64_t *__restrict__ partial, uint32_t S,
-                                                 uint32_t *__restrict__ cand_ids) {
+// tau_out (optional): key of the kp-th best so far -> the exact shared threshold for the next pass.
+__global__ __launch_bounds__(64) void k_bf_merge(const uint64_t *__restrict__ partial, uint32_t S, uint32_t Stot,
+                                                 uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
+                                                 uint32_t kp) {
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    const uint64_t *p = partial + (size_t)q * S * KP;
+    const uint64_t *p = partial + (size_t)q * Stot * KP;
     uint64_t best = p[lane];
     for (uint32_t s = 1; s < S; ++s) {
         const uint64_t nw = p[(size_t)s * KP + lane];
@@ -290,23 +1075,36 @@ __global__ __launch_bounds__(64) void k_bf_merge(const uint64_t *__restrict__ pa
             continue;  // empty list (its smallest key is the sentinel)
         best = wave_merge64(best, nw, lane);
     }
-    cand_ids[(size_t)q * KP + lane] = best == ~0ull ? 0xFFFFFFFFu : (uint32_t)best;
+    if (cand_ids) cand_ids[(size_t)q * KP + lane] = best == ~0ull ? 0xFFFFFFFFu : (uint32_t)best;
+    if (tau_out) {
+        const uint64_t kth = shfl64(best, (int)kp - 1);
+        if (lane == 0) tau_out[q] = (uint32_t)(kth >> 32);  // 0xFFFFFFFF when fewer than kp candidates exist
+    }
 }
 
-// queries -> operand layout of the scan: [nq_pad][row_bytes], zero padded; bf16 RNE for the
-// bf16 screen.
+// queries -> operand layout of the scan: [nq_pad][row_bytes], zero padded.
+// mode 0: fp32 copy; 1: bf16 RNE; 2: int8 with the index's quantisation (q_lo, q_inv, affine).
 __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict__ q, uint32_t nq,
                                                          uint32_t dim, unsigned char *__restrict__ out,
-                                                         uint32_t nq_pad, uint32_t row_elems, int bf16) {
+                                                         uint32_t nq_pad, uint32_t row_elems, int mode,
+                                                         float q_lo, float q_inv, int affine) {
     const uint64_t total = (uint64_t)nq_pad * row_elems;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)(t / row_elems), c = (uint32_t)(t - (uint64_t)r * row_elems);
-        const float v = (r < nq && c < dim) ? q[(size_t)r * dim + c] : 0.0f;
-        if (bf16) {
+        const bool live = r < nq && c < dim;
+        const float v = live ? q[(size_t)r * dim + c] : 0.0f;
+        if (mode == 1) {
             uint32_t u = __float_as_uint(v);
             u += 0x7FFFu + ((u >> 16) & 1u);
             reinterpret_cast<uint16_t *>(out)[t] = (uint16_t)(u >> 16);
+        } else if (mode == 2) {
+            int qv = 0;
+            if (live) {
+                const float f = affine ? __builtin_rintf((v - q_lo) * q_inv) - 128.0f : __builtin_rintf(v * q_inv);
+                qv = (int)fminf(fmaxf(f, -128.0f), 127.0f);
+            }
+            reinterpret_cast<int8_t *>(out)[t] = (int8_t)qv;
         } else {
             reinterpret_cast<float *>(out)[t] = v;
         }
@@ -314,19 +1112,40 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
 }
 
 struct BfPlan {
-    uint32_t nq_pad, QT, S, NT, KT, row_bytes;
-    uint64_t off_q, off_cand, off_partial, off_ids, total;
+    uint32_t tile, cap, nq_pad, QT, S, NT, KT, row_bytes, row_elems;
+    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, total;
 };
+
+int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v3 | v4 (default): older generations kept for A/B
+    static const int v = [] {
+        const char *e = getenv("ZVDB_BF_KERNEL");
+        return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? e[1] - '0' : 4;
+    }();
+    return v;
+}
+bool use_v1() { return kernel_version() == 1; }
+uint32_t debug_flags() {
+    static const uint32_t f = [] {
+        const char *e = getenv("ZVDB_BF_DEBUG");
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    return f;
+}
 
 BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     BfPlan p{};
-    p.nq_pad = round_up(std::max(nq, 1u), BM);
-    p.QT = p.nq_pad / BM;
-    p.NT = (uint32_t)((h->count + BN - 1) / BN);
-    p.row_bytes = mode == ZVDB_BF_BF16 ? h->ldh * 2 : h->ld * 4;
+    const bool v1 = use_v1() && mode != ZVDB_BF_I8;
+    p.tile = v1 ? BM : T2;
+    p.cap = v1 ? CAP : CAP2;
+    p.nq_pad = round_up(std::max(nq, 1u), p.tile);
+    p.QT = p.nq_pad / p.tile;
+    p.NT = (uint32_t)((h->count + p.tile - 1) / p.tile);
+    if (mode == ZVDB_BF_BF16) { p.row_elems = h->ldh; p.row_bytes = h->ldh * 2; }
+    else if (mode == ZVDB_BF_I8) { p.row_elems = round_up(h->dim, 128); p.row_bytes = p.row_elems; }
+    else { p.row_elems = h->ld; p.row_bytes = h->ld * 4; }
     p.KT = p.row_bytes / KB;
-    // 2 workgroups per CU x 256 CUs resident; streams in multiples of 8 (XCD groups)
-    const uint32_t resident = 512;
+    // resident workgroups: v1 2 per CU, v2 1 per CU; streams in multiples of 8 (XCD groups)
+    const uint32_t resident = v1 ? 512 : 256;
     uint32_t S = std::max(8u, (resident / p.QT) / 8 * 8);
     while (S > 8 && S > p.NT) S -= 8;  // do not create streams with no tiles
     p.S = S;
@@ -334,13 +1153,40 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     p.off_q = off;
     off += round_up64((uint64_t)p.nq_pad * p.row_bytes, 256);
     p.off_cand = off;
-    off += (uint64_t)p.QT * p.S * BM * CAP * 8;
+    off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap, (uint64_t)p.QT * p.S * BLK4_ENTRIES) * 8;
     p.off_partial = off;
-    off += (uint64_t)p.nq_pad * p.S * KP * 8;
+    off += (uint64_t)p.nq_pad * (8 + 2 * p.S) * KP * 8;  // lists of up to three passes
     p.off_ids = off;
     off += (uint64_t)p.nq_pad * KP * 4;
+    p.off_taug = off;
+    off += round_up64((uint64_t)p.nq_pad * 4, 256) + 256;  // + debug counters
     p.total = off;
     return p;
+}
+
+template <int MODE>
+int launch_scan4(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
+                 uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
+                 uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, hipStream_t s) {
+    ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan4<MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+    hipLaunchKernelGGL(k_bf_scan4<MODE>, dim3(p.QT * p.S), dim3(512), LDS4, s, q_op, rows, p.row_bytes,
+                       p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
+                       (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, debug_flags(),
+                       reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad));
+    return ZVDB_OK;
+}
+
+template <int MODE>
+int launch_scan3(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
+                 uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
+                 uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, hipStream_t s) {
+    ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan3<MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS3));
+    hipLaunchKernelGGL(k_bf_scan3<MODE>, dim3(p.QT * p.S), dim3(512), LDS3, s, q_op, rows, p.row_bytes,
+                       p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
+                       (debug_flags() & 2) ? nullptr : tau_g, t_first, list_base, Stot, debug_flags());
+    return ZVDB_OK;
 }
 
 }  // namespace
@@ -356,8 +1202,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                       uint64_t *d_ids, float *d_dist, uint32_t *d_count, hipStream_t s) {
     if (nq == 0) return ZVDB_OK;
     // the screen keeps k' = 64 candidates per query; the exact re-rank needs a margin over k to
-    // absorb the screen's rounding (bf16 inputs: wider margin).  TODO(next round): 2 keys/lane.
-    const uint32_t kmax = mode == ZVDB_BF_BF16 ? KP - 16 : KP - 8;
+    // absorb the screen's rounding (reduced-precision inputs: wider margin).  TODO: 2 keys/lane.
+    const uint32_t kmax = mode == ZVDB_BF_F32 ? KP - 8 : KP - 16;
     if (k > kmax) {
         set_error("brute force supports k <= %u in this mode (k' = %d candidates are re-ranked exactly)", kmax, KP);
         return ZVDB_ERR_UNSUPPORTED;
@@ -366,10 +1212,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         set_error("ZVDB_BF_BF16 needs an index created with ZVDB_FLAG_BF16_MIRROR");
         return ZVDB_ERR_INVALID;
     }
-    if (h->count > 0xFFFFFFFFull - BN) {
+    if (h->count > 0xFFFFFFFFull - T2) {
         set_error("shard too large");
         return ZVDB_ERR_UNSUPPORTED;
     }
+    if (mode == ZVDB_BF_I8) ZV_CHECK(ensure_i8_mirror(h, s));
     const BfPlan p = make_plan(h, nq, mode);
     if (ws_bytes < p.total) {
         set_error("workspace too small: need %llu bytes, got %llu", (unsigned long long)p.total,
@@ -382,37 +1229,115 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint64_t *partial = reinterpret_cast<uint64_t *>(ws + p.off_partial);
     uint32_t *cand_ids = reinterpret_cast<uint32_t *>(ws + p.off_ids);
 
-    const bool bf16 = mode == ZVDB_BF_BF16;
-    const uint32_t row_elems = bf16 ? h->ldh : h->ld;
+    const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
     {
-        const uint64_t total = (uint64_t)p.nq_pad * row_elems;
+        const uint64_t total = (uint64_t)p.nq_pad * p.row_elems;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);
         hipLaunchKernelGGL(k_bf_prep_queries, dim3(grid), dim3(256), 0, s, d_queries, nq, h->dim, q_op,
-                           p.nq_pad, row_elems, bf16 ? 1 : 0);
+                           p.nq_pad, p.row_elems, (int)mode, h->q_lo, h->q_inv, l2 ? 1 : 0);
     }
-    // screen key: L2 -> |v|^2 - 2 q.v ; dot / cosine -> -q.v (norm array unused: alpha only)
-    const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
-    const float alpha = l2 ? -2.0f : -1.0f;
-    const float *vn = l2 ? (bf16 ? h->norm_h : h->norm) : nullptr;
-    const size_t lds = 4 * TILE_BYTES + 3 * BM * 4;
-    const uint32_t grid = p.QT * p.S;
+    // screen key: L2 -> |v|^2 - 2 q.v ; dot / cosine -> -q.v (no norm term)
+    const int alpha_i = l2 ? -2 : -1;
+    const uint32_t N = (uint32_t)h->count;
+    uint32_t nlists = p.S, stot_lists = p.S;
+    ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
+    if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
-    if (bf16) {
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bf_scan<true>, dim3(grid), dim3(256), lds, s,
-                           q_op, reinterpret_cast<const unsigned char *>(h->rows_h), p.row_bytes, p.KT, vn,
-                           (uint32_t)h->count, nq, alpha, p.QT, p.S, p.NT, cand, partial);
+    if (p.tile == BM) {  // v1 (kept for A/B: ZVDB_BF_KERNEL=v1)
+        const bool bf16 = mode == ZVDB_BF_BF16;
+        const float *vn = l2 ? (bf16 ? h->norm_h : h->norm) : nullptr;
+        const size_t lds = 4 * TILE_BYTES + 3 * BM * 4;
+        if (bf16) {
+            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_bf_scan<true>, dim3(p.QT * p.S), dim3(256), lds, s, q_op,
+                               reinterpret_cast<const unsigned char *>(h->rows_h), p.row_bytes, p.KT, vn, N, nq,
+                               (float)alpha_i, p.QT, p.S, p.NT, cand, partial);
+        } else {
+            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_bf_scan<false>, dim3(p.QT * p.S), dim3(256), lds, s, q_op,
+                               reinterpret_cast<const unsigned char *>(h->rows), p.row_bytes, p.KT, vn, N, nq,
+                               (float)alpha_i, p.QT, p.S, p.NT, cand, partial);
+        }
     } else {
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_bf_scan<false>, dim3(grid), dim3(256), lds, s,
-                           q_op, reinterpret_cast<const unsigned char *>(h->rows), p.row_bytes, p.KT, vn,
-                           (uint32_t)h->count, nq, alpha, p.QT, p.S, p.NT, cand, partial);
+        // v3 / v4.  TWO PASSES share one exact threshold: pass A scans the first ~1/16 of the rows;
+        // a merge of its per-stream lists yields, per query, the exact k'-th best screen key so far
+        // (tau_G); pass B scans the rest against it (folded in at every tile start, together with
+        // whatever tighter bound other workgroups publish meanwhile).  Without it every workgroup
+        // re-learns a threshold from its own 1/64 of the data and appends ~100x more candidates.
+        uint32_t *tau_g = reinterpret_cast<uint32_t *>(ws + p.off_taug);
+        const uint32_t kp = kernel_version() == 4 ? ((k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP) : (uint32_t)KP;
+        const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
+                                    : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
+                                                         : reinterpret_cast<const unsigned char *>(h->rows);
+        const void *vn = !l2 ? nullptr : mode == ZVDB_BF_BF16 ? (const void *)h->norm_h
+                                       : mode == ZVDB_BF_I8 ? (const void *)h->norm_q : (const void *)h->norm;
+        // pass schedule: {first tile, tiles, streams}.  A: 64 tiles on 8 streams per query tile (a small
+        // sample learns a first threshold cheaply: the learning cost is per WORKGROUP, so few of them);
+        // B: ~1/32 of the corpus on all streams; C: the rest.  After A and after B a merge of all lists
+        // so far gives the exact k'-th best key per query = the shared threshold of the next pass.
+        struct Pass { uint32_t t0, nt, S; };
+        Pass passes[3];
+        int np = 0;
+        const uint32_t Stot = 8 + 2 * p.S;
+        if (p.NT >= 1024 && p.NT >= 4 * p.S && !(debug_flags() & 64)) {
+            uint32_t t0 = 0;
+            passes[np++] = {0, 64, 8};
+            t0 = 64;
+            const uint32_t ntB = p.NT / 32;
+            if (ntB >= 2 * p.S) {
+                passes[np++] = {t0, ntB, p.S};
+                t0 += ntB;
+            }
+            passes[np++] = {t0, p.NT - t0, p.S};
+        } else {
+            passes[np++] = {0, p.NT, p.S};
+        }
+        auto scan = [&](const Pass &ps, uint32_t list_base) -> int {
+            BfPlan q = p;
+            q.S = ps.S;
+            if (kernel_version() == 4) {
+                if (mode == ZVDB_BF_BF16) return launch_scan4<1>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                if (mode == ZVDB_BF_I8) return launch_scan4<2>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                return launch_scan4<0>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+            }
+            if (mode == ZVDB_BF_BF16) return launch_scan3<1>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, ps.t0, ps.nt, list_base, Stot, s);
+            if (mode == ZVDB_BF_I8) return launch_scan3<2>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, ps.t0, ps.nt, list_base, Stot, s);
+            return launch_scan3<0>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, ps.t0, ps.nt, list_base, Stot, s);
+        };
+        uint32_t lists = 0;
+        for (int i = 0; i < np; ++i) {
+            ZV_CHECK(scan(passes[i], lists));
+            lists += passes[i].S;
+            if (debug_flags() & (16 | 32)) {
+                unsigned long long c[9];
+                ZV_HIP(hipMemcpyAsync(c, ws + p.off_taug + (size_t)p.nq_pad * 4, sizeof(c), hipMemcpyDeviceToHost, s));
+                ZV_HIP(hipStreamSynchronize(s));
+                const double nb = (double)p.QT * passes[i].S;
+                fprintf(stderr, "[zvdb dbg] pass %d (tiles %u, streams %u): wave-tiles %llu, with-pass %llu, prunes %llu, appends %llu, rounds/blk %.1f | "
+                        "cycles/blk: kernel %.0f, rounds %.0f, phaseA %.0f, phaseB %.0f\n",
+                        i, passes[i].nt, passes[i].S, c[0], c[1], c[2], c[3], (double)c[8] / nb, c[4] / nb, c[5] / nb, c[6] / nb, c[7] / nb);
+                ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
+            }
+            if (i + 1 < np)
+                hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, lists, Stot, (uint32_t *)nullptr, tau_g, kp);
+        }
+        nlists = lists;
+        stot_lists = Stot;
     }
     timing_end(h, s);
     ZV_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, p.S, cand_ids);
+    if (debug_flags() & (16 | 32)) {  // diagnostic run (results are garbage)
+        unsigned long long c[9];
+        ZV_HIP(hipMemcpyAsync(c, ws + p.off_taug + (size_t)p.nq_pad * 4, sizeof(c), hipMemcpyDeviceToHost, s));
+        ZV_HIP(hipStreamSynchronize(s));
+        fprintf(stderr, "[zvdb dbg] wave-tiles %llu, with-pass %llu, prunes %llu, appends %llu | per block (wave 0, shader cycles): "
+                "kernel %.0f, prune rounds %.0f (%.1f rounds), phase A %.0f, phase B %.0f\n",
+                c[0], c[1], c[2], c[3], (double)c[4] / (p.QT * p.S), (double)c[5] / (p.QT * p.S),
+                (double)c[8] / (p.QT * p.S), (double)c[6] / (p.QT * p.S), (double)c[7] / (p.QT * p.S));
+    }
+    hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, nlists, stot_lists, cand_ids, (uint32_t *)nullptr, (uint32_t)KP);
     ZV_HIP(hipGetLastError());
     return launch_rerank(h, d_queries, nq, cand_ids, KP, k, id_offset, d_ids, d_dist, d_count, s);
 }

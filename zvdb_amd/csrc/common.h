@@ -91,6 +91,13 @@ struct zvdb_hip_index {
     float *norm_h = nullptr;
     uint32_t *adj = nullptr;
     uint32_t *deg = nullptr;
+    // int8 scalar-quantised mirror for ZVDB_BF_I8 (lazy; rebuilt when rows were added)
+    int8_t *rows_q = nullptr;   // [cap_q][ldq], ldq = round_up(dim, 128)
+    int32_t *norm_q = nullptr;  // [cap_q] sum q^2
+    uint32_t *q_range = nullptr;  // device: {key(min), key(max)} of all elements
+    uint32_t ldq = 0;
+    uint64_t cap_q = 0, count_q = 0;
+    float q_lo = 0.0f, q_inv = 1.0f;  // q = clamp(rint((x - q_lo) * q_inv) - 128) (L2) / rint(x * q_inv) (dot)
     hipStream_t stream = nullptr;
     // pinned host staging + device scratch for the host-pointer entry points
     zvdb::PinnedBuf pin;
@@ -133,6 +140,7 @@ int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld
                      hipStream_t s);
 int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
+int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
 int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,
                       uint32_t G, uint32_t nq, uint32_t k, uint64_t *o_ids, float *o_dist,
                       uint32_t *o_count, hipStream_t s);

@@ -2,6 +2,8 @@
 // and the k-way merge that consumes the RCCL all-gather of per-shard top-k lists.
 #include "common.h"
 
+#include <cmath>
+
 namespace zvdb {
 
 // Synthetic U[0,1) rows (distribution of benchmarks/shared_benchmarks.zig:53-59; the
@@ -140,6 +142,105 @@ int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hi
     hipLaunchKernelGGL(k_finalize_rows, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
                        h->ld, h->rows_h, h->ldh, h->norm, h->norm_h, first, n);
     ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+
+// ---- int8 scalar-quantised mirror (ZVDB_BF_I8) -------------------------------------------------
+// One global range for the whole shard: L2 uses the affine map q = rint((x - lo) * 255/(hi-lo)) - 128
+// (offsets cancel in q_a - q_b); dot/cosine use the symmetric map q = rint(x * 127/max|x|).
+__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ rows, uint32_t dim, uint32_t ld,
+                                                uint64_t n, uint32_t *__restrict__ range) {
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    const uint64_t total = n * ld;
+    for (uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total;
+         t += (uint64_t)gridDim.x * blockDim.x * 4) {
+        const uint32_t c = (uint32_t)(t % ld);
+        const float4 v = *reinterpret_cast<const float4 *>(rows + t);
+        if (c + 0 < dim) { lo = fminf(lo, v.x); hi = fmaxf(hi, v.x); }
+        if (c + 1 < dim) { lo = fminf(lo, v.y); hi = fmaxf(hi, v.y); }
+        if (c + 2 < dim) { lo = fminf(lo, v.z); hi = fmaxf(hi, v.z); }
+        if (c + 3 < dim) { lo = fminf(lo, v.w); hi = fmaxf(hi, v.w); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&range[0], f32_key(lo));
+        atomicMax(&range[1], f32_key(hi));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_quantize_rows(const float *__restrict__ rows, uint32_t dim,
+                                                       uint32_t ld, int8_t *__restrict__ rows_q,
+                                                       uint32_t ldq, int32_t *__restrict__ norm_q,
+                                                       uint64_t n, float q_lo, float q_inv, int affine) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float *v = rows + r * ld;
+    int s = 0;
+    for (uint32_t c = lane * 4; c < ldq; c += 256) {
+        int q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int qv = 0;
+            if (c + j < dim) {
+                const float x = v[c + j];
+                const float f = affine ? __builtin_rintf((x - q_lo) * q_inv) - 128.0f : __builtin_rintf(x * q_inv);
+                qv = (int)fminf(fmaxf(f, -128.0f), 127.0f);
+            }
+            q[j] = qv;
+            s += qv * qv;
+        }
+        *reinterpret_cast<uint32_t *>(rows_q + r * ldq + c) =
+            (uint32_t)(q[0] & 255) | ((uint32_t)(q[1] & 255) << 8) | ((uint32_t)(q[2] & 255) << 16) |
+            ((uint32_t)(q[3] & 255) << 24);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) norm_q[r] = s;
+}
+
+int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
+    if (h->rows_q && h->count_q == h->count) return ZVDB_OK;
+    if (h->count == 0) return ZVDB_OK;
+    h->ldq = round_up(h->dim, 128);
+    if (h->cap_q < h->count) {
+        if (h->rows_q) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_q)); ZV_HIP(hipFree(h->norm_q)); }
+        h->rows_q = nullptr;
+        h->norm_q = nullptr;
+        const uint64_t ncap = std::max<uint64_t>(h->count, h->cap);
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->rows_q), ncap * h->ldq));
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->norm_q), ncap * sizeof(int32_t)));
+        h->cap_q = ncap;
+    }
+    if (!h->q_range) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->q_range), 8));
+    const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+    ZV_HIP(hipMemcpyAsync(h->q_range, init, 8, hipMemcpyHostToDevice, s));
+    const uint64_t total4 = h->count * h->ld / 4;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_minmax, dim3(grid), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, h->q_range);
+    ZV_HIP(hipGetLastError());
+    uint32_t got[2];
+    ZV_HIP(hipMemcpyAsync(got, h->q_range, 8, hipMemcpyDeviceToHost, s));
+    ZV_HIP(hipStreamSynchronize(s));  // (lazy one-off build; not on the steady-state search path)
+    const float lo = f32_unkey(got[0]), hi = f32_unkey(got[1]);
+    const bool affine = h->metric == ZVDB_METRIC_L2SQ;
+    if (affine) {
+        h->q_lo = lo;
+        h->q_inv = hi > lo ? 255.0f / (hi - lo) : 1.0f;
+    } else {
+        const float m = std::max(std::fabs(lo), std::fabs(hi));
+        h->q_lo = 0.0f;
+        h->q_inv = m > 0.0f ? 127.0f / m : 1.0f;
+    }
+    hipLaunchKernelGGL(k_quantize_rows, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
+                       h->ld, h->rows_q, h->ldq, h->norm_q, h->count, h->q_lo, h->q_inv, affine ? 1 : 0);
+    ZV_HIP(hipGetLastError());
+    h->count_q = h->count;
     return ZVDB_OK;
 }
 
