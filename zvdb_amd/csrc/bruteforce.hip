@@ -661,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan3(
 // wave merges the query's kept list with its 4 sub-buffers (bitonic sort/merge of 64-bit keys),
 // keeps the exact best k' (32 or 64), tightens tau and publishes it to the shared threshold.
 // =====================================================================================
-constexpr int SUBCAP = 256, SUBHW = 64, SUBURG = 192, NSUB = 4;  // capacity, soft mark, must-prune mark
+constexpr int SUBCAP = 256, SUBHW = 48, SUBURG = 192, NSUB = 4;  // capacity, soft mark, must-prune mark
 constexpr int PTHRESH = 32;  // start a prune round once this many sub-buffers crossed the soft mark
 constexpr int LDS4_VN = NSTAGE3 * STAGE3;        // vn[4][256]
 constexpr int LDS4_TG = LDS4_VN + 4 * T2 * 4;    // tg[4][256]
@@ -1155,7 +1155,7 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     p.off_cand = off;
     off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap, (uint64_t)p.QT * p.S * BLK4_ENTRIES) * 8;
     p.off_partial = off;
-    off += (uint64_t)p.nq_pad * (8 + 2 * p.S) * KP * 8;  // lists of up to three passes
+    off += (uint64_t)p.nq_pad * 3 * p.S * KP * 8;  // lists of up to three passes
     p.off_ids = off;
     off += (uint64_t)p.nq_pad * KP * 4;
     p.off_taug = off;
@@ -1273,18 +1273,20 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                                          : reinterpret_cast<const unsigned char *>(h->rows);
         const void *vn = !l2 ? nullptr : mode == ZVDB_BF_BF16 ? (const void *)h->norm_h
                                        : mode == ZVDB_BF_I8 ? (const void *)h->norm_q : (const void *)h->norm;
-        // pass schedule: {first tile, tiles, streams}.  A: 64 tiles on 8 streams per query tile (a small
-        // sample learns a first threshold cheaply: the learning cost is per WORKGROUP, so few of them);
-        // B: ~1/32 of the corpus on all streams; C: the rest.  After A and after B a merge of all lists
-        // so far gives the exact k'-th best key per query = the shared threshold of the next pass.
+        // pass schedule: {first tile, tiles, streams}; after each pass but the last, a merge of ALL
+        // lists so far gives, per query, the exact k'-th best key over the rows scanned so far = the
+        // shared threshold of the next pass (learning a threshold costs one flooded tile + one sort per
+        // WORKGROUP however long its stream is, so it is paid once, on one tile per stream):
+        //   A: 1 tile per stream   -> threshold over S*256 rows (every stream floods + sorts once)
+        //   B: ~1/32 of the corpus -> threshold over ~N/32 rows (no flood any more)
+        //   C: the rest            -> ~32x fewer candidates than B's threshold would admit
         struct Pass { uint32_t t0, nt, S; };
         Pass passes[3];
         int np = 0;
-        const uint32_t Stot = 8 + 2 * p.S;
-        if (p.NT >= 1024 && p.NT >= 4 * p.S && !(debug_flags() & 64)) {
-            uint32_t t0 = 0;
-            passes[np++] = {0, 64, 8};
-            t0 = 64;
+        const uint32_t Stot = 3 * p.S;
+        if (p.NT >= 16 * p.S && !(debug_flags() & 64)) {
+            uint32_t t0 = p.S;
+            passes[np++] = {0, p.S, p.S};
             const uint32_t ntB = p.NT / 32;
             if (ntB >= 2 * p.S) {
                 passes[np++] = {t0, ntB, p.S};
