@@ -716,13 +716,14 @@ __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, con
     return best;
 }
 
-template <int MODE>
+template <int MODE, bool DBG>
 __global__ __launch_bounds__(512, 2) void k_bf_scan4(
     const unsigned char *__restrict__ Q /* query operand */, const unsigned char *__restrict__ V /* corpus operand */,
     uint32_t row_bytes, uint32_t KT /* 64-B slices per row */, const void *__restrict__ vnorm, uint32_t N,
     uint32_t nq, int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
-    uint32_t list_base, uint32_t Stot, uint32_t dbg, unsigned long long *__restrict__ dbgbuf) {
+    uint32_t list_base, uint32_t Stot, uint32_t dbg_in, unsigned long long *__restrict__ dbgbuf) {
+    const uint32_t dbg = DBG ? dbg_in : 0u;  // all diagnostics compile out of the production instantiation
     using acc_t = typename AccT<MODE>::type;
     constexpr bool INT = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -934,32 +935,40 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
                     acc[mi][1] = init;
                 }
             }
-            issue_slice((islice + 3) & 3);
+            // Fragment reads of BOTH 32-byte k-steps of the slice are issued up front (12 x ds_read_b128,
+            // 48 VGPRs), then the DMA of slice i+3 is issued while they fly, then 16 MFMAs run back to
+            // back behind counted lgkmcnt waits: one exposed LDS latency per slice instead of eight.
             const unsigned char *st = smem + (islice & 3) * STAGE3;
+            u32x4 fa[2][4], fb[2][2];
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                u32x4 fa[4], fb[2];
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
-                    fa[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[cc]);
+                    fa[cc][mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[cc]);
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    fb[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[cc]);
+                    fb[cc][ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[cc]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_slice((islice + 3) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         if constexpr (MODE == 1) {
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
+                                __builtin_bit_cast(bf16x8, fa[cc][mi]), __builtin_bit_cast(bf16x8, fb[cc][ni]),
                                 acc[mi][ni], 0, 0, 0);
                         } else if constexpr (MODE == 2) {
                             acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                                __builtin_bit_cast(i32x4, fa[mi]), __builtin_bit_cast(i32x4, fb[ni]),
+                                __builtin_bit_cast(i32x4, fa[cc][mi]), __builtin_bit_cast(i32x4, fb[cc][ni]),
                                 acc[mi][ni], 0, 0, 0);
                         } else {
-                            const f32x4 xa = __builtin_bit_cast(f32x4, fa[mi]);
-                            const f32x4 xb = __builtin_bit_cast(f32x4, fb[ni]);
+                            const f32x4 xa = __builtin_bit_cast(f32x4, fa[cc][mi]);
+                            const f32x4 xb = __builtin_bit_cast(f32x4, fb[cc][ni]);
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
@@ -1168,12 +1177,20 @@ template <int MODE>
 int launch_scan4(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
                  uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
                  uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, hipStream_t s) {
-    ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan4<MODE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-    hipLaunchKernelGGL(k_bf_scan4<MODE>, dim3(p.QT * p.S), dim3(512), LDS4, s, q_op, rows, p.row_bytes,
-                       p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
-                       (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, debug_flags(),
-                       reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad));
+    unsigned long long *dbgbuf = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);
+    if (debug_flags()) {
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan4<MODE, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        hipLaunchKernelGGL((k_bf_scan4<MODE, true>), dim3(p.QT * p.S), dim3(512), LDS4, s, q_op, rows, p.row_bytes,
+                           p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
+                           (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, debug_flags(), dbgbuf);
+    } else {
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan4<MODE, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        hipLaunchKernelGGL((k_bf_scan4<MODE, false>), dim3(p.QT * p.S), dim3(512), LDS4, s, q_op, rows, p.row_bytes,
+                           p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
+                           list_base, Stot, 0u, dbgbuf);
+    }
     return ZVDB_OK;
 }
 
