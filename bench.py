@@ -40,8 +40,10 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--mode", choices=["bf16", "f32", "i8"], default="bf16",
-                    help="screen arithmetic (final distances are exact fp32 either way)")
+    ap.add_argument("--mode", choices=["auto", "bf16", "f32", "i8"], default="auto",
+                    help="screen arithmetic of the headline path (final distances are exact fp32 either way); "
+                         "auto = i8 headline + short bf16 / f32 legs reported under 'paths'")
+    ap.add_argument("--no-paths", action="store_true", help="auto mode: skip the secondary bf16 / f32 legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
@@ -118,7 +120,11 @@ def main():
     lo = rank * N // world
     hi = (rank + 1) * N // world
     n_local = hi - lo
-    mode = {"bf16": zv.BF_BF16, "f32": zv.BF_F32, "i8": zv.BF_I8}[args.mode]
+    MODES = {"bf16": zv.BF_BF16, "f32": zv.BF_F32, "i8": zv.BF_I8}
+    auto = args.mode == "auto"
+    if auto:
+        args.mode = "i8"
+    mode = MODES[args.mode]
 
     # ---- resident inputs -------------------------------------------------------------------
     idx = zv.Index(dim=D, capacity=n_local, device=local_rank, flags=zv.FLAG_BF16_MIRROR)
@@ -171,21 +177,37 @@ def main():
     chk_q = queries[total_steps].cpu().numpy()
 
     # ---- timed region ----------------------------------------------------------------------------
-    for i in range(args.warmup):
-        step(queries[i], mode)
-    sync()
-    idx.timing_enable(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(queries[args.warmup + i], mode)
-    sync()
-    elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = idx.timing_read()
-    idx.timing_enable(False)
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(m, steps, warmup):
+        for i in range(warmup):
+            step(queries[i % total_steps], m)
+        sync()
+        idx.timing_enable(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(queries[(warmup + i) % total_steps], m)
+        sync()
+        el = time.perf_counter() - t0
+        kms, kn = idx.timing_read()
+        idx.timing_enable(False)
+        if dist_on:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, kms, kn
+
+    elapsed, kern_ms, kern_n = timed(mode, args.steps, args.warmup)
+    paths = {}
+    if auto and not args.no_paths:
+        for name, st in (("bf16", 5), ("f32", 2)):
+            g_ids2, _ = step(queries[total_steps], MODES[name])
+            torch.cuda.synchronize()
+            a2 = g_ids2.cpu().numpy()
+            rec2 = float(np.mean([len(set(a2[i]) & set(b[i])) / K for i in range(B)]))
+            el2, km2, kn2 = timed(MODES[name], st, 1)
+            paths[name] = {"value": B * st / el2, "unit": "QPS", "steps": st, "recall_at_10": rec2,
+                           "kernel_ms_per_step": km2 / max(kn2, 1),
+                           "achieved_tflops": 2.0 * B * n_local * D / (km2 / max(kn2, 1) * 1e-3) / 1e12,
+                           "peak_tflops": PEAK_TFLOPS[name]}
 
     if rank == 0:
         qps = B * args.steps / elapsed
@@ -193,6 +215,13 @@ def main():
         kavg = kern_ms / max(kern_n, 1) * 1e-3
         achieved = flops / kavg / 1e12 if kavg > 0 else 0.0
         peak = PEAK_TFLOPS[args.mode]
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "r1", "traffic_10Mx768.json")
+        if world == 1 and os.path.exists(tf):
+            tj = json.load(open(tf)).get(args.mode)
+            if tj and (tj["rows"], tj["dim"], tj["batch"]) == (N, D, B):
+                traffic = tj["hbm_bytes_per_step"]
+                traffic_src = "profiles/r1/traffic_10Mx768.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command)"
         out = {
             "metric": "QPS at recall@10>=0.95, 10Mx768 fp32, batch=1024",
             "value": qps,
@@ -209,25 +238,31 @@ def main():
             "recall_at_10": recall,
             "config": {
                 "workload": (f"{N}x{D} fp32 corpus (U[0,1) seeded), batch={B}, k={K}: brute-force "
-                             f"{args.mode}-MFMA screen + fused top-64 + exact fp32 re-rank"),
+                             f"{args.mode}-MFMA screen (mirror of the fp32 rows) + fused threshold top-k' + exact fp32 re-rank"),
                 "rows": N, "dim": D, "batch": B, "k": K,
                 "parallelism": f"id-range shards x{world}, all-gather top-k" if world > 1 else "1 GPU",
                 "recall_ground_truth": "fp32-MFMA route + exact re-rank (oracle-parity-tested)",
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": f"k_bf_scan2<{args.mode}>",
+                "kernel": f"k_bf_scan4<{args.mode}>",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s" if args.mode != "i8" else "TOP/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms_avg": kavg * 1e3,
-                "launches": kern_n,
+                "timed_regions": kern_n,
+                "region": "per step: 3 launches of the scan kernel (threshold cascade passes A/B/C) + 2 threshold merges",
+                "hbm_achieved_GBps": float(n_local) * D * {"bf16": 2, "f32": 4, "i8": 1}[args.mode] / kavg / 1e9 if kavg > 0 else 0.0,
+                "hbm_peak_GBps": 8000.0,
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": float(n_local) * D * {"bf16": 2, "f32": 4, "i8": 1}[args.mode],
             },
         }
+        if paths:
+            out["paths"] = paths
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, chk_ids, chk_dist, chk_q)
         print(json.dumps(out), flush=True)

@@ -726,6 +726,7 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
     const uint32_t dbg = DBG ? dbg_in : 0u;  // all diagnostics compile out of the production instantiation
     using acc_t = typename AccT<MODE>::type;
     constexpr bool INT = MODE == 2;
+    constexpr bool PIPE = MODE == 2;  // software-pipelined fragment reads (register budget allows it for i8 only)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS4_VN);
     uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS4_TG);
@@ -855,6 +856,28 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
         const uint32_t col0 = t * T2;
         const uint32_t *vn_t = vn_lds + ((t - t_begin) & 3) * T2;
         acc_t acc[4][2];
+        u32x4 fx_a[4], fx_b[2], fy_a[4], fy_b[2];
+        auto mma8 = [&](const u32x4 (&a4)[4], const u32x4 (&b2)[2]) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (MODE == 1) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4[mi]),
+                                                                              __builtin_bit_cast(bf16x8, b2[ni]), acc[mi][ni], 0, 0, 0);
+                    } else if constexpr (MODE == 2) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a4[mi]),
+                                                                            __builtin_bit_cast(i32x4, b2[ni]), acc[mi][ni], 0, 0, 0);
+                    } else {
+                        const f32x4 xa = __builtin_bit_cast(f32x4, a4[mi]);
+                        const f32x4 xb = __builtin_bit_cast(f32x4, b2[ni]);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc[mi][ni], 0, 0, 0);
+                    }
+                }
+        };
         uint32_t thr[2];   // fp: bits of the accumulator bound; int: tau
         uint32_t cntr[2], cnt0[2];
 
@@ -916,66 +939,101 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
                 // dropped parity bit perturbs the int screen by < 1 unit and equally for equal rows);
                 // rows past N start at -inf / -2^30 and can never pass.  The finished accumulator IS the
                 // negated screen key, so the selection test is one compare per element.
+                const bool full_tile = col0 + T2 <= N;  // wave-uniform: only the corpus' last tile is ragged
+                if (full_tile) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    acc_t init;
+                    for (int mi = 0; mi < 4; ++mi) {
+                        acc_t init;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t rl = rbase + mi * 32 + 8 * g;
-                        u32x4 v4 = {0, 0, 0, 0};
-                        if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rl);
+                        for (int g = 0; g < 4; ++g) {
+                            u32x4 v4 = {0, 0, 0, 0};
+                            if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rbase + mi * 32 + 8 * g);
 #pragma unroll
-                        for (int j2 = 0; j2 < 4; ++j2) {
-                            const bool ok = (col0 + rl + j2) < N;
-                            if constexpr (INT) init[4 * g + j2] = ok ? -((int)v4[j2] >> 1) : -0x40000000;
-                            else init[4 * g + j2] = ok ? -0.5f * __uint_as_float(v4[j2]) : -__builtin_inff();
+                            for (int j2 = 0; j2 < 4; ++j2) {
+                                if constexpr (INT) init[4 * g + j2] = -((int)v4[j2] >> 1);
+                                else init[4 * g + j2] = -0.5f * __uint_as_float(v4[j2]);
+                            }
                         }
+                        acc[mi][0] = init;
+                        acc[mi][1] = init;
                     }
-                    acc[mi][0] = init;
-                    acc[mi][1] = init;
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        acc_t init;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const uint32_t rl = rbase + mi * 32 + 8 * g;
+                            u32x4 v4 = {0, 0, 0, 0};
+                            if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rl);
+#pragma unroll
+                            for (int j2 = 0; j2 < 4; ++j2) {
+                                const bool ok = (col0 + rl + j2) < N;
+                                if constexpr (INT) init[4 * g + j2] = ok ? -((int)v4[j2] >> 1) : -0x40000000;
+                                else init[4 * g + j2] = ok ? -0.5f * __uint_as_float(v4[j2]) : -__builtin_inff();
+                            }
+                        }
+                        acc[mi][0] = init;
+                        acc[mi][1] = init;
+                    }
                 }
             }
-            // Fragment reads of BOTH 32-byte k-steps of the slice are issued up front (12 x ds_read_b128,
-            // 48 VGPRs), then the DMA of slice i+3 is issued while they fly, then 16 MFMAs run back to
-            // back behind counted lgkmcnt waits: one exposed LDS latency per slice instead of eight.
+            if constexpr (PIPE) {
+            // Software pipeline across the barrier (per wave): the slice's first k-step (cc0) is read
+            // into X right after the barrier; the MFMAs of the PREVIOUS slice's second k-step (still in
+            // Y) run while those reads and the DMA issue of slice i+3 are in flight; then cc1 is read
+            // into Y behind the MFMAs of cc0.  LDS latency and DMA issue hide behind the wave's own
+            // MFMAs instead of stalling both waves of a SIMD in lockstep.
             const unsigned char *st = smem + (islice & 3) * STAGE3;
-            u32x4 fa[2][4], fb[2][2];
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
+            for (int mi = 0; mi < 4; ++mi)
+                fx_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[0]);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    fa[cc][mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[cc]);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    fb[cc][ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[cc]);
-            }
+            for (int ni = 0; ni < 2; ++ni)
+                fx_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[0]);
             __builtin_amdgcn_sched_barrier(0);
-            issue_slice((islice + 3) & 3);
+            if (!(dbg & 256)) issue_slice((islice + 3) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt > 0 && !(dbg & 128)) mma8(fy_a, fy_b);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
+            for (int mi = 0; mi < 4; ++mi)
+                fy_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[1]);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int ni = 0; ni < 2; ++ni)
+                fy_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 128)) mma8(fx_a, fx_b);
+            else {
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        if constexpr (MODE == 1) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, fa[cc][mi]), __builtin_bit_cast(bf16x8, fb[cc][ni]),
-                                acc[mi][ni], 0, 0, 0);
-                        } else if constexpr (MODE == 2) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                                __builtin_bit_cast(i32x4, fa[cc][mi]), __builtin_bit_cast(i32x4, fb[cc][ni]),
-                                acc[mi][ni], 0, 0, 0);
-                        } else {
-                            const f32x4 xa = __builtin_bit_cast(f32x4, fa[cc][mi]);
-                            const f32x4 xb = __builtin_bit_cast(f32x4, fb[cc][ni]);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc[mi][ni], 0, 0, 0);
-                        }
-                    }
+                for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(fx_a[mi]), "v"(fy_a[mi]));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) asm volatile("" :: "v"(fx_b[ni]), "v"(fy_b[ni]));
             }
+            } else {
+                // fp32 / bf16: both k-steps' fragments up front (the pipelined form spills there)
+                const unsigned char *st = smem + (islice & 3) * STAGE3;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    fx_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[0]);
+                    fy_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[1]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    fx_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[0]);
+                    fy_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 256)) issue_slice((islice + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 128)) {
+                    mma8(fx_a, fx_b);
+                    mma8(fy_a, fy_b);
+                }
+            }
+        }
+        if constexpr (PIPE) {
+            if (!(dbg & 128)) mma8(fy_a, fy_b);  // flush the tile's last k-step
         }
 
         // ---- fused selection epilogue: registers only on the common path -----------------------
