@@ -44,6 +44,10 @@ def parse_args():
                     help="screen arithmetic of the headline path (final distances are exact fp32 either way); "
                          "auto = i8 headline + short bf16 / f32 legs reported under 'paths'")
     ap.add_argument("--no-paths", action="store_true", help="auto mode: skip the secondary bf16 / f32 legs")
+    ap.add_argument("--extras", action="store_true",
+                    help="also measure BASELINE configs[1] (1M x 128 fp32 brute force, batch 256) and the reference's own "
+                         "benchmark shape (compat-mode HNSW search, 128-d, k = 10) on GPU and CPU; adds ~1-2 min")
+    ap.add_argument("--extras-points", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
@@ -90,6 +94,91 @@ def cpu_baseline(args, gpu_ids, gpu_dist, q_host):
         "host_cores_available": os.cpu_count(),
         "gpu_result_check": "ok" if ok else "MISMATCH",
     }
+
+
+def extras(args, zv, torch):
+    """Secondary measurements (not the headline): C2 and the reference-continuity shape."""
+    import numpy as np
+
+    import oracle
+    out = {}
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    # ---- BASELINE configs[1]: 1M x 128 fp32 brute force, batch 256, fp32-MFMA screen ---------------
+    N2, D2, B2, K = 1_000_000, 128, 256, args.k
+    idx = zv.Index(dim=D2, capacity=N2, flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(N2, D2, CORPUS_SEED)
+    q = torch.empty((B2, D2), dtype=torch.float32, device=dev)
+    zv.fill_synthetic_dev(q.data_ptr(), B2, D2, QUERY_SEED, 0, stream)
+    ws_b = max(idx.bruteforce_workspace(B2, K, m) for m in (zv.BF_F32, zv.BF_BF16, zv.BF_I8))
+    ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
+    ids = torch.empty((B2, K), dtype=torch.int64, device=dev)
+    dd = torch.empty((B2, K), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B2,), dtype=torch.int32, device=dev)
+    c2 = {}
+    for name, m in (("f32", zv.BF_F32), ("bf16", zv.BF_BF16), ("i8", zv.BF_I8)):
+        for _ in range(3):
+            idx.search_bruteforce_dev(q.data_ptr(), B2, D2, K, m, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(),
+                                      cnt.data_ptr(), stream)
+        torch.cuda.synchronize()
+        idx.timing_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            idx.search_bruteforce_dev(q.data_ptr(), B2, D2, K, m, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(),
+                                      cnt.data_ptr(), stream)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kms, kn = idx.timing_read()
+        idx.timing_enable(False)
+        c2[name] = {"qps": B2 * 20 / el, "ms_per_batch": el / 20 * 1e3, "scan_ms": kms / kn,
+                    "achieved_tflops": 2.0 * B2 * N2 * D2 / (kms / kn * 1e-3) / 1e12}
+    # exactness spot check of the f32 leg against the oracle on 4 queries
+    Vh = oracle.uniform_rows(CORPUS_SEED, 0, N2, D2)
+    qh = q.cpu().numpy()
+    idx.search_bruteforce_dev(q.data_ptr(), B2, D2, K, zv.BF_F32, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(),
+                              cnt.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ri, rd, _ = oracle.bruteforce_topk(Vh, qh[:4], K)
+    c2["oracle_check"] = bool(np.array_equal(ids.cpu().numpy()[:4].astype(np.uint64), ri)
+                              and np.array_equal(dd.cpu().numpy()[:4], rd))
+    out["c2_1Mx128_batch256"] = c2
+    del idx
+
+    # ---- the reference's own benchmark shape: compat-mode search (hnsw.zig:194-236) ---------------------
+    # benchmarks/shared_benchmarks.zig:90-125: index of P points (untimed build), then timed k = 10 searches.
+    P, D3, NQ = args.extras_points, 128, 10_000
+    V = oracle.uniform_rows(CORPUS_SEED, 0, P, D3)
+    Q = oracle.uniform_rows(QUERY_SEED, 0, NQ, D3)
+    h = zv.HNSW(16, 200)                      # product insert path: host bookkeeping + HIP distances
+    t0 = time.perf_counter()
+    for r in V:
+        h.insert(r, _level=0)
+    t_ins_gpu = time.perf_counter() - t0
+    ref = oracle.HNSW(16, 200)
+    t0 = time.perf_counter()
+    for r in V:
+        ref.insert(r, 0)
+    t_ins_cpu = time.perf_counter() - t0
+    gidx = h.index
+    t0 = time.perf_counter()
+    gi, gd, gc, (ev, pp) = gidx.search_graph(Q, K, with_stats=True)   # one batched launch, host pointers (PCIe incl.)
+    t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    same = True
+    for qi in range(NQ):
+        ri, rd = ref.search(Q[qi], K)
+        if qi < 500 and not (np.array_equal(ri, gi[qi, :len(ri)]) and np.array_equal(rd, gd[qi, :len(ri)])):
+            same = False
+    t_cpu = time.perf_counter() - t0
+    out["reference_shape_compat_search"] = {
+        "points": P, "dim": D3, "queries": NQ, "k": K, "m": 16,
+        "gpu_qps_batched_host_api": NQ / t_gpu, "cpu_oracle_qps_1thread": NQ / t_cpu,
+        "gpu_insert_pts_per_s": P / t_ins_gpu, "cpu_oracle_insert_pts_per_s": P / t_ins_cpu,
+        "dist_evals_per_query": ev / NQ, "pops_per_query": pp / NQ,
+        "bit_exact_vs_oracle_first_500": same,
+        "reference_published": {"search_qps": 2678.13, "insert_pts_per_s": 8392.22, "source": "benchmarks/benchmark.md:102-113 (100k x 128, unstated CPU)"},
+    }
+    return out
 
 
 def main():
@@ -263,6 +352,9 @@ def main():
         }
         if paths:
             out["paths"] = paths
+        if args.extras and world == 1:
+            del ws
+            out["extras"] = extras(args, zv, torch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, chk_ids, chk_dist, chk_q)
         print(json.dumps(out), flush=True)
