@@ -661,6 +661,74 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan3(
 // wave merges the query's kept list with its 4 sub-buffers (bitonic sort/merge of 64-bit keys),
 // keeps the exact best k' (32 or 64), tightens tau and publishes it to the shared threshold.
 // =====================================================================================
+
+// =====================================================================================
+// Exact selection without sorting: MSD radix select (8 bits per pass) on 64-bit (key,id) words
+// held E per lane, using a wave-private 256-bin LDS histogram.  Distances of a candidate set
+// share their leading bits, so the walk typically ends after 3-4 passes (early exit as soon as
+// the chosen bin holds one candidate).  Replaces the bitonic sort/merge networks (21 + 7
+// dependent ds_bpermute stages per 64 keys) in the prune rounds and the list merges.
+// =====================================================================================
+constexpr int SEL_HIST_BYTES = 1024, SEL_STAGE_BYTES = 512;
+constexpr int SEL_SCRATCH = SEL_HIST_BYTES + SEL_STAGE_BYTES;  // per wave
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(v, off);
+        if (lane >= off) v += y;
+    }
+    return v;
+}
+
+// kth (1-based) smallest of the valid (!= ~0) keys; precondition: kth <= number of valid keys.
+// KeyAt(e) returns the lane's e-th key, e < E (E may be a runtime count for LDS-resident sets).
+// EC > 0: compile-time element count (register-resident keys, fully unrolled); EC == 0: runtime E.
+template <int EC, typename KeyAt>
+__device__ __forceinline__ uint64_t wave_kth_key(KeyAt key_at, uint32_t E_rt, uint32_t kth, uint32_t *hist, int lane) {
+    const uint32_t E = EC > 0 ? (uint32_t)EC : E_rt;
+    uint64_t prefix = 0;
+    uint32_t need = kth;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        *reinterpret_cast<u32x4 *>(hist + 4 * lane) = u32x4{0, 0, 0, 0};
+#pragma unroll(EC > 0 ? EC : 1)
+        for (uint32_t e = 0; e < E; ++e) {
+            const uint64_t k = key_at(e);
+            if (k != ~0ull && (shift == 56 || (k >> (shift + 8)) == prefix))
+                atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+        }
+        const u32x4 c = *reinterpret_cast<const u32x4 *>(hist + 4 * lane);
+        const uint32_t sl = c.x + c.y + c.z + c.w;
+        const uint32_t inc = wave_incl_scan(sl, lane);
+        const unsigned long long b = __ballot(inc >= need);
+        const int L = __builtin_ctzll(b);
+        uint32_t r = need - (inc - sl);  // rank inside this lane's four bins (meaningful in lane L)
+        uint32_t j = 0, cj = c.x;
+        if (r > c.x) { r -= c.x; j = 1; cj = c.y; if (r > c.y) { r -= c.y; j = 2; cj = c.z; if (r > c.z) { r -= c.z; j = 3; cj = c.w; } } }
+        const uint32_t d = (uint32_t)__shfl((int)(4 * lane + j), L);
+        need = (uint32_t)__shfl((int)r, L);
+        const uint32_t cnt_d = (uint32_t)__shfl((int)cj, L);
+        prefix = (prefix << 8) | d;
+        if (cnt_d == 1 && shift > 0) {  // a single candidate left on the path: it is the answer
+            uint64_t found = ~0ull;
+#pragma unroll(EC > 0 ? EC : 1)
+            for (uint32_t e = 0; e < E; ++e) {
+                const uint64_t k = key_at(e);
+                if (k != ~0ull && (k >> shift) == prefix) found = k;
+            }
+            const unsigned long long fb = __ballot(found != ~0ull);
+            return shfl64(found, __builtin_ctzll(fb));
+        }
+    }
+    return prefix;
+}
+
+__device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = umax64(v, shfl_xor64(v, off));
+    return v;
+}
+
 constexpr int SUBCAP = 256, SUBHW = 48, SUBURG = 192, NSUB = 4;  // capacity, soft mark, must-prune mark
 constexpr int PTHRESH = 32;  // start a prune round once this many sub-buffers crossed the soft mark
 constexpr int LDS4_VN = NSTAGE3 * STAGE3;        // vn[4][256]
@@ -669,39 +737,62 @@ constexpr int LDS4_TAU = LDS4_TG + 4 * T2 * 4;   // tau[256]
 constexpr int LDS4_NK = LDS4_TAU + T2 * 4;       // nkept[256]
 constexpr int LDS4_SC = LDS4_NK + T2 * 4;        // subcnt[256][4]
 constexpr int LDS4_FLAG = LDS4_SC + T2 * NSUB * 4;
-constexpr int LDS4 = LDS4_FLAG + 16;
+constexpr int LDS4_SEL = LDS4_FLAG + 16;          // 8 waves x (histogram + compaction stage)
+constexpr int LDS4 = LDS4_SEL + 8 * SEL_SCRATCH;
 constexpr size_t BLK4_KEPT = (size_t)T2 * KP;                 // u64 entries
 constexpr size_t BLK4_ENTRIES = BLK4_KEPT + (size_t)T2 * NSUB * SUBCAP;
 
-// merge query q's kept list with its sub-buffers -> exact best kp, sorted; resets the sub-buffers
+// merge query q's kept list with its sub-buffers -> exact best kp (UNSORTED, compacted to the front of
+// kept[q]); resets the sub-buffers.  Rounds of <= 64 carried + 256 new keys, radix-selected.
 template <bool INTKEY>
 __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, const uint64_t *__restrict__ sub,
                                                 float *tau, uint32_t *nkept, uint32_t *subcnt, int q, int lane,
-                                                uint32_t kp, uint32_t *tau_g) {
+                                                uint32_t kp, uint32_t *tau_g, unsigned char *scratch) {
+    uint32_t *hist = reinterpret_cast<uint32_t *>(scratch);
+    uint64_t *stage = reinterpret_cast<uint64_t *>(scratch + SEL_HIST_BYTES);
     const uint32_t n0 = min(subcnt[q * NSUB + 0], (uint32_t)SUBCAP), n1 = min(subcnt[q * NSUB + 1], (uint32_t)SUBCAP);
     const uint32_t n2 = min(subcnt[q * NSUB + 2], (uint32_t)SUBCAP), n3 = min(subcnt[q * NSUB + 3], (uint32_t)SUBCAP);
     const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, total = p3 + n3;
-    const uint32_t nk = nkept[q];
-    uint64_t best = (uint32_t)lane < nk ? kept[(size_t)q * KP + lane] : ~0ull;
-    for (uint32_t base = 0; base < total; base += kWave) {
-        const uint32_t i = base + lane;
-        uint64_t key = ~0ull;
-        if (i < total) {
-            const uint32_t si = (i >= p1) + (i >= p2) + (i >= p3);
-            const uint32_t off = i - (si == 0 ? 0u : si == 1 ? p1 : si == 2 ? p2 : p3);
-            key = sub[((size_t)q * NSUB + si) * SUBCAP + off];
+    uint32_t ncarry = nkept[q];
+    uint64_t carry = (uint32_t)lane < ncarry ? kept[(size_t)q * KP + lane] : ~0ull;
+    uint32_t done = 0;
+    while (done < total) {
+        uint64_t k[5];
+        k[0] = carry;
+#pragma unroll
+        for (int e = 1; e < 5; ++e) {
+            const uint32_t i = done + (e - 1) * kWave + lane;
+            uint64_t v = ~0ull;
+            if (i < total) {
+                const uint32_t si = (i >= p1) + (i >= p2) + (i >= p3);
+                const uint32_t off = i - (si == 0 ? 0u : si == 1 ? p1 : si == 2 ? p2 : p3);
+                v = sub[((size_t)q * NSUB + si) * SUBCAP + off];
+            }
+            k[e] = v;
         }
-        key = wave_sort64(key, lane);
-        best = wave_merge64(best, key, lane);
+        const uint32_t nnew = min(256u, total - done);
+        done += nnew;
+        const uint32_t nvalid = ncarry + nnew;
+        uint64_t T = ~0ull - 1;  // everything valid passes
+        if (nvalid > kp) T = wave_kth_key<5>([&](uint32_t e) { return k[e]; }, 5, kp, hist, lane);
+        uint32_t base = 0;
+#pragma unroll
+        for (int e = 0; e < 5; ++e) {
+            const bool selv = k[e] <= T;
+            const unsigned long long m = __ballot(selv);
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (selv && pos < (uint32_t)KP) stage[pos] = k[e];
+            base += (uint32_t)__popcll(m);
+        }
+        ncarry = min(nvalid, kp);
+        carry = (uint32_t)lane < ncarry ? stage[lane] : ~0ull;
     }
-    if ((uint32_t)lane >= kp) best = ~0ull;
-    kept[(size_t)q * KP + lane] = best;
-    const uint32_t nkn = (uint32_t)__popcll(__ballot(best != ~0ull));
-    const uint64_t last = shfl64(best, (int)kp - 1);
+    kept[(size_t)q * KP + lane] = carry;
+    const uint64_t last = ncarry == kp ? wave_max64((uint32_t)lane < ncarry ? carry : 0ull) : ~0ull;
     if (lane == 0) {
-        nkept[q] = nkn;
+        nkept[q] = ncarry;
         subcnt[q * NSUB + 0] = 0; subcnt[q * NSUB + 1] = 0; subcnt[q * NSUB + 2] = 0; subcnt[q * NSUB + 3] = 0;
-        if (nkn == kp) {
+        if (ncarry == kp) {
             if (INTKEY) {
                 int32_t *ti = reinterpret_cast<int32_t *>(tau);
                 const int32_t nt = (int32_t)((uint32_t)(last >> 32) ^ 0x80000000u);
@@ -713,7 +804,7 @@ __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, con
             if (tau_g) atomicMin(tau_g + q, (uint32_t)(last >> 32));
         }
     }
-    return best;
+    return carry;
 }
 
 template <int MODE, bool DBG>
@@ -899,7 +990,7 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
                         const u32x4 c4 = *reinterpret_cast<const u32x4 *>(subcnt + q * NSUB);
                         if (max(max(c4.x, c4.y), max(c4.z, c4.w)) > (uint32_t)SUBHW) {
                             if ((dbg & 16) && lane == 0) atomicAdd(&dbgbuf[2], 1ull);
-                            prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g);
+                            prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, smem + LDS4_SEL + wave * SEL_SCRATCH);
                         }
                     }
                     __syncthreads();
@@ -1120,7 +1211,7 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
     for (int q = wave; q < T2; q += 8) {
         const uint32_t qg = qt * T2 + q;
         if (qg >= nq) continue;
-        const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr);
+        const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
         partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
     }
 }
@@ -1146,6 +1237,66 @@ __global__ __launch_bounds__(64) void k_bf_merge(const uint64_t *__restrict__ pa
     if (tau_out) {
         const uint64_t kth = shfl64(best, (int)kp - 1);
         if (lane == 0) tau_out[q] = (uint32_t)(kth >> 32);  // 0xFFFFFFFF when fewer than kp candidates exist
+    }
+}
+
+
+// v4 lists are UNSORTED (valid entries compacted to the front, ~0 padded).  Select-based merge: the
+// valid keys of all lists of a query are gathered into LDS (one lane per list, 64 lists at a time),
+// then one radix select yields the kp best.  Output: candidate ids (unordered) and/or the kp-th key.
+__global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict__ partial, uint32_t S, uint32_t Stot,
+                                                     uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
+                                                     uint32_t kp, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    uint64_t *stage = reinterpret_cast<uint64_t *>(smem + SEL_HIST_BYTES);
+    uint64_t *pool = reinterpret_cast<uint64_t *>(smem + SEL_SCRATCH);  // [cap]
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint64_t *p = partial + (size_t)q * Stot * KP;
+    uint32_t n = 0;       // keys in the pool (wave-uniform)
+    uint64_t T = ~0ull - 1;
+    auto reduce_pool = [&]() {  // pool -> its kp best, compacted to the front
+        if (n <= kp) return;
+        const uint32_t E = (n + kWave - 1) / kWave;
+        T = wave_kth_key<0>([&](uint32_t e) { const uint32_t i = e * kWave + lane; return i < n ? pool[i] : ~0ull; }, E, kp, hist, lane);
+        uint32_t base = 0;
+        for (uint32_t e = 0; e < E; ++e) {
+            const uint32_t i = e * kWave + lane;
+            const uint64_t k = i < n ? pool[i] : ~0ull;
+            const bool selv = k <= T;
+            const unsigned long long m = __ballot(selv);
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (selv && pos < (uint32_t)KP) stage[pos] = k;
+            base += (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        if ((uint32_t)lane < kp) pool[lane] = stage[lane];
+        n = kp;
+        __syncthreads();
+    };
+    for (uint32_t s0 = 0; s0 < S; s0 += kWave) {
+        // one lane per list: count its valid prefix (lists are short: scan until the first sentinel)
+        const uint32_t li = s0 + lane;
+        const uint64_t *lp = p + (size_t)li * KP;
+        uint32_t cnt = 0;
+        if (li < S) while (cnt < (uint32_t)KP && lp[cnt] != ~0ull) ++cnt;
+        const uint32_t inc = wave_incl_scan(cnt, lane);
+        const uint32_t tot = (uint32_t)__shfl((int)inc, 63);
+        if (n + tot > cap) reduce_pool();  // make room (cap >= kp + 64 * KP)
+        const uint32_t off = n + inc - cnt;
+        for (uint32_t j2 = 0; j2 < cnt; ++j2) pool[off + j2] = lp[j2];
+        n += tot;
+        __syncthreads();
+    }
+    reduce_pool();
+    if (cand_ids) {
+        const uint64_t k = (uint32_t)lane < n ? pool[lane] : ~0ull;
+        cand_ids[(size_t)q * KP + lane] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
+    }
+    if (tau_out) {
+        uint64_t mx = wave_max64((uint32_t)lane < n ? pool[lane] : 0ull);
+        if (lane == 0) tau_out[q] = n >= kp ? (uint32_t)(mx >> 32) : 0xFFFFFFFFu;
     }
 }
 
@@ -1398,7 +1549,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
             }
             if (i + 1 < np)
-                hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, lists, Stot, (uint32_t *)nullptr, tau_g, kp);
+                if (kernel_version() == 4) {
+                    const uint32_t cap = kp + 64 * KP;
+                    hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, lists, Stot,
+                                       (uint32_t *)nullptr, tau_g, kp, cap);
+                } else {
+                    hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, lists, Stot, (uint32_t *)nullptr, tau_g, kp);
+                }
         }
         nlists = lists;
         stot_lists = Stot;
@@ -1414,7 +1571,14 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 c[0], c[1], c[2], c[3], (double)c[4] / (p.QT * p.S), (double)c[5] / (p.QT * p.S),
                 (double)c[8] / (p.QT * p.S), (double)c[6] / (p.QT * p.S), (double)c[7] / (p.QT * p.S));
     }
-    hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, nlists, stot_lists, cand_ids, (uint32_t *)nullptr, (uint32_t)KP);
+    if (p.tile != BM && kernel_version() == 4) {
+        const uint32_t kpf = (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+        const uint32_t cap = kpf + 64 * KP;
+        hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, nlists, stot_lists, cand_ids,
+                           (uint32_t *)nullptr, kpf, cap);
+    } else {
+        hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, nlists, stot_lists, cand_ids, (uint32_t *)nullptr, (uint32_t)KP);
+    }
     ZV_HIP(hipGetLastError());
     return launch_rerank(h, d_queries, nq, cand_ids, KP, k, id_offset, d_ids, d_dist, d_count, s);
 }
