@@ -124,6 +124,12 @@ int zvdb_hip_upload_graph(zvdb_hip_index *h, const uint32_t *adj, const uint32_t
                           uint64_t n, uint32_t stride);
 int zvdb_hip_get_neighbors(zvdb_hip_index *h, uint64_t node, uint64_t *out_ids, uint32_t cap,
                            uint32_t *out_n);
+/* Batched GPU construction of the layer-0 graph (NOT reference-parity: the
+ * reference insert links one edge per layer, hnsw.zig:106-108).  Every node gets its `degree`
+ * exact nearest neighbours (by the reference distance; ties by lower id; self excluded), found
+ * with the brute-force MFMA path in batches of rows; lists are stored nearest first.  degree <=
+ * graph_stride.  `mode` = enum zvdb_bf_mode of the screen (final order is exact either way). */
+int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode);
 
 /* ---- a1/a2/a3 seam: distance(query, rows[ids]) (hnsw.zig:86,:96,:160-161) -- */
 /* out[i] = distance(query, row ids[i]) in EXACT reference arithmetic (strict

@@ -237,3 +237,32 @@ def test_greedy_layer0_seam(zv, oracle):
         # (the python loop above moves ep only after the full scan, like hnsw.zig:92-101)
         g_ep, g_dist, g_ev = idx.greedy_layer0(owner, 0, float(oracle.distance(V[owner], V[0])))
         assert (g_ep, np.float32(g_dist)) == (ep, np.float32(dist))
+
+
+def test_gpu_knn_graph_build_and_ef_search(zv, oracle):
+    """batched GPU construction of the layer-0 graph (exact kNN lists via the
+    brute-force MFMA path) + ef-mode search over it; both pinned to the oracle (exact kNN by
+    (distance, id); ef-mode spec)."""
+    n, d, M = 3000, 32, 8
+    V = oracle.uniform_rows(91, 0, n, d)
+    idx = zv.Index(m=M, flags=zv.FLAG_BF16_MIRROR)
+    idx.add(V)
+    for mode in (zv.BF_F32, zv.BF_I8):
+        idx.build_knn_graph(M, mode)
+        nn, _, _ = oracle.bruteforce_topk(V, V, M + 1)
+        ref = oracle.HNSW(M, 200)
+        for r in V:
+            ref.insert(r, 0)
+        for i in range(n):
+            want = [int(x) for x in nn[i] if int(x) != i][:M]
+            assert [int(x) for x in idx.get_neighbors(i)] == want, i
+            ref.set_neighbors(i, 0, want)
+    Q = oracle.uniform_rows(92, 0, 48, d)
+    ids, dist, cnt = idx.search_graph(Q, 10, ef=64)
+    gt, _, _ = oracle.bruteforce_topk(V, Q, 10)
+    hits = 0
+    for qi, q in enumerate(Q):
+        ri, rd = ref.search_ef(q, 10, 64)
+        assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)
+        hits += len(set(ri.tolist()) & set(gt[qi].tolist()))
+    assert hits / (10 * len(Q)) > 0.6

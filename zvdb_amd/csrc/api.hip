@@ -646,6 +646,36 @@ int zvdb_hip_search_bruteforce(zvdb_hip_index *h, const float *queries, uint32_t
     return ZVDB_OK;
 }
 
+int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_ARG(mode <= ZVDB_BF_I8, "unknown brute-force mode");
+    ZV_ARG(degree >= 1 && degree <= h->gstride, "degree must be in [1, graph_stride]");
+    if (h->count == 0) return ZVDB_OK;
+    const uint32_t k = degree + 1;  // the row itself is (one of) its own nearest
+    const uint32_t B = 1024;        // rows per search batch
+    const size_t ib = round_up64((size_t)B * k * 8, 256), db = round_up64((size_t)B * k * 4, 256);
+    const size_t cb = round_up64((size_t)B * 4, 256), qb = round_up64((size_t)B * h->dim * 4, 256);
+    const uint64_t wsb = bruteforce_workspace_bytes(h, B, k, mode);
+    ZV_CHECK(ensure_scratch(h, qb + ib + db + cb + wsb));
+    unsigned char *scr = static_cast<unsigned char *>(h->scratch);
+    float *d_q = reinterpret_cast<float *>(scr);
+    uint64_t *d_ids = reinterpret_cast<uint64_t *>(scr + qb);
+    float *d_dist = reinterpret_cast<float *>(scr + qb + ib);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(scr + qb + ib + db);
+    for (uint64_t r0 = 0; r0 < h->count; r0 += B) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(B, h->count - r0);
+        // queries = rows [r0, r0+n) as dense [n][dim]
+        ZV_HIP(hipMemcpy2DAsync(d_q, h->dim * sizeof(float), h->rows + r0 * h->ld, h->ld * sizeof(float),
+                                h->dim * sizeof(float), n, hipMemcpyDeviceToDevice, h->stream));
+        ZV_CHECK(launch_bruteforce(h, d_q, n, k, mode, 0, scr + qb + ib + db + cb, wsb, d_ids, d_dist, d_cnt, h->stream));
+        ZV_CHECK(launch_results_to_adj(h, d_ids, d_cnt, k, r0, n, degree, h->stream));
+    }
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    return ZVDB_OK;
+}
+
 int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d_count, uint32_t G,
                             uint32_t nq, uint32_t k, void *d_out_ids, void *d_out_dist,
                             void *d_out_count, void *stream) {

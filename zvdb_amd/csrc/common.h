@@ -141,6 +141,8 @@ int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld
 int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
 int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
+int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const uint32_t *d_cnt, uint32_t k,
+                          uint64_t r0, uint32_t n, uint32_t degree, hipStream_t s);
 int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,
                       uint32_t G, uint32_t nq, uint32_t k, uint64_t *o_ids, float *o_dist,
                       uint32_t *o_count, hipStream_t s);

@@ -244,6 +244,34 @@ int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
     return ZVDB_OK;
 }
 
+// kNN-graph construction: search results of rows [r0, r0+n) (ids u64 [n][k], counts) -> adjacency rows
+// (self dropped, nearest first, at most `degree` entries)
+__global__ __launch_bounds__(256) void k_results_to_adj(const uint64_t *__restrict__ ids,
+                                                        const uint32_t *__restrict__ cnt, uint32_t k,
+                                                        uint64_t r0, uint32_t n, uint32_t degree,
+                                                        uint32_t *__restrict__ adj, uint32_t *__restrict__ deg,
+                                                        uint32_t gstride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t self = r0 + i;
+    uint32_t w = 0;
+    const uint32_t c = min(cnt[i], k);
+    for (uint32_t j = 0; j < c && w < degree; ++j) {
+        const uint64_t id = ids[(size_t)i * k + j];
+        if (id != self) adj[self * gstride + w++] = (uint32_t)id;
+    }
+    deg[self] = w;
+}
+
+int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const uint32_t *d_cnt, uint32_t k,
+                          uint64_t r0, uint32_t n, uint32_t degree, hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    hipLaunchKernelGGL(k_results_to_adj, dim3((n + 255) / 256), dim3(256), 0, s, d_ids, d_cnt, k, r0, n, degree,
+                       h->adj, h->deg, h->gstride);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 // C1 consumer: global top-k of G all-gathered shard lists, order (dist, id).  One wave per
 // query; rank by counting over the <= G*k live candidates held in LDS.
 __global__ __launch_bounds__(64) void k_merge_topk(const uint64_t *__restrict__ ids,

@@ -93,6 +93,10 @@ class Index:
         check(self._L.zvdb_hip_upload_graph(self._h, adj.ctypes.data_as(_u32p), deg.ctypes.data_as(_u32p),
                                             adj.shape[0], adj.shape[1]))
 
+    def build_knn_graph(self, degree: int, mode: int = _lib.BF_F32) -> None:
+        """Batched GPU construction of the layer-0 graph: exact `degree`-NN lists."""
+        check(self._L.zvdb_hip_build_knn_graph(self._h, degree, mode))
+
     def get_neighbors(self, node: int) -> np.ndarray:
         out = np.zeros(4096, dtype=np.uint64)
         n = C.c_uint32(0)
