@@ -48,6 +48,7 @@ def parse_args():
                     help="also measure BASELINE configs[1] (1M x 128 fp32 brute force, batch 256) and the reference's own "
                          "benchmark shape (compat-mode HNSW search, 128-d, k = 10) on GPU and CPU; adds ~1-2 min")
     ap.add_argument("--extras-points", type=int, default=100_000)
+    ap.add_argument("--extras-graph-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
@@ -178,6 +179,48 @@ def extras(args, zv, torch):
         "bit_exact_vs_oracle_first_500": same,
         "reference_published": {"search_qps": 2678.13, "insert_pts_per_s": 8392.22, "source": "benchmarks/benchmark.md:102-113 (100k x 128, unstated CPU)"},
     }
+    del h, ref, gidx
+
+    # ---- graph route at scale (BASELINE configs[2] shape, reduced N): GPU-built exact 16-NN layer-0 graph,
+    # ef-mode beam search from node 0 (extension; spec = oracle), recall vs the brute-force route ------------
+    NG, DG, BG = args.extras_graph_rows, 768, 1024
+    g = zv.Index(dim=DG, capacity=NG, m=16, flags=zv.FLAG_BF16_MIRROR)
+    g.add_synthetic(NG, DG, CORPUS_SEED)
+    t0 = time.perf_counter()
+    g.build_knn_graph(16, zv.BF_I8)
+    t_build = time.perf_counter() - t0
+    qg = torch.empty((BG, DG), dtype=torch.float32, device=dev)
+    zv.fill_synthetic_dev(qg.data_ptr(), BG, DG, QUERY_SEED, 0, stream)
+    ids = torch.empty((BG, K), dtype=torch.int64, device=dev)
+    dd = torch.empty((BG, K), dtype=torch.float32, device=dev)
+    cnt = torch.empty((BG,), dtype=torch.int32, device=dev)
+    st = torch.zeros(4, dtype=torch.int64, device=dev)
+    wsb = g.bruteforce_workspace(BG, K, zv.BF_I8)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    g.search_bruteforce_dev(qg.data_ptr(), BG, DG, K, zv.BF_I8, 0, ws.data_ptr(), wsb, ids.data_ptr(), dd.data_ptr(),
+                            cnt.data_ptr(), stream)
+    torch.cuda.synchronize()
+    gt = ids.cpu().numpy().copy()
+    graph = {"rows": NG, "dim": DG, "M": 16, "batch": BG, "knn_graph_build_s": t_build,
+             "knn_graph_build_rows_per_s": NG / t_build, "ef": {}}
+    for ef in (64, 128, 256):
+        st.zero_()
+        g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, 0, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+                           st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = ids.cpu().numpy()
+        rec = float(np.mean([len(set(got[i]) & set(gt[i])) / K for i in range(BG)]))
+        ev = int(st[0].item())
+        t0 = time.perf_counter()
+        for _ in range(3):
+            g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, 0, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 3
+        bytes_q = ev / BG * DG * 4
+        graph["ef"][str(ef)] = {"qps": BG / el, "ms_per_batch": el * 1e3, "recall_at_10": rec,
+                                "dist_evals_per_query": ev / BG, "algorithmic_GBps": ev * DG * 4 / el / 1e9,
+                                "hbm_frac_of_8TBps": ev * DG * 4 / el / 8e12}
+    out["graph_route_ef_mode"] = graph
     return out
 
 
@@ -225,13 +268,14 @@ def main():
 
     ws_bytes = max(idx.bruteforce_workspace(B, K, m) for m in (zv.BF_BF16, zv.BF_F32, zv.BF_I8))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    l_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
-    l_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
-    l_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    # one packed send buffer per rank (ids u64 | dist f32 | count u32): ONE all-gather per batch
+    pk_bytes = zv.packed_result_bytes(B, K)
+    l_pack = torch.empty(pk_bytes, dtype=torch.uint8, device=dev)
+    l_ids = l_pack[:B * K * 8].view(torch.int64).view(B, K)
+    l_dist = l_pack[B * K * 8:B * K * 12].view(torch.float32).view(B, K)
+    l_cnt = l_pack[B * K * 12:B * K * 12 + B * 4].view(torch.int32)
     if dist_on:
-        g_ids = torch.empty((world * B, K), dtype=torch.int64, device=dev)   # == [G][B][K] row-major
-        g_dist = torch.empty((world * B, K), dtype=torch.float32, device=dev)
-        g_cnt = torch.empty((world * B,), dtype=torch.int32, device=dev)
+        g_pack = torch.empty(world * pk_bytes, dtype=torch.uint8, device=dev)
     o_ids = torch.empty((B, K), dtype=torch.int64, device=dev)
     o_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
     o_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -240,11 +284,9 @@ def main():
         idx.search_bruteforce_dev(q.data_ptr(), B, D, K, m, lo, ws.data_ptr(), ws_bytes, l_ids.data_ptr(),
                                   l_dist.data_ptr(), l_cnt.data_ptr(), stream)
         if dist_on:
-            dist.all_gather_into_tensor(g_ids, l_ids)
-            dist.all_gather_into_tensor(g_dist, l_dist)
-            dist.all_gather_into_tensor(g_cnt, l_cnt)
-            zv.merge_topk_dev(g_ids.data_ptr(), g_dist.data_ptr(), g_cnt.data_ptr(), world, B, K,
-                              o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), stream)
+            dist.all_gather_into_tensor(g_pack, l_pack)
+            zv.merge_topk_packed_dev(g_pack.data_ptr(), pk_bytes, world, B, K, o_ids.data_ptr(), o_dist.data_ptr(),
+                                     o_cnt.data_ptr(), stream)
             return o_ids, o_dist
         return l_ids, l_dist
 

@@ -188,6 +188,13 @@ int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d
                             uint32_t G, uint32_t nq, uint32_t k,
                             void *d_out_ids, void *d_out_dist, void *d_out_count, void *stream);
 
+/* Same merge over ONE all-gathered byte buffer: rank g's chunk starts at g * rank_stride_bytes and
+ * holds ids u64[nq*k] at offset 0, dist f32[nq*k] at nq*k*8, count u32[nq] at nq*k*12 (so a rank
+ * sends its three result arrays with a single collective). */
+int zvdb_hip_merge_topk_packed_dev(const void *d_packed, uint64_t rank_stride_bytes, uint32_t G,
+                                   uint32_t nq, uint32_t k, void *d_out_ids, void *d_out_dist,
+                                   void *d_out_count, void *stream);
+
 /* Kernel timing hook for bench.py's roofline object: the library records HIP
  * events around the dominant kernel of the last *_dev brute-force/graph call
  * on the stream it was launched on; this returns the elapsed ms of the last

@@ -1,0 +1,67 @@
+"""GPU tests of the multi-GPU data path on ONE GPU: two id-range shards as two device indexes,
+per-shard brute-force search with global id offsets (`_dev` entry points on torch-owned memory),
+the [G][nq][k] gathered layout, and the HIP k-way merge (`zvdb_hip_merge_topk_dev`) -- against
+the oracle's exact top-k over the whole corpus.  (The collective itself is covered on CPU by
+tests/test_sharded_gloo.py; RCCL needs one GPU per rank.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["f32", "i8"])
+def test_two_shards_merge_equals_global_topk(oracle, mode):
+    import torch
+    import zvdb_amd as zv
+    from zvdb_amd.sharded import shard_range
+    assert zv.device_count() > 0
+    n, d, nq, k, G = 7001, 64, 37, 10, 2
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    dev = torch.device("cuda", 0)
+    m = zv.BF_F32 if mode == "f32" else zv.BF_I8
+    q_t = torch.from_numpy(Q).to(dev)
+    g_ids = torch.empty((G * nq, k), dtype=torch.int64, device=dev)
+    g_dist = torch.empty((G * nq, k), dtype=torch.float32, device=dev)
+    g_cnt = torch.empty((G * nq,), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    keep = []
+    for r in range(G):
+        lo, hi = shard_range(n, G, r)
+        idx = zv.Index(dim=d, capacity=hi - lo, flags=zv.FLAG_BF16_MIRROR)
+        idx.add_synthetic(hi - lo, d, 0x5EED, first_row=lo)       # same global stream, shard rows
+        assert np.array_equal(idx.get_vector(0), V[lo])
+        wsb = idx.bruteforce_workspace(nq, k, m)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        idx.search_bruteforce_dev(q_t.data_ptr(), nq, d, k, m, lo, ws.data_ptr(), wsb,
+                                  g_ids[r * nq:(r + 1) * nq].data_ptr(), g_dist[r * nq:(r + 1) * nq].data_ptr(),
+                                  g_cnt[r * nq:(r + 1) * nq].data_ptr(), s)
+        keep.append((idx, ws))
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    o_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    zv.merge_topk_dev(g_ids.data_ptr(), g_dist.data_ptr(), g_cnt.data_ptr(), G, nq, k, o_ids.data_ptr(),
+                      o_dist.data_ptr(), o_cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
+    assert np.array_equal(o_ids.cpu().numpy().astype(np.uint64), ri)
+    assert np.array_equal(o_dist.cpu().numpy(), rd)
+    assert np.array_equal(o_cnt.cpu().numpy().astype(np.uint32), rc)
+    # packed single-buffer variant (what bench.py all-gathers): rank chunks = ids | dist | count
+    pb = zv.packed_result_bytes(nq, k)
+    pack = torch.zeros(G * pb, dtype=torch.uint8, device=dev)
+    for r in range(G):
+        c = pack[r * pb:(r + 1) * pb]
+        c[:nq * k * 8].view(torch.int64).copy_(g_ids[r * nq:(r + 1) * nq].reshape(-1))
+        c[nq * k * 8:nq * k * 12].view(torch.float32).copy_(g_dist[r * nq:(r + 1) * nq].reshape(-1))
+        c[nq * k * 12:nq * k * 12 + nq * 4].view(torch.int32).copy_(g_cnt[r * nq:(r + 1) * nq])
+    o_ids.zero_(); o_dist.zero_(); o_cnt.zero_()
+    zv.merge_topk_packed_dev(pack.data_ptr(), pb, G, nq, k, o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_ids.cpu().numpy().astype(np.uint64), ri) and np.array_equal(o_dist.cpu().numpy(), rd)
+    # the HIP merge equals the oracle merge on the same gathered lists (incl. a short list)
+    gi = g_ids.cpu().numpy().astype(np.uint64).reshape(G, nq, k)
+    gd = g_dist.cpu().numpy().reshape(G, nq, k)
+    gc = g_cnt.cpu().numpy().astype(np.uint32).reshape(G, nq)
+    mi, md, mc = oracle.merge_topk(gi, gd, gc, k)
+    assert np.array_equal(mi, ri) and np.array_equal(md, rd)

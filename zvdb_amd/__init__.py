@@ -8,8 +8,8 @@ There is no CPU fallback: importing the bindings without the built library raise
 from ._lib import (BF_BF16, BF_F32, BF_I8, FLAG_BF16_MIRROR, METRIC_COSINE, METRIC_DOT, METRIC_L2SQ, ZvdbError,
                    ZvdbPanic, device_count)
 from .hnsw import HNSW, Node
-from .index import Index, fill_synthetic_dev, merge_topk_dev
+from .index import Index, fill_synthetic_dev, merge_topk_dev, merge_topk_packed_dev, packed_result_bytes
 
 __all__ = ["HNSW", "Node", "Index", "ZvdbError", "ZvdbPanic", "device_count", "fill_synthetic_dev",
-           "merge_topk_dev", "METRIC_L2SQ", "METRIC_DOT", "METRIC_COSINE", "BF_F32", "BF_BF16", "BF_I8",
+           "merge_topk_dev", "merge_topk_packed_dev", "packed_result_bytes", "METRIC_L2SQ", "METRIC_DOT", "METRIC_COSINE", "BF_F32", "BF_BF16", "BF_I8",
            "FLAG_BF16_MIRROR"]

@@ -687,6 +687,20 @@ int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d
                              static_cast<uint32_t *>(d_out_count), static_cast<hipStream_t>(stream));
 }
 
+int zvdb_hip_merge_topk_packed_dev(const void *d_packed, uint64_t rank_stride_bytes, uint32_t G, uint32_t nq,
+                                   uint32_t k, void *d_out_ids, void *d_out_dist, void *d_out_count, void *stream) {
+    ZV_ARG(d_packed && d_out_ids && d_out_dist && d_out_count, "null argument");
+    ZV_ARG(G >= 1, "G must be >= 1");
+    ZV_ARG(rank_stride_bytes >= (uint64_t)nq * k * 12 + (uint64_t)nq * 4 && rank_stride_bytes % 8 == 0,
+           "rank stride too small / misaligned");
+    const unsigned char *b = static_cast<const unsigned char *>(d_packed);
+    return launch_merge_topk_strided(reinterpret_cast<const uint64_t *>(b), rank_stride_bytes,
+                                     reinterpret_cast<const float *>(b + (size_t)nq * k * 8), rank_stride_bytes,
+                                     reinterpret_cast<const uint32_t *>(b + (size_t)nq * k * 12), rank_stride_bytes, G,
+                                     nq, k, static_cast<uint64_t *>(d_out_ids), static_cast<float *>(d_out_dist),
+                                     static_cast<uint32_t *>(d_out_count), static_cast<hipStream_t>(stream));
+}
+
 int zvdb_hip_timing_enable(zvdb_hip_index *h, int enable) {
     ZV_ARG(h, "null argument");
     std::lock_guard<std::mutex> g(h->mu);

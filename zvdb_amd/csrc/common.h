@@ -147,6 +147,10 @@ int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t
                       uint32_t G, uint32_t nq, uint32_t k, uint64_t *o_ids, float *o_dist,
                       uint32_t *o_count, hipStream_t s);
 
+int launch_merge_topk_strided(const uint64_t *d_ids, uint64_t rs_ids, const float *d_dist, uint64_t rs_dist,
+                              const uint32_t *d_count, uint64_t rs_cnt, uint32_t G, uint32_t nq, uint32_t k,
+                              uint64_t *o_ids, float *o_dist, uint32_t *o_count, hipStream_t s);
+
 // ---- bruteforce.hip ---------------------------------------------------------
 uint64_t bruteforce_workspace_bytes(const zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t mode);
 int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,

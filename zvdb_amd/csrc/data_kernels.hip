@@ -274,9 +274,10 @@ int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const 
 
 // C1 consumer: global top-k of G all-gathered shard lists, order (dist, id).  One wave per
 // query; rank by counting over the <= G*k live candidates held in LDS.
-__global__ __launch_bounds__(64) void k_merge_topk(const uint64_t *__restrict__ ids,
-                                                   const float *__restrict__ dist,
-                                                   const uint32_t *__restrict__ count, uint32_t G,
+// rank g's arrays start at ids0 + g*rs_i, dist0 + g*rs_d, count0 + g*rs_c (byte strides)
+__global__ __launch_bounds__(64) void k_merge_topk(const uint64_t *__restrict__ ids0,
+                                                   const float *__restrict__ dist0,
+                                                   const uint32_t *__restrict__ count0, uint64_t rs_i, uint64_t rs_d, uint64_t rs_c, uint32_t G,
                                                    uint32_t nq, uint32_t k,
                                                    uint64_t *__restrict__ o_ids,
                                                    float *__restrict__ o_dist,
@@ -289,8 +290,11 @@ __global__ __launch_bounds__(64) void k_merge_topk(const uint64_t *__restrict__ 
     const uint32_t tot = G * k;
     for (uint32_t t = lane; t < tot; t += kWave) {
         const uint32_t g = t / k, j = t - g * k;
-        const bool live = j < count[(size_t)g * nq + qi];
-        const size_t src = ((size_t)g * nq + qi) * k + j;
+        const uint64_t *ids = reinterpret_cast<const uint64_t *>(reinterpret_cast<const unsigned char *>(ids0) + g * rs_i);
+        const float *dist = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(dist0) + g * rs_d);
+        const uint32_t *count = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(count0) + g * rs_c);
+        const bool live = j < count[qi];
+        const size_t src = (size_t)qi * k + j;
         ci[t] = live ? ids[src] : ~0ull;
         cd[t] = live ? dist[src] : __builtin_inff();
     }
@@ -326,6 +330,15 @@ __global__ __launch_bounds__(64) void k_merge_topk(const uint64_t *__restrict__ 
 int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,
                       uint32_t G, uint32_t nq, uint32_t k, uint64_t *o_ids, float *o_dist,
                       uint32_t *o_count, hipStream_t s) {
+    // separate [G][nq][k] arrays: rank stride differs per array -> express via per-array strides = 0 and
+    // pre-offset pointers is impossible; launch once per layout: ids stride nq*k*8, dist nq*k*4, count nq*4
+    return launch_merge_topk_strided(d_ids, (uint64_t)nq * k * 8, d_dist, (uint64_t)nq * k * 4, d_count,
+                                     (uint64_t)nq * 4, G, nq, k, o_ids, o_dist, o_count, s);
+}
+
+int launch_merge_topk_strided(const uint64_t *d_ids, uint64_t rs_ids, const float *d_dist, uint64_t rs_dist,
+                              const uint32_t *d_count, uint64_t rs_cnt, uint32_t G, uint32_t nq, uint32_t k,
+                              uint64_t *o_ids, float *o_dist, uint32_t *o_count, hipStream_t s) {
     if (nq == 0 || k == 0) return ZVDB_OK;
     const size_t lds = (size_t)G * k * 12;
     if (lds > 160 * 1024) {
@@ -335,8 +348,8 @@ int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t
     if (lds > 48 * 1024)
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_merge_topk),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(64), lds, s, d_ids, d_dist, d_count, G, nq, k,
-                       o_ids, o_dist, o_count);
+    hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(64), lds, s, d_ids, d_dist, d_count, rs_ids, rs_dist, rs_cnt,
+                       G, nq, k, o_ids, o_dist, o_count);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

@@ -188,3 +188,14 @@ def merge_topk_dev(ids_ptr: int, dist_ptr: int, cnt_ptr: int, G: int, nq: int, k
                    out_dist: int, out_cnt: int, stream: int = 0) -> None:
     check(_lib.hip().zvdb_hip_merge_topk_dev(ids_ptr, dist_ptr, cnt_ptr, G, nq, k, out_ids, out_dist, out_cnt,
                                              stream))
+
+
+def packed_result_bytes(nq: int, k: int) -> int:
+    """Bytes of one rank's packed result chunk (ids u64 | dist f32 | count u32), padded to 16."""
+    return (nq * k * 12 + nq * 4 + 15) // 16 * 16
+
+
+def merge_topk_packed_dev(packed_ptr: int, rank_stride: int, G: int, nq: int, k: int, out_ids: int, out_dist: int,
+                          out_cnt: int, stream: int = 0) -> None:
+    check(_lib.hip().zvdb_hip_merge_topk_packed_dev(packed_ptr, rank_stride, G, nq, k, out_ids, out_dist, out_cnt,
+                                                    stream))
