@@ -1070,37 +1070,37 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
                 }
             }
             if constexpr (PIPE) {
-            // Software pipeline across the barrier (per wave): the slice's first k-step (cc0) is read
-            // into X right after the barrier; the MFMAs of the PREVIOUS slice's second k-step (still in
-            // Y) run while those reads and the DMA issue of slice i+3 are in flight; then cc1 is read
-            // into Y behind the MFMAs of cc0.  LDS latency and DMA issue hide behind the wave's own
-            // MFMAs instead of stalling both waves of a SIMD in lockstep.
-            const unsigned char *st = smem + (islice & 3) * STAGE3;
+                // Software pipeline across the barrier (per wave): the slice's first k-step (cc0) is read
+                // into X right after the barrier; the MFMAs of the PREVIOUS slice's second k-step (still in
+                // Y) run while those reads and the DMA issue of slice i+3 are in flight; then cc1 is read
+                // into Y behind the MFMAs of cc0.  (A staggered variant that gives the two waves of a SIMD
+                // different orders was tried: hipcc then spills 300 VGPRs -- needs hand scheduling.)
+                const unsigned char *st = smem + (islice & 3) * STAGE3;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                fx_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[0]);
+                for (int mi = 0; mi < 4; ++mi)
+                    fx_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[0]);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                fx_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 256)) issue_slice((islice + 3) & 3);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt > 0 && !(dbg & 128)) mma8(fy_a, fy_b);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int ni = 0; ni < 2; ++ni)
+                    fx_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 256)) issue_slice((islice + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt > 0 && !(dbg & 128)) mma8(fy_a, fy_b);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                fy_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[1]);
+                for (int mi = 0; mi < 4; ++mi)
+                    fy_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[1]);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                fy_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 128)) mma8(fx_a, fx_b);
-            else {
+                for (int ni = 0; ni < 2; ++ni)
+                    fy_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 128)) mma8(fx_a, fx_b);
+                else {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(fx_a[mi]), "v"(fy_a[mi]));
+                    for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(fx_a[mi]), "v"(fy_a[mi]));
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) asm volatile("" :: "v"(fx_b[ni]), "v"(fy_b[ni]));
-            }
+                    for (int ni = 0; ni < 2; ++ni) asm volatile("" :: "v"(fx_b[ni]), "v"(fy_b[ni]));
+                }
             } else {
                 // fp32 / bf16: both k-steps' fragments up front (the pipelined form spills there)
                 const unsigned char *st = smem + (islice & 3) * STAGE3;
@@ -1209,6 +1209,413 @@ __global__ __launch_bounds__(512, 2) void k_bf_scan4(
         }
     }
     for (int q = wave; q < T2; q += 8) {
+        const uint32_t qg = qt * T2 + q;
+        if (qg >= nq) continue;
+        const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
+        partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
+    }
+}
+
+// k_bf_scan5: the v4 kernel generalised over the wave tile: NI = 2 -> 8 waves of 128 x 64 (two per
+// SIMD); NI = 4 -> 4 waves of 128 x 128, ONE per SIMD with the whole 512-register file (256 accumulators):
+// a third fewer LDS fragment bytes per MFMA and half the barrier participants.
+template <int MODE, bool DBG, int NI, int KBV>
+__global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_scan5(
+    const unsigned char *__restrict__ Q /* query operand */, const unsigned char *__restrict__ V /* corpus operand */,
+    uint32_t row_bytes, uint32_t KT /* KBV-byte slices per row */, const void *__restrict__ vnorm, uint32_t N,
+    uint32_t nq, int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
+    uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
+    uint32_t list_base, uint32_t Stot, uint32_t dbg_in, unsigned long long *__restrict__ dbgbuf) {
+    const uint32_t dbg = DBG ? dbg_in : 0u;  // all diagnostics compile out of the production instantiation
+    using acc_t = typename AccT<MODE>::type;
+    constexpr bool INT = MODE == 2;
+    constexpr int NW = 16 / NI;          // waves per workgroup: 8 (wave tile 128x64) or 4 (128x128, one wave per SIMD)
+    constexpr int NWN = NW / 2;          // waves along the query axis
+    constexpr int NCC = KBV / 32;        // 32-byte k-steps (one MFMA deep) per slice: 2 or 4
+    constexpr int LPR = KBV / 16;        // lanes (16-B chunks) per row of a slice
+    constexpr int RPP = 1024 / KBV;      // rows per 1-KiB DMA piece: 16 (64-B rows) or 8 (full 128-B lines)
+    constexpr int NPC = 256 / RPP / NW;  // DMA pieces per operand per wave per slice
+    constexpr int STAGE = 2 * T2 * KBV;  // 32 or 64 KiB
+    constexpr int NST = 131072 / STAGE;  // ring stages: 4 or 2
+    constexpr bool PIPE = MODE == 2 || NI == 4;  // software-pipelined fragment reads where registers allow
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS4_VN);
+    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS4_TG);
+    float *tau = reinterpret_cast<float *>(smem + LDS4_TAU);
+    uint32_t *nkept = reinterpret_cast<uint32_t *>(smem + LDS4_NK);
+    uint32_t *subcnt = reinterpret_cast<uint32_t *>(smem + LDS4_SC);
+    uint32_t *pflag = reinterpret_cast<uint32_t *>(smem + LDS4_FLAG);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;  // wm: corpus half of the tile, wn: query slice
+
+    const uint32_t b = blockIdx.x;
+    const uint32_t x = b & 7, jb = b >> 3;
+    const uint32_t qt = jb % QT;
+    const uint32_t s = (jb / QT) * 8 + x;
+    const uint32_t per = (NT + S - 1) / S;
+    // this launch covers tiles [t_first, t_first + NT) of the corpus (NT = tiles of this pass)
+    const uint32_t t_begin = t_first + min(s * per, NT), t_end = min(t_begin + per, t_first + NT);
+    const uint32_t ntiles = t_end - t_begin;
+    uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
+
+    uint64_t *kept = cand + (size_t)b * BLK4_ENTRIES;
+    uint64_t *subs = kept + BLK4_KEPT;
+    for (int tq = tid; tq < T2; tq += NW * 64) {
+        const int tid_q = tq;
+        const bool live = (qt * T2 + tid_q) < nq;
+        // screen key of (query, row) = -(q.v - |v|^2/2) = d'/2 (L2) or -q.v (dot): tau lives in that domain.
+        // int: live rows satisfy acc >= -2^29 (dim <= 16384), rows past N start at -2^30: tau0 = 0x30000000
+        // lets every live row pass and no padded one.
+        // start from the shared threshold of the previous pass (if any): pass <=> key < next_up(tau_G)
+        const uint32_t g = (tau_g && live) ? __hip_atomic_load(tau_g + tid_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : 0xFFFFFFFFu;
+        if (INT) {
+            int32_t t0 = live ? 0x30000000 : -0x7FFFFFFF;
+            if (g != 0xFFFFFFFFu) { const int32_t gv = (int32_t)(g ^ 0x80000000u); t0 = min(t0, gv == 0x7FFFFFFF ? gv : gv + 1); }
+            reinterpret_cast<int32_t *>(tau)[tid_q] = t0;
+        } else {
+            float t0 = live ? __builtin_inff() : -__builtin_inff();
+            if (g != 0xFFFFFFFFu) t0 = fminf(t0, f32_unkey(g + 1));
+            tau[tid_q] = t0;
+        }
+        nkept[tid_q] = 0;
+    }
+    for (int i = tid; i < T2 * NSUB; i += NW * 64) subcnt[i] = 0;
+    if (tid == 0) { pflag[0] = 0; pflag[1] = 0; }
+
+    // ---- DMA issue side: A region <- corpus tile, B region <- my query tile ------------------
+    const unsigned char *q_base = Q + (size_t)qt * T2 * row_bytes;
+    auto swz = [](uint32_t r) -> uint32_t { return KBV == 64 ? ((r >> 2) & 3) : ((r >> 1) & 7); };
+    const uint32_t prow = RPP * NPC * wave + lane / LPR;  // + RPP*i : LDS row this lane fills
+    uint32_t q_off[NPC], c_off[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const uint32_t r = prow + RPP * i;
+        q_off[i] = r * row_bytes + ((((uint32_t)lane % LPR) ^ swz(r)) << 4);
+    }
+    uint32_t it = t_begin, ikt = 0;
+    auto issue_slice = [&](uint32_t stage_idx) {
+        const uint32_t tcl = min(it, t_end - 1);
+        const uint32_t col0 = tcl * T2;
+        if (ikt == 0) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const uint32_t r = prow + RPP * i;
+                const uint32_t rc = min(r, N - 1 - col0);
+                c_off[i] = rc * row_bytes + ((((uint32_t)lane % LPR) ^ swz(r)) << 4);
+            }
+            if (tau_g && (NW == 4 || wave >= 4) && it < t_end) {
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)(tau_g + 64 * (wave & 3) + lane),
+                    (lptr_t)(reinterpret_cast<unsigned char *>(tg_lds) + ((it - t_begin) & 3) * T2 * 4 + (wave & 3) * 256),
+                    4, 0, 16);
+            }
+            if (vnorm && wave < 4 && it < t_end) {
+                const uint32_t c = min(col0 + 64 * wave + lane, N - 1);
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)(reinterpret_cast<const unsigned char *>(vnorm) + (size_t)c * 4),
+                    (lptr_t)(reinterpret_cast<unsigned char *>(vn_lds) + ((it - t_begin) & 3) * T2 * 4 + wave * 256), 4, 0, 0);
+            }
+        }
+        unsigned char *dst = smem + stage_idx * STAGE;
+        const unsigned char *cp = V + (size_t)col0 * row_bytes + (size_t)ikt * KBV;
+        const unsigned char *qp = q_base + (size_t)ikt * KBV;
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(cp + c_off[i]),
+                                             (lptr_t)(dst + (NPC * wave + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(qp + q_off[i]),
+                                             (lptr_t)(dst + T2 * KBV + (NPC * wave + i) * 1024), 16, 0, 0);
+        }
+        if (++ikt == KT) {
+            ikt = 0;
+            if (it < t_end) ++it;
+        }
+    };
+
+    const uint32_t fr = lane & 31, fh = lane >> 5;
+    uint32_t f_off[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) f_off[cc] = fr * KBV + ((((uint32_t)(2 * cc) + fh) ^ swz(fr)) << 4);
+
+    // the lane's two queries and its private sub-buffers
+    const uint32_t sub_id = wm * 2 + fh;
+    uint32_t ql[NI];
+    uint64_t *sbuf[NI];
+    uint32_t sc_addr[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        ql[ni] = wn * (32 * NI) + ni * 32 + fr;
+        sbuf[ni] = subs + ((size_t)ql[ni] * NSUB + sub_id) * SUBCAP;
+        sc_addr[ni] = (uint32_t)(size_t)(lptr_t)(subcnt + ql[ni] * NSUB + sub_id);
+    }
+    const uint32_t rbase = wm * 128 + 4 * fh;  // corpus row of accumulator register (mi, r): rbase + mi*32 + (r&3) + 8*(r>>2)
+    const uint32_t pflag_lds_addr = (uint32_t)(size_t)(lptr_t)pflag;
+
+    if (ntiles > 0) {
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i) issue_slice(i);
+    }
+    __syncthreads();  // state arrays initialised (plain LDS stores) before anyone reads them
+    uint32_t islice = 0;
+    unsigned long long tk0 = 0, t_round = 0, t_phb = 0, t_pha = 0, n_round = 0;
+    if (dbg & 32) tk0 = __builtin_amdgcn_s_memtime();
+
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        const uint32_t col0 = t * T2;
+        const uint32_t *vn_t = vn_lds + ((t - t_begin) & 3) * T2;
+        acc_t acc[4][NI];
+        u32x4 fx_a[4], fx_b[NI], fy_a[4], fy_b[NI];
+        auto mma8 = [&](const u32x4 (&a4)[4], const u32x4 (&b2)[NI]) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (MODE == 1) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4[mi]),
+                                                                              __builtin_bit_cast(bf16x8, b2[ni]), acc[mi][ni], 0, 0, 0);
+                    } else if constexpr (MODE == 2) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a4[mi]),
+                                                                            __builtin_bit_cast(i32x4, b2[ni]), acc[mi][ni], 0, 0, 0);
+                    } else {
+                        const f32x4 xa = __builtin_bit_cast(f32x4, a4[mi]);
+                        const f32x4 xb = __builtin_bit_cast(f32x4, b2[ni]);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc[mi][ni], 0, 0, 0);
+                    }
+                }
+        };
+        uint32_t thr[NI];   // fp: bits of the accumulator bound; int: tau
+        uint32_t cntr[NI], cnt0[NI];
+
+        for (uint32_t kt = 0; kt < KT; ++kt, ++islice) {
+            // slice `islice` has landed once at most this wave's (NST-2) youngest slices' DMA ops are pending
+            if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt == 0) {
+                // prune ROUND: batched so that all 8 waves have queries to merge (a round stalls the
+                    // whole pipeline); started when enough sub-buffers crossed the soft mark or one is
+                    // close to its capacity (a tile adds at most 64 entries to a sub-buffer)
+                if (pflag[0] != 0 || pflag[1] >= (uint32_t)PTHRESH) {
+                    unsigned long long ts = 0;
+                    if (dbg & 32) ts = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everyone's appends are complete
+                    __builtin_amdgcn_s_barrier();                     // ... and everyone has read the flags
+                    if (tid == 0) { pflag[0] = 0; pflag[1] = 0; }
+                    for (int q = wave; q < T2; q += NW) {
+                        const u32x4 c4 = *reinterpret_cast<const u32x4 *>(subcnt + q * NSUB);
+                        if (max(max(c4.x, c4.y), max(c4.z, c4.w)) > (uint32_t)SUBHW) {
+                            if ((dbg & 16) && lane == 0) atomicAdd(&dbgbuf[2], 1ull);
+                            prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, smem + LDS4_SEL + wave * SEL_SCRATCH);
+                        }
+                    }
+                    __syncthreads();
+                    if (dbg & 32) { t_round += __builtin_amdgcn_s_memtime() - ts; n_round += 1; }
+                }
+                for (int tq = tid; tau_g && tq < T2; tq += NW * 64) {  // fold the shared threshold (see v3)
+                    const int tid_f = tq;
+                    const uint32_t g = tg_lds[((t - t_begin) & 3) * T2 + tid_f];
+                    if (g != 0xFFFFFFFFu) {
+                        uint32_t nb;
+                        bool tighter;
+                        if (INT) {
+                            const int32_t gv = (int32_t)(g ^ 0x80000000u);
+                            const int32_t bv = gv == 0x7FFFFFFF ? gv : gv + 1;
+                            tighter = bv < reinterpret_cast<int32_t *>(tau)[tid_f];
+                            nb = (uint32_t)bv;
+                        } else {
+                            const float bv = f32_unkey(g + 1);
+                            tighter = bv < tau[tid_f];
+                            nb = __float_as_uint(bv);
+                        }
+                        if (tighter) {
+                            const uint32_t addr = (uint32_t)(size_t)(lptr_t)(tau + tid_f);
+                            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(nb) : "memory");
+                        }
+                    }
+                }
+                // per-lane selection state for this tile
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    cntr[ni] = subcnt[ql[ni] * NSUB + sub_id];
+                    cnt0[ni] = cntr[ni];
+                    // pass <=> key < tau <=> acc > -tau
+                    if constexpr (INT) thr[ni] = (uint32_t)(-reinterpret_cast<const int32_t *>(tau)[ql[ni]]);
+                    else thr[ni] = __float_as_uint(-tau[ql[ni]]);
+                }
+                // accumulator init = -|v|^2/2 of the register's corpus row (fp) / -(|v|^2 >> 1) (int; the
+                // dropped parity bit perturbs the int screen by < 1 unit and equally for equal rows);
+                // rows past N start at -inf / -2^30 and can never pass.  The finished accumulator IS the
+                // negated screen key, so the selection test is one compare per element.
+                const bool full_tile = col0 + T2 <= N;  // wave-uniform: only the corpus' last tile is ragged
+                if (full_tile) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        acc_t init;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            u32x4 v4 = {0, 0, 0, 0};
+                            if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rbase + mi * 32 + 8 * g);
+#pragma unroll
+                            for (int j2 = 0; j2 < 4; ++j2) {
+                                if constexpr (INT) init[4 * g + j2] = -((int)v4[j2] >> 1);
+                                else init[4 * g + j2] = -0.5f * __uint_as_float(v4[j2]);
+                            }
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = init;
+                    }
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        acc_t init;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const uint32_t rl = rbase + mi * 32 + 8 * g;
+                            u32x4 v4 = {0, 0, 0, 0};
+                            if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rl);
+#pragma unroll
+                            for (int j2 = 0; j2 < 4; ++j2) {
+                                const bool ok = (col0 + rl + j2) < N;
+                                if constexpr (INT) init[4 * g + j2] = ok ? -((int)v4[j2] >> 1) : -0x40000000;
+                                else init[4 * g + j2] = ok ? -0.5f * __uint_as_float(v4[j2]) : -__builtin_inff();
+                            }
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = init;
+                    }
+                }
+            }
+            // generic k-step pipeline over the slice's NCC 32-byte steps: fragments of step j+1 are read
+            // (alternating register sets X / Y) while step j is multiplied; the last step's MFMAs are
+            // deferred behind the next slice's barrier, reads and DMA issue (PIPE) or run at once.
+            const unsigned char *st = smem + (islice % NST) * STAGE;
+            auto read_set = [&](u32x4 (&fa)[4], u32x4 (&fb)[NI], int cc) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    fa[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KBV + f_off[cc]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    fb[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KBV + (wn * (32 * NI) + ni * 32) * KBV + f_off[cc]);
+            };
+            read_set(fx_a, fx_b, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 256)) issue_slice((islice + NST - 1) % NST);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PIPE && kt > 0 && !(dbg & 128)) mma8(fy_a, fy_b);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 1; cc < NCC; ++cc) {
+                if (cc & 1) read_set(fy_a, fy_b, cc); else read_set(fx_a, fx_b, cc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 128)) { if (cc & 1) mma8(fx_a, fx_b); else mma8(fy_a, fy_b); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!PIPE && !(dbg & 128)) mma8(fy_a, fy_b);
+            if (dbg & 128) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(fx_a[mi]), "v"(fy_a[mi]));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) asm volatile("" :: "v"(fx_b[ni]), "v"(fy_b[ni]));
+            }
+        }
+        if constexpr (PIPE) {
+            if (!(dbg & 128)) mma8(fy_a, fy_b);  // flush the tile's last k-step
+        }
+
+        // ---- fused selection epilogue: registers only on the common path -----------------------
+        if (!(dbg & 1)) {
+            unsigned long long te0 = 0;
+            if (dbg & 32) te0 = __builtin_amdgcn_s_memtime();
+            // Phase A: per 32x32 fragment, the lane's maximum over its 16 accumulator registers
+            // (v_max3) against the lane's bound: 8 compares + 8 mask tests per tile on the common path.
+            unsigned long long fany[4][NI];
+            unsigned long long any = 0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (INT) {
+                        int m = acc[mi][ni][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) m = max(m, acc[mi][ni][r]);
+                        fany[mi][ni] = __ballot(m > (int)thr[ni]);
+                    } else {
+                        float m = acc[mi][ni][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
+                        fany[mi][ni] = __ballot(m > __uint_as_float(thr[ni]));
+                    }
+                    any |= fany[mi][ni];
+                }
+            if (dbg & 32) { const unsigned long long x2 = __builtin_amdgcn_s_memtime(); t_pha += x2 - te0; te0 = x2; }
+            if (dbg & 16) { if (lane == 0) { atomicAdd(&dbgbuf[0], 1ull); if (any) atomicAdd(&dbgbuf[1], 1ull); } }
+            if (any && !(dbg & 4)) {
+                // Phase B: only fragments in which some lane passed are walked element by element
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if (fany[mi][ni] == 0) continue;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            bool pass;
+                            if constexpr (INT) pass = acc[mi][ni][r] > (int)thr[ni];
+                            else pass = acc[mi][ni][r] > __uint_as_float(thr[ni]);
+                            if (pass) {
+                                uint32_t keyhi;
+                                if constexpr (INT) keyhi = (uint32_t)(-acc[mi][ni][r]) ^ 0x80000000u;
+                                else keyhi = f32_key(-acc[mi][ni][r]);
+                                const uint32_t id = col0 + rbase + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                if (cntr[ni] < (uint32_t)SUBCAP) sbuf[ni][cntr[ni]] = ((uint64_t)keyhi << 32) | id;
+                                cntr[ni] += 1;
+                                if (dbg & 16) atomicAdd(&dbgbuf[3], 1ull);
+                            }
+                        }
+                    }
+                // publish the fills; request a prune when a sub-buffer passed its high-water mark
+uint32_t ncross = 0;
+                bool urgent = false;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    asm volatile("ds_write_b32 %0, %1" :: "v"(sc_addr[ni]), "v"(cntr[ni]) : "memory");
+                    ncross += (uint32_t)(cnt0[ni] <= (uint32_t)SUBHW && cntr[ni] > (uint32_t)SUBHW);
+                    urgent |= cntr[ni] > (uint32_t)SUBURG;
+                }
+                if (ncross) {
+                    const uint32_t a1 = pflag_lds_addr + 4;
+                    asm volatile("ds_add_u32 %0, %1" :: "v"(a1), "v"(ncross) : "memory");
+                }
+                if (urgent) {
+                    const uint32_t one = 1;
+                    asm volatile("ds_write_b32 %0, %1" :: "v"(pflag_lds_addr), "v"(one) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (dbg & 32) t_phb += __builtin_amdgcn_s_memtime() - te0;
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (dbg & 32) {
+        if (tid == 0) {
+            atomicAdd(&dbgbuf[4], __builtin_amdgcn_s_memtime() - tk0);
+            atomicAdd(&dbgbuf[5], t_round);
+            atomicAdd(&dbgbuf[6], t_pha);
+            atomicAdd(&dbgbuf[7], t_phb);
+            atomicAdd(&dbgbuf[8], n_round);
+        }
+    }
+    for (int q = wave; q < T2; q += NW) {
         const uint32_t qg = qt * T2 + q;
         if (qg >= nq) continue;
         const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
@@ -1334,14 +1741,21 @@ struct BfPlan {
     uint64_t off_q, off_cand, off_partial, off_ids, off_taug, total;
 };
 
-int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v3 | v4 (default): older generations kept for A/B
+int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v3 | v4 | v6 (default): older generations kept for A/B.
+    // v6 = v4 with full-line (8 rows x 128 B) LDS-DMA pieces, 128-byte slices and a 2-stage ring; it shares
+    // every host-side path with v4, so kernel_version() reports 4 for both and is_v6() tells them apart.
     static const int v = [] {
         const char *e = getenv("ZVDB_BF_KERNEL");
+        if (e && e[0] == 'v' && e[1] == '6') return 4;
         return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? e[1] - '0' : 4;
     }();
     return v;
 }
 bool use_v1() { return kernel_version() == 1; }
+bool is_v6() {
+    static const bool v = [] { const char *e = getenv("ZVDB_BF_KERNEL"); return !e || (e[0] == 'v' && e[1] == '6'); }();
+    return v;
+}
 uint32_t debug_flags() {
     static const uint32_t f = [] {
         const char *e = getenv("ZVDB_BF_DEBUG");
@@ -1398,6 +1812,37 @@ int launch_scan4(const BfPlan &p, const unsigned char *q_op, const unsigned char
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         hipLaunchKernelGGL((k_bf_scan4<MODE, false>), dim3(p.QT * p.S), dim3(512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
+                           list_base, Stot, 0u, dbgbuf);
+    }
+    return ZVDB_OK;
+}
+
+int wave_tile_ni() {
+    static const int v = [] { const char *e = getenv("ZVDB_BF_NI"); return (e && e[0] == '4') ? 4 : 2; }();
+    return v;
+}
+
+int slice_bytes() {
+    static const int v = [] { const char *e = getenv("ZVDB_BF_KBV"); return (e && e[0] == '6') ? 64 : 128; }();
+    return v;
+}
+
+template <int MODE, int NI, int KBV>
+int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
+                 uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
+                 uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, hipStream_t s) {
+    unsigned long long *dbgbuf = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);
+    if (debug_flags()) {
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, true, NI, KBV>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        hipLaunchKernelGGL((k_bf_scan5<MODE, true, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
+                           p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
+                           (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, debug_flags(), dbgbuf);
+    } else {
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, false, NI, KBV>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        hipLaunchKernelGGL((k_bf_scan5<MODE, false, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
+                           p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
                            list_base, Stot, 0u, dbgbuf);
     }
     return ZVDB_OK;
@@ -1525,6 +1970,16 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         auto scan = [&](const Pass &ps, uint32_t list_base) -> int {
             BfPlan q = p;
             q.S = ps.S;
+            if (kernel_version() == 4 && wave_tile_ni() == 4) {  // experimental: one wave per SIMD
+                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                if (mode == ZVDB_BF_I8) return launch_scan5<2, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                return launch_scan5<0, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+            }
+            if (kernel_version() == 4 && is_v6()) {  // default: full-line DMA pieces, 2-stage ring
+                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                return launch_scan5<0, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+            }
             if (kernel_version() == 4) {
                 if (mode == ZVDB_BF_BF16) return launch_scan4<1>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
                 if (mode == ZVDB_BF_I8) return launch_scan4<2>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
