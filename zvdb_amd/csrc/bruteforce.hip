@@ -314,353 +314,10 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 template <int MODE> struct AccT { using type = f32x16; };
 template <> struct AccT<2> { using type = i32x16; };
 
-// =====================================================================================
-// v3 scan: the v2 tile (256 x 256, 8 waves 2x4, LDS-DMA) with a DEEPER operand pipeline.
-// K is walked in 64-byte row slices; four 32 KiB LDS stages form a ring with three slices
-// (96 KiB) in flight behind the one being multiplied, so an L2/HBM round trip (1-2 us under
-// load) is covered by ~3 slices of MFMA work instead of one.  Hand-off uses a COUNTED
-// s_waitcnt vmcnt(8) (this wave's 2 youngest slices may still be in flight) + a raw s_barrier;
-// nothing in the steady-state loop drains the VMEM queue: |v|^2 of the tile's 256 columns also
-// arrives by LDS-DMA, and the epilogue's appends are plain stores.  The DMA stream runs past
-// the end of the block's work (dummy re-reads) so the wait count is the same for every slice.
-// LDS image per operand and stage: [256 rows][64 B], 16-B chunk c of row r stored at slot
-// c ^ ((r>>2)&3) (conflict-free ds_read_b128: 16 consecutive rows hit 16 distinct slots);
-// the swizzle is applied to the per-lane SOURCE chunk (LDS-DMA writes lane-linear).
-// =====================================================================================
+// ring geometry shared by the 64-byte-slice variants
 constexpr int KB3 = 64;                       // bytes of every row per slice
 constexpr int STAGE3 = 2 * T2 * KB3;          // A + B = 32 KiB
 constexpr int NSTAGE3 = 4;
-constexpr int LDS3_VN = NSTAGE3 * STAGE3;     // vn[4][256] fp32/int32: the DMA runs up to 3 tiles ahead
-constexpr int LDS3_TG = LDS3_VN + 4 * T2 * 4;      // tg[4][256]: shared-threshold keys, DMA'd per tile
-constexpr int LDS3_STATE = LDS3_TG + 4 * T2 * 4;
-constexpr int LDS3 = LDS3_STATE + 3 * T2 * 4 + 16;  // tau, cnt, nsorted, prune flag
-
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void k_bf_scan3(
-    const unsigned char *__restrict__ A, const unsigned char *__restrict__ B, uint32_t row_bytes,
-    uint32_t KT /* 64-B slices per row */, const void *__restrict__ vnorm, uint32_t N, uint32_t nq,
-    int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
-    uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g, uint32_t t_first, uint32_t list_base,
-    uint32_t Stot, uint32_t dbg) {
-    using acc_t = typename AccT<MODE>::type;
-    constexpr bool INT = MODE == 2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS3_VN);   // [4][T2]
-    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS3_TG);   // [4][T2]
-    float *tau = reinterpret_cast<float *>(smem + LDS3_STATE);          // [T2]
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(tau + T2);             // [T2]
-    uint32_t *nsorted = cnt + T2;                                       // [T2]
-    uint32_t *pflag = nsorted + T2;                                     // [1]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const uint32_t b = blockIdx.x;
-    const uint32_t x = b & 7, jb = b >> 3;
-    const uint32_t qt = jb % QT;
-    const uint32_t s = (jb / QT) * 8 + x;
-    const uint32_t per = (NT + S - 1) / S;
-    // this launch covers tiles [t_first, t_first + NT) of the corpus (NT = tiles of this pass)
-    const uint32_t t_begin = t_first + min(s * per, NT), t_end = min(t_begin + per, t_first + NT);
-    const uint32_t ntiles = t_end - t_begin;
-
-    uint64_t *mybuf = cand + (size_t)b * T2 * CAP2;
-    if (tid < T2) {
-        const bool live = (qt * T2 + tid) < nq;
-        if (INT) reinterpret_cast<int32_t *>(tau)[tid] = live ? 0x7FFFFFFF : (int32_t)0x80000000;
-        else tau[tid] = live ? __builtin_inff() : -__builtin_inff();
-        cnt[tid] = 0;
-        nsorted[tid] = 0;
-    }
-    if (tid == 0) pflag[0] = 0;
-
-    // ---- DMA issue side -------------------------------------------------------------
-    // per slice and operand 16 pieces of 16 rows x 64 B; wave w issues pieces 2w, 2w+1
-    const unsigned char *a_base = A + (size_t)qt * T2 * row_bytes;
-    const uint32_t prow = 32 * wave + (lane >> 2);  // + 16*i : LDS row this lane fills
-    uint32_t a_off[2], b_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t r = prow + 16 * i;
-        a_off[i] = r * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
-    }
-    uint32_t it = t_begin, ikt = 0;      // next slice to issue (tile, k slice)
-    auto issue_slice = [&](uint32_t stage_idx) {
-        const uint32_t tcl = min(it, t_end - 1);               // past the end: dummy re-read
-        const uint32_t col0 = tcl * T2;
-        if (ikt == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t r = prow + 16 * i;
-                const uint32_t rc = min(r, N - 1 - col0);       // rows past N: clamp (masked later)
-                b_off[i] = rc * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
-            }
-            if (tau_g && wave >= 4 && it < t_end) {             // shared thresholds of my 256 queries
-                // sc1: served from L2, never from a stale L1 line (other CUs publish with atomics)
-                __builtin_amdgcn_global_load_lds(
-                    (gptr_t)(tau_g + (size_t)qt * T2 + 64 * (wave - 4) + lane),
-                    (lptr_t)(reinterpret_cast<unsigned char *>(tg_lds) + ((it - t_begin) & 3) * T2 * 4 + (wave - 4) * 256),
-                    4, 0, 16);
-            }
-            if (vnorm && wave < 4 && it < t_end) {              // |v|^2 of the tile's 256 columns
-                const uint32_t c = min(col0 + 64 * wave + lane, N - 1);
-                __builtin_amdgcn_global_load_lds(
-                    (gptr_t)(reinterpret_cast<const unsigned char *>(vnorm) + (size_t)c * 4),
-                    (lptr_t)(reinterpret_cast<unsigned char *>(vn_lds) + ((it - t_begin) & 3) * T2 * 4 + wave * 256), 4, 0, 0);
-            }
-        }
-        unsigned char *dst = smem + stage_idx * STAGE3;
-        const unsigned char *ap = a_base + (size_t)ikt * KB3;
-        const unsigned char *bp = B + (size_t)col0 * row_bytes + (size_t)ikt * KB3;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(ap + a_off[i]),
-                                             (lptr_t)(dst + (2 * wave + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(bp + b_off[i]),
-                                             (lptr_t)(dst + T2 * KB3 + (2 * wave + i) * 1024), 16, 0, 0);
-        }
-        if (++ikt == KT) {
-            ikt = 0;
-            if (it < t_end) ++it;
-        }
-    };
-
-    // fragment reads: lane -> row (l&31), chunk 2*cc + (l>>5) of the 4 chunks, swizzled
-    const uint32_t fr = lane & 31, fh = lane >> 5;
-    uint32_t f_off[2];
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) f_off[cc] = fr * KB3 + ((((uint32_t)(2 * cc) + fh) ^ ((fr >> 2) & 3)) << 4);
-
-    if (ntiles > 0) {
-        issue_slice(0);
-        issue_slice(1);
-        issue_slice(2);
-    }
-    uint32_t islice = 0;  // slice being consumed (ring stage = islice & 3)
-
-    for (uint32_t t = t_begin; t < t_end; ++t) {
-        const uint32_t col0 = t * T2;
-        const uint32_t *vn_t = vn_lds + ((t - t_begin) & 3) * T2;
-        acc_t acc[4][2];
-
-        for (uint32_t kt = 0; kt < KT; ++kt, ++islice) {
-            // slice `islice` has landed once at most this wave's 8 youngest VMEM ops are pending
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt == 0) {  // tile start: a buffer crossed its high-water mark last tile?
-                if (pflag[0] != 0) {
-                    // rare path: every wave's appends must be complete (and the flag read) before
-                    // any wave reads the buffers
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (tid == 0) pflag[0] = 0;
-                    for (int row = wave; row < T2; row += 8)
-                        if (cnt[row] > (uint32_t)HW) {
-                            if ((dbg & 16) && lane == 0) atomicAdd(&partial[2], 1ull);
-                            prune_row<CAP2, INT>(mybuf + (size_t)row * CAP2, cnt, nsorted, tau, row, lane,
-                                                 tau_g ? tau_g + (size_t)qt * T2 + row : nullptr);
-                        }
-                    __syncthreads();
-                }
-                // fold the shared threshold into the local bound: pass <=> d < min(tau_local, next_up(tau_G))
-                // (non-strict on tau_G: an equal distance in ANOTHER stream may carry a lower id).
-                // Benign race with other waves' epilogue reads: both old and new are valid bounds.
-                if (tau_g && tid < T2) {
-                    const uint32_t g = tg_lds[((t - t_begin) & 3) * T2 + tid];
-                    if (g != 0xFFFFFFFFu) {
-                        uint32_t nb;
-                        bool tighter;
-                        if (INT) {
-                            const int32_t gv = (int32_t)(g ^ 0x80000000u);
-                            const int32_t bv = gv == 0x7FFFFFFF ? gv : gv + 1;
-                            tighter = bv < reinterpret_cast<int32_t *>(tau)[tid];
-                            nb = (uint32_t)bv;
-                        } else {
-                            const float bv = f32_unkey(g + 1);
-                            tighter = bv < tau[tid];
-                            nb = __float_as_uint(bv);
-                        }
-                        if (tighter) {
-                            const uint32_t addr = (uint32_t)(size_t)(lptr_t)(tau + tid);
-                            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(nb) : "memory");
-                        }
-                    }
-                }
-                // accumulator init.  fp modes: acc starts at -|v|^2/2 of its column (|v|^2 arrived by
-                // LDS-DMA with this tile's first slice), so the finished accumulator is q.v - |v|^2/2 =
-                // -d'/2 and the selection test is ONE compare per element: acc > -tau/2.  Columns past
-                // N start at -inf and can never pass.
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const uint32_t cl = wn * 64 + ni * 32 + fr;
-                    acc_t init;
-                    if constexpr (INT) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) init[r] = 0;
-                    } else {
-                        const float v0 = (col0 + cl) < N ? (vnorm ? -0.5f * __uint_as_float(vn_t[cl]) : 0.0f)
-                                                         : -__builtin_inff();
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) init[r] = v0;
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = init;
-                }
-            }
-            issue_slice((islice + 3) & 3);
-            const unsigned char *st = smem + (islice & 3) * STAGE3;
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                u32x4 fa[4], fb[2];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    fa[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[cc]);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    fb[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[cc]);
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        if constexpr (MODE == 1) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
-                                acc[mi][ni], 0, 0, 0);
-                        } else if constexpr (MODE == 2) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(
-                                __builtin_bit_cast(i32x4, fa[mi]), __builtin_bit_cast(i32x4, fb[ni]),
-                                acc[mi][ni], 0, 0, 0);
-                        } else {
-                            const f32x4 xa = __builtin_bit_cast(f32x4, fa[mi]);
-                            const f32x4 xb = __builtin_bit_cast(f32x4, fb[ni]);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc[mi][ni], 0, 0, 0);
-                        }
-                    }
-            }
-        }
-
-        // ---- fused selection epilogue (three slices of the next tile are in flight) -----------
-        // Phase A is branch-free: one compare per element (fp) and an OR of the lane masks; phase B
-        // (the appends) only runs when some lane of the wave passed something in this tile.
-        if (!(dbg & 1)) {
-            const uint32_t qb = wm * 128 + 4 * fh;
-            const uint32_t cnt_lds_addr = (uint32_t)(size_t)(lptr_t)cnt;
-            const uint32_t pflag_lds_addr = (uint32_t)(size_t)(lptr_t)pflag;
-            // fp: scale = alpha/2 * -2 ... the finished accumulator a = q.v - |v|^2/2 (L2, alpha = -2)
-            // or a = q.v (dot, alpha = -1): d' = fscale * a with fscale = -2 or -1; pass <=> a > tau / fscale
-            const float fscale = (float)alpha_i;
-            const float finv = 1.0f / fscale;  // -0.5 or -1: exact
-            int vni[2];
-            bool colok[2];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const uint32_t cl = wn * 64 + ni * 32 + fr;
-                colok[ni] = (col0 + cl) < N;
-                vni[ni] = (INT && vnorm) ? (int)vn_t[cl] : 0;
-            }
-            unsigned long long any = 0;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const u32x4 t4 = *reinterpret_cast<const u32x4 *>(tau + qb + mi * 32 + 8 * g);
-#pragma unroll
-                    for (int j2 = 0; j2 < 4; ++j2) {
-                        const int r = 4 * g + j2;
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            bool pass;
-                            if constexpr (INT) pass = colok[ni] && (vni[ni] + alpha_i * acc[mi][ni][r]) < (int)t4[j2];
-                            else pass = acc[mi][ni][r] > __uint_as_float(t4[j2]) * finv;
-                            any |= __ballot(pass);
-                        }
-                    }
-                }
-            }
-            if (dbg & 16) { if (lane == 0) { atomicAdd(&partial[0], 1ull); if (any) atomicAdd(&partial[1], 1ull); } }
-            if (any && !(dbg & 4)) {
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const u32x4 t4 = *reinterpret_cast<const u32x4 *>(tau + qb + mi * 32 + 8 * g);
-#pragma unroll
-                        for (int j2 = 0; j2 < 4; ++j2) {
-                            const int r = 4 * g + j2;
-#pragma unroll
-                            for (int ni = 0; ni < 2; ++ni) {
-                                bool pass;
-                                uint32_t keyhi;
-                                if constexpr (INT) {
-                                    const int d = vni[ni] + alpha_i * acc[mi][ni][r];
-                                    pass = colok[ni] && d < (int)t4[j2];
-                                    keyhi = (uint32_t)d ^ 0x80000000u;
-                                } else {
-                                    pass = acc[mi][ni][r] > __uint_as_float(t4[j2]) * finv;
-                                    keyhi = __float_as_uint(acc[mi][ni][r] * fscale);
-                                }
-                                if (pass) {
-                                    uint32_t qrow = qb + mi * 32 + 8 * g + j2;
-                                    asm volatile("" : "+v"(qrow));
-                                    if constexpr (!INT) keyhi = f32_key(__uint_as_float(keyhi));
-                                    const uint32_t col = col0 + wn * 64 + ni * 32 + fr;
-                                    uint32_t slot;
-                                    {
-                                        const uint32_t addr = cnt_lds_addr + qrow * 4, one = 1;
-                                        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                                     : "=&v"(slot) : "v"(addr), "v"(one) : "memory");
-                                    }
-                                    if (dbg & 16) atomicAdd(&partial[3], 1ull);
-                                    if (slot < (uint32_t)CAP2)
-                                        mybuf[(size_t)qrow * CAP2 + slot] = ((uint64_t)keyhi << 32) | col;
-                                    if (slot >= (uint32_t)HW) {
-                                        const uint32_t one = 1;
-                                        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                                                     :: "v"(pflag_lds_addr), "v"(one) : "memory");
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-
-    // drain the DMA ring (dummy slices included) before the LDS is released / state is read
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (dbg & 16) return;  // counting run: partial[0..3] hold {wave-tiles, wave-tiles with a pass, prunes, appends}
-    for (int row = wave; row < T2; row += 8) {
-        const uint32_t q = qt * T2 + row;
-        if (q >= nq) continue;
-        uint64_t best = ~0ull;
-        if (cnt[row] > 0) best = prune_row<CAP2, INT>(mybuf + (size_t)row * CAP2, cnt, nsorted, tau, row, lane);
-        partial[((size_t)q * Stot + list_base + s) * KP + lane] = best;
-    }
-}
-
-
-// =====================================================================================
-// v4 scan (default): v3's operand pipeline with the roles of the MFMA operands SWAPPED so that
-// a lane owns QUERIES, not corpus rows: A = corpus tile (rows -> accumulator registers),
-// B = query tile (columns -> lanes).  Each lane then serves exactly 2 queries for the whole
-// stream, so the selection state of the hot path lives in REGISTERS:
-//   * thr[2]   the pass bound of the lane's 2 queries (re-read from LDS once per tile);
-//   * cnt[2]   fill of the lane's 2 PRIVATE sub-buffers (4 lanes = 2 waves x 2 lane halves
-//              serve one query; each appends to its own 128-entry sub-buffer: no atomics, no
-//              LDS traffic, no waits -- an append is one predicated 8-byte store);
-//   * the epilogue's phase A is one v_cmp per accumulator element + a mask OR.
-// When a sub-buffer passes 64 entries the block prunes that query at the next tile start: one
-// wave merges the query's kept list with its 4 sub-buffers (bitonic sort/merge of 64-bit keys),
-// keeps the exact best k' (32 or 64), tightens tau and publishes it to the shared threshold.
-// =====================================================================================
 
 // =====================================================================================
 // Exact selection without sorting: MSD radix select (8 bits per pass) on 64-bit (key,id) words
@@ -805,415 +462,6 @@ __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, con
         }
     }
     return carry;
-}
-
-template <int MODE, bool DBG>
-__global__ __launch_bounds__(512, 2) void k_bf_scan4(
-    const unsigned char *__restrict__ Q /* query operand */, const unsigned char *__restrict__ V /* corpus operand */,
-    uint32_t row_bytes, uint32_t KT /* 64-B slices per row */, const void *__restrict__ vnorm, uint32_t N,
-    uint32_t nq, int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
-    uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
-    uint32_t list_base, uint32_t Stot, uint32_t dbg_in, unsigned long long *__restrict__ dbgbuf) {
-    const uint32_t dbg = DBG ? dbg_in : 0u;  // all diagnostics compile out of the production instantiation
-    using acc_t = typename AccT<MODE>::type;
-    constexpr bool INT = MODE == 2;
-    constexpr bool PIPE = MODE == 2;  // software-pipelined fragment reads (register budget allows it for i8 only)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS4_VN);
-    uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS4_TG);
-    float *tau = reinterpret_cast<float *>(smem + LDS4_TAU);
-    uint32_t *nkept = reinterpret_cast<uint32_t *>(smem + LDS4_NK);
-    uint32_t *subcnt = reinterpret_cast<uint32_t *>(smem + LDS4_SC);
-    uint32_t *pflag = reinterpret_cast<uint32_t *>(smem + LDS4_FLAG);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;   // wm: corpus half of the tile, wn: query quarter
-
-    const uint32_t b = blockIdx.x;
-    const uint32_t x = b & 7, jb = b >> 3;
-    const uint32_t qt = jb % QT;
-    const uint32_t s = (jb / QT) * 8 + x;
-    const uint32_t per = (NT + S - 1) / S;
-    // this launch covers tiles [t_first, t_first + NT) of the corpus (NT = tiles of this pass)
-    const uint32_t t_begin = t_first + min(s * per, NT), t_end = min(t_begin + per, t_first + NT);
-    const uint32_t ntiles = t_end - t_begin;
-    uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
-
-    uint64_t *kept = cand + (size_t)b * BLK4_ENTRIES;
-    uint64_t *subs = kept + BLK4_KEPT;
-    if (tid < T2) {
-        const bool live = (qt * T2 + tid) < nq;
-        // screen key of (query, row) = -(q.v - |v|^2/2) = d'/2 (L2) or -q.v (dot): tau lives in that domain.
-        // int: live rows satisfy acc >= -2^29 (dim <= 16384), rows past N start at -2^30: tau0 = 0x30000000
-        // lets every live row pass and no padded one.
-        // start from the shared threshold of the previous pass (if any): pass <=> key < next_up(tau_G)
-        const uint32_t g = (tau_g && live) ? __hip_atomic_load(tau_g + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                           : 0xFFFFFFFFu;
-        if (INT) {
-            int32_t t0 = live ? 0x30000000 : -0x7FFFFFFF;
-            if (g != 0xFFFFFFFFu) { const int32_t gv = (int32_t)(g ^ 0x80000000u); t0 = min(t0, gv == 0x7FFFFFFF ? gv : gv + 1); }
-            reinterpret_cast<int32_t *>(tau)[tid] = t0;
-        } else {
-            float t0 = live ? __builtin_inff() : -__builtin_inff();
-            if (g != 0xFFFFFFFFu) t0 = fminf(t0, f32_unkey(g + 1));
-            tau[tid] = t0;
-        }
-        nkept[tid] = 0;
-    }
-    for (int i = tid; i < T2 * NSUB; i += 512) subcnt[i] = 0;
-    if (tid == 0) { pflag[0] = 0; pflag[1] = 0; }
-
-    // ---- DMA issue side: A region <- corpus tile, B region <- my query tile ------------------
-    const unsigned char *q_base = Q + (size_t)qt * T2 * row_bytes;
-    const uint32_t prow = 32 * wave + (lane >> 2);  // + 16*i : LDS row this lane fills
-    uint32_t q_off[2], c_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t r = prow + 16 * i;
-        q_off[i] = r * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
-    }
-    uint32_t it = t_begin, ikt = 0;
-    auto issue_slice = [&](uint32_t stage_idx) {
-        const uint32_t tcl = min(it, t_end - 1);
-        const uint32_t col0 = tcl * T2;
-        if (ikt == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t r = prow + 16 * i;
-                const uint32_t rc = min(r, N - 1 - col0);
-                c_off[i] = rc * row_bytes + ((((uint32_t)lane & 3) ^ ((r >> 2) & 3)) << 4);
-            }
-            if (tau_g && wave >= 4 && it < t_end) {
-                __builtin_amdgcn_global_load_lds(
-                    (gptr_t)(tau_g + 64 * (wave - 4) + lane),
-                    (lptr_t)(reinterpret_cast<unsigned char *>(tg_lds) + ((it - t_begin) & 3) * T2 * 4 + (wave - 4) * 256),
-                    4, 0, 16);
-            }
-            if (vnorm && wave < 4 && it < t_end) {
-                const uint32_t c = min(col0 + 64 * wave + lane, N - 1);
-                __builtin_amdgcn_global_load_lds(
-                    (gptr_t)(reinterpret_cast<const unsigned char *>(vnorm) + (size_t)c * 4),
-                    (lptr_t)(reinterpret_cast<unsigned char *>(vn_lds) + ((it - t_begin) & 3) * T2 * 4 + wave * 256), 4, 0, 0);
-            }
-        }
-        unsigned char *dst = smem + stage_idx * STAGE3;
-        const unsigned char *cp = V + (size_t)col0 * row_bytes + (size_t)ikt * KB3;
-        const unsigned char *qp = q_base + (size_t)ikt * KB3;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(cp + c_off[i]),
-                                             (lptr_t)(dst + (2 * wave + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(qp + q_off[i]),
-                                             (lptr_t)(dst + T2 * KB3 + (2 * wave + i) * 1024), 16, 0, 0);
-        }
-        if (++ikt == KT) {
-            ikt = 0;
-            if (it < t_end) ++it;
-        }
-    };
-
-    const uint32_t fr = lane & 31, fh = lane >> 5;
-    uint32_t f_off[2];
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) f_off[cc] = fr * KB3 + ((((uint32_t)(2 * cc) + fh) ^ ((fr >> 2) & 3)) << 4);
-
-    // the lane's two queries and its private sub-buffers
-    const uint32_t sub_id = wm * 2 + fh;
-    uint32_t ql[2];
-    uint64_t *sbuf[2];
-    uint32_t sc_addr[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        ql[ni] = wn * 64 + ni * 32 + fr;
-        sbuf[ni] = subs + ((size_t)ql[ni] * NSUB + sub_id) * SUBCAP;
-        sc_addr[ni] = (uint32_t)(size_t)(lptr_t)(subcnt + ql[ni] * NSUB + sub_id);
-    }
-    const uint32_t rbase = wm * 128 + 4 * fh;  // corpus row of accumulator register (mi, r): rbase + mi*32 + (r&3) + 8*(r>>2)
-    const uint32_t pflag_lds_addr = (uint32_t)(size_t)(lptr_t)pflag;
-
-    if (ntiles > 0) {
-        issue_slice(0);
-        issue_slice(1);
-        issue_slice(2);
-    }
-    __syncthreads();  // state arrays initialised (plain LDS stores) before anyone reads them
-    uint32_t islice = 0;
-    unsigned long long tk0 = 0, t_round = 0, t_phb = 0, t_pha = 0, n_round = 0;
-    if (dbg & 32) tk0 = __builtin_amdgcn_s_memtime();
-
-    for (uint32_t t = t_begin; t < t_end; ++t) {
-        const uint32_t col0 = t * T2;
-        const uint32_t *vn_t = vn_lds + ((t - t_begin) & 3) * T2;
-        acc_t acc[4][2];
-        u32x4 fx_a[4], fx_b[2], fy_a[4], fy_b[2];
-        auto mma8 = [&](const u32x4 (&a4)[4], const u32x4 (&b2)[2]) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (MODE == 1) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4[mi]),
-                                                                              __builtin_bit_cast(bf16x8, b2[ni]), acc[mi][ni], 0, 0, 0);
-                    } else if constexpr (MODE == 2) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a4[mi]),
-                                                                            __builtin_bit_cast(i32x4, b2[ni]), acc[mi][ni], 0, 0, 0);
-                    } else {
-                        const f32x4 xa = __builtin_bit_cast(f32x4, a4[mi]);
-                        const f32x4 xb = __builtin_bit_cast(f32x4, b2[ni]);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, xb.x, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, xb.y, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, xb.z, acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, xb.w, acc[mi][ni], 0, 0, 0);
-                    }
-                }
-        };
-        uint32_t thr[2];   // fp: bits of the accumulator bound; int: tau
-        uint32_t cntr[2], cnt0[2];
-
-        for (uint32_t kt = 0; kt < KT; ++kt, ++islice) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt == 0) {
-                // prune ROUND: batched so that all 8 waves have queries to merge (a round stalls the
-                    // whole pipeline); started when enough sub-buffers crossed the soft mark or one is
-                    // close to its capacity (a tile adds at most 64 entries to a sub-buffer)
-                if (pflag[0] != 0 || pflag[1] >= (uint32_t)PTHRESH) {
-                    unsigned long long ts = 0;
-                    if (dbg & 32) ts = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // everyone's appends are complete
-                    __builtin_amdgcn_s_barrier();                     // ... and everyone has read the flags
-                    if (tid == 0) { pflag[0] = 0; pflag[1] = 0; }
-                    for (int q = wave; q < T2; q += 8) {
-                        const u32x4 c4 = *reinterpret_cast<const u32x4 *>(subcnt + q * NSUB);
-                        if (max(max(c4.x, c4.y), max(c4.z, c4.w)) > (uint32_t)SUBHW) {
-                            if ((dbg & 16) && lane == 0) atomicAdd(&dbgbuf[2], 1ull);
-                            prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, smem + LDS4_SEL + wave * SEL_SCRATCH);
-                        }
-                    }
-                    __syncthreads();
-                    if (dbg & 32) { t_round += __builtin_amdgcn_s_memtime() - ts; n_round += 1; }
-                }
-                if (tau_g && tid < T2) {  // fold the shared threshold (see v3)
-                    const uint32_t g = tg_lds[((t - t_begin) & 3) * T2 + tid];
-                    if (g != 0xFFFFFFFFu) {
-                        uint32_t nb;
-                        bool tighter;
-                        if (INT) {
-                            const int32_t gv = (int32_t)(g ^ 0x80000000u);
-                            const int32_t bv = gv == 0x7FFFFFFF ? gv : gv + 1;
-                            tighter = bv < reinterpret_cast<int32_t *>(tau)[tid];
-                            nb = (uint32_t)bv;
-                        } else {
-                            const float bv = f32_unkey(g + 1);
-                            tighter = bv < tau[tid];
-                            nb = __float_as_uint(bv);
-                        }
-                        if (tighter) {
-                            const uint32_t addr = (uint32_t)(size_t)(lptr_t)(tau + tid);
-                            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(addr), "v"(nb) : "memory");
-                        }
-                    }
-                }
-                // per-lane selection state for this tile
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    cntr[ni] = subcnt[ql[ni] * NSUB + sub_id];
-                    cnt0[ni] = cntr[ni];
-                    // pass <=> key < tau <=> acc > -tau
-                    if constexpr (INT) thr[ni] = (uint32_t)(-reinterpret_cast<const int32_t *>(tau)[ql[ni]]);
-                    else thr[ni] = __float_as_uint(-tau[ql[ni]]);
-                }
-                // accumulator init = -|v|^2/2 of the register's corpus row (fp) / -(|v|^2 >> 1) (int; the
-                // dropped parity bit perturbs the int screen by < 1 unit and equally for equal rows);
-                // rows past N start at -inf / -2^30 and can never pass.  The finished accumulator IS the
-                // negated screen key, so the selection test is one compare per element.
-                const bool full_tile = col0 + T2 <= N;  // wave-uniform: only the corpus' last tile is ragged
-                if (full_tile) {
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        acc_t init;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            u32x4 v4 = {0, 0, 0, 0};
-                            if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rbase + mi * 32 + 8 * g);
-#pragma unroll
-                            for (int j2 = 0; j2 < 4; ++j2) {
-                                if constexpr (INT) init[4 * g + j2] = -((int)v4[j2] >> 1);
-                                else init[4 * g + j2] = -0.5f * __uint_as_float(v4[j2]);
-                            }
-                        }
-                        acc[mi][0] = init;
-                        acc[mi][1] = init;
-                    }
-                } else {
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        acc_t init;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const uint32_t rl = rbase + mi * 32 + 8 * g;
-                            u32x4 v4 = {0, 0, 0, 0};
-                            if (vnorm) v4 = *reinterpret_cast<const u32x4 *>(vn_t + rl);
-#pragma unroll
-                            for (int j2 = 0; j2 < 4; ++j2) {
-                                const bool ok = (col0 + rl + j2) < N;
-                                if constexpr (INT) init[4 * g + j2] = ok ? -((int)v4[j2] >> 1) : -0x40000000;
-                                else init[4 * g + j2] = ok ? -0.5f * __uint_as_float(v4[j2]) : -__builtin_inff();
-                            }
-                        }
-                        acc[mi][0] = init;
-                        acc[mi][1] = init;
-                    }
-                }
-            }
-            if constexpr (PIPE) {
-                // Software pipeline across the barrier (per wave): the slice's first k-step (cc0) is read
-                // into X right after the barrier; the MFMAs of the PREVIOUS slice's second k-step (still in
-                // Y) run while those reads and the DMA issue of slice i+3 are in flight; then cc1 is read
-                // into Y behind the MFMAs of cc0.  (A staggered variant that gives the two waves of a SIMD
-                // different orders was tried: hipcc then spills 300 VGPRs -- needs hand scheduling.)
-                const unsigned char *st = smem + (islice & 3) * STAGE3;
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    fx_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[0]);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    fx_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(dbg & 256)) issue_slice((islice + 3) & 3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kt > 0 && !(dbg & 128)) mma8(fy_a, fy_b);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    fy_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[1]);
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    fy_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(dbg & 128)) mma8(fx_a, fx_b);
-                else {
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(fx_a[mi]), "v"(fy_a[mi]));
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) asm volatile("" :: "v"(fx_b[ni]), "v"(fy_b[ni]));
-                }
-            } else {
-                // fp32 / bf16: both k-steps' fragments up front (the pipelined form spills there)
-                const unsigned char *st = smem + (islice & 3) * STAGE3;
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    fx_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[0]);
-                    fy_a[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KB3 + f_off[1]);
-                }
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    fx_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[0]);
-                    fy_b[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KB3 + (wn * 64 + ni * 32) * KB3 + f_off[1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(dbg & 256)) issue_slice((islice + 3) & 3);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(dbg & 128)) {
-                    mma8(fx_a, fx_b);
-                    mma8(fy_a, fy_b);
-                }
-            }
-        }
-        if constexpr (PIPE) {
-            if (!(dbg & 128)) mma8(fy_a, fy_b);  // flush the tile's last k-step
-        }
-
-        // ---- fused selection epilogue: registers only on the common path -----------------------
-        if (!(dbg & 1)) {
-            unsigned long long te0 = 0;
-            if (dbg & 32) te0 = __builtin_amdgcn_s_memtime();
-            // Phase A: per 32x32 fragment, the lane's maximum over its 16 accumulator registers
-            // (v_max3) against the lane's bound: 8 compares + 8 mask tests per tile on the common path.
-            unsigned long long fany[4][2];
-            unsigned long long any = 0;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    if constexpr (INT) {
-                        int m = acc[mi][ni][0];
-#pragma unroll
-                        for (int r = 1; r < 16; ++r) m = max(m, acc[mi][ni][r]);
-                        fany[mi][ni] = __ballot(m > (int)thr[ni]);
-                    } else {
-                        float m = acc[mi][ni][0];
-#pragma unroll
-                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
-                        fany[mi][ni] = __ballot(m > __uint_as_float(thr[ni]));
-                    }
-                    any |= fany[mi][ni];
-                }
-            if (dbg & 32) { const unsigned long long x2 = __builtin_amdgcn_s_memtime(); t_pha += x2 - te0; te0 = x2; }
-            if (dbg & 16) { if (lane == 0) { atomicAdd(&dbgbuf[0], 1ull); if (any) atomicAdd(&dbgbuf[1], 1ull); } }
-            if (any && !(dbg & 4)) {
-                // Phase B: only fragments in which some lane passed are walked element by element
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        if (fany[mi][ni] == 0) continue;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            bool pass;
-                            if constexpr (INT) pass = acc[mi][ni][r] > (int)thr[ni];
-                            else pass = acc[mi][ni][r] > __uint_as_float(thr[ni]);
-                            if (pass) {
-                                uint32_t keyhi;
-                                if constexpr (INT) keyhi = (uint32_t)(-acc[mi][ni][r]) ^ 0x80000000u;
-                                else keyhi = f32_key(-acc[mi][ni][r]);
-                                const uint32_t id = col0 + rbase + mi * 32 + (r & 3) + 8 * (r >> 2);
-                                if (cntr[ni] < (uint32_t)SUBCAP) sbuf[ni][cntr[ni]] = ((uint64_t)keyhi << 32) | id;
-                                cntr[ni] += 1;
-                                if (dbg & 16) atomicAdd(&dbgbuf[3], 1ull);
-                            }
-                        }
-                    }
-                // publish the fills; request a prune when a sub-buffer passed its high-water mark
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    asm volatile("ds_write_b32 %0, %1" :: "v"(sc_addr[ni]), "v"(cntr[ni]) : "memory");
-                const uint32_t ncross = (uint32_t)(cnt0[0] <= (uint32_t)SUBHW && cntr[0] > (uint32_t)SUBHW) +
-                                        (uint32_t)(cnt0[1] <= (uint32_t)SUBHW && cntr[1] > (uint32_t)SUBHW);
-                if (ncross) {
-                    const uint32_t a1 = pflag_lds_addr + 4;
-                    asm volatile("ds_add_u32 %0, %1" :: "v"(a1), "v"(ncross) : "memory");
-                }
-                if (cntr[0] > (uint32_t)SUBURG || cntr[1] > (uint32_t)SUBURG) {
-                    const uint32_t one = 1;
-                    asm volatile("ds_write_b32 %0, %1" :: "v"(pflag_lds_addr), "v"(one) : "memory");
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            if (dbg & 32) t_phb += __builtin_amdgcn_s_memtime() - te0;
-        }
-    }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (dbg & 32) {
-        if (tid == 0) {
-            atomicAdd(&dbgbuf[4], __builtin_amdgcn_s_memtime() - tk0);
-            atomicAdd(&dbgbuf[5], t_round);
-            atomicAdd(&dbgbuf[6], t_pha);
-            atomicAdd(&dbgbuf[7], t_phb);
-            atomicAdd(&dbgbuf[8], n_round);
-        }
-    }
-    for (int q = wave; q < T2; q += 8) {
-        const uint32_t qg = qt * T2 + q;
-        if (qg >= nq) continue;
-        const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
-        partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
-    }
 }
 
 // k_bf_scan5: the v4 kernel generalised over the wave tile: NI = 2 -> 8 waves of 128 x 64 (two per
@@ -1420,7 +668,7 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
                     __syncthreads();
                     if (dbg & 32) { t_round += __builtin_amdgcn_s_memtime() - ts; n_round += 1; }
                 }
-                for (int tq = tid; tau_g && tq < T2; tq += NW * 64) {  // fold the shared threshold (see v3)
+                for (int tq = tid; tau_g && tq < T2; tq += NW * 64) {  // fold the shared threshold: pass <=> key < min(tau_local, next_up(tau_G)), non-strict on tau_G
                     const int tid_f = tq;
                     const uint32_t g = tg_lds[((t - t_begin) & 3) * T2 + tid_f];
                     if (g != 0xFFFFFFFFu) {
@@ -1741,13 +989,12 @@ struct BfPlan {
     uint64_t off_q, off_cand, off_partial, off_ids, off_taug, total;
 };
 
-int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v3 | v4 | v6 (default): older generations kept for A/B.
+int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v4 | v6 (default): older generations kept for A/B.
     // v6 = v4 with full-line (8 rows x 128 B) LDS-DMA pieces, 128-byte slices and a 2-stage ring; it shares
     // every host-side path with v4, so kernel_version() reports 4 for both and is_v6() tells them apart.
     static const int v = [] {
         const char *e = getenv("ZVDB_BF_KERNEL");
-        if (e && e[0] == 'v' && e[1] == '6') return 4;
-        return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? e[1] - '0' : 4;
+        return (e && e[0] == 'v' && e[1] == '1') ? 1 : 4;
     }();
     return v;
 }
@@ -1796,27 +1043,6 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     return p;
 }
 
-template <int MODE>
-int launch_scan4(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
-                 uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
-                 uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, hipStream_t s) {
-    unsigned long long *dbgbuf = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);
-    if (debug_flags()) {
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan4<MODE, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        hipLaunchKernelGGL((k_bf_scan4<MODE, true>), dim3(p.QT * p.S), dim3(512), LDS4, s, q_op, rows, p.row_bytes,
-                           p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
-                           (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, debug_flags(), dbgbuf);
-    } else {
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan4<MODE, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
-        hipLaunchKernelGGL((k_bf_scan4<MODE, false>), dim3(p.QT * p.S), dim3(512), LDS4, s, q_op, rows, p.row_bytes,
-                           p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
-                           list_base, Stot, 0u, dbgbuf);
-    }
-    return ZVDB_OK;
-}
-
 int wave_tile_ni() {
     static const int v = [] { const char *e = getenv("ZVDB_BF_NI"); return (e && e[0] == '4') ? 4 : 2; }();
     return v;
@@ -1845,18 +1071,6 @@ int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
                            list_base, Stot, 0u, dbgbuf);
     }
-    return ZVDB_OK;
-}
-
-template <int MODE>
-int launch_scan3(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
-                 uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
-                 uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, hipStream_t s) {
-    ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan3<MODE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS3));
-    hipLaunchKernelGGL(k_bf_scan3<MODE>, dim3(p.QT * p.S), dim3(512), LDS3, s, q_op, rows, p.row_bytes,
-                       p.row_bytes / KB3, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
-                       (debug_flags() & 2) ? nullptr : tau_g, t_first, list_base, Stot, debug_flags());
     return ZVDB_OK;
 }
 
@@ -1932,13 +1146,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                (float)alpha_i, p.QT, p.S, p.NT, cand, partial);
         }
     } else {
-        // v3 / v4.  TWO PASSES share one exact threshold: pass A scans the first ~1/16 of the rows;
+        // The passes share one exact threshold: each pass but the last is followed by a merge of all lists;
         // a merge of its per-stream lists yields, per query, the exact k'-th best screen key so far
         // (tau_G); pass B scans the rest against it (folded in at every tile start, together with
         // whatever tighter bound other workgroups publish meanwhile).  Without it every workgroup
         // re-learns a threshold from its own 1/64 of the data and appends ~100x more candidates.
         uint32_t *tau_g = reinterpret_cast<uint32_t *>(ws + p.off_taug);
-        const uint32_t kp = kernel_version() == 4 ? ((k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP) : (uint32_t)KP;
+        const uint32_t kp = (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
                                     : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
                                                          : reinterpret_cast<const unsigned char *>(h->rows);
@@ -1980,14 +1194,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
                 return launch_scan5<0, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
             }
-            if (kernel_version() == 4) {
-                if (mode == ZVDB_BF_BF16) return launch_scan4<1>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-                if (mode == ZVDB_BF_I8) return launch_scan4<2>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-                return launch_scan4<0>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-            }
-            if (mode == ZVDB_BF_BF16) return launch_scan3<1>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, ps.t0, ps.nt, list_base, Stot, s);
-            if (mode == ZVDB_BF_I8) return launch_scan3<2>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, ps.t0, ps.nt, list_base, Stot, s);
-            return launch_scan3<0>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, ps.t0, ps.nt, list_base, Stot, s);
+            // v4 = the same kernel with 64-byte slices / 16 x 64 B DMA pieces / 4-stage ring
+            if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+            if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+            return launch_scan5<0, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
         };
         uint32_t lists = 0;
         for (int i = 0; i < np; ++i) {
@@ -2004,12 +1214,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
             }
             if (i + 1 < np)
-                if (kernel_version() == 4) {
+                {
                     const uint32_t cap = kp + 64 * KP;
                     hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, lists, Stot,
                                        (uint32_t *)nullptr, tau_g, kp, cap);
-                } else {
-                    hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, lists, Stot, (uint32_t *)nullptr, tau_g, kp);
                 }
         }
         nlists = lists;
