@@ -473,7 +473,8 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
     uint32_t row_bytes, uint32_t KT /* KBV-byte slices per row */, const void *__restrict__ vnorm, uint32_t N,
     uint32_t nq, int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
-    uint32_t list_base, uint32_t Stot, uint32_t dbg_in, unsigned long long *__restrict__ dbgbuf) {
+    uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, uint32_t dbg_in,
+    unsigned long long *__restrict__ dbgbuf) {
     const uint32_t dbg = DBG ? dbg_in : 0u;  // all diagnostics compile out of the production instantiation
     using acc_t = typename AccT<MODE>::type;
     constexpr bool INT = MODE == 2;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
     constexpr int NPC = 256 / RPP / NW;  // DMA pieces per operand per wave per slice
     constexpr int STAGE = 2 * T2 * KBV;  // 32 or 64 KiB
     constexpr int NST = 131072 / STAGE;  // ring stages: 4 or 2
-    constexpr bool PIPE = MODE == 2 || NI == 4;  // software-pipelined fragment reads where registers allow
+    constexpr bool PIPE = MODE == 2 || NI == 4;  // defer a slice's last k-step behind the next barrier (bf16/fp32 spill with it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS4_VN);
     uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS4_TG);
@@ -868,6 +869,7 @@ uint32_t ncross = 0;
         if (qg >= nq) continue;
         const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
         partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
+        if (lane == 0) pcnt[(size_t)qg * Stot + list_base + s] = nkept[q];  // valid entries (compacted to the front)
     }
 }
 
@@ -899,7 +901,8 @@ __global__ __launch_bounds__(64) void k_bf_merge(const uint64_t *__restrict__ pa
 // v4 lists are UNSORTED (valid entries compacted to the front, ~0 padded).  Select-based merge: the
 // valid keys of all lists of a query are gathered into LDS (one lane per list, 64 lists at a time),
 // then one radix select yields the kp best.  Output: candidate ids (unordered) and/or the kp-th key.
-__global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict__ partial, uint32_t S, uint32_t Stot,
+__global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict__ partial,
+                                                     const uint32_t *__restrict__ pcnt, uint32_t S, uint32_t Stot,
                                                      uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
                                                      uint32_t kp, uint32_t cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -931,11 +934,10 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
         __syncthreads();
     };
     for (uint32_t s0 = 0; s0 < S; s0 += kWave) {
-        // one lane per list: count its valid prefix (lists are short: scan until the first sentinel)
+        // one lane per list; its valid-entry count was written by the scan
         const uint32_t li = s0 + lane;
         const uint64_t *lp = p + (size_t)li * KP;
-        uint32_t cnt = 0;
-        if (li < S) while (cnt < (uint32_t)KP && lp[cnt] != ~0ull) ++cnt;
+        const uint32_t cnt = li < S ? min(pcnt[(size_t)q * Stot + li], (uint32_t)KP) : 0u;
         const uint32_t inc = wave_incl_scan(cnt, lane);
         const uint32_t tot = (uint32_t)__shfl((int)inc, 63);
         if (n + tot > cap) reduce_pool();  // make room (cap >= kp + 64 * KP)
@@ -986,7 +988,7 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
 
 struct BfPlan {
     uint32_t tile, cap, nq_pad, QT, S, NT, KT, row_bytes, row_elems;
-    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, total;
+    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_pcnt, total;
 };
 
 int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v4 | v6 (default): older generations kept for A/B.
@@ -1039,6 +1041,8 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     off += (uint64_t)p.nq_pad * KP * 4;
     p.off_taug = off;
     off += round_up64((uint64_t)p.nq_pad * 4, 256) + 256;  // + debug counters
+    p.off_pcnt = off;
+    off += round_up64((uint64_t)p.nq_pad * 3 * p.S * 4, 256);  // valid-entry count of every list
     p.total = off;
     return p;
 }
@@ -1056,20 +1060,21 @@ int slice_bytes() {
 template <int MODE, int NI, int KBV>
 int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
                  uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
-                 uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, hipStream_t s) {
+                 uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, uint32_t *pcnt,
+                 hipStream_t s) {
     unsigned long long *dbgbuf = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);
     if (debug_flags()) {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, true, NI, KBV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         hipLaunchKernelGGL((k_bf_scan5<MODE, true, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
-                           (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, debug_flags(), dbgbuf);
+                           (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, pcnt, debug_flags(), dbgbuf);
     } else {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, false, NI, KBV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         hipLaunchKernelGGL((k_bf_scan5<MODE, false, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
-                           list_base, Stot, 0u, dbgbuf);
+                           list_base, Stot, pcnt, 0u, dbgbuf);
     }
     return ZVDB_OK;
 }
@@ -1152,6 +1157,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         // whatever tighter bound other workgroups publish meanwhile).  Without it every workgroup
         // re-learns a threshold from its own 1/64 of the data and appends ~100x more candidates.
         uint32_t *tau_g = reinterpret_cast<uint32_t *>(ws + p.off_taug);
+        uint32_t *pcnt = reinterpret_cast<uint32_t *>(ws + p.off_pcnt);
         const uint32_t kp = (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
                                     : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
@@ -1185,19 +1191,19 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             BfPlan q = p;
             q.S = ps.S;
             if (kernel_version() == 4 && wave_tile_ni() == 4) {  // experimental: one wave per SIMD
-                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-                if (mode == ZVDB_BF_I8) return launch_scan5<2, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-                return launch_scan5<0, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                if (mode == ZVDB_BF_I8) return launch_scan5<2, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                return launch_scan5<0, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             }
             if (kernel_version() == 4 && is_v6()) {  // default: full-line DMA pieces, 2-stage ring
-                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-                if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-                return launch_scan5<0, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                return launch_scan5<0, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             }
             // v4 = the same kernel with 64-byte slices / 16 x 64 B DMA pieces / 4-stage ring
-            if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-            if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
-            return launch_scan5<0, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, s);
+            if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            return launch_scan5<0, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
         };
         uint32_t lists = 0;
         for (int i = 0; i < np; ++i) {
@@ -1216,7 +1222,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             if (i + 1 < np)
                 {
                     const uint32_t cap = kp + 64 * KP;
-                    hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, lists, Stot,
+                    hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, lists, Stot,
                                        (uint32_t *)nullptr, tau_g, kp, cap);
                 }
         }
@@ -1237,7 +1243,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     if (p.tile != BM && kernel_version() == 4) {
         const uint32_t kpf = (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const uint32_t cap = kpf + 64 * KP;
-        hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, nlists, stot_lists, cand_ids,
+        hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial,
+                           reinterpret_cast<const uint32_t *>(ws + p.off_pcnt), nlists, stot_lists, cand_ids,
                            (uint32_t *)nullptr, kpf, cap);
     } else {
         hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, nlists, stot_lists, cand_ids, (uint32_t *)nullptr, (uint32_t)KP);
