@@ -1175,7 +1175,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         Pass passes[3];
         int np = 0;
         const uint32_t Stot = 3 * p.S;
-        if (p.NT >= 16 * p.S && !(debug_flags() & 64)) {
+        if (p.NT >= 4 * p.S && !(debug_flags() & 64)) {
             uint32_t t0 = p.S;
             passes[np++] = {0, p.S, p.S};
             const uint32_t ntB = p.NT / 32;
