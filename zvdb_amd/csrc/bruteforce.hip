@@ -1176,8 +1176,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         int np = 0;
         const uint32_t Stot = 3 * p.S;
         if (p.NT >= 4 * p.S && !(debug_flags() & 64)) {
-            uint32_t t0 = p.S;
-            passes[np++] = {0, p.S, p.S};
+            // pass A streams: every workgroup of pass A floods one tile (256 candidates per query, 8-byte
+            // scattered stores) -- the fewer the cheaper, as long as pass B's candidates (rows_B * k' /
+            // rows_A per query) stay far below the sub-buffer capacity.  ZVDB_BF_SA overrides (tuning).
+            static const uint32_t sa_env = [] { const char *e = getenv("ZVDB_BF_SA"); return e ? (uint32_t)atoi(e) : 0u; }();
+            const uint32_t SA = sa_env ? std::min(p.S, std::max(8u, sa_env / 8 * 8)) : std::min(p.S, 16u);
+            uint32_t t0 = SA;
+            passes[np++] = {0, SA, SA};
             const uint32_t ntB = p.NT / 32;
             if (ntB >= 2 * p.S) {
                 passes[np++] = {t0, ntB, p.S};
