@@ -329,12 +329,15 @@ constexpr int NSTAGE3 = 4;
 constexpr int SEL_HIST_BYTES = 1024, SEL_STAGE_BYTES = 512;
 constexpr int SEL_SCRATCH = SEL_HIST_BYTES + SEL_STAGE_BYTES;  // per wave
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t y = __shfl_up(v, off);
-        if (lane >= off) v += y;
-    }
+// inclusive prefix sum across the wave on DPP (row_shr 1/2/4/8 + row_bcast15/31): 6 VALU ops, no LDS
+// crossbar round trips (the __shfl_up form costs six dependent ds_bpermute)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -358,13 +361,13 @@ __device__ __forceinline__ uint64_t wave_kth_key(KeyAt key_at, uint32_t E_rt, ui
         const uint32_t sl = c.x + c.y + c.z + c.w;
         const uint32_t inc = wave_incl_scan(sl, lane);
         const unsigned long long b = __ballot(inc >= need);
-        const int L = __builtin_ctzll(b);
+        const int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(b));  // wave-uniform -> v_readlane below
         uint32_t r = need - (inc - sl);  // rank inside this lane's four bins (meaningful in lane L)
         uint32_t j = 0, cj = c.x;
         if (r > c.x) { r -= c.x; j = 1; cj = c.y; if (r > c.y) { r -= c.y; j = 2; cj = c.z; if (r > c.z) { r -= c.z; j = 3; cj = c.w; } } }
-        const uint32_t d = (uint32_t)__shfl((int)(4 * lane + j), L);
-        need = (uint32_t)__shfl((int)r, L);
-        const uint32_t cnt_d = (uint32_t)__shfl((int)cj, L);
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)(4 * lane + j), L);
+        need = (uint32_t)__builtin_amdgcn_readlane((int)r, L);
+        const uint32_t cnt_d = (uint32_t)__builtin_amdgcn_readlane((int)cj, L);
         prefix = (prefix << 8) | d;
         if (cnt_d == 1 && shift > 0) {  // a single candidate left on the path: it is the answer
             uint64_t found = ~0ull;
@@ -374,7 +377,9 @@ __device__ __forceinline__ uint64_t wave_kth_key(KeyAt key_at, uint32_t E_rt, ui
                 if (k != ~0ull && (k >> shift) == prefix) found = k;
             }
             const unsigned long long fb = __ballot(found != ~0ull);
-            return shfl64(found, __builtin_ctzll(fb));
+            const int FL = __builtin_amdgcn_readfirstlane(__builtin_ctzll(fb));
+            return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(found >> 32), FL) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)found, FL);
         }
     }
     return prefix;
@@ -939,7 +944,7 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
         const uint64_t *lp = p + (size_t)li * KP;
         const uint32_t cnt = li < S ? min(pcnt[(size_t)q * Stot + li], (uint32_t)KP) : 0u;
         const uint32_t inc = wave_incl_scan(cnt, lane);
-        const uint32_t tot = (uint32_t)__shfl((int)inc, 63);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (n + tot > cap) reduce_pool();  // make room (cap >= kp + 64 * KP)
         const uint32_t off = n + inc - cnt;
         for (uint32_t j2 = 0; j2 < cnt; ++j2) pool[off + j2] = lp[j2];
