@@ -298,13 +298,25 @@ def main():
     # ---- ground truth for recall: fp32-MFMA route on the last query batch (untimed) ------------
     gt_ids, _ = step(queries[total_steps], zv.BF_F32)
     gt_ids = gt_ids.clone()
-    got_ids, got_dist = step(queries[total_steps], mode)
-    torch.cuda.synchronize()
-    a = got_ids.cpu().numpy()
     b = gt_ids.cpu().numpy()
-    recall = float(np.mean([len(set(a[i]) & set(b[i])) / K for i in range(B)]))
+
+    def recall_of(m):
+        gi, gd = step(queries[total_steps], m)
+        torch.cuda.synchronize()
+        an = gi.cpu().numpy()
+        return float(np.mean([len(set(an[i]) & set(b[i])) / K for i in range(B)])), an, gd.cpu().numpy().copy()
+
+    recall, a, got_dist_h = recall_of(mode)
+    if auto and recall < 0.95:
+        # the int8 screen depends on the data's value range; the metric is QPS AT recall >= 0.95, so fall
+        # back to the wider screens rather than report a fast number below the bar
+        for alt in ("bf16", "f32"):
+            r2, a2, d2 = recall_of(MODES[alt])
+            if r2 >= 0.95:
+                args.mode, mode, recall, a, got_dist_h = alt, MODES[alt], r2, a2, d2
+                break
     chk_ids = a.astype(np.uint64)
-    chk_dist = got_dist.cpu().numpy().copy()
+    chk_dist = got_dist_h
     chk_q = queries[total_steps].cpu().numpy()
 
     # ---- timed region ----------------------------------------------------------------------------
