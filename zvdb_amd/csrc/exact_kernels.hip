@@ -503,9 +503,11 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     if (ef < k) ef = k;
     const uint64_t N = h->count;
     const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
-    // visited set: every node can be visited at most once; budget for the expected
-    // ef * stride evaluations x4, capped by N and by what LDS can hold.
-    uint64_t want = std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 4 + 64);
+    // visited set: every node is visited at most once.  Measured evaluations per query are ~1.1 x
+    // ef * stride; the table takes >= 3 x ef * stride slots (75 % load cap => room for 2.2 x), because its
+    // LDS footprint sets the waves per CU (the first version reserved 8 x and ran ONE wave per CU).
+    // A query that still exhausts it is flagged in stats[2] (the host entry point reports it).
+    uint64_t want = std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 3 / 2 + 64);
     uint32_t hash_bits = bits_for(want);
     for (;;) {
         const size_t lds = 4ull * (dim_pad + 3ull * (ef + 1) + (1ull << hash_bits) + 2 * kWave);
