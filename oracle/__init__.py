@@ -55,6 +55,8 @@ def lib():
     L.orc_distance_f64.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t]
     L.orc_distance_i32.restype = C.c_int32
     L.orc_distance_i32.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_size_t]
+    L.orc_distance_blocked16_f32.restype = C.c_float
+    L.orc_distance_blocked16_f32.argtypes = [f32p, f32p, C.c_size_t]
     L.orc_mix64.restype = C.c_uint64
     L.orc_mix64.argtypes = [C.c_uint64, C.c_uint64]
     L.orc_fill_uniform.restype = None
@@ -110,6 +112,11 @@ def distance(a, b) -> np.float32:
     a, b = _f32(a), _f32(b)
     assert a.shape == b.shape and a.ndim == 1
     return np.float32(lib().orc_distance_f32(_p(a, C.c_float), _p(b, C.c_float), a.size))
+
+
+def distance_blocked16(a, b) -> np.float32:
+    a, b = _f32(a), _f32(b)
+    return np.float32(lib().orc_distance_blocked16_f32(_p(a, C.c_float), _p(b, C.c_float), a.size))
 
 
 def distance_f64(a, b) -> float:

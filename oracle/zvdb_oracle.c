@@ -46,6 +46,28 @@ int32_t orc_distance_i32(const int32_t *a, const int32_t *b, size_t d) {
     return sum;
 }
 
+float orc_distance_blocked16_f32(const float *a, const float *b, size_t d) {
+    float p[16];
+    for (int l = 0; l < 16; ++l) p[l] = 0.0f;
+    const size_t nchunks = (d + 3) / 4;
+    for (size_t c = 0; c < nchunks; ++c) {
+        const int l = (int)(c & 15);
+        for (size_t j = 0; j < 4; ++j) {
+            const size_t i = 4 * c + j;
+            if (i < d) {
+                const float diff = a[i] - b[i];
+                p[l] += diff * diff;
+            }
+        }
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+        float t[16];
+        for (int l = 0; l < 16; ++l) t[l] = p[l] + p[l ^ off];
+        for (int l = 0; l < 16; ++l) p[l] = t[l];
+    }
+    return p[0];
+}
+
 float orc_neg_dot_f32(const float *a, const float *b, size_t d) {
     float sum = 0.0f;
     for (size_t i = 0; i < d; ++i) sum += a[i] * b[i];
@@ -378,7 +400,7 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
     size_t wn = 0;
 
     const size_t entry = h->entry_point;
-    wd[0] = orc_distance_f32(query, h->nodes[entry].point, d);
+    wd[0] = orc_distance_blocked16_f32(query, h->nodes[entry].point, d);
     h->ctr.search_dist_evals += 1;
     wi[0] = entry; wx[0] = 0; wn = 1;
     visited[entry] = 1;
@@ -394,7 +416,7 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
             const size_t nb = (size_t)lst->items[i];
             if (visited[nb]) continue;
             visited[nb] = 1;
-            const float dn = orc_distance_f32(query, h->nodes[nb].point, d);
+            const float dn = orc_distance_blocked16_f32(query, h->nodes[nb].point, d);
             h->ctr.search_dist_evals += 1;
             if (wn == ef && !lex_less(dn, nb, wd[wn - 1], wi[wn - 1])) continue;
             size_t pos = wn < ef ? wn : ef - 1; /* slot that gets freed / appended */
@@ -407,7 +429,17 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
         }
     }
     const size_t nres = wn < k ? wn : k;
-    for (size_t i = 0; i < nres; ++i) { out_ids[i] = wi[i]; out_dist[i] = wd[i]; }
+    /* first k of W, re-evaluated exactly (a1) and ordered by (exact distance, id) */
+    for (size_t i = 0; i < nres; ++i) {
+        const uint64_t id = wi[i];
+        const float de = orc_distance_f32(query, h->nodes[id].point, d);
+        size_t pos = i;
+        while (pos > 0 && lex_less(de, id, out_dist[pos - 1], out_ids[pos - 1])) {
+            out_dist[pos] = out_dist[pos - 1]; out_ids[pos] = out_ids[pos - 1];
+            --pos;
+        }
+        out_dist[pos] = de; out_ids[pos] = id;
+    }
     free(wd); free(wi); free(wx); free(visited);
     return nres;
 }

@@ -68,8 +68,17 @@ int orc_hnsw_insert(orc_hnsw *h, const float *point, size_t d, int level);
 size_t orc_hnsw_search(orc_hnsw *h, const float *query, size_t d, size_t k,
                        uint64_t *out_ids, float *out_dist);
 
+/* 16-way blocked squared-L2 used by the ef-mode TRAVERSAL (extension): the 4-float chunk c of the
+ * rows goes to partial sum (c mod 16), each partial accumulates its chunks in increasing order
+ * (x,y,z,w sequentially, un-contracted); the 16 partials are then combined by the butterfly
+ * p[l] = p[l] + p[l ^ off] for off = 8, 4, 2, 1.  This is the order a 16-lane group of a wave64
+ * produces with coalesced 16-byte loads; it differs from a1 only in rounding. */
+float orc_distance_blocked16_f32(const float *a, const float *b, size_t d);
+
 /* ef-mode beam search over layer 0 (EXTENSION, parity unpinned by the
- * reference; this function IS the specification the HIP kernel must match):
+ * reference; this function IS the specification the HIP kernel must match).
+ * Traversal distances are orc_distance_blocked16_f32; the returned k entries are the first k of W,
+ * re-evaluated with the exact a1 distance and ordered by (exact distance, id):
  *   W = list of <= ef (dist,id) entries kept sorted ascending by (dist,id);
  *   seed W with node `entry`; visited = {entry};
  *   repeat: c = first entry of W not yet expanded; none -> stop; mark expanded;

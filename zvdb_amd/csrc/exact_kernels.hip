@@ -12,6 +12,7 @@
 //   k_search_ef         ext.   ef-mode beam search (spec: oracle/zvdb_oracle.h)
 //   k_rerank            K5     exact re-rank + (dist,id) top-k of brute-force candidates
 #include "common.h"
+#include "wave_select.h"
 
 #pragma clang fp contract(off)
 
@@ -374,117 +375,263 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
 
 // ---- ef-mode beam search (extension; specification: oracle/zvdb_oracle.h) --------
 // W = sorted (dist,id) list of <= ef entries with an "expanded" flag, LDS resident.
+//
+// Traversal distances use the oracle's 16-way BLOCKED order (orc_distance_blocked16_f32): a 16-lane
+// group of the wave walks one neighbour row with coalesced 16-byte loads (lane t takes the 4-float
+// chunks t, t+16, ...; each lane accumulates its chunks sequentially, un-contracted), then the 16
+// partials are combined by the xor butterfly 8,4,2,1.  Four neighbour rows are in flight per wave
+// step instead of one row per lane walking 3 KB alone: same bytes, coalesced, 4x fewer dependent
+// loads per lane.  The k results are re-evaluated with the exact reference arithmetic (a1).
+template <int METRIC>
+__device__ __forceinline__ float blocked16_dist(const float *__restrict__ q /*LDS, zero padded to x4*/,
+                                                const float *__restrict__ row, uint32_t nchunks, int t) {
+    float s = 0.0f;
+    for (uint32_t c = t; c < nchunks; c += 16) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * c);  // rows are zero padded to ld
+        const float4 a = *reinterpret_cast<const float4 *>(q + 4 * c);
+        float u;
+        if (METRIC == ZVDB_METRIC_L2SQ) {
+            u = a.x - v.x; u = u * u; s = s + u;
+            u = a.y - v.y; u = u * u; s = s + u;
+            u = a.z - v.z; u = u * u; s = s + u;
+            u = a.w - v.w; u = u * u; s = s + u;
+        } else {
+            u = a.x * v.x; s = s + u;
+            u = a.y * v.y; s = s + u;
+            u = a.z * v.z; s = s + u;
+            u = a.w * v.w; s = s + u;
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s = s + __shfl_xor(s, off);
+    return METRIC == ZVDB_METRIC_L2SQ ? s : -s;
+}
+
+// Beam W: UNSORTED set of <= ef 64-bit keys ((monotone fp32 key << 32) | id) + an "expanded" flag per slot,
+// double buffered in LDS.  The oracle's sorted-list formulation is equivalent to set semantics:
+//   next node to expand = minimum key among unexpanded entries          (one wave min-reduction)
+//   after an expansion   W = best ef of (W u fresh candidates)           (one radix select per expansion,
+//                                                                         only when a candidate beats the worst)
+// so the per-candidate sorted insertions (two barriers per 64 slots shifted) of the first version are gone.
 __global__ __launch_bounds__(64) void k_search_ef(
     const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
-    uint32_t hash_bits) {
+    uint32_t hash_bits, uint32_t efp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *q = reinterpret_cast<float *>(smem);
-    float *wd = q + dim_pad;
-    uint32_t *wi = reinterpret_cast<uint32_t *>(wd + ef + 1);
-    uint32_t *wx = wi + ef + 1;
-    uint32_t *hash = wx + ef + 1;
+    uint64_t *wk = reinterpret_cast<uint64_t *>(q + dim_pad);          // [2][efp]
+    uint32_t *wx = reinterpret_cast<uint32_t *>(wk + 2 * efp);         // [2][efp] expanded flags
+    uint32_t *hist = wx + 2 * efp;                                     // [256] select scratch
+    uint32_t *hash = hist + 256;
     float *nb_d = reinterpret_cast<float *>(hash + (1u << hash_bits));
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
 
     const int lane = threadIdx.x;
+    const int g = lane >> 4, t = lane & 15;  // 4 row groups of 16 lanes
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
     for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
     __syncthreads();
+    const uint32_t nchunks = (dim + 3) / 4;
 
-    uint32_t wn = 0;
+    uint32_t wn = 0, cur = 0;
+    uint64_t worst = ~0ull;  // max key of W, valid when wn == ef
     unsigned long long evals = 0, pops = 0;
     const uint32_t hash_limit = (1u << hash_bits) - (1u << (hash_bits - 2));  // 75 % load cap
     uint32_t hash_used = 0;
     bool overflow = false;
     if (N > 0 && k > 0) {
-        const float d0 = exact_dist_rt(metric, q, rows + (size_t)entry * ld, dim);
-        if (lane == 0) { wd[0] = d0; wi[0] = entry; wx[0] = 0; }
+        const float *erow = rows + (size_t)entry * ld;
+        const float d0 = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, erow, nchunks, t)
+                                                    : blocked16_dist<ZVDB_METRIC_DOT>(q, erow, nchunks, t);
+        if (lane == 0) { wk[0] = ((uint64_t)f32_key(d0) << 32) | entry; wx[0] = 0; }
         wn = 1;
         evals = 1;
         hash_insert_uniform(hash, hash_bits, entry);
         hash_used = 1;
         __syncthreads();
         for (;;) {
-            // first entry of W not yet expanded
-            uint32_t c = 0xFFFFFFFFu;
-            for (uint32_t base = 0; base < wn && c == 0xFFFFFFFFu; base += kWave) {
-                const uint32_t i = base + lane;
-                const bool open = i < wn && wx[i] == 0;
-                const unsigned long long b = __ballot(open);
-                if (b) c = base + (uint32_t)__builtin_ctzll(b);
-            }
-            if (c == 0xFFFFFFFFu) break;
-            const uint32_t cid = wi[c];
-            __syncthreads();
-            if (lane == 0) wx[c] = 1;
+            uint64_t *W = wk + cur * efp;
+            uint32_t *X = wx + cur * efp;
+            // next to expand: the smallest unexpanded key
+            uint64_t lm = ~0ull;
+            for (uint32_t i = lane; i < wn; i += kWave)
+                if (X[i] == 0) lm = umin64(lm, W[i]);
+            const uint64_t kbest = wave_min64(lm);
+            if (kbest == ~0ull) break;
+            for (uint32_t i = lane; i < wn; i += kWave)
+                if (W[i] == kbest) X[i] = 1;
+            const uint32_t cid = (uint32_t)kbest;
             pops += 1;
-            const uint32_t dg = deg[cid];
-            for (uint32_t base = 0; base < dg; base += kWave) {
-                const uint32_t j = base + lane;
-                const uint32_t cnt = min(dg - base, (uint32_t)kWave);
+            const uint32_t dg_all = deg[cid];  // lists longer than 64 are walked 64 entries at a time
+            for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
+                const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
                 __syncthreads();
-                bool fresh = false;
-                uint32_t nb = 0;
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
-                if (j < dg && !overflow) {
-                    nb = adj[(size_t)cid * gstride + j];
-                    fresh = hash_insert_atomic(hash, hash_bits, nb);
+                // (1) one lane per neighbour: visited test-and-set; fb = fresh list positions
+                uint32_t nbl = 0;
+                bool fresh1 = false;
+                if ((uint32_t)lane < cnt && !overflow) {
+                    nbl = adj[(size_t)cid * gstride + lbase + lane];
+                    fresh1 = hash_insert_atomic(hash, hash_bits, nbl);
                 }
-                float dn = 0.0f;
-                if (fresh) dn = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
-                const unsigned long long fb = __ballot(fresh);
-                nb_i[lane] = nb;
-                nb_d[lane] = dn;
+                nb_i[lane] = nbl;
+                const unsigned long long fb = __ballot(fresh1);
+                __syncthreads();
+                // (2) blocked distances, 16 rows per step: group g walks rows r16 + 4u + g (u = 0..3) with
+                // four independent accumulators, so 16 rows x 3 KB are in flight per wave step
+                for (uint32_t r16 = 0; r16 < cnt; r16 += 16) {
+                    if (((fb >> r16) & 0xFFFFull) == 0) continue;
+                    const float *rp[4];
+                    bool fr[4];
+                    float sacc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t j = r16 + 4 * u + g;
+                        fr[u] = j < cnt && ((fb >> j) & 1ull);
+                        rp[u] = rows + (size_t)(fr[u] ? nb_i[j] : 0u) * ld;
+                        sacc[u] = 0.0f;
+                    }
+                    // super-steps of 64 chunks: each lane loads its 4 chunks of all 4 rows first (16 independent
+                    // 16-byte loads in flight, branch-free: a stale group re-reads row 0, ~95 % are fresh),
+                    // then accumulates them in increasing chunk order (the blocked16 spec)
+                    const uint32_t lastc = ld / 4 - 1;
+                    for (uint32_t c0 = 0; c0 < nchunks; c0 += 64) {
+                        float4 vv[4][4];
+                        float4 aa[4];
+                        bool okc[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t c = c0 + t + 16 * i;
+                            okc[i] = c < nchunks;
+                            const uint32_t ce = min(c, lastc);
+                            aa[i] = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) vv[i][u] = *reinterpret_cast<const float4 *>(rp[u] + 4 * ce);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const float4 a = aa[i], v = vv[i][u];
+                                float w0, w1, w2, w3;
+                                if (metric == ZVDB_METRIC_L2SQ) {
+                                    w0 = a.x - v.x; w0 = w0 * w0; w1 = a.y - v.y; w1 = w1 * w1;
+                                    w2 = a.z - v.z; w2 = w2 * w2; w3 = a.w - v.w; w3 = w3 * w3;
+                                } else {
+                                    w0 = a.x * v.x; w1 = a.y * v.y; w2 = a.z * v.z; w3 = a.w * v.w;
+                                }
+                                if (!okc[i]) { w0 = 0.0f; w1 = 0.0f; w2 = 0.0f; w3 = 0.0f; }  // +0 leaves the sum unchanged
+                                sacc[u] = sacc[u] + w0; sacc[u] = sacc[u] + w1;
+                                sacc[u] = sacc[u] + w2; sacc[u] = sacc[u] + w3;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float sv = sacc[u];
+#pragma unroll
+                        for (int off = 8; off > 0; off >>= 1) sv = sv + __shfl_xor(sv, off);
+                        if (fr[u] && t == 0) nb_d[r16 + 4 * u + g] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
+                    }
+                }
                 hash_used += (uint32_t)__popcll(fb);
                 evals += (unsigned long long)__popcll(fb);
                 __syncthreads();
-                // merge the fresh candidates into W one at a time (set semantics: the result
-                // is the best ef of the union, independent of the insertion order)
-                unsigned long long todo = fb;
-                while (todo) {
-                    const int jj = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const float cd = nb_d[jj];
-                    const uint32_t ci = nb_i[jj];
-                    if (wn == ef && !lex_less(cd, ci, wd[wn - 1], wi[wn - 1])) continue;
-                    // position = number of entries lexicographically smaller
-                    uint32_t pos = 0;
-                    for (uint32_t b2 = 0; b2 < wn; b2 += kWave) {
-                        const uint32_t i = b2 + lane;
-                        const bool lt = i < wn && lex_less(wd[i], wi[i], cd, ci);
-                        pos += (uint32_t)__popcll(__ballot(lt));
+                // (3) W = best ef of (W u fresh candidates): lane j holds candidate j
+                uint64_t ck = ~0ull;
+                if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
+                const bool pass = ck != ~0ull && (wn < ef || ck < worst);
+                const unsigned long long pm = __ballot(pass);
+                const uint32_t na = (uint32_t)__popcll(pm);
+                if (na == 0) continue;
+                W = wk + cur * efp;
+                X = wx + cur * efp;
+                if (wn + na <= ef) {  // room: append
+                    const uint32_t pos = wn + (uint32_t)__popcll(pm & ((1ull << lane) - 1));
+                    if (pass) { W[pos] = ck; X[pos] = 0; }
+                    wn += na;
+                    __syncthreads();
+                    if (wn == ef) {
+                        uint64_t mx = 0;
+                        for (uint32_t i = lane; i < wn; i += kWave) mx = umax64(mx, W[i]);
+                        worst = wave_max64(mx);
                     }
-                    const uint32_t last = wn < ef ? wn : ef - 1;  // index that receives the shifted tail
-                    // shift [pos, last) one slot right, top chunk first
-                    for (int b2 = (int)((last - pos + kWave - 1) / kWave) - 1; b2 >= 0; --b2) {
-                        const uint32_t i = pos + (uint32_t)b2 * kWave + lane;
-                        float td = 0.0f;
-                        uint32_t ti = 0, tx = 0;
-                        const bool mv = i < last;
-                        if (mv) { td = wd[i]; ti = wi[i]; tx = wx[i]; }
-                        __syncthreads();
-                        if (mv) { wd[i + 1] = td; wi[i + 1] = ti; wx[i + 1] = tx; }
-                        __syncthreads();
+                } else {  // select the ef best of the union, compact into the other buffer
+                    const uint32_t Ew = (wn + kWave - 1) / kWave;
+                    const uint64_t ckp = pass ? ck : ~0ull;
+                    const uint64_t T = wave_kth_key<0>(
+                        [&](uint32_t e) -> uint64_t {
+                            if (e == Ew) return ckp;
+                            const uint32_t i = e * kWave + lane;
+                            return i < wn ? W[i] : ~0ull;
+                        },
+                        Ew + 1, ef, hist, lane);
+                    uint64_t *W2 = wk + (cur ^ 1) * efp;
+                    uint32_t *X2 = wx + (cur ^ 1) * efp;
+                    uint32_t base = 0;
+                    for (uint32_t e = 0; e <= Ew; ++e) {
+                        const uint32_t i = e * kWave + lane;
+                        const uint64_t kk = e == Ew ? ckp : (i < wn ? W[i] : ~0ull);
+                        const uint32_t xf = (e == Ew || i >= wn) ? 0u : X[i];
+                        const bool keep = kk <= T;
+                        const unsigned long long m = __ballot(keep);
+                        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                        if (keep) { W2[pos] = kk; X2[pos] = xf; }
+                        base += (uint32_t)__popcll(m);
                     }
-                    if (lane == 0) { wd[pos] = cd; wi[pos] = ci; wx[pos] = 0; }
-                    if (wn < ef) wn += 1;
+                    wn = ef;
+                    cur ^= 1;
+                    worst = T;
                     __syncthreads();
                 }
             }
         }
         __syncthreads();
     }
+    // the k smallest keys of W, re-evaluated with the exact reference arithmetic, ordered by (exact distance, id)
     const uint32_t nres = wn < k ? wn : k;
-    for (uint32_t i = lane; i < k; i += kWave) {
-        const bool ok = i < nres;
-        out_ids[(size_t)qi * k + i] = ok ? (uint64_t)wi[i] + id_offset : ~0ull;
-        out_dist[(size_t)qi * k + i] = ok ? wd[i] : __builtin_inff();
+    uint64_t *W = wk + cur * efp;
+    uint64_t *R = wk + (cur ^ 1) * efp;  // result ids (low 32 bits) gathered here
+    float *RD = reinterpret_cast<float *>(wx);
+    if (nres > 0) {
+        uint64_t T = ~0ull - 1;
+        if (wn > nres) {
+            const uint32_t Ew = (wn + kWave - 1) / kWave;
+            T = wave_kth_key<0>([&](uint32_t e) -> uint64_t { const uint32_t i = e * kWave + lane; return i < wn ? W[i] : ~0ull; },
+                                Ew, nres, hist, lane);
+        }
+        uint32_t base = 0;
+        for (uint32_t e = 0; e * kWave < wn; ++e) {
+            const uint32_t i = e * kWave + lane;
+            const uint64_t kk = i < wn ? W[i] : ~0ull;
+            const bool keep = kk <= T;
+            const unsigned long long m = __ballot(keep);
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if (keep) R[pos] = kk;
+            base += (uint32_t)__popcll(m);
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < nres; i += kWave)
+            RD[i] = exact_dist_rt(metric, q, rows + (size_t)(uint32_t)R[i] * ld, dim);
+        __syncthreads();
+        for (uint32_t i = lane; i < nres; i += kWave) {
+            const float di = RD[i];
+            const uint32_t ii = (uint32_t)R[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nres; ++j)
+                if (lex_less(RD[j], (uint32_t)R[j], di, ii)) ++rank;
+            out_ids[(size_t)qi * k + rank] = (uint64_t)ii + id_offset;
+            out_dist[(size_t)qi * k + rank] = di;
+        }
+    }
+    for (uint32_t i = nres + lane; i < k; i += kWave) {
+        out_ids[(size_t)qi * k + i] = ~0ull;
+        out_dist[(size_t)qi * k + i] = __builtin_inff();
     }
     if (lane == 0) {
         out_count[qi] = nres;
@@ -509,17 +656,17 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // A query that still exhausts it is flagged in stats[2] (the host entry point reports it).
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 3 / 2 + 64);
     uint32_t hash_bits = bits_for(want);
-    for (;;) {
-        const size_t lds = 4ull * (dim_pad + 3ull * (ef + 1) + (1ull << hash_bits) + 2 * kWave);
-        if (lds <= 160 * 1024 || hash_bits <= 8) break;
-        --hash_bits;
-    }
-    const size_t lds = 4ull * (dim_pad + 3ull * (ef + 1) + (1ull << hash_bits) + 2 * kWave);
+    const uint32_t efp = round_up(ef, kWave);
+    auto lds_bytes = [&](uint32_t hb) -> size_t {
+        return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
+    };
+    while (lds_bytes(hash_bits) > 160 * 1024 && hash_bits > 8) --hash_bits;
+    const size_t lds = lds_bytes(hash_bits);
     ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef), lds));
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     hipLaunchKernelGGL(k_search_ef, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj,
                        h->deg, h->gstride, (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids,
-                       d_dist, d_count, d_stats, dim_pad, hash_bits);
+                       d_dist, d_count, d_stats, dim_pad, hash_bits, efp);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

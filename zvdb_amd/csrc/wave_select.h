@@ -1,0 +1,99 @@
+// wave_select.h -- wave64 selection primitives shared by the brute-force scan (prune / merge) and the
+// ef-mode graph search (beam maintenance): exact k-th smallest of 64-bit (key,id) words by MSD radix
+// select with a wave-private LDS histogram, DPP prefix scan, 64-bit shuffles / reductions.
+#pragma once
+#include "common.h"
+
+namespace zvdb {
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    return (uint64_t)__shfl((unsigned long long)v, src);
+}
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    return (uint64_t)__shfl_xor((unsigned long long)v, m);
+}
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a < b ? b : a; }
+
+// =====================================================================================
+// Exact selection without sorting: MSD radix select (8 bits per pass) on 64-bit (key,id) words
+// held E per lane, using a wave-private 256-bin LDS histogram.  Distances of a candidate set
+// share their leading bits, so the walk typically ends after 3-4 passes (early exit as soon as
+// the chosen bin holds one candidate).  Replaces the bitonic sort/merge networks (21 + 7
+// dependent ds_bpermute stages per 64 keys) in the prune rounds and the list merges.
+// =====================================================================================
+constexpr int SEL_HIST_BYTES = 1024, SEL_STAGE_BYTES = 512;
+constexpr int SEL_SCRATCH = SEL_HIST_BYTES + SEL_STAGE_BYTES;  // per wave
+
+// inclusive prefix sum across the wave on DPP (row_shr 1/2/4/8 + row_bcast15/31): 6 VALU ops, no LDS
+// crossbar round trips (the __shfl_up form costs six dependent ds_bpermute)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// kth (1-based) smallest of the valid (!= ~0) keys; precondition: kth <= number of valid keys.
+// KeyAt(e) returns the lane's e-th key, e < E (E may be a runtime count for LDS-resident sets).
+// EC > 0: compile-time element count (register-resident keys, fully unrolled); EC == 0: runtime E.
+template <int EC, typename KeyAt>
+__device__ __forceinline__ uint64_t wave_kth_key(KeyAt key_at, uint32_t E_rt, uint32_t kth, uint32_t *hist, int lane) {
+    const uint32_t E = EC > 0 ? (uint32_t)EC : E_rt;
+    uint64_t prefix = 0;
+    uint32_t need = kth;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        *reinterpret_cast<u32x4 *>(hist + 4 * lane) = u32x4{0, 0, 0, 0};
+#pragma unroll(EC > 0 ? EC : 1)
+        for (uint32_t e = 0; e < E; ++e) {
+            const uint64_t k = key_at(e);
+            if (k != ~0ull && (shift == 56 || (k >> (shift + 8)) == prefix))
+                atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+        }
+        const u32x4 c = *reinterpret_cast<const u32x4 *>(hist + 4 * lane);
+        const uint32_t sl = c.x + c.y + c.z + c.w;
+        const uint32_t inc = wave_incl_scan(sl, lane);
+        const unsigned long long b = __ballot(inc >= need);
+        const int L = __builtin_amdgcn_readfirstlane(__builtin_ctzll(b));  // wave-uniform -> v_readlane below
+        uint32_t r = need - (inc - sl);  // rank inside this lane's four bins (meaningful in lane L)
+        uint32_t j = 0, cj = c.x;
+        if (r > c.x) { r -= c.x; j = 1; cj = c.y; if (r > c.y) { r -= c.y; j = 2; cj = c.z; if (r > c.z) { r -= c.z; j = 3; cj = c.w; } } }
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)(4 * lane + j), L);
+        need = (uint32_t)__builtin_amdgcn_readlane((int)r, L);
+        const uint32_t cnt_d = (uint32_t)__builtin_amdgcn_readlane((int)cj, L);
+        prefix = (prefix << 8) | d;
+        if (cnt_d == 1 && shift > 0) {  // a single candidate left on the path: it is the answer
+            uint64_t found = ~0ull;
+#pragma unroll(EC > 0 ? EC : 1)
+            for (uint32_t e = 0; e < E; ++e) {
+                const uint64_t k = key_at(e);
+                if (k != ~0ull && (k >> shift) == prefix) found = k;
+            }
+            const unsigned long long fb = __ballot(found != ~0ull);
+            const int FL = __builtin_amdgcn_readfirstlane(__builtin_ctzll(fb));
+            return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(found >> 32), FL) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)found, FL);
+        }
+    }
+    return prefix;
+}
+
+__device__ __forceinline__ uint64_t wave_max64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = umax64(v, shfl_xor64(v, off));
+    return v;
+}
+
+
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = umin64(v, shfl_xor64(v, off));
+    return v;
+}
+
+}  // namespace zvdb
