@@ -1,0 +1,68 @@
+// mfma_peak_bench.hip -- measured dense MFMA issue rate on this part for the three screens' instructions:
+// 8 independent 32x32 accumulators per wave, 8 waves per workgroup (2 per SIMD), 1 workgroup per CU, no memory.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k(int iters, int *sink) {
+    i32x4 a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, 6, (int)threadIdx.x};
+    if constexpr (MODE == 2) {
+        i32x16 acc[8] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[j], 0, 0, 0);
+        int s = 0;
+        for (int j = 0; j < 8; ++j) s += acc[j][0];
+        if (s == 12345) sink[0] = s;
+    } else if constexpr (MODE == 1) {
+        f32x16 acc[8] = {};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[j], 0, 0, 0);
+        float s = 0;
+        for (int j = 0; j < 8; ++j) s += acc[j][0];
+        if (s == 12345.f) sink[0] = 1;
+    } else {
+        f32x16 acc[8] = {};
+        const float fa = threadIdx.x, fb = 2.f;
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[j], 0, 0, 0);
+        float s = 0;
+        for (int j = 0; j < 8; ++j) s += acc[j][0];
+        if (s == 12345.f) sink[0] = 1;
+    }
+}
+
+template <int MODE, int WAVES>
+static void run(const char *name, double ops_per_mfma, int *sink) {
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k<MODE, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, iters, sink);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double ops = 256.0 * WAVES * iters * 8 * ops_per_mfma;
+    printf("%-28s %d waves/CU: %.3f ms  %.1f TOP/s  (%.1f clk per MFMA per SIMD at 2.4 GHz)\n", name, WAVES, best,
+           ops / best / 1e9, best * 1e-3 * 2.4e9 / (iters * 8.0 * WAVES / 4));
+}
+
+int main() {
+    int *sink; (void)hipMalloc(&sink, 4);
+    run<2, 8>("mfma_i32_32x32x32_i8", 2.0 * 32 * 32 * 32, sink);
+    run<2, 4>("mfma_i32_32x32x32_i8", 2.0 * 32 * 32 * 32, sink);
+    run<1, 8>("mfma_f32_32x32x16_bf16", 2.0 * 32 * 32 * 16, sink);
+    run<1, 4>("mfma_f32_32x32x16_bf16", 2.0 * 32 * 32 * 16, sink);
+    run<0, 8>("mfma_f32_32x32x2f32", 2.0 * 32 * 32 * 2, sink);
+    return 0;
+}

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
     uint32_t row_bytes, uint32_t KT /* KBV-byte slices per row */, const void *__restrict__ vnorm, uint32_t N,
     uint32_t nq, int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
-    uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, uint32_t dbg_in,
+    uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, uint32_t rot_tab, uint32_t dbg_in,
     unsigned long long *__restrict__ dbgbuf) {
     const uint32_t dbg = DBG ? dbg_in : 0u;  // all diagnostics compile out of the production instantiation
     using acc_t = typename AccT<MODE>::type;
@@ -469,8 +469,15 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
         const uint32_t r = prow + RPP * i;
         q_off[i] = r * row_bytes + ((((uint32_t)lane % LPR) ^ swz(r)) << 4);
     }
+    // the QT workgroups that share a corpus stream (same XCD, same tiles at the same time) walk the k-slices
+    // of a tile in ROTATED orders: a slice is then pulled from HBM by one of them and hit in L2 by the others a
+    // slice-time later, instead of all of them waiting on the same in-flight L2 miss (tools/dma_l2_bench.hip:
+    // 24 -> 36 B/clk per CU).  The dot product does not care about the order of k.
+    const uint32_t krot = (rot_tab >> (4 * (qt & 7))) & 15u;
     uint32_t it = t_begin, ikt = 0;
-    auto issue_slice = [&](uint32_t stage_idx) {
+    unsigned char *i_dst = nullptr;
+    const unsigned char *i_cp = nullptr, *i_qp = nullptr;
+    auto issue_prep = [&](uint32_t stage_idx) {
         const uint32_t tcl = min(it, t_end - 1);
         const uint32_t col0 = tcl * T2;
         if (ikt == 0) {
@@ -493,26 +500,39 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
                     (lptr_t)(reinterpret_cast<unsigned char *>(vn_lds) + ((it - t_begin) & 3) * T2 * 4 + wave * 256), 4, 0, 0);
             }
         }
-        unsigned char *dst = smem + stage_idx * STAGE;
-        const unsigned char *cp = V + (size_t)col0 * row_bytes + (size_t)ikt * KBV;
-        const unsigned char *qp = q_base + (size_t)ikt * KBV;
-#pragma unroll
-        for (int i = 0; i < NPC; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(cp + c_off[i]),
-                                             (lptr_t)(dst + (NPC * wave + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(qp + q_off[i]),
-                                             (lptr_t)(dst + T2 * KBV + (NPC * wave + i) * 1024), 16, 0, 0);
-        }
+        i_dst = smem + stage_idx * STAGE;
+        uint32_t ks = ikt + krot;
+        if (ks >= KT) ks -= KT;
+        i_cp = V + (size_t)col0 * row_bytes + (size_t)ks * KBV;
+        i_qp = q_base + (size_t)ks * KBV;
         if (++ikt == KT) {
             ikt = 0;
             if (it < t_end) ++it;
         }
+    };
+    // piece i of the slice prepared by issue_prep: 1 KiB of the corpus tile + 1 KiB of the query tile
+    auto issue_piece = [&](int i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(i_cp + c_off[i]), (lptr_t)(i_dst + (NPC * wave + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(i_qp + q_off[i]), (lptr_t)(i_dst + T2 * KBV + (NPC * wave + i) * 1024), 16, 0, 0);
+    };
+    auto issue_slice = [&](uint32_t stage_idx) {
+        issue_prep(stage_idx);
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) issue_piece(i);
     };
 
     const uint32_t fr = lane & 31, fh = lane >> 5;
     uint32_t f_off[NCC];
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc) f_off[cc] = fr * KBV + ((((uint32_t)(2 * cc) + fh) ^ swz(fr)) << 4);
+
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+    uint32_t fa_base[NCC], fb_base[NCC];
+#pragma unroll
+    for (int cc = 0; cc < NCC; ++cc) {
+        fa_base[cc] = lds0 + (wm * 128) * KBV + f_off[cc];
+        fb_base[cc] = lds0 + T2 * KBV + (wn * (32 * NI)) * KBV + f_off[cc];
+    }
 
     // the lane's two queries and its private sub-buffers
     const uint32_t sub_id = wm * 2 + fh;
@@ -534,7 +554,7 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
     }
     __syncthreads();  // state arrays initialised (plain LDS stores) before anyone reads them
     uint32_t islice = 0;
-    unsigned long long tk0 = 0, t_round = 0, t_phb = 0, t_pha = 0, n_round = 0;
+    unsigned long long tk0 = 0, t_round = 0, t_phb = 0, t_pha = 0, n_round = 0, t_sync = 0, t_front = 0, t_body = 0, ts0 = 0;
     if (dbg & 32) tk0 = __builtin_amdgcn_s_memtime();
 
     for (uint32_t t = t_begin; t < t_end; ++t) {
@@ -542,11 +562,13 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
         const uint32_t *vn_t = vn_lds + ((t - t_begin) & 3) * T2;
         acc_t acc[4][NI];
         u32x4 fx_a[4], fx_b[NI], fy_a[4], fy_b[NI];
-        auto mma8 = [&](const u32x4 (&a4)[4], const u32x4 (&b2)[NI]) {
+        // MFMAs [lo, hi) of the 4 x NI fragment products of one k-step (constant after unrolling)
+        auto mma_some = [&](const u32x4 (&a4)[4], const u32x4 (&b2)[NI], int lo, int hi) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
+                    if (mi * NI + ni < lo || mi * NI + ni >= hi) continue;
                     if constexpr (MODE == 1) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4[mi]),
                                                                               __builtin_bit_cast(bf16x8, b2[ni]), acc[mi][ni], 0, 0, 0);
@@ -563,16 +585,19 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
                     }
                 }
         };
+        auto mma8 = [&](const u32x4 (&a4)[4], const u32x4 (&b2)[NI]) { mma_some(a4, b2, 0, 4 * NI); };
         uint32_t thr[NI];   // fp: bits of the accumulator bound; int: tau
         uint32_t cntr[NI], cnt0[NI];
 
         for (uint32_t kt = 0; kt < KT; ++kt, ++islice) {
+            if (dbg & 32) ts0 = __builtin_amdgcn_s_memtime();
             // slice `islice` has landed once at most this wave's (NST-2) youngest slices' DMA ops are pending
             if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (dbg & 32) { const unsigned long long x2 = __builtin_amdgcn_s_memtime(); t_sync += x2 - ts0; ts0 = x2; }
             if (kt == 0) {
                 // prune ROUND: batched so that all 8 waves have queries to merge (a round stalls the
                     // whole pipeline); started when enough sub-buffers crossed the soft mark or one is
@@ -670,29 +695,71 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
             // generic k-step pipeline over the slice's NCC 32-byte steps: fragments of step j+1 are read
             // (alternating register sets X / Y) while step j is multiplied; the last step's MFMAs are
             // deferred behind the next slice's barrier, reads and DMA issue (PIPE) or run at once.
-            const unsigned char *st = smem + (islice % NST) * STAGE;
+            // The fragment reads and their waits are hand-written: hipcc waits with lgkmcnt(0) in front of a
+            // k-step's MFMAs, i.e. also for the NEXT step's reads it has just issued, which serialises LDS
+            // latency and MFMA on every other step.  LDS returns in order, so lgkmcnt(<reads of the newer set>)
+            // is the exact wait; the registers are tied to the wait so the MFMAs cannot move above it.
+            const uint32_t st_off = (islice % NST) * STAGE;
             auto read_set = [&](u32x4 (&fa)[4], u32x4 (&fb)[NI], int cc) {
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    fa[mi] = *reinterpret_cast<const u32x4 *>(st + (wm * 128 + mi * 32) * KBV + f_off[cc]);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    fb[ni] = *reinterpret_cast<const u32x4 *>(st + T2 * KBV + (wn * (32 * NI) + ni * 32) * KBV + f_off[cc]);
+                const uint32_t aa = st_off + fa_base[cc], ab = st_off + fb_base[cc];
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\t"
+                             "ds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7"
+                             : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fa[2]), "=&v"(fa[3])
+                             : "v"(aa), "n"(32 * KBV), "n"(64 * KBV), "n"(96 * KBV));
+                if constexpr (NI == 2) {
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3"
+                                 : "=&v"(fb[0]), "=&v"(fb[1]) : "v"(ab), "n"(32 * KBV));
+                } else {
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\t"
+                                 "ds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7"
+                                 : "=&v"(fb[0]), "=&v"(fb[1]), "=&v"(fb[2]), "=&v"(fb[3])
+                                 : "v"(ab), "n"(32 * KBV), "n"(64 * KBV), "n"(96 * KBV));
+                }
             };
+            // wait until `fa/fb` have landed given that `newer` sets of reads were issued after them
+            auto wait_set = [&](u32x4 (&fa)[4], u32x4 (&fb)[NI], auto newer) {
+                constexpr int cnt = decltype(newer)::value * (4 + NI);
+                if constexpr (NI == 2)
+                    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]) : "n"(cnt));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]),
+                                 "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]) : "n"(cnt));
+            };
+            using one_t = std::integral_constant<int, 1>;
+            using zero_t = std::integral_constant<int, 0>;
             read_set(fx_a, fx_b, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (!(dbg & 256)) issue_slice((islice + NST - 1) % NST);
-            __builtin_amdgcn_sched_barrier(0);
-            if (PIPE && kt > 0 && !(dbg & 128)) mma8(fy_a, fy_b);
-            __builtin_amdgcn_sched_barrier(0);
+            // the next slice's DMA goes out first (its latency bounds the slice) with the previous slice's
+            // deferred MFMAs between the pieces: a wave blocks on MFMA issue while the pipe is busy, the
+            // VMEM issue of the following piece runs in that shadow
+            if constexpr (PIPE) {
+                if (!(dbg & 256)) issue_prep((islice + NST - 1) % NST);
+                if (kt > 0 && !(dbg & 128)) wait_set(fy_a, fy_b, one_t{});
+                constexpr int MPP = 4 * NI / NPC;  // MFMAs per DMA piece pair
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) {
+                    if (!(dbg & 256)) issue_piece(i);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt > 0 && !(dbg & 128)) mma_some(fy_a, fy_b, i * MPP, (i + 1) * MPP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                if (!(dbg & 256)) issue_slice((islice + NST - 1) % NST);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (dbg & 32) { const unsigned long long x2 = __builtin_amdgcn_s_memtime(); t_front += x2 - ts0; ts0 = x2; }
 #pragma unroll
             for (int cc = 1; cc < NCC; ++cc) {
                 if (cc & 1) read_set(fy_a, fy_b, cc); else read_set(fx_a, fx_b, cc);
                 __builtin_amdgcn_sched_barrier(0);
+                if (cc & 1) wait_set(fx_a, fx_b, one_t{}); else wait_set(fy_a, fy_b, one_t{});
                 if (!(dbg & 128)) { if (cc & 1) mma8(fx_a, fx_b); else mma8(fy_a, fy_b); }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // the slice's last set: landed before the next barrier (the stage is then overwritten by DMA)
+            wait_set(fy_a, fy_b, zero_t{});
             if (!PIPE && !(dbg & 128)) mma8(fy_a, fy_b);
+            if (dbg & 32) t_body += __builtin_amdgcn_s_memtime() - ts0;
             if (dbg & 128) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) asm volatile("" :: "v"(fx_a[mi]), "v"(fy_a[mi]));
@@ -786,6 +853,9 @@ uint32_t ncross = 0;
             atomicAdd(&dbgbuf[6], t_pha);
             atomicAdd(&dbgbuf[7], t_phb);
             atomicAdd(&dbgbuf[8], n_round);
+            atomicAdd(&dbgbuf[9], t_sync);
+            atomicAdd(&dbgbuf[10], t_front);
+            atomicAdd(&dbgbuf[11], t_body);
         }
     }
     for (int q = wave; q < T2; q += NW) {
@@ -976,6 +1046,14 @@ int wave_tile_ni() {
     return v;
 }
 
+// k-slice rotation per query tile (nibble qt&7), each < KT.  ZVDB_BF_ROT=<hex> overrides (A/B).
+uint32_t rot_table(uint32_t KT) {
+    static const uint32_t env = [] { const char *e = getenv("ZVDB_BF_ROT"); return e ? (uint32_t)strtoul(e, nullptr, 16) : 0x53145420u; }();
+    uint32_t t = 0;
+    for (int i = 0; i < 8; ++i) t |= (((env >> (4 * i)) & 15u) % KT) << (4 * i);
+    return t;
+}
+
 int slice_bytes() {
     static const int v = [] { const char *e = getenv("ZVDB_BF_KBV"); return (e && e[0] == '6') ? 64 : 128; }();
     return v;
@@ -992,13 +1070,14 @@ int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         hipLaunchKernelGGL((k_bf_scan5<MODE, true, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
-                           (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, pcnt, debug_flags(), dbgbuf);
+                           (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, pcnt, rot_table(p.row_bytes / KBV),
+                           debug_flags(), dbgbuf);
     } else {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, false, NI, KBV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         hipLaunchKernelGGL((k_bf_scan5<MODE, false, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
-                           list_base, Stot, pcnt, 0u, dbgbuf);
+                           list_base, Stot, pcnt, rot_table(p.row_bytes / KBV), 0u, dbgbuf);
     }
     return ZVDB_OK;
 }
@@ -1139,10 +1218,12 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             ZV_CHECK(scan(passes[i], lists));
             lists += passes[i].S;
             if (debug_flags() & (16 | 32)) {
-                unsigned long long c[9];
+                unsigned long long c[12];
                 ZV_HIP(hipMemcpyAsync(c, ws + p.off_taug + (size_t)p.nq_pad * 4, sizeof(c), hipMemcpyDeviceToHost, s));
                 ZV_HIP(hipStreamSynchronize(s));
                 const double nb = (double)p.QT * passes[i].S;
+                fprintf(stderr, "[zvdb dbg] pass %d slice loop cycles/blk (wave 0): wait+barrier %.0f, reads+DMA issue (+tile init) %.0f, k-steps %.0f\n",
+                        i, c[9] / nb, c[10] / nb, c[11] / nb);
                 fprintf(stderr, "[zvdb dbg] pass %d (tiles %u, streams %u): wave-tiles %llu, with-pass %llu, prunes %llu, appends %llu, rounds/blk %.1f | "
                         "cycles/blk: kernel %.0f, rounds %.0f, phaseA %.0f, phaseB %.0f\n",
                         i, passes[i].nt, passes[i].S, c[0], c[1], c[2], c[3], (double)c[8] / nb, c[4] / nb, c[5] / nb, c[6] / nb, c[7] / nb);
