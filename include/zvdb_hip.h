@@ -57,9 +57,14 @@ enum zvdb_metric {
 enum zvdb_bf_mode {
     ZVDB_BF_F32 = 0,  /* fp32 MFMA (v_mfma_f32_32x32x2_f32) screen + exact fp32 re-rank */
     ZVDB_BF_BF16 = 1, /* bf16 MFMA screen over the bf16 mirror + exact fp32 re-rank */
-    ZVDB_BF_I8 = 2    /* int8 MFMA (v_mfma_i32_32x32x32_i8) screen over a scalar-quantised mirror
+    ZVDB_BF_I8 = 2,   /* int8 MFMA (v_mfma_i32_32x32x32_i8) screen over a scalar-quantised mirror
                          (global affine range for L2, symmetric for dot/cosine; built lazily from
                          the fp32 rows) + exact fp32 re-rank */
+    ZVDB_BF_FP4 = 3   /* fp4 (OCP E2M1) MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales) screen over
+                         a 4-bit scalar-quantised mirror (same global range, 2 elements per byte; built lazily)
+                         + exact fp32 re-rank of k' = 64 survivors.  APPROXIMATE: a true neighbour whose 4-bit
+                         key is not among the 64 best is lost (recall is measured, not guaranteed); returned
+                         distances are still the reference's exact arithmetic */
 };
 
 typedef struct zvdb_hip_index zvdb_hip_index; /* opaque */

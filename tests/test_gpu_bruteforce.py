@@ -15,7 +15,7 @@ def zv():
 
 
 def MODES(zv):
-    return {"f32": zv.BF_F32, "bf16": zv.BF_BF16, "i8": zv.BF_I8}
+    return {"f32": zv.BF_F32, "bf16": zv.BF_BF16, "i8": zv.BF_I8, "fp4": zv.BF_FP4}
 
 
 def _index(zv, V, **kw):
@@ -42,12 +42,13 @@ def test_bruteforce_bit_exact_vs_oracle(zv, oracle, n, d, nq, k, mode):
         assert np.all(ids[qi, c:] == np.uint64(0xFFFFFFFFFFFFFFFF))
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16", "i8"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "i8", "fp4"])
 def test_bruteforce_ties_by_lower_id(zv, oracle, mode):
     """Duplicated rows and grid data: exactly equal distances must come back lowest id first."""
     rng = np.random.default_rng(4)
-    base = rng.integers(0, 4, size=(300, 8)).astype(np.float32)
-    V = np.concatenate([base, base, base[:100]], axis=0)  # every row appears 2-3 times
+    nb = 24 if mode == "fp4" else 300  # fp4: 60 rows <= k' = 64, so every row reaches the exact re-rank
+    base = rng.integers(0, 4, size=(nb, 8)).astype(np.float32)
+    V = np.concatenate([base, base, base[:nb // 3]], axis=0)  # every row appears 2-3 times
     Q = rng.integers(0, 4, size=(40, 8)).astype(np.float32)
     idx = _index(zv, V)
     ids, dist, cnt = idx.search_bruteforce(Q, 20, MODES(zv)[mode])
@@ -64,7 +65,7 @@ def test_bruteforce_adversarial_order_forces_prunes(zv, oracle):
     V = V[np.argsort(-d, kind="stable")]
     Q = np.stack([q, V[0], V[-1]])
     idx = _index(zv, V)
-    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8, zv.BF_FP4):
         ids, dist, _ = idx.search_bruteforce(Q, 10, mode)
         ri, rd, _ = oracle.bruteforce_topk(V, Q, 10)
         assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
@@ -87,6 +88,42 @@ def test_bruteforce_large_self_consistency(zv, oracle):
     assert np.array_equal(idx.get_vector(123_456), V[123_456])
     ri, rd, _ = oracle.bruteforce_topk(V, Q[:8], 10)
     assert np.array_equal(i32[:8], ri) and np.array_equal(d32[:8], rd)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(400, 64, 8, 10), (100, 128, 5, 10), (1, 16, 3, 4), (129, 256, 1, 1), (60, 300, 70, 48)])
+def test_bruteforce_fp4_exact_when_corpus_fits_the_survivor_list(zv, oracle, n, d, nq, k):
+    """fp4 screen, N <= a few x k' = 64 survivors: (almost) every row reaches the exact re-rank, so the result
+    must equal the oracle's bit for bit -- checks the operand packing, the MFMA lane map (a wrong map scrambles
+    the keys and loses neighbours even here for n = 400), norms, ragged tiles and padding."""
+    V = oracle.uniform_rows(3000 + n, 0, n, d)
+    Q = oracle.uniform_rows(4000 + n, 0, nq, d)
+    idx = _index(zv, V)
+    ids, dist, cnt = idx.search_bruteforce(Q, k, zv.BF_FP4)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
+    assert np.array_equal(cnt, rc)
+    for qi in range(nq):
+        c = int(rc[qi])
+        assert np.array_equal(ids[qi, :c], ri[qi, :c]), (qi, ids[qi], ri[qi])
+        assert np.array_equal(dist[qi, :c], rd[qi, :c])
+
+
+@pytest.mark.parametrize("n,d,nq", [(20000, 96, 130), (50000, 768, 64), (200_000, 256, 32)])
+def test_bruteforce_fp4_recall_and_exact_distances(zv, oracle, n, d, nq):
+    """The 4-bit screen is approximate: recall@10 against the exact route is MEASURED (bar: >= 0.95, the
+    headline metric's bar); whatever it returns carries the reference's exact distance, ascending, ties by id,
+    and every returned id that is a true neighbour sits at the oracle's distance."""
+    idx = zv.Index()
+    idx.add_synthetic(n, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    ei, ed, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)
+    ai, ad, ac = idx.search_bruteforce(Q, 10, zv.BF_FP4)
+    assert np.all(ac == 10)
+    rec = np.mean([len(set(ai[i]) & set(ei[i])) / 10 for i in range(nq)])
+    assert rec >= 0.95, rec
+    assert np.all(np.diff(ad, axis=1) >= 0)
+    for qi in range(0, nq, 7):
+        for j in range(10):
+            assert oracle.distance(Q[qi], idx.get_vector(int(ai[qi, j]))) == ad[qi, j]
 
 
 def test_bruteforce_dot_metric(zv, oracle):

@@ -207,6 +207,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->scratch);
     (void)hipFree(h->rows_q);
     (void)hipFree(h->norm_q);
+    (void)hipFree(h->rows_p);
+    (void)hipFree(h->norm_p);
     (void)hipFree(h->q_range);
     if (h->pin.ptr) (void)hipHostFree(h->pin.ptr);
     for (auto &e : h->events) {
@@ -589,7 +591,7 @@ int zvdb_hip_bruteforce_workspace(zvdb_hip_index *h, uint32_t nq, uint32_t k, ui
                                   uint64_t *out_bytes) {
     ZV_ARG(h && out_bytes, "null argument");
     std::lock_guard<std::mutex> g(h->mu);
-    ZV_ARG(mode <= ZVDB_BF_I8, "unknown brute-force mode");
+    ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
     *out_bytes = bruteforce_workspace_bytes(h, nq, k, mode);
     return ZVDB_OK;
 }
@@ -602,7 +604,7 @@ int zvdb_hip_search_bruteforce_dev(zvdb_hip_index *h, const void *d_queries, uin
     std::lock_guard<std::mutex> g(h->mu);
     ZV_CHECK(use_device(h));
     ZV_CHECK(check_query_args(h, dim, k));
-    ZV_ARG(mode <= ZVDB_BF_I8, "unknown brute-force mode");
+    ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
     ZV_ARG(h->count > 0 && k > 0, "search_bruteforce_dev needs a non-empty index and k > 0");
     return launch_bruteforce(h, static_cast<const float *>(d_queries), nq, k, mode, id_offset, d_workspace,
                              workspace_bytes, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
@@ -617,7 +619,7 @@ int zvdb_hip_search_bruteforce(zvdb_hip_index *h, const float *queries, uint32_t
     std::lock_guard<std::mutex> g(h->mu);
     ZV_CHECK(use_device(h));
     ZV_CHECK(check_query_args(h, dim, k));
-    ZV_ARG(mode <= ZVDB_BF_I8, "unknown brute-force mode");
+    ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
     if (h->count == 0 || k == 0) {
         fill_empty(nq, k, out_ids, out_dist, out_count);
         return ZVDB_OK;
@@ -650,7 +652,7 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode) 
     ZV_ARG(h, "null argument");
     std::lock_guard<std::mutex> g(h->mu);
     ZV_CHECK(use_device(h));
-    ZV_ARG(mode <= ZVDB_BF_I8, "unknown brute-force mode");
+    ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
     ZV_ARG(degree >= 1 && degree <= h->gstride, "degree must be in [1, graph_stride]");
     if (h->count == 0) return ZVDB_OK;
     const uint32_t k = degree + 1;  // the row itself is (one of) its own nearest

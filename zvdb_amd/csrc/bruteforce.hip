@@ -290,8 +290,11 @@ __global__ __launch_bounds__(256, 2) void k_bf_scan(
 // LDS-DMA writes wave-uniform base + lane*16, i.e. 8 whole 128-B rows per wave-instruction, so
 // the XOR swizzle of the LDS image is applied to the per-lane SOURCE chunk: the lane that fills
 // (row r, slot c') fetches chunk c' ^ ((r>>1)&7) of row r.
-// MODE: 0 = fp32 (32x32x2 f32), 1 = bf16 (32x32x16), 2 = int8 (32x32x32, i32 accumulate).
+// MODE: 0 = fp32 (32x32x2 f32), 1 = bf16 (32x32x16), 2 = int8 (32x32x32, i32 accumulate),
+//       3 = fp4 E2M1 (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, fp32 accumulate: products and
+//           sums of fp4 values are small multiples of 1/4, so the fp32 accumulation is exact).
 // =====================================================================================
+constexpr bool kFp4Pipe = false;
 constexpr int T2 = 256;                      // tile edge (queries and corpus rows)
 constexpr int CAP2 = HW + T2;                // per-row candidate buffer of the v2 scan
 constexpr int STAGE2 = 2 * T2 * KB;          // A + B = 64 KiB per stage
@@ -299,6 +302,7 @@ constexpr int LDS2 = 2 * STAGE2 + 3 * T2 * 4;
 
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
     constexpr int NPC = 256 / RPP / NW;  // DMA pieces per operand per wave per slice
     constexpr int STAGE = 2 * T2 * KBV;  // 32 or 64 KiB
     constexpr int NST = 131072 / STAGE;  // ring stages: 4 or 2
-    constexpr bool PIPE = MODE == 2 || NI == 4;  // defer a slice's last k-step behind the next barrier (bf16/fp32 spill with it)
+    constexpr bool PIPE = MODE == 2 || (MODE == 3 && kFp4Pipe) || NI == 4;  // defer a slice's last k-step behind the next barrier (bf16/fp32 spill with it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *vn_lds = reinterpret_cast<uint32_t *>(smem + LDS4_VN);
     uint32_t *tg_lds = reinterpret_cast<uint32_t *>(smem + LDS4_TG);
@@ -575,6 +579,12 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
                     } else if constexpr (MODE == 2) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a4[mi]),
                                                                             __builtin_bit_cast(i32x4, b2[ni]), acc[mi][ni], 0, 0, 0);
+                    } else if constexpr (MODE == 3) {
+                        // a lane's 16-byte chunk = its 32 fp4 k-elements of this 64-deep step (cbsz = blgp = 4: fp4
+                        // reads operand registers 0-3 only); E8M0 scale 127 = 2^0 for every 32-element block
+                        const i32x4 xa = __builtin_bit_cast(i32x4, a4[mi]), xb = __builtin_bit_cast(i32x4, b2[ni]);
+                        const i32x8 wa = {xa.x, xa.y, xa.z, xa.w, 0, 0, 0, 0}, wb = {xb.x, xb.y, xb.z, xb.w, 0, 0, 0, 0};
+                        acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, wb, acc[mi][ni], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
                     } else {
                         const f32x4 xa = __builtin_bit_cast(f32x4, a4[mi]);
                         const f32x4 xb = __builtin_bit_cast(f32x4, b2[ni]);
@@ -952,7 +962,8 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
 }
 
 // queries -> operand layout of the scan: [nq_pad][row_bytes], zero padded.
-// mode 0: fp32 copy; 1: bf16 RNE; 2: int8 with the index's quantisation (q_lo, q_inv, affine).
+// mode 0: fp32 copy; 1: bf16 RNE; 2: int8 with the index's quantisation (q_lo, q_inv, affine);
+// 3: fp4 codes, two per byte (q_lo = the index's p_mid, q_inv = p_scale; row_elems counts BYTES here).
 __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict__ q, uint32_t nq,
                                                          uint32_t dim, unsigned char *__restrict__ out,
                                                          uint32_t nq_pad, uint32_t row_elems, int mode,
@@ -961,6 +972,15 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)(t / row_elems), c = (uint32_t)(t - (uint64_t)r * row_elems);
+        if (mode == 3) {
+            uint32_t b = 0;
+            if (r < nq) {
+                if (2 * c < dim) b = fp4_e2m1_code((q[(size_t)r * dim + 2 * c] - q_lo) * q_inv);
+                if (2 * c + 1 < dim) b |= fp4_e2m1_code((q[(size_t)r * dim + 2 * c + 1] - q_lo) * q_inv) << 4;
+            }
+            out[t] = (unsigned char)b;
+            continue;
+        }
         const bool live = r < nq && c < dim;
         const float v = live ? q[(size_t)r * dim + c] : 0.0f;
         if (mode == 1) {
@@ -1009,7 +1029,7 @@ uint32_t debug_flags() {
 
 BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     BfPlan p{};
-    const bool v1 = use_v1() && mode != ZVDB_BF_I8;
+    const bool v1 = use_v1() && mode != ZVDB_BF_I8 && mode != ZVDB_BF_FP4;
     p.tile = v1 ? BM : T2;
     p.cap = v1 ? CAP : CAP2;
     p.nq_pad = round_up(std::max(nq, 1u), p.tile);
@@ -1017,6 +1037,7 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     p.NT = (uint32_t)((h->count + p.tile - 1) / p.tile);
     if (mode == ZVDB_BF_BF16) { p.row_elems = h->ldh; p.row_bytes = h->ldh * 2; }
     else if (mode == ZVDB_BF_I8) { p.row_elems = round_up(h->dim, 128); p.row_bytes = p.row_elems; }
+    else if (mode == ZVDB_BF_FP4) { p.row_bytes = round_up(h->dim, 256) / 2; p.row_elems = p.row_bytes; /* prep kernel: per byte */ }
     else { p.row_elems = h->ld; p.row_bytes = h->ld * 4; }
     p.KT = p.row_bytes / KB;
     // resident workgroups: v1 2 per CU, v2 1 per CU; streams in multiples of 8 (XCD groups)
@@ -1110,6 +1131,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         return ZVDB_ERR_UNSUPPORTED;
     }
     if (mode == ZVDB_BF_I8) ZV_CHECK(ensure_i8_mirror(h, s));
+    if (mode == ZVDB_BF_FP4) ZV_CHECK(ensure_fp4_mirror(h, s));
     const BfPlan p = make_plan(h, nq, mode);
     if (ws_bytes < p.total) {
         set_error("workspace too small: need %llu bytes, got %llu", (unsigned long long)p.total,
@@ -1127,7 +1149,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         const uint64_t total = (uint64_t)p.nq_pad * p.row_elems;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);
         hipLaunchKernelGGL(k_bf_prep_queries, dim3(grid), dim3(256), 0, s, d_queries, nq, h->dim, q_op,
-                           p.nq_pad, p.row_elems, (int)mode, h->q_lo, h->q_inv, l2 ? 1 : 0);
+                           p.nq_pad, p.row_elems, (int)mode, mode == ZVDB_BF_FP4 ? h->p_mid : h->q_lo,
+                           mode == ZVDB_BF_FP4 ? h->p_scale : h->q_inv, l2 ? 1 : 0);
     }
     // screen key: L2 -> |v|^2 - 2 q.v ; dot / cosine -> -q.v (no norm term)
     const int alpha_i = l2 ? -2 : -1;
@@ -1161,12 +1184,15 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         // re-learns a threshold from its own 1/64 of the data and appends ~100x more candidates.
         uint32_t *tau_g = reinterpret_cast<uint32_t *>(ws + p.off_taug);
         uint32_t *pcnt = reinterpret_cast<uint32_t *>(ws + p.off_pcnt);
-        const uint32_t kp = (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+        // survivors per query: 32 suffice for k <= 16 with the (near-)exact screens; the 4-bit screen keeps 64
+        const uint32_t kp = (k <= 16 && mode != ZVDB_BF_FP4 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
                                     : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
+                                    : mode == ZVDB_BF_FP4 ? reinterpret_cast<const unsigned char *>(h->rows_p)
                                                          : reinterpret_cast<const unsigned char *>(h->rows);
         const void *vn = !l2 ? nullptr : mode == ZVDB_BF_BF16 ? (const void *)h->norm_h
-                                       : mode == ZVDB_BF_I8 ? (const void *)h->norm_q : (const void *)h->norm;
+                                       : mode == ZVDB_BF_I8 ? (const void *)h->norm_q
+                                       : mode == ZVDB_BF_FP4 ? (const void *)h->norm_p : (const void *)h->norm;
         // pass schedule: {first tile, tiles, streams}; after each pass but the last, a merge of ALL
         // lists so far gives, per query, the exact k'-th best key over the rows scanned so far = the
         // shared threshold of the next pass (learning a threshold costs one flooded tile + one sort per
@@ -1198,6 +1224,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         auto scan = [&](const Pass &ps, uint32_t list_base) -> int {
             BfPlan q = p;
             q.S = ps.S;
+            if (mode == ZVDB_BF_FP4)  // one geometry only: full-line pieces, 128-byte (256-element) slices
+                return launch_scan5<3, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             if (kernel_version() == 4 && wave_tile_ni() == 4) {  // experimental: one wave per SIMD
                 if (mode == ZVDB_BF_BF16) return launch_scan5<1, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
                 if (mode == ZVDB_BF_I8) return launch_scan5<2, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
@@ -1251,7 +1279,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 (double)c[8] / (p.QT * p.S), (double)c[6] / (p.QT * p.S), (double)c[7] / (p.QT * p.S));
     }
     if (p.tile != BM && kernel_version() == 4) {
-        const uint32_t kpf = (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+        const uint32_t kpf = (k <= 16 && mode != ZVDB_BF_FP4 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const uint32_t cap = kpf + 64 * KP;
         hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial,
                            reinterpret_cast<const uint32_t *>(ws + p.off_pcnt), nlists, stot_lists, cand_ids,

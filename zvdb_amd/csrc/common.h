@@ -66,6 +66,24 @@ __host__ __device__ inline float f32_unkey(uint32_t k) {
 #endif
 }
 
+// OCP fp4 E2M1: magnitudes {0, .5, 1, 1.5, 2, 3, 4, 6}, bit 3 = sign.  Nearest value, ties to the smaller
+// magnitude; ONE function for rows and queries so equal inputs get equal codes.
+__host__ __device__ inline uint32_t fp4_e2m1_code(float y) {
+    const float a = y < 0.0f ? -y : y;
+    const uint32_t m = (uint32_t)(a > 0.25f) + (uint32_t)(a > 0.75f) + (uint32_t)(a > 1.25f) + (uint32_t)(a > 1.75f) +
+                       (uint32_t)(a > 2.5f) + (uint32_t)(a > 3.5f) + (uint32_t)(a > 5.0f);
+    return m | (y < 0.0f ? 8u : 0u);
+}
+__host__ __device__ inline float fp4_e2m1_sq(uint32_t code) {  // value^2 of a code
+    const uint32_t m = code & 7u;
+    const float v = m < 4u ? 0.5f * (float)m : m == 4u ? 2.0f : m == 5u ? 3.0f : m == 6u ? 4.0f : 6.0f;
+    return v * v;
+}
+// the shard's value range is mapped onto [-kFp4Amax, kFp4Amax]: |y| > 5 would round to 6, (3.5, 5] to 4; with
+// 4.5 the coarse top step is unused and the quantisation error of uniformly spread data is smallest
+// (DESIGN.md "fp4 screen": recall sweep)
+constexpr float kFp4Amax = 4.5f;
+
 struct PinnedBuf {
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -98,6 +116,12 @@ struct zvdb_hip_index {
     uint32_t ldq = 0;
     uint64_t cap_q = 0, count_q = 0;
     float q_lo = 0.0f, q_inv = 1.0f;  // q = clamp(rint((x - q_lo) * q_inv) - 128) (L2) / rint(x * q_inv) (dot)
+    // fp4 (E2M1) scalar-quantised mirror for ZVDB_BF_FP4 (lazy, like the int8 one)
+    unsigned char *rows_p = nullptr;  // [cap_p][ldp] bytes, 2 codes per byte (low nibble = even element), ldp = round_up(dim, 256) / 2
+    float *norm_p = nullptr;          // [cap_p] sum of the squared fp4 VALUES (exact in fp32)
+    uint32_t ldp = 0;
+    uint64_t cap_p = 0, count_p = 0;
+    float p_mid = 0.0f, p_scale = 1.0f;  // code = fp4_e2m1_code((x - p_mid) * p_scale)
     hipStream_t stream = nullptr;
     // pinned host staging + device scratch for the host-pointer entry points
     zvdb::PinnedBuf pin;
@@ -141,6 +165,7 @@ int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld
 int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
 int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
+int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s);
 int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const uint32_t *d_cnt, uint32_t k,
                           uint64_t r0, uint32_t n, uint32_t degree, hipStream_t s);
 int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,

@@ -244,6 +244,76 @@ int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
     return ZVDB_OK;
 }
 
+// ---- fp4 (E2M1) scalar-quantised mirror (ZVDB_BF_FP4) -------------------------------------------
+// Same global range as the int8 mirror, mapped onto [-kFp4Amax, kFp4Amax] and rounded to the nearest fp4
+// value: L2 centres the range (offsets cancel in q_a - q_b), dot/cosine scale symmetrically around 0.
+// One wave per row; a lane packs 8 consecutive elements into one dword (low nibble = even element).
+__global__ __launch_bounds__(256) void k_quantize_rows_fp4(const float *__restrict__ rows, uint32_t dim, uint32_t ld,
+                                                           unsigned char *__restrict__ rows_p, uint32_t ldp,
+                                                           float *__restrict__ norm_p, uint64_t n, float mid,
+                                                           float scale) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float *v = rows + r * ld;
+    float s = 0.0f;  // multiples of 1/4 below 2^24: exact in any summation order
+    for (uint32_t c = lane * 8; c < ldp * 2; c += 512) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t code = 0;
+            if (c + j < dim) {
+                code = fp4_e2m1_code((v[c + j] - mid) * scale);
+                s += fp4_e2m1_sq(code);
+            }
+            w |= code << (4 * j);
+        }
+        *reinterpret_cast<uint32_t *>(rows_p + r * ldp + c / 2) = w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) norm_p[r] = s;
+}
+
+int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s) {
+    if (h->rows_p && h->count_p == h->count) return ZVDB_OK;
+    if (h->count == 0) return ZVDB_OK;
+    h->ldp = round_up(h->dim, 256) / 2;
+    if (h->cap_p < h->count) {
+        if (h->rows_p) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_p)); ZV_HIP(hipFree(h->norm_p)); }
+        h->rows_p = nullptr;
+        h->norm_p = nullptr;
+        const uint64_t ncap = std::max<uint64_t>(h->count, h->cap);
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->rows_p), ncap * h->ldp));
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->norm_p), ncap * sizeof(float)));
+        h->cap_p = ncap;
+    }
+    if (!h->q_range) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->q_range), 8));
+    const uint32_t init[2] = {0xFFFFFFFFu, 0u};
+    ZV_HIP(hipMemcpyAsync(h->q_range, init, 8, hipMemcpyHostToDevice, s));
+    const uint64_t total4 = h->count * h->ld / 4;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((total4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_minmax, dim3(grid), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, h->q_range);
+    ZV_HIP(hipGetLastError());
+    uint32_t got[2];
+    ZV_HIP(hipMemcpyAsync(got, h->q_range, 8, hipMemcpyDeviceToHost, s));
+    ZV_HIP(hipStreamSynchronize(s));  // (lazy one-off build; not on the steady-state search path)
+    const float lo = f32_unkey(got[0]), hi = f32_unkey(got[1]);
+    if (h->metric == ZVDB_METRIC_L2SQ) {
+        h->p_mid = 0.5f * (lo + hi);
+        h->p_scale = hi > lo ? kFp4Amax / (0.5f * (hi - lo)) : 1.0f;
+    } else {
+        const float m = std::max(std::fabs(lo), std::fabs(hi));
+        h->p_mid = 0.0f;
+        h->p_scale = m > 0.0f ? kFp4Amax / m : 1.0f;
+    }
+    hipLaunchKernelGGL(k_quantize_rows_fp4, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
+                       h->ld, h->rows_p, h->ldp, h->norm_p, h->count, h->p_mid, h->p_scale);
+    ZV_HIP(hipGetLastError());
+    h->count_p = h->count;
+    return ZVDB_OK;
+}
+
 // kNN-graph construction: search results of rows [r0, r0+n) (ids u64 [n][k], counts) -> adjacency rows
 // (self dropped, nearest first, at most `degree` entries)
 __global__ __launch_bounds__(256) void k_results_to_adj(const uint64_t *__restrict__ ids,
