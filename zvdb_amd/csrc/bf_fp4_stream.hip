@@ -1,0 +1,397 @@
+// bf_fp4_stream.hip -- K4 "v7": barrier-free fp4 (OCP E2M1) brute-force screen.
+//
+// The LDS-staged 256 x 256 scan (bruteforce.hip) moves BOTH operands through L2 -> LDS for every tile and
+// synchronises 8 waves once per k-slice; at fp4 rates (v_mfma_scale_f32_32x32x64_f8f6f4: 64 k per 32 cycles)
+// that staging, not the MFMA pipe, sets the time (ablation in DESIGN.md).  Here
+//
+//   * the QUERY tile (256 queries) is loaded ONCE per workgroup into LDS, already in MFMA fragment order
+//     ([group of 32 queries][k-step][lane][16 B]: a B fragment is one conflict-free linear ds_read_b128);
+//   * the CORPUS mirror is stored in HBM in the same fragment order ([group of 32 rows][k-step][lane][16 B]),
+//     so an A fragment is ONE fully coalesced 1-KiB global_load_dwordx4 straight into registers: no LDS
+//     staging, no LDS-DMA, no ds_write, and -- because no wave ever reads LDS data another wave produced --
+//     NO BARRIER in the steady state.  Every wave streams its own row groups (32 rows x 256 queries per
+//     step, 8 accumulator fragments) with a 6-deep register prefetch ring;
+//   * selection: the accumulator starts at -|v|^2/2 (first MFMA takes it as srcC), so the finished
+//     accumulator is the negated screen key; a lane owns one query per fragment (8 per step), the max of its
+//     16 registers is tested against the query's bound (one v_max3 chain + one compare per fragment); rare
+//     passes append (key, id) to the query's buffer through an LDS slot counter.  A prune round (exact radix
+//     select, shared with the staged kernel) is a workgroup rendezvous requested through an LDS flag.
+//
+// fp4 keys are exact: values are multiples of 1/2, products of 1/4, |v|^2/2 of 1/8, all far below 2^24, so
+// fp32 accumulation is exact and equal rows get equal keys (ties -> lower id by the (key,id) select).
+// The thresholds are applied NON-strictly (key <= k'-th best) because the waves of a workgroup do not walk
+// the rows in id order.  No reference symbol (a10); parity: tests/test_gpu_bruteforce.py.
+#include "common.h"
+#include "wave_select.h"
+#include "bf_select.h"
+
+namespace zvdb {
+
+namespace {
+
+constexpr int F7_NF = 8;                  // query fragments per wave step (8 x 32 = 256 queries per workgroup)
+constexpr int F7_KC = 6;                  // k-steps per unrolled chunk = depth of the A prefetch ring
+constexpr int F7_CAP = NSUB * SUBCAP;     // append-buffer entries per (workgroup, query)
+constexpr int F7_HW = 384;                // an append at this slot requests a prune round (CAP - HW > 8 waves x 2 steps x 32 rows)
+constexpr int F7_MARK = 64;               // a round merges the queries holding more than this many new entries
+constexpr int F7_NW = 8;                  // waves per workgroup
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int, i>) for i = 0 .. N-1: i usable as an asm immediate
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LDS map (dynamic): [Q tile: 8 * KS KiB][tau 256 f32][cnt 256][nkept 256][subcnt 1024][ctl 4][select scratch 8 waves]
+__host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS) {
+    return F7_NF * KS * 1024 + T2 * 4 * 3 + T2 * NSUB * 4 + 16 + F7_NW * SEL_SCRATCH;
+}
+
+// KS = 64-element k-steps per row (compile time: every LDS offset of the resident tile is an instruction immediate)
+template <int KS>
+__global__ __launch_bounds__(512, 2) void k_fp4_stream(
+    const unsigned char *__restrict__ Qf /* [query group][KS][64][16 B] */,
+    const unsigned char *__restrict__ Vf /* [row group][KS][64][16 B] */, const float *__restrict__ vnorm /* padded to groups, +inf past N */,
+    uint32_t N, uint32_t nq, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
+    uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
+    uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt) {
+    static_assert(KS % F7_KC == 0 && (4 * KS - 1) * 1024 <= 65535, "ring wrap / ds_read immediate offsets");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t qbytes = F7_NF * KS * 1024;
+    float *tau = reinterpret_cast<float *>(smem + qbytes);           // exclusive bound: pass <=> key < tau
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(tau + T2);          // append slots handed out since the last merge
+    uint32_t *nkept = cnt + T2;
+    uint32_t *subcnt = nkept + T2;                                   // prune_query's view of the append buffer
+    uint32_t *ctl = subcnt + T2 * NSUB;                              // [0] round request, [1] waves that finished their steps
+    unsigned char *sel = reinterpret_cast<unsigned char *>(ctl + 4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t fr = lane & 31, fh = lane >> 5;
+
+    // block -> (stream s, query tile qt): the QT workgroups of a stream share (blockIdx % 8), i.e. one XCD under
+    // round-robin placement, and read the same row groups at about the same time (one HBM fetch, QT - 1 L2 hits)
+    const uint32_t b = blockIdx.x;
+    const uint32_t x = b & 7, jb = b >> 3;
+    const uint32_t qt = jb % QT;
+    const uint32_t s = (jb / QT) * 8 + x;
+    const uint32_t per = (NT + S - 1) / S;
+    const uint32_t t_begin = t_first + min(s * per, NT), t_end = min(t_begin + per, t_first + NT);
+    const uint32_t g_begin = 8 * t_begin, g_end = min(8 * t_end, (N + 31) / 32);  // row groups of 32
+    const uint32_t nsteps = g_end > g_begin ? (g_end - g_begin + F7_NW - 1) / F7_NW : 0;  // the same for every wave
+    uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
+    uint64_t *kept = cand + (size_t)b * BLK4_ENTRIES;
+    uint64_t *subs = kept + BLK4_KEPT;
+
+    for (int tq = tid; tq < T2; tq += 512) {
+        const bool live = (qt * T2 + tq) < nq;
+        const uint32_t g = (tau_g && live) ? __hip_atomic_load(tau_g + tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        float t0 = live ? __builtin_inff() : -__builtin_inff();
+        if (g != 0xFFFFFFFFu) t0 = fminf(t0, f32_unkey(g + 1));
+        tau[tq] = t0;
+        cnt[tq] = 0;
+        nkept[tq] = 0;
+    }
+    for (int i = tid; i < T2 * NSUB; i += 512) subcnt[i] = 0;
+    if (tid < 4) ctl[tid] = 0;
+    // the query tile: a linear 8 * KS KiB copy (the host wrote it in fragment order), 1 KiB per LDS-DMA
+    for (uint32_t p = wave; p < F7_NF * KS; p += F7_NW)
+        __builtin_amdgcn_global_load_lds((gptr_t)(Qf + (size_t)qt * qbytes + (size_t)p * 1024 + lane * 16),
+                                         (lptr_t)(smem + p * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // workgroup rendezvous: merge the append buffers that filled up, tighten tau, publish the k'-th best
+    auto round = [&]() {
+        __syncthreads();  // every wave is here, all appends have landed (vmcnt(0) is part of the fence)
+        if (tid == 0) ctl[0] = 0;
+        for (int q = wave; q < T2; q += F7_NW) {
+            const uint32_t c = min(lds_load_u32(cnt + q), (uint32_t)F7_CAP);
+            if (c > (uint32_t)F7_MARK) {
+                if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
+                if (lane == 0) cnt[q] = 0;
+                prune_query<false, true>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---- per-wave stream state: the 6-deep A ring runs ahead of the MFMAs across row groups -------------
+    // (KS is a multiple of the ring depth, so the ring wraps into the wave's next group at a chunk boundary:
+    // no control flow inside the unrolled k-steps)
+    constexpr size_t gbytes = (size_t)KS * 1024;
+    const uint32_t g_last = g_end - 1;  // (only used when nsteps > 0)
+    u32x4 A[F7_KC];
+    if (nsteps > 0) {
+        const unsigned char *p0 = Vf + (size_t)min(g_begin + (uint32_t)wave, g_last) * gbytes + lane * 16;
+#pragma unroll
+        for (int i = 0; i < F7_KC; ++i) A[i] = *reinterpret_cast<const u32x4 *>(p0 + i * 1024);
+    }
+    const uint32_t qlds = (uint32_t)(size_t)(lptr_t)smem + (uint32_t)lane * 16;
+    const uint32_t scale1 = 0x7F7F7F7Fu;  // E8M0 127 = 2^0 for every 32-element block
+    u32x4 BX[4], BY[4];
+    // fragments f0 .. f0+3 of k-step J: ((f * KS + J) << 10) + lane * 16; two long-lived base registers (one per half
+    // of the tile), everything else is an instruction immediate
+    const uint32_t qb_lo = qlds, qb_hi = qlds + 4 * KS * 1024;
+    auto rd4 = [&](u32x4 (&d)[4], auto jc, auto hc) {
+        constexpr int J = decltype(jc)::value;
+        const uint32_t base = decltype(hc)::value ? qb_hi : qb_lo;
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
+                     "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                     : "v"(base), "n"((0 * KS + J) * 1024), "n"((1 * KS + J) * 1024), "n"((2 * KS + J) * 1024), "n"((3 * KS + J) * 1024));
+    };
+    auto wait4 = [&](u32x4 (&d)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+    };
+    using c0_t = std::integral_constant<int, 0>;
+    using c1_t = std::integral_constant<int, 1>;
+    rd4(BX, c0_t{}, c0_t{});  // k-step 0 of the first step (kept in flight across steps: the tile never changes)
+    rd4(BY, c0_t{}, c1_t{});
+
+    for (uint32_t it = 0; it < nsteps; ++it) {
+        if (lds_load_u32(ctl) != 0) round();
+        const uint32_t g = g_begin + wave + F7_NW * it;
+        if (g >= g_end) continue;  // (wave-uniform; only the last iteration of some waves)
+
+        // this step's bounds (one query per fragment per lane) and the shared threshold of my 32 queries
+        // accumulator start = -|v|^2/2 of the register's corpus row: row = 32 g + (r&3) + 8 (r>>2) + 4 (lane>>5).
+        // The 32 norms of the group come through SCALAR loads (uniform address): a vector load here would sit behind
+        // the A ring in the in-order vmcnt queue and waiting for it would drain the whole prefetch.
+        f32x16 init;
+        if (vnorm) {
+            const f32x16 *vn_u = reinterpret_cast<const f32x16 *>(vnorm + (size_t)32 * g);  // wave-uniform, 128-B aligned
+            const f32x16 n0 = vn_u[0], n1 = vn_u[1];                                       // rows 0-15 / 16-31 of the group
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                init[j2] = -0.5f * (fh ? n0[4 + j2] : n0[j2]);
+                init[4 + j2] = -0.5f * (fh ? n0[12 + j2] : n0[8 + j2]);
+                init[8 + j2] = -0.5f * (fh ? n1[4 + j2] : n1[j2]);
+                init[12 + j2] = -0.5f * (fh ? n1[12 + j2] : n1[8 + j2]);
+            }
+        } else {  // dot / cosine: no norm term; rows past N must still never pass
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                init[r] = (32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh) < N ? 0.0f : -__builtin_inff();
+        }
+
+        // B fragments: two half sets (fragments 0-3 / 4-7) ping-pong one half k-step ahead of the MFMAs.  The reads
+        // and their waits are hand-written (LDS returns in order: lgkmcnt(4) = "all but the 4 younger reads"), and
+        // sched_barriers pin the order read -> MFMA -> read, otherwise hipcc hoists all 48 reads of a chunk.
+        f32x16 acc[F7_NF];
+        const unsigned char *cur = Vf + (size_t)g * gbytes + lane * 16;
+        const unsigned char *nxt = Vf + (size_t)min(g + F7_NW, g_last) * gbytes + lane * 16;  // past the end: a re-read, never used
+        static_for<KS>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            constexpr int JN = (J + 1) % KS;    // the query tile is resident: the read-ahead wraps into the next step
+            constexpr int SLOT = J % F7_KC;
+            const i32x4 xa = __builtin_bit_cast(i32x4, A[SLOT]);
+            const i32x8 wa = {xa.x, xa.y, xa.z, xa.w, 0, 0, 0, 0};
+            auto mma4 = [&](u32x4 (&bh)[4], int f0) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const i32x4 xb = __builtin_bit_cast(i32x4, bh[f]);
+                    const i32x8 wb = {xb.x, xb.y, xb.z, xb.w, 0, 0, 0, 0};
+                    acc[f0 + f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, wb, J == 0 ? init : acc[f0 + f], 4, 4, 0,
+                                                                                  scale1, 0, scale1);
+                }
+            };
+            wait4(BX);
+            __builtin_amdgcn_sched_barrier(0);
+            mma4(BX, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd4(BX, std::integral_constant<int, JN>{}, c0_t{});
+            wait4(BY);
+            __builtin_amdgcn_sched_barrier(0);
+            mma4(BY, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            rd4(BY, std::integral_constant<int, JN>{}, c1_t{});
+            // the ring slot is free again: k-step J + 6 of my stream (KS is a multiple of the ring depth)
+            if constexpr (J + F7_KC < KS) A[SLOT] = *reinterpret_cast<const u32x4 *>(cur + (J + F7_KC) * 1024);
+            else A[SLOT] = *reinterpret_cast<const u32x4 *>(nxt + (J + F7_KC - KS) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        // this step's bounds, one query per fragment per lane (read here, not before the MFMAs: 8 fewer live registers)
+        float thr[F7_NF];
+#pragma unroll
+        for (int f = 0; f < F7_NF; ++f) thr[f] = -tau[f * 32 + fr];
+        unsigned long long fany[F7_NF];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int f = 0; f < F7_NF; ++f) {
+            float m = acc[f][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[f][r]);
+            fany[f] = __ballot(m > thr[f]);
+            any |= fany[f];
+        }
+        if (any) {
+#pragma unroll
+            for (int f = 0; f < F7_NF; ++f) {
+                if (fany[f] == 0) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (acc[f][r] > thr[f]) {
+                        uint32_t q = (uint32_t)f * 32 + fr;
+                        asm volatile("" : "+v"(q));  // keep the rare path's address arithmetic inside the branch
+                        const uint32_t slot = atomicAdd(cnt + q, 1u);
+                        const uint32_t id = 32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
+                        if (slot < (uint32_t)F7_CAP) subs[(size_t)q * F7_CAP + slot] = ((uint64_t)f32_key(-acc[f][r]) << 32) | id;
+                        if (slot == (uint32_t)F7_HW) ctl[0] = 1;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- drain: finished waves keep serving round requests until every wave is done --------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(ctl + 1, 1u);
+    for (;;) {
+        if (lds_load_u32(ctl) != 0) { round(); continue; }
+        if (lds_load_u32(ctl + 1) >= (uint32_t)F7_NW) {
+            // no wave appends any more; a request raised before the last wave finished is visible by now
+            if (lds_load_u32(ctl) != 0) { round(); continue; }
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+
+    for (int q = wave; q < T2; q += F7_NW) {
+        const uint32_t qg = qt * T2 + q;
+        if (qg >= nq) continue;
+        const uint32_t c = min(lds_load_u32(cnt + q), (uint32_t)F7_CAP);
+        if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
+        const uint64_t best = prune_query<false, true>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
+        partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
+        if (lane == 0) pcnt[(size_t)qg * Stot + list_base + s] = nkept[q];
+    }
+}
+
+// rows (fp32, row-major) -> fp4 fragment order: unit (group g, k-step j, lane l) = 16 bytes = the 32 codes of
+// row 32 g + (l & 31), elements 64 j + 32 (l >> 5) + [0, 32), low nibble first.  Rows >= n and elements >= dim are 0.
+__global__ __launch_bounds__(256) void k_fp4_pack_frag(const float *__restrict__ src, uint32_t dim, uint32_t ld,
+                                                       uint64_t n, uint64_t units, uint32_t KS, float mid, float scale,
+                                                       unsigned char *__restrict__ out) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const uint32_t l = (uint32_t)(u & 63);
+    const uint64_t gj = u >> 6;
+    const uint32_t j = (uint32_t)(gj % KS);
+    const uint64_t row = (gj / KS) * 32 + (l & 31);
+    const uint32_t k0 = 64 * j + 32 * (l >> 5);
+    u32x4 w = {0, 0, 0, 0};
+    if (row < n) {
+        const float *v = src + row * ld;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const uint32_t k = k0 + e;
+            const uint32_t code = k < dim ? fp4_e2m1_code((v[k] - mid) * scale) : 0u;
+            w[e >> 3] |= code << (4 * (e & 7));
+        }
+    }
+    *reinterpret_cast<u32x4 *>(out + u * 16) = w;
+}
+
+// |v'|^2 of the quantised row (exact in fp32); rows in [n, n_pad) get +inf so that padded rows never pass
+__global__ __launch_bounds__(256) void k_fp4_norms(const float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
+                                                   uint64_t n_pad, float mid, float scale, float *__restrict__ norm) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_pad) return;
+    if (r >= n) {
+        if (lane == 0) norm[r] = __builtin_inff();
+        return;
+    }
+    const float *v = rows + r * ld;
+    float s = 0.0f;
+    for (uint32_t c = lane; c < dim; c += 64) s += fp4_e2m1_sq(fp4_e2m1_code((v[c] - mid) * scale));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) norm[r] = s;
+}
+
+}  // namespace
+
+uint32_t fp4s_ksteps(uint32_t dim) { return round_up((dim + 63) / 64, F7_KC); }
+
+bool fp4s_eligible(const zvdb_hip_index *h) {
+    static const bool off = [] { const char *e = getenv("ZVDB_BF_FP4_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    return !off && h->dim > 0 && fp4s_ksteps(h->dim) <= 12;  // instantiated: KS = 6 (dim <= 384), 12 (dim <= 768)
+}
+
+uint64_t fp4s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad) { return (uint64_t)nq_pad * fp4s_ksteps(h->dim) * 32; }
+
+int ensure_fp4_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
+    if (h->rows_pf && h->count_pf == h->count) return ZVDB_OK;
+    if (h->count == 0) return ZVDB_OK;
+    const uint32_t KS = fp4s_ksteps(h->dim);
+    const uint64_t rows_pad = round_up64(h->count, 256);
+    if (h->cap_pf < rows_pad) {
+        if (h->rows_pf) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_pf)); ZV_HIP(hipFree(h->norm_pf)); }
+        h->rows_pf = nullptr;
+        h->norm_pf = nullptr;
+        const uint64_t ncap = round_up64(std::max<uint64_t>(h->count, h->cap), 256);
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->rows_pf), ncap * KS * 32));
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->norm_pf), ncap * sizeof(float)));
+        h->cap_pf = ncap;
+    }
+    ZV_CHECK(fp4_range(h, s));
+    const uint64_t units = rows_pad / 32 * KS * 64;
+    hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, h->rows, h->dim, h->ld,
+                       h->count, units, KS, h->p_mid, h->p_scale, h->rows_pf);
+    hipLaunchKernelGGL(k_fp4_norms, dim3((uint32_t)((rows_pad + 3) / 4)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count,
+                       rows_pad, h->p_mid, h->p_scale, h->norm_pf);
+    ZV_HIP(hipGetLastError());
+    h->count_pf = h->count;
+    return ZVDB_OK;
+}
+
+int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad,
+                             unsigned char *q_op, hipStream_t s) {
+    const uint32_t KS = fp4s_ksteps(h->dim);
+    const uint64_t units = (uint64_t)nq_pad / 32 * KS * 64;
+    hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim,
+                       (uint64_t)nq, units, KS, h->p_mid, h->p_scale, q_op);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
+                     uint32_t Stot, uint32_t *pcnt, hipStream_t s) {
+    const uint32_t KS = fp4s_ksteps(h->dim);
+    const uint32_t lds = f7_lds_bytes(KS);
+    const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
+    const float *vn = l2 ? h->norm_pf : (const float *)nullptr;
+    if (KS == 6) {
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fp4_stream<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fp4_stream<6>, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_pf, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
+                           partial, tau_g, kp, t_first, list_base, Stot, pcnt);
+    } else {
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fp4_stream<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fp4_stream<12>, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_pf, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
+                           partial, tau_g, kp, t_first, list_base, Stot, pcnt);
+    }
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+}  // namespace zvdb

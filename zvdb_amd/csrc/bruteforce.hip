@@ -21,6 +21,7 @@
 // stream on one XCD so each 128-row corpus slab is fetched from HBM once per XCD L2.
 #include "common.h"
 #include "wave_select.h"
+#include "bf_select.h"
 
 namespace zvdb {
 
@@ -28,7 +29,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128;   // output tile: queries x corpus rows
 constexpr int KB = 128;             // bytes of every row consumed per K slice
-constexpr int KP = 64;              // k' : candidates kept per (query, stream) and re-ranked
 constexpr int HW = 192;             // prune when a buffer holds more than this
 constexpr int CAP = HW + BN;        // appends of one tile can never overflow
 constexpr int TILE_BYTES = BM * KB; // 16 KiB per operand per stage
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_scan(
 //           sums of fp4 values are small multiples of 1/4, so the fp32 accumulation is exact).
 // =====================================================================================
 constexpr bool kFp4Pipe = false;
-constexpr int T2 = 256;                      // tile edge (queries and corpus rows)
+static_assert(T2 == 256, "bf_select.h");  //                    // tile edge (queries and corpus rows)
 constexpr int CAP2 = HW + T2;                // per-row candidate buffer of the v2 scan
 constexpr int STAGE2 = 2 * T2 * KB;          // A + B = 64 KiB per stage
 constexpr int LDS2 = 2 * STAGE2 + 3 * T2 * 4;
@@ -314,7 +314,6 @@ constexpr int KB3 = 64;                       // bytes of every row per slice
 constexpr int STAGE3 = 2 * T2 * KB3;          // A + B = 32 KiB
 constexpr int NSTAGE3 = 4;
 
-constexpr int SUBCAP = 256, SUBHW = 48, SUBURG = 192, NSUB = 4;  // capacity, soft mark, must-prune mark
 constexpr int PTHRESH = 32;  // start a prune round once this many sub-buffers crossed the soft mark
 constexpr int LDS4_VN = NSTAGE3 * STAGE3;        // vn[4][256]
 constexpr int LDS4_TG = LDS4_VN + 4 * T2 * 4;    // tg[4][256]
@@ -324,73 +323,6 @@ constexpr int LDS4_SC = LDS4_NK + T2 * 4;        // subcnt[256][4]
 constexpr int LDS4_FLAG = LDS4_SC + T2 * NSUB * 4;
 constexpr int LDS4_SEL = LDS4_FLAG + 16;          // 8 waves x (histogram + compaction stage)
 constexpr int LDS4 = LDS4_SEL + 8 * SEL_SCRATCH;
-constexpr size_t BLK4_KEPT = (size_t)T2 * KP;                 // u64 entries
-constexpr size_t BLK4_ENTRIES = BLK4_KEPT + (size_t)T2 * NSUB * SUBCAP;
-
-// merge query q's kept list with its sub-buffers -> exact best kp (UNSORTED, compacted to the front of
-// kept[q]); resets the sub-buffers.  Rounds of <= 64 carried + 256 new keys, radix-selected.
-template <bool INTKEY>
-__device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, const uint64_t *__restrict__ sub,
-                                                float *tau, uint32_t *nkept, uint32_t *subcnt, int q, int lane,
-                                                uint32_t kp, uint32_t *tau_g, unsigned char *scratch) {
-    uint32_t *hist = reinterpret_cast<uint32_t *>(scratch);
-    uint64_t *stage = reinterpret_cast<uint64_t *>(scratch + SEL_HIST_BYTES);
-    const uint32_t n0 = min(subcnt[q * NSUB + 0], (uint32_t)SUBCAP), n1 = min(subcnt[q * NSUB + 1], (uint32_t)SUBCAP);
-    const uint32_t n2 = min(subcnt[q * NSUB + 2], (uint32_t)SUBCAP), n3 = min(subcnt[q * NSUB + 3], (uint32_t)SUBCAP);
-    const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, total = p3 + n3;
-    uint32_t ncarry = nkept[q];
-    uint64_t carry = (uint32_t)lane < ncarry ? kept[(size_t)q * KP + lane] : ~0ull;
-    uint32_t done = 0;
-    while (done < total) {
-        uint64_t k[5];
-        k[0] = carry;
-#pragma unroll
-        for (int e = 1; e < 5; ++e) {
-            const uint32_t i = done + (e - 1) * kWave + lane;
-            uint64_t v = ~0ull;
-            if (i < total) {
-                const uint32_t si = (i >= p1) + (i >= p2) + (i >= p3);
-                const uint32_t off = i - (si == 0 ? 0u : si == 1 ? p1 : si == 2 ? p2 : p3);
-                v = sub[((size_t)q * NSUB + si) * SUBCAP + off];
-            }
-            k[e] = v;
-        }
-        const uint32_t nnew = min(256u, total - done);
-        done += nnew;
-        const uint32_t nvalid = ncarry + nnew;
-        uint64_t T = ~0ull - 1;  // everything valid passes
-        if (nvalid > kp) T = wave_kth_key<5>([&](uint32_t e) { return k[e]; }, 5, kp, hist, lane);
-        uint32_t base = 0;
-#pragma unroll
-        for (int e = 0; e < 5; ++e) {
-            const bool selv = k[e] <= T;
-            const unsigned long long m = __ballot(selv);
-            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (selv && pos < (uint32_t)KP) stage[pos] = k[e];
-            base += (uint32_t)__popcll(m);
-        }
-        ncarry = min(nvalid, kp);
-        carry = (uint32_t)lane < ncarry ? stage[lane] : ~0ull;
-    }
-    kept[(size_t)q * KP + lane] = carry;
-    const uint64_t last = ncarry == kp ? wave_max64((uint32_t)lane < ncarry ? carry : 0ull) : ~0ull;
-    if (lane == 0) {
-        nkept[q] = ncarry;
-        subcnt[q * NSUB + 0] = 0; subcnt[q * NSUB + 1] = 0; subcnt[q * NSUB + 2] = 0; subcnt[q * NSUB + 3] = 0;
-        if (ncarry == kp) {
-            if (INTKEY) {
-                int32_t *ti = reinterpret_cast<int32_t *>(tau);
-                const int32_t nt = (int32_t)((uint32_t)(last >> 32) ^ 0x80000000u);
-                if (nt < ti[q]) ti[q] = nt;
-            } else {
-                const float nt = f32_unkey((uint32_t)(last >> 32));
-                if (nt < tau[q]) tau[q] = nt;
-            }
-            if (tau_g) atomicMin(tau_g + q, (uint32_t)(last >> 32));
-        }
-    }
-    return carry;
-}
 
 // k_bf_scan5: the v4 kernel generalised over the wave tile: NI = 2 -> 8 waves of 128 x 64 (two per
 // SIMD); NI = 4 -> 4 waves of 128 x 128, ONE per SIMD with the whole 512-register file (256 accumulators):
@@ -1047,7 +979,8 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     p.S = S;
     uint64_t off = 0;
     p.off_q = off;
-    off += round_up64((uint64_t)p.nq_pad * p.row_bytes, 256);
+    off += round_up64(std::max<uint64_t>((uint64_t)p.nq_pad * p.row_bytes,
+                                         mode == ZVDB_BF_FP4 && fp4s_eligible(h) ? fp4s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
     off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap, (uint64_t)p.QT * p.S * BLK4_ENTRIES) * 8;
     p.off_partial = off;
@@ -1131,7 +1064,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         return ZVDB_ERR_UNSUPPORTED;
     }
     if (mode == ZVDB_BF_I8) ZV_CHECK(ensure_i8_mirror(h, s));
-    if (mode == ZVDB_BF_FP4) ZV_CHECK(ensure_fp4_mirror(h, s));
+    // fp4: barrier-free stream kernel over the fragment-order mirror when the query tile fits LDS, else the staged scan
+    const bool f7 = mode == ZVDB_BF_FP4 && fp4s_eligible(h);
+    if (mode == ZVDB_BF_FP4) ZV_CHECK(f7 ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
     const BfPlan p = make_plan(h, nq, mode);
     if (ws_bytes < p.total) {
         set_error("workspace too small: need %llu bytes, got %llu", (unsigned long long)p.total,
@@ -1145,7 +1080,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t *cand_ids = reinterpret_cast<uint32_t *>(ws + p.off_ids);
 
     const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
-    {
+    if (f7) {
+        ZV_CHECK(launch_fp4s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
+    } else {
         const uint64_t total = (uint64_t)p.nq_pad * p.row_elems;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);
         hipLaunchKernelGGL(k_bf_prep_queries, dim3(grid), dim3(256), 0, s, d_queries, nq, h->dim, q_op,
@@ -1224,7 +1161,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         auto scan = [&](const Pass &ps, uint32_t list_base) -> int {
             BfPlan q = p;
             q.S = ps.S;
-            if (mode == ZVDB_BF_FP4)  // one geometry only: full-line pieces, 128-byte (256-element) slices
+            if (f7) return launch_fp4s_scan(h, q_op, nq, q.QT, ps.S, ps.nt, cand, partial, tau_g, kp, ps.t0, list_base, Stot, pcnt, s);
+            if (mode == ZVDB_BF_FP4 && !is_v6())  // A/B: 64-byte slices, 4-stage ring (3 slices in flight)
+                return launch_scan5<3, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            if (mode == ZVDB_BF_FP4)  // default: full-line pieces, 128-byte (256-element) slices
                 return launch_scan5<3, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             if (kernel_version() == 4 && wave_tile_ni() == 4) {  // experimental: one wave per SIMD
                 if (mode == ZVDB_BF_BF16) return launch_scan5<1, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);

@@ -122,6 +122,11 @@ struct zvdb_hip_index {
     uint32_t ldp = 0;
     uint64_t cap_p = 0, count_p = 0;
     float p_mid = 0.0f, p_scale = 1.0f;  // code = fp4_e2m1_code((x - p_mid) * p_scale)
+    // the same codes in MFMA fragment order for the barrier-free stream kernel (bf_fp4_stream.hip):
+    // [group of 32 rows][k-step of 64 elements][lane 0..63][16 B]; rows padded to a multiple of 256
+    unsigned char *rows_pf = nullptr;
+    float *norm_pf = nullptr;         // [cap_pf], +inf past count
+    uint64_t cap_pf = 0, count_pf = 0;
     hipStream_t stream = nullptr;
     // pinned host staging + device scratch for the host-pointer entry points
     zvdb::PinnedBuf pin;
@@ -166,6 +171,7 @@ int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, 
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
 int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
 int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s);
+int fp4_range(zvdb_hip_index *h, hipStream_t s);  // sets p_mid / p_scale from the rows' value range
 int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const uint32_t *d_cnt, uint32_t k,
                           uint64_t r0, uint32_t n, uint32_t degree, hipStream_t s);
 int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,
@@ -175,6 +181,17 @@ int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t
 int launch_merge_topk_strided(const uint64_t *d_ids, uint64_t rs_ids, const float *d_dist, uint64_t rs_dist,
                               const uint32_t *d_count, uint64_t rs_cnt, uint32_t G, uint32_t nq, uint32_t k,
                               uint64_t *o_ids, float *o_dist, uint32_t *o_count, hipStream_t s);
+
+// ---- bf_fp4_stream.hip -------------------------------------------------------
+bool fp4s_eligible(const zvdb_hip_index *h);
+uint32_t fp4s_ksteps(uint32_t dim);
+uint64_t fp4s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad);
+int ensure_fp4_frag_mirror(zvdb_hip_index *h, hipStream_t s);
+int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad,
+                             unsigned char *q_op, hipStream_t s);
+int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
+                     uint32_t Stot, uint32_t *pcnt, hipStream_t s);
 
 // ---- bruteforce.hip ---------------------------------------------------------
 uint64_t bruteforce_workspace_bytes(const zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t mode);

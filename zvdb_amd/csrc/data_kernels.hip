@@ -288,6 +288,15 @@ int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s) {
         ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->norm_p), ncap * sizeof(float)));
         h->cap_p = ncap;
     }
+    ZV_CHECK(fp4_range(h, s));
+    hipLaunchKernelGGL(k_quantize_rows_fp4, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
+                       h->ld, h->rows_p, h->ldp, h->norm_p, h->count, h->p_mid, h->p_scale);
+    ZV_HIP(hipGetLastError());
+    h->count_p = h->count;
+    return ZVDB_OK;
+}
+
+int fp4_range(zvdb_hip_index *h, hipStream_t s) {
     if (!h->q_range) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->q_range), 8));
     const uint32_t init[2] = {0xFFFFFFFFu, 0u};
     ZV_HIP(hipMemcpyAsync(h->q_range, init, 8, hipMemcpyHostToDevice, s));
@@ -307,10 +316,6 @@ int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s) {
         h->p_mid = 0.0f;
         h->p_scale = m > 0.0f ? kFp4Amax / m : 1.0f;
     }
-    hipLaunchKernelGGL(k_quantize_rows_fp4, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
-                       h->ld, h->rows_p, h->ldp, h->norm_p, h->count, h->p_mid, h->p_scale);
-    ZV_HIP(hipGetLastError());
-    h->count_p = h->count;
     return ZVDB_OK;
 }
 
