@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--extras-points", type=int, default=100_000)
     ap.add_argument("--extras-graph-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--same-queries", action="store_true", help="(experiments) every step answers the same query batch")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
     return ap.parse_args()
@@ -326,12 +327,12 @@ def main():
     # ---- timed region ----------------------------------------------------------------------------
     def timed(m, steps, warmup):
         for i in range(warmup):
-            step(queries[i % total_steps], m)
+            step(queries[total_steps if args.same_queries else i % total_steps], m)
         sync()
         idx.timing_enable(True)
         t0 = time.perf_counter()
         for i in range(steps):
-            step(queries[(warmup + i) % total_steps], m)
+            step(queries[total_steps if args.same_queries else (warmup + i) % total_steps], m)
         sync()
         el = time.perf_counter() - t0
         kms, kn = idx.timing_read()

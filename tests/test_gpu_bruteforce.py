@@ -126,6 +126,37 @@ def test_bruteforce_fp4_recall_and_exact_distances(zv, oracle, n, d, nq):
             assert oracle.distance(Q[qi], idx.get_vector(int(ai[qi, j]))) == ad[qi, j]
 
 
+def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp_path):
+    """Large corpus, fp4 stream kernel: ONE scan against thresholds GUESSED from sample moments, verified by the
+    merge, repaired by a gated exact re-scan.  All of these must return the same ids and distances, because each
+    ends with the exact k' best (fp4 key, id) pairs per query before the exact re-rank:
+      default (guess holds) == cascade with learned thresholds (ZVDB_BF_GUESS=0) == staged kernel (ZVDB_BF_FP4_KERNEL=v6)
+      == guess forced far too tight (ZSHIFT=-3: every query is repaired) == guess far too loose (ZSHIFT=+2: prune rounds)."""
+    import subprocess, sys, os
+    code = (
+        "import sys, numpy as np, oracle, zvdb_amd as zv\n"
+        "idx = zv.Index(); idx.add_synthetic(600_000, 96, 0x5EED)\n"
+        "Q = oracle.uniform_rows(0xC0FFEE, 0, 300, 96)\n"
+        "i, d, c = idx.search_bruteforce(Q, 10, zv.BF_FP4)\n"
+        "e, ed, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)\n"
+        "np.savez(sys.argv[1], i=i, d=d, c=c, e=e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in {"guess": {}, "cascade": {"ZVDB_BF_GUESS": "0"}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"},
+                      "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2"}}.items():
+        out = tmp_path / (name + ".npz")
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, name + ": " + r.stdout + r.stderr
+        res[name] = np.load(out)
+    base = res["cascade"]
+    rec = np.mean([len(set(base["i"][q]) & set(base["e"][q])) / 10 for q in range(300)])
+    assert rec >= 0.95, rec
+    for name in ("guess", "staged", "tight", "loose"):
+        assert np.array_equal(res[name]["i"], base["i"]), name
+        assert np.array_equal(res[name]["d"], base["d"]), name
+        assert np.array_equal(res[name]["c"], base["c"]), name
+
+
 def test_bruteforce_dot_metric(zv, oracle):
     V = oracle.uniform_rows(5, 0, 3000, 64) - 0.5
     Q = oracle.uniform_rows(6, 0, 32, 64) - 0.5

@@ -62,13 +62,21 @@ __host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS) {
 }
 
 // KS = 64-element k-steps per row (compile time: every LDS offset of the resident tile is an instruction immediate)
-template <int KS>
+// DBG: timing ablations (ZVDB_BF_DEBUG: 1 = no selection epilogue, 2 = no corpus loads, 4 = no query-fragment reads;
+// results are garbage); compiled out of the production instantiation.
+// DBG == 8: MOMENTS mode (not a debug build): instead of selecting, every wave sums key and key^2 of its rows per
+// query -> mom[(block * 8 + wave)][256][2] (+ the row count behind it); k_fp4_guess turns them into thresholds.
+template <int KS, int DBG>
 __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const unsigned char *__restrict__ Qf /* [query group][KS][64][16 B] */,
     const unsigned char *__restrict__ Vf /* [row group][KS][64][16 B] */, const float *__restrict__ vnorm /* padded to groups, +inf past N */,
     uint32_t N, uint32_t nq, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
-    uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt) {
+    uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, uint32_t max_tiles /* per stream; 0 = all */,
+    const uint32_t *__restrict__ gate /* optional: the launch is a no-op unless *gate != 0 */, float *__restrict__ mom) {
+    if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
+    constexpr bool MOM = DBG == 8;
+    constexpr uint32_t dbg = MOM ? 0 : DBG;  // compile-time: a runtime flag inside the unrolled k-steps breaks the schedule
     static_assert(KS % F7_KC == 0 && (4 * KS - 1) * 1024 <= 65535, "ring wrap / ds_read immediate offsets");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t qbytes = F7_NF * KS * 1024;
@@ -91,7 +99,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const uint32_t qt = jb % QT;
     const uint32_t s = (jb / QT) * 8 + x;
     const uint32_t per = (NT + S - 1) / S;
-    const uint32_t t_begin = t_first + min(s * per, NT), t_end = min(t_begin + per, t_first + NT);
+    const uint32_t t_begin = t_first + min(s * per, NT);
+    const uint32_t t_end = min(t_begin + (max_tiles ? min(per, max_tiles) : per), t_first + NT);
     const uint32_t g_begin = 8 * t_begin, g_end = min(8 * t_end, (N + 31) / 32);  // row groups of 32
     const uint32_t nsteps = g_end > g_begin ? (g_end - g_begin + F7_NW - 1) / F7_NW : 0;  // the same for every wave
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
@@ -164,8 +173,13 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     rd4(BX, c0_t{}, c0_t{});  // k-step 0 of the first step (kept in flight across steps: the tile never changes)
     rd4(BY, c0_t{}, c1_t{});
 
+    float m1[F7_NF], m2[F7_NF];  // moments mode only
+    uint32_t mrows = 0;
+#pragma unroll
+    for (int f = 0; f < F7_NF; ++f) { m1[f] = 0.0f; m2[f] = 0.0f; }
+
     for (uint32_t it = 0; it < nsteps; ++it) {
-        if (lds_load_u32(ctl) != 0) round();
+        if (!MOM && lds_load_u32(ctl) != 0) round();
         const uint32_t g = g_begin + wave + F7_NW * it;
         if (g >= g_end) continue;  // (wave-uniform; only the last iteration of some waves)
 
@@ -215,19 +229,42 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             __builtin_amdgcn_sched_barrier(0);
             mma4(BX, 0);
             __builtin_amdgcn_sched_barrier(0);
-            rd4(BX, std::integral_constant<int, JN>{}, c0_t{});
+            if constexpr (!(dbg & 4)) rd4(BX, std::integral_constant<int, JN>{}, c0_t{});
             wait4(BY);
             __builtin_amdgcn_sched_barrier(0);
             mma4(BY, 4);
             __builtin_amdgcn_sched_barrier(0);
-            rd4(BY, std::integral_constant<int, JN>{}, c1_t{});
+            if constexpr (!(dbg & 4)) rd4(BY, std::integral_constant<int, JN>{}, c1_t{});
             // the ring slot is free again: k-step J + 6 of my stream (KS is a multiple of the ring depth)
-            if constexpr (J + F7_KC < KS) A[SLOT] = *reinterpret_cast<const u32x4 *>(cur + (J + F7_KC) * 1024);
-            else A[SLOT] = *reinterpret_cast<const u32x4 *>(nxt + (J + F7_KC - KS) * 1024);
+            if constexpr (!(dbg & 2)) {
+                if constexpr (J + F7_KC < KS) A[SLOT] = *reinterpret_cast<const u32x4 *>(cur + (J + F7_KC) * 1024);
+                else A[SLOT] = *reinterpret_cast<const u32x4 *>(nxt + (J + F7_KC - KS) * 1024);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
 
         // this step's bounds, one query per fragment per lane (read here, not before the MFMAs: 8 fewer live registers)
+        if constexpr (dbg & 1) {
+#pragma unroll
+            for (int f = 0; f < F7_NF; ++f) asm volatile("" :: "v"(acc[f]));
+            continue;
+        }
+        if constexpr (MOM) {  // acc = -key; rows past N sit at -inf and are left out
+#pragma unroll
+            for (int f = 0; f < F7_NF; ++f) {
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = acc[f][r] > -3.0e38f ? acc[f][r] : 0.0f;
+                    s1 += a;
+                    s2 += a * a;
+                }
+                m1[f] += s1;
+                m2[f] += s2;
+            }
+            mrows += min(32u, N - 32 * g);
+            continue;
+        }
         float thr[F7_NF];
 #pragma unroll
         for (int f = 0; f < F7_NF; ++f) thr[f] = -tau[f * 32 + fr];
@@ -260,6 +297,20 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
         }
     }
 
+    if constexpr (MOM) {  // fixed slots, no atomics: the reduction order (and so the thresholds) is deterministic
+        float *slot = mom + (size_t)(b * F7_NW + wave) * (T2 * 2);
+#pragma unroll
+        for (int f = 0; f < F7_NF; ++f) {
+            const float a1 = m1[f] + __shfl_xor(m1[f], 32), a2 = m2[f] + __shfl_xor(m2[f], 32);
+            if (lane < 32) {
+                slot[(f * 32 + fr) * 2 + 0] = a1;
+                slot[(f * 32 + fr) * 2 + 1] = a2;
+            }
+        }
+        if (lane == 0) mom[(size_t)gridDim.x * F7_NW * (T2 * 2) + b * F7_NW + wave] = (float)mrows;
+        return;
+    }
+
     // ---- drain: finished waves keep serving round requests until every wave is done --------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) atomicAdd(ctl + 1, 1u);
@@ -282,6 +333,41 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
         const uint64_t best = prune_query<false, true>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
         partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
         if (lane == 0) pcnt[(size_t)qg * Stot + list_base + s] = nkept[q];
+    }
+}
+
+// moments -> per-query screen threshold: tau = mean(key) + z * stddev(key), z = the standard-normal quantile of
+// (target candidates) / N.  One wave per query; fixed summation order in fp64.  A GUESS: the scan verifies it (a
+// query that ends with fewer than k' candidates is re-scanned exactly), so a bad guess costs time, never results.
+__global__ __launch_bounds__(64) void k_fp4_guess(const float *__restrict__ mom, uint32_t nblocks, uint32_t QT, uint32_t S,
+                                                  uint32_t nq, float z, uint32_t *__restrict__ tau_g) {
+    const int lane = threadIdx.x;
+    const uint32_t qg = blockIdx.x, qt = qg / T2, q = qg % T2;
+    double s1 = 0.0, s2 = 0.0, n = 0.0;
+    for (uint32_t i = lane; i < S * F7_NW; i += 64) {
+        const uint32_t st = i / F7_NW, w = i % F7_NW;
+        const uint32_t b = ((st >> 3) * QT + qt) * 8 + (st & 7);  // inverse of the scan's block -> (stream, tile) map
+        const float *slot = mom + (size_t)(b * F7_NW + w) * (T2 * 2);
+        s1 += slot[q * 2 + 0];
+        s2 += slot[q * 2 + 1];
+        n += mom[(size_t)nblocks * F7_NW * (T2 * 2) + b * F7_NW + w];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+        n += __shfl_xor(n, off);
+    }
+    if (lane == 0 && qg < nq) {
+        uint32_t out = 0xFFFFFFFFu;  // no bound
+        if (n >= 64.0) {
+            const double mu = s1 / n, var = s2 / n - mu * mu;
+            if (var > 0.0) {
+                const float tk = (float)(-mu + (double)z * sqrt(var));  // key = -acc
+                if (tk == tk && fabsf(tk) < 3.0e38f) out = f32_key(tk);
+            }
+        }
+        tau_g[qg] = out;
     }
 }
 
@@ -374,22 +460,48 @@ int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
     return ZVDB_OK;
 }
 
-int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
-                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
-                     uint32_t Stot, uint32_t *pcnt, hipStream_t s) {
+namespace {
+template <int DBG>
+int launch_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                  uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
+                  uint32_t Stot, uint32_t *pcnt, uint32_t max_tiles, const uint32_t *gate, float *mom, hipStream_t s) {
     const uint32_t KS = fp4s_ksteps(h->dim);
     const uint32_t lds = f7_lds_bytes(KS);
-    const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
-    const float *vn = l2 ? h->norm_pf : (const float *)nullptr;
-    if (KS == 6) {
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fp4_stream<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_fp4_stream<6>, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_pf, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
-                           partial, tau_g, kp, t_first, list_base, Stot, pcnt);
-    } else {
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fp4_stream<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_fp4_stream<12>, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_pf, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
-                           partial, tau_g, kp, t_first, list_base, Stot, pcnt);
-    }
+    const float *vn = h->metric == ZVDB_METRIC_L2SQ ? h->norm_pf : (const float *)nullptr;
+    auto go = [&](auto kern) -> int {
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_pf, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
+                           partial, tau_g, kp, t_first, list_base, Stot, pcnt, max_tiles, gate, mom);
+        return ZVDB_OK;
+    };
+    if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, DBG == 8 ? 8 : 0>));
+    else ZV_CHECK(go(k_fp4_stream<12, DBG>));
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+}  // namespace
+
+int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
+                     uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
+    static const uint32_t dbg = [] { const char *e = getenv("ZVDB_BF_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+#define ZV_F7_ARGS h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, (float *)nullptr, s
+    if (dbg == 1) return launch_stream<1>(ZV_F7_ARGS);
+    if (dbg == 3) return launch_stream<3>(ZV_F7_ARGS);
+    if (dbg == 5) return launch_stream<5>(ZV_F7_ARGS);
+    if (dbg == 7) return launch_stream<7>(ZV_F7_ARGS);
+    return launch_stream<0>(ZV_F7_ARGS);
+#undef ZV_F7_ARGS
+}
+
+// sample moments of the screen keys (one 256-row tile per stream, spread over the corpus) -> tau_g[q] = guessed
+// threshold that about `target` rows of the corpus pass.  mom: scratch of fp4s_moment_bytes().
+uint64_t fp4s_moment_bytes(uint32_t QT, uint32_t S) { return ((uint64_t)QT * S * F7_NW * (T2 * 2) + (uint64_t)QT * S * F7_NW) * sizeof(float); }
+
+int launch_fp4s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                      float *mom, float z, uint32_t *tau_g, hipStream_t s) {
+    ZV_CHECK(launch_stream<8>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s));
+    hipLaunchKernelGGL(k_fp4_guess, dim3(QT * T2), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, tau_g);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

@@ -837,17 +837,23 @@ __global__ __launch_bounds__(64) void k_bf_merge(const uint64_t *__restrict__ pa
 // v4 lists are UNSORTED (valid entries compacted to the front, ~0 padded).  Select-based merge: the
 // valid keys of all lists of a query are gathered into LDS (one lane per list, 64 lists at a time),
 // then one radix select yields the kp best.  Output: candidate ids (unordered) and/or the kp-th key.
+// vmode 0: plain.  vmode 1 (verification of guessed thresholds): a query whose lists hold fewer than kp keys cannot
+// prove that it has the kp best -> defq[q] = 1, its repair threshold tau_out[q] = "no bound" and *flag = 1 (the
+// gated repair scan re-reads the corpus for those queries only); other queries get tau_out[q] = 0 ("nothing
+// passes").  vmode 2 (repair merge, lists [l0, l0 + S)): a no-op unless *flag, and then only for defq queries.
 __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict__ partial,
                                                      const uint32_t *__restrict__ pcnt, uint32_t S, uint32_t Stot,
                                                      uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
-                                                     uint32_t kp, uint32_t cap) {
+                                                     uint32_t kp, uint32_t cap, uint32_t l0 = 0, int vmode = 0,
+                                                     uint32_t *__restrict__ flag = nullptr, uint32_t *__restrict__ defq = nullptr) {
+    if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     uint64_t *stage = reinterpret_cast<uint64_t *>(smem + SEL_HIST_BYTES);
     uint64_t *pool = reinterpret_cast<uint64_t *>(smem + SEL_SCRATCH);  // [cap]
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    const uint64_t *p = partial + (size_t)q * Stot * KP;
+    const uint64_t *p = partial + ((size_t)q * Stot + l0) * KP;
     uint32_t n = 0;       // keys in the pool (wave-uniform)
     uint64_t T = ~0ull - 1;
     auto reduce_pool = [&]() {  // pool -> its kp best, compacted to the front
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
         // one lane per list; its valid-entry count was written by the scan
         const uint32_t li = s0 + lane;
         const uint64_t *lp = p + (size_t)li * KP;
-        const uint32_t cnt = li < S ? min(pcnt[(size_t)q * Stot + li], (uint32_t)KP) : 0u;
+        const uint32_t cnt = li < S ? min(pcnt[(size_t)q * Stot + l0 + li], (uint32_t)KP) : 0u;
         const uint32_t inc = wave_incl_scan(cnt, lane);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (n + tot > cap) reduce_pool();  // make room (cap >= kp + 64 * KP)
@@ -887,10 +893,32 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
         const uint64_t k = (uint32_t)lane < n ? pool[lane] : ~0ull;
         cand_ids[(size_t)q * KP + lane] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
     }
-    if (tau_out) {
+    if (vmode == 1) {
+        if (lane == 0) {
+            const bool deficient = n < kp;
+            defq[q] = deficient ? 1u : 0u;
+            tau_out[q] = deficient ? 0xFFFFFFFFu : 0u;
+            if (deficient) atomicOr(flag, 1u);
+        }
+    } else if (tau_out) {
         uint64_t mx = wave_max64((uint32_t)lane < n ? pool[lane] : 0ull);
         if (lane == 0) tau_out[q] = n >= kp ? (uint32_t)(mx >> 32) : 0xFFFFFFFFu;
     }
+}
+
+// standard-normal quantile (Acklam's rational approximation, |rel err| < 1.2e-9): the z of a tail probability
+double norm_quantile(double p) {
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    if (p < 0.02425) {
+        const double q = std::sqrt(-2.0 * std::log(p));
+        return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+    }
+    const double q = p - 0.5, r = q * q;
+    return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+           (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
 }
 
 // queries -> operand layout of the scan: [nq_pad][row_bytes], zero padded.
@@ -934,7 +962,7 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
 
 struct BfPlan {
     uint32_t tile, cap, nq_pad, QT, S, NT, KT, row_bytes, row_elems;
-    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_pcnt, total;
+    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_verify, off_pcnt, total;
 };
 
 int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v4 | v6 (default): older generations kept for A/B.
@@ -989,6 +1017,8 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     off += (uint64_t)p.nq_pad * KP * 4;
     p.off_taug = off;
     off += round_up64((uint64_t)p.nq_pad * 4, 256) + 256;  // + debug counters
+    p.off_verify = off;  // guessed-threshold pipeline: [flag 256 B][defq nq_pad][tau_rep nq_pad]
+    off += 256 + 2 * round_up64((uint64_t)p.nq_pad * 4, 256);
     p.off_pcnt = off;
     off += round_up64((uint64_t)p.nq_pad * 3 * p.S * 4, 256);  // valid-entry count of every list
     p.total = off;
@@ -1141,6 +1171,36 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         Pass passes[3];
         int np = 0;
         const uint32_t Stot = 3 * p.S;
+        // ---- fp4 stream kernel, large corpus: ONE scan against GUESSED thresholds, then verification ------------
+        // The cascade below learns exact thresholds by flooding a tile per stream (pass A) and scanning N/32 rows
+        // against the loose result (pass B): ~0.8 ms of appends / merges at 10M x 768.  Instead: (1) moments of the
+        // screen keys over one tile per stream -> tau = mean + z sigma with z = the normal quantile of target / N
+        // (k_fp4_guess); (2) one scan of everything against tau; (3) the merge VERIFIES: a query left with fewer
+        // than kp candidates has no proof that it holds the kp best -> (4) gated repair scan + merge re-read the corpus
+        // for those queries with no bound (exact; no-ops when the guess held, which is the common case).  A guess that
+        // is too loose is self-correcting (the append buffers fill and the prune rounds tighten the bound).
+        static const int guess_off = [] { const char *e = getenv("ZVDB_BF_GUESS"); return e && e[0] == '0'; }();
+        if (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) {
+            static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 512.0; }();
+            static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
+            const double tail = std::min(0.25, target / (double)N);
+            const float z = (float)(norm_quantile(tail) + zshift);
+            uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
+            uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
+            uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
+            ZV_HIP(hipMemsetAsync(vflag, 0, 256, s));
+            ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, p.S, p.NT, reinterpret_cast<float *>(cand), z, tau_g, s));  // (cand is free until the scan)
+            ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, p.S, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, s));
+            const uint32_t cap = kp + 64 * KP;
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep,
+                               kp, cap, 0u, 1, vflag, defq);
+            ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, p.S, p.NT, cand, partial, tau_rep, kp, 0, p.S, Stot, pcnt, vflag, s));
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, p.S, Stot, cand_ids,
+                               (uint32_t *)nullptr, kp, cap, p.S, 2, vflag, defq);
+            timing_end(h, s);
+            ZV_HIP(hipGetLastError());
+            return launch_rerank(h, d_queries, nq, cand_ids, KP, k, id_offset, d_ids, d_dist, d_count, s);
+        }
         if (p.NT >= 4 * p.S && !(debug_flags() & 64)) {
             // pass A streams: every workgroup of pass A floods one tile (256 candidates per query, 8-byte
             // scattered stores) -- the fewer the cheaper, as long as pass B's candidates (rows_B * k' /
@@ -1161,7 +1221,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         auto scan = [&](const Pass &ps, uint32_t list_base) -> int {
             BfPlan q = p;
             q.S = ps.S;
-            if (f7) return launch_fp4s_scan(h, q_op, nq, q.QT, ps.S, ps.nt, cand, partial, tau_g, kp, ps.t0, list_base, Stot, pcnt, s);
+            if (f7) return launch_fp4s_scan(h, q_op, nq, q.QT, ps.S, ps.nt, cand, partial, tau_g, kp, ps.t0, list_base, Stot, pcnt, nullptr, s);
             if (mode == ZVDB_BF_FP4 && !is_v6())  // A/B: 64-byte slices, 4-stage ring (3 slices in flight)
                 return launch_scan5<3, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             if (mode == ZVDB_BF_FP4)  // default: full-line pieces, 128-byte (256-element) slices

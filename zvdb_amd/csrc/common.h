@@ -191,7 +191,10 @@ int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
                              unsigned char *q_op, hipStream_t s);
 int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
-                     uint32_t Stot, uint32_t *pcnt, hipStream_t s);
+                     uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, hipStream_t s);
+uint64_t fp4s_moment_bytes(uint32_t QT, uint32_t S);
+int launch_fp4s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                      float *mom, float z, uint32_t *tau_g, hipStream_t s);
 
 // ---- bruteforce.hip ---------------------------------------------------------
 uint64_t bruteforce_workspace_bytes(const zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t mode);
