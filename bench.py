@@ -2,11 +2,12 @@
 """bench.py -- headline benchmark of the zvdb hot path on MI355X.
 
 Metric (BASELINE.json): QPS at recall@10 >= 0.95, 10M x 768 fp32 corpus, batch = 1024 queries,
-1/2/4/8 MI355X.  One "step" = one batch of 1024 synthetic queries answered end to end (k = 10)
-by the recall-guaranteed route: bf16-MFMA screen over the bf16 mirror of the corpus with a
-fused running-threshold top-64, per-stream merge, then an EXACT fp32 re-rank in the reference's
-arithmetic (hnsw.zig:182-192).  Recall@10 is measured in the same run against the fp32-MFMA
-route (whose ids/distances are parity-tested against the CPU oracle).
+1/2/4/8 MI355X.  One "step" = one batch of 1024 synthetic queries answered end to end (k = 10):
+MFMA screen over a reduced-precision mirror of the corpus (fp4 E2M1 by default; int8 / bf16 / fp32
+selectable) with a fused threshold top-64 per query, merge, then an EXACT fp32 re-rank of the
+survivors in the reference's arithmetic (hnsw.zig:182-192).  Recall@10 is measured in the same run
+against the fp32-MFMA route (whose ids/distances are parity-tested against the CPU oracle); auto mode
+falls back to a wider screen if the measured recall is below the metric's 0.95 bar.
 
 N > 1 (one process per GPU, torch.distributed over RCCL): the corpus is sharded by vector-id
 range, every rank answers every query on its shard, ONE all-gather of the per-shard top-k
@@ -395,7 +396,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": f"k_bf_scan5<{args.mode}>",
+                "kernel": "k_fp4_stream<12>" if args.mode == "fp4" else f"k_bf_scan5<{args.mode}>",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s" if args.mode != "i8" else "TOP/s",
@@ -406,7 +407,11 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel_ms_avg": kavg * 1e3,
                 "timed_regions": kern_n,
-                "region": "per step: 3 launches of the scan kernel (threshold cascade passes A/B/C) + 2 threshold merges",
+                "region": ("per step: sample-moments launch + threshold guess + ONE scan of the whole shard (k_fp4_stream) + verifying merge "
+                           "+ gated repair scan/merge (no-ops when the guess held)" if args.mode == "fp4" else
+                           "per step: 3 launches of the scan kernel (threshold cascade passes A/B/C) + 2 threshold merges"),
+                "peak_note": ("spec dense fp4 MFMA peak; tools/mfma_peak_bench.hip measures 6.7 PFLOP/s for back-to-back "
+                              "v_mfma_scale_f32_32x32x64_f8f6f4 on random operands (the chip lowers its clock under load)" if args.mode == "fp4" else None),
                 "hbm_achieved_GBps": float(n_local) * D * ELT_BYTES[args.mode] / kavg / 1e9 if kavg > 0 else 0.0,
                 "hbm_peak_GBps": 8000.0,
                 "algorithmic_flops_per_launch": flops,

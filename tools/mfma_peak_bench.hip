@@ -23,7 +23,18 @@ __global__ __launch_bounds__(WAVES * 64) void k(int iters, int *sink) {
             for (int i = 0; i < 4; ++i) { a[i] = (a[i] & 0x807F807F) | 0x3F803F80; b[i] = (b[i] & 0x807F807F) | 0x3F803F80; }
         }
     }
-    if constexpr (MODE == 3) {
+    if constexpr (MODE == 4) {  // fp4, 16x16x128 shape: 16 independent accumulators of 4 registers
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 acc[16] = {};
+        const i32x8 wa = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, wb = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, wb, acc[j], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        float s = 0;
+        for (int j = 0; j < 16; ++j) s += acc[j][0];
+        if (s == 12345.f) sink[0] = 1;
+    } else if constexpr (MODE == 3) {
         f32x16 acc[8] = {};
         const i32x8 wa = {a.x, a.y, a.z, a.w, 0, 0, 0, 0}, wb = {b.x, b.y, b.z, b.w, 0, 0, 0, 0};
         for (int i = 0; i < iters; ++i)
@@ -90,6 +101,9 @@ int main() {
     run<3, 8>("mfma_scale_32x32x64 fp4", 2.0 * 32 * 32 * 64, sink);
     run<3, 8, 1>("mfma_scale_32x32x64 fp4 RANDOM", 2.0 * 32 * 32 * 64, sink);
     run<3, 4, 1>("mfma_scale_32x32x64 fp4 RANDOM", 2.0 * 32 * 32 * 64, sink);
+    run<4, 8>("mfma_scale_16x16x128 fp4 (x2 per iter)", 2.0 * 2 * 16 * 16 * 128, sink);
+    run<4, 8, 1>("mfma_scale_16x16x128 fp4 RANDOM (x2)", 2.0 * 2 * 16 * 16 * 128, sink);
+    run<3, 8, 1>("mfma_scale_32x32x64 fp4 RANDOM again", 2.0 * 32 * 32 * 64, sink);
     run<2, 8, 1>("mfma_i32_32x32x32_i8 RANDOM", 2.0 * 32 * 32 * 32, sink);
     run<1, 8, 1>("mfma_f32_32x32x16_bf16 RANDOM", 2.0 * 32 * 32 * 16, sink);
     return 0;

@@ -1152,7 +1152,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         uint32_t *tau_g = reinterpret_cast<uint32_t *>(ws + p.off_taug);
         uint32_t *pcnt = reinterpret_cast<uint32_t *>(ws + p.off_pcnt);
         // survivors per query: 32 suffice for k <= 16 with the (near-)exact screens; the 4-bit screen keeps 64
-        const uint32_t kp = (k <= 16 && mode != ZVDB_BF_FP4 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+        static const uint32_t fp4_kp = [] { const char *e = getenv("ZVDB_BF_FP4_KP"); return e ? (uint32_t)atoi(e) : (uint32_t)KP; }();  // tuning
+        const uint32_t kp = mode == ZVDB_BF_FP4 ? std::min<uint32_t>(std::max<uint32_t>(fp4_kp, k + 16), KP)
+                                                : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
                                     : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
                                     : mode == ZVDB_BF_FP4 ? reinterpret_cast<const unsigned char *>(h->rows_p)
@@ -1279,7 +1281,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 (double)c[8] / (p.QT * p.S), (double)c[6] / (p.QT * p.S), (double)c[7] / (p.QT * p.S));
     }
     if (p.tile != BM && kernel_version() == 4) {
-        const uint32_t kpf = (k <= 16 && mode != ZVDB_BF_FP4 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+        const uint32_t kpf = mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const uint32_t cap = kpf + 64 * KP;
         hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial,
                            reinterpret_cast<const uint32_t *>(ws + p.off_pcnt), nlists, stot_lists, cand_ids,

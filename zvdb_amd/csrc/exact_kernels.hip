@@ -28,7 +28,9 @@ __device__ __forceinline__ float exact_dist(const float *__restrict__ q,
     float sum = 0.0f;
     const uint32_t d4 = dim & ~3u;
     uint32_t i = 0;
-#pragma unroll 4
+    // 16 x 16-byte loads in flight per lane: the walk is bound by memory latency (rows are random 3-KB gathers),
+    // not by the dependent add chain
+#pragma unroll 16
     for (; i < d4; i += 4) {
         const float4 v = *reinterpret_cast<const float4 *>(row + i);
         const float4 a = *reinterpret_cast<const float4 *>(q + i);
