@@ -131,6 +131,7 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
     merge, repaired by a gated exact re-scan.  All of these must return the same ids and distances, because each
     ends with the exact k' best (fp4 key, id) pairs per query before the exact re-rank:
       default (guess holds) == cascade with learned thresholds (ZVDB_BF_GUESS=0) == staged kernel (ZVDB_BF_FP4_KERNEL=v6)
+      == the 16x16x128 MFMA shape of the stream kernel (ZVDB_BF_FP4_SHAPE=16, different mirror layout)
       == guess forced far too tight (ZSHIFT=-3: every query is repaired) == guess far too loose (ZSHIFT=+2: prune rounds)."""
     import subprocess, sys, os
     code = (
@@ -142,7 +143,7 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
         "np.savez(sys.argv[1], i=i, d=d, c=c, e=e)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for name, env in {"guess": {}, "cascade": {"ZVDB_BF_GUESS": "0"}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"},
+    for name, env in {"guess": {}, "cascade": {"ZVDB_BF_GUESS": "0"}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"}, "shape16": {"ZVDB_BF_FP4_SHAPE": "16"},
                       "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2"}}.items():
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
@@ -151,7 +152,7 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
     base = res["cascade"]
     rec = np.mean([len(set(base["i"][q]) & set(base["e"][q])) / 10 for q in range(300)])
     assert rec >= 0.95, rec
-    for name in ("guess", "staged", "tight", "loose"):
+    for name in ("guess", "staged", "shape16", "tight", "loose"):
         assert np.array_equal(res[name]["i"], base["i"]), name
         assert np.array_equal(res[name]["d"], base["d"]), name
         assert np.array_equal(res[name]["c"], base["c"]), name

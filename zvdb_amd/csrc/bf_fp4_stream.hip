@@ -52,6 +52,22 @@ __device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int,
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
+// 8 floats at LDS byte address a + {0, 64, ..., 448}: one address register, immediates, one wait
+__device__ __forceinline__ void lds_read8_f32(float *d, uint32_t a) {
+    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\tds_read_b32 %3, %8 offset:192\n\t"
+                 "ds_read_b32 %4, %8 offset:256\n\tds_read_b32 %5, %8 offset:320\n\tds_read_b32 %6, %8 offset:384\n\tds_read_b32 %7, %8 offset:448\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+                 : "v"(a));
+}
+
+// tell the compiler a pointer is wave-uniform (SGPR pair): loads become saddr + 32-bit lane offset
+__device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char *p) {
+    const uint64_t v = (uint64_t)(size_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<const unsigned char *>((size_t)(((uint64_t)hi << 32) | lo));
+}
+
 __device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -66,7 +82,11 @@ __host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS) {
 // results are garbage); compiled out of the production instantiation.
 // DBG == 8: MOMENTS mode (not a debug build): instead of selecting, every wave sums key and key^2 of its rows per
 // query -> mom[(block * 8 + wave)][256][2] (+ the row count behind it); k_fp4_guess turns them into thresholds.
-template <int KS, int DBG>
+// SH = MFMA shape: 32 -> v_mfma_scale_f32_32x32x64 (8 accumulators of 16 registers per 32-row step), 16 ->
+// v_mfma_scale_f32_16x16x128 (2 x 16 accumulators of 4 registers): same bytes, same cadence (4 ds_read_b128 per 128
+// MFMA cycles), but the chip holds a higher clock on the 16x16 shape (tools/mfma_peak_bench.hip, random operands:
+// 7.6 vs 6.7 PFLOP/s).  The operand layouts differ (fragment = 16 rows x 128 k), so the mirror is packed per shape.
+template <int KS, int DBG, int SH>
 __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const unsigned char *__restrict__ Qf /* [query group][KS][64][16 B] */,
     const unsigned char *__restrict__ Vf /* [row group][KS][64][16 B] */, const float *__restrict__ vnorm /* padded to groups, +inf past N */,
@@ -78,6 +98,10 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     constexpr bool MOM = DBG == 8;
     constexpr uint32_t dbg = MOM ? 0 : DBG;  // compile-time: a runtime flag inside the unrolled k-steps breaks the schedule
     static_assert(KS % F7_KC == 0 && (4 * KS - 1) * 1024 <= 65535, "ring wrap / ds_read immediate offsets");
+    static_assert(SH == 32 || SH == 16, "MFMA shape");
+    constexpr int K128 = KS / 2;  // SH == 16: 128-element k-steps per row
+    constexpr int RD16 = (K128 % 2 == 0) ? 2 : 3;  // SH == 16: ring depth in 128-element k-steps (x 2 row fragments)
+    constexpr int NRING = SH == 32 ? F7_KC : 2 * RD16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t qbytes = F7_NF * KS * 1024;
     float *tau = reinterpret_cast<float *>(smem + qbytes);           // exclusive bound: pass <=> key < tau
@@ -145,11 +169,12 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     // no control flow inside the unrolled k-steps)
     constexpr size_t gbytes = (size_t)KS * 1024;
     const uint32_t g_last = g_end - 1;  // (only used when nsteps > 0)
-    u32x4 A[F7_KC];
+    const uint32_t lane16 = (uint32_t)lane * 16;  // uniform 64-bit base + this 32-bit offset: saddr-form loads, no 64-bit VGPR pointers
+    u32x4 A[NRING];  // SH 32: 6 k-steps of 64; SH 16: 2 (3) k-steps of 128 x 2 row fragments
     if (nsteps > 0) {
-        const unsigned char *p0 = Vf + (size_t)min(g_begin + (uint32_t)wave, g_last) * gbytes + lane * 16;
+        const unsigned char *p0 = uniform_ptr(Vf + (size_t)min(g_begin + (uint32_t)wave, g_last) * gbytes);
 #pragma unroll
-        for (int i = 0; i < F7_KC; ++i) A[i] = *reinterpret_cast<const u32x4 *>(p0 + i * 1024);
+        for (int i = 0; i < NRING; ++i) A[i] = *reinterpret_cast<const u32x4 *>(p0 + lane16 + i * 1024);
     }
     const uint32_t qlds = (uint32_t)(size_t)(lptr_t)smem + (uint32_t)lane * 16;
     const uint32_t scale1 = 0x7F7F7F7Fu;  // E8M0 127 = 2^0 for every 32-element block
@@ -157,6 +182,17 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     // fragments f0 .. f0+3 of k-step J: ((f * KS + J) << 10) + lane * 16; two long-lived base registers (one per half
     // of the tile), everything else is an instruction immediate
     const uint32_t qb_lo = qlds, qb_hi = qlds + 4 * KS * 1024;
+    // SH 16: fragments 4 qd .. 4 qd + 3 (16 queries each) of 128-element k-step J: ((f * K128 + J) << 10)
+    auto rd4s = [&](u32x4 (&d)[4], auto jc, auto qdc) {
+        constexpr int J = decltype(jc)::value, QD = decltype(qdc)::value;
+        const uint32_t base = QD >= 2 ? qb_hi : qb_lo;  // qb_hi = fragment 8 = byte 8 * K128 KiB = 4 * KS KiB
+        constexpr int F0 = 4 * (QD & 1);
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
+                     "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                     : "v"(base), "n"(((F0 + 0) * K128 + J) * 1024), "n"(((F0 + 1) * K128 + J) * 1024),
+                       "n"(((F0 + 2) * K128 + J) * 1024), "n"(((F0 + 3) * K128 + J) * 1024));
+    };
     auto rd4 = [&](u32x4 (&d)[4], auto jc, auto hc) {
         constexpr int J = decltype(jc)::value;
         const uint32_t base = decltype(hc)::value ? qb_hi : qb_lo;
@@ -170,34 +206,42 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     };
     using c0_t = std::integral_constant<int, 0>;
     using c1_t = std::integral_constant<int, 1>;
-    rd4(BX, c0_t{}, c0_t{});  // k-step 0 of the first step (kept in flight across steps: the tile never changes)
-    rd4(BY, c0_t{}, c1_t{});
+    if constexpr (SH == 32) {
+        rd4(BX, c0_t{}, c0_t{});  // k-step 0 of the first step (kept in flight across steps: the tile never changes)
+        rd4(BY, c0_t{}, c1_t{});
+    } else {
+        rd4s(BX, c0_t{}, c0_t{});
+        rd4s(BY, c0_t{}, c1_t{});
+    }
 
-    float m1[F7_NF], m2[F7_NF];  // moments mode only
+    constexpr int NQF = SH == 32 ? F7_NF : 16;  // query fragments per step
+    float m1[NQF], m2[NQF];  // moments mode only
     uint32_t mrows = 0;
 #pragma unroll
-    for (int f = 0; f < F7_NF; ++f) { m1[f] = 0.0f; m2[f] = 0.0f; }
+    for (int f = 0; f < NQF; ++f) { m1[f] = 0.0f; m2[f] = 0.0f; }
+
+    float vn_next = 0.0f;
+    if (nsteps > 0 && vnorm) vn_next = vnorm[(size_t)32 * min(g_begin + (uint32_t)wave, g_last) + fr];
 
     for (uint32_t it = 0; it < nsteps; ++it) {
         if (!MOM && lds_load_u32(ctl) != 0) round();
-        const uint32_t g = g_begin + wave + F7_NW * it;
+        const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g_begin + wave + F7_NW * it));
         if (g >= g_end) continue;  // (wave-uniform; only the last iteration of some waves)
+        // |v|^2 of the group's 32 rows: lane l < 32 holds row l's (loaded one step ahead, ONE register; a load issued
+        // here would sit behind the A ring in the in-order vmcnt queue and waiting for it would drain the prefetch);
+        // the accumulator start values are gathered from it by lane shuffles
+        const float vn_mine = vn_next;
+        if (vnorm) vn_next = vnorm[(size_t)32 * min(g + F7_NW, g_last) + fr];
 
+        if constexpr (SH == 32) {
         // this step's bounds (one query per fragment per lane) and the shared threshold of my 32 queries
         // accumulator start = -|v|^2/2 of the register's corpus row: row = 32 g + (r&3) + 8 (r>>2) + 4 (lane>>5).
         // The 32 norms of the group come through SCALAR loads (uniform address): a vector load here would sit behind
         // the A ring in the in-order vmcnt queue and waiting for it would drain the whole prefetch.
         f32x16 init;
         if (vnorm) {
-            const f32x16 *vn_u = reinterpret_cast<const f32x16 *>(vnorm + (size_t)32 * g);  // wave-uniform, 128-B aligned
-            const f32x16 n0 = vn_u[0], n1 = vn_u[1];                                       // rows 0-15 / 16-31 of the group
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                init[j2] = -0.5f * (fh ? n0[4 + j2] : n0[j2]);
-                init[4 + j2] = -0.5f * (fh ? n0[12 + j2] : n0[8 + j2]);
-                init[8 + j2] = -0.5f * (fh ? n1[4 + j2] : n1[j2]);
-                init[12 + j2] = -0.5f * (fh ? n1[12 + j2] : n1[8 + j2]);
-            }
+            for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn_mine, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
         } else {  // dot / cosine: no norm term; rows past N must still never pass
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -208,8 +252,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
         // and their waits are hand-written (LDS returns in order: lgkmcnt(4) = "all but the 4 younger reads"), and
         // sched_barriers pin the order read -> MFMA -> read, otherwise hipcc hoists all 48 reads of a chunk.
         f32x16 acc[F7_NF];
-        const unsigned char *cur = Vf + (size_t)g * gbytes + lane * 16;
-        const unsigned char *nxt = Vf + (size_t)min(g + F7_NW, g_last) * gbytes + lane * 16;  // past the end: a re-read, never used
+        const unsigned char *cur = uniform_ptr(Vf + (size_t)g * gbytes);                      // wave-uniform bases
+        const unsigned char *nxt = uniform_ptr(Vf + (size_t)min(g + F7_NW, g_last) * gbytes);  // past the end: a re-read, never used
         static_for<KS>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             constexpr int JN = (J + 1) % KS;    // the query tile is resident: the read-ahead wraps into the next step
@@ -237,8 +281,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             if constexpr (!(dbg & 4)) rd4(BY, std::integral_constant<int, JN>{}, c1_t{});
             // the ring slot is free again: k-step J + 6 of my stream (KS is a multiple of the ring depth)
             if constexpr (!(dbg & 2)) {
-                if constexpr (J + F7_KC < KS) A[SLOT] = *reinterpret_cast<const u32x4 *>(cur + (J + F7_KC) * 1024);
-                else A[SLOT] = *reinterpret_cast<const u32x4 *>(nxt + (J + F7_KC - KS) * 1024);
+                if constexpr (J + F7_KC < KS) A[SLOT] = *reinterpret_cast<const u32x4 *>(cur + lane16 + (J + F7_KC) * 1024);
+                else A[SLOT] = *reinterpret_cast<const u32x4 *>(nxt + lane16 + (J + F7_KC - KS) * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -295,16 +339,145 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
                 }
             }
         }
+        } else {
+        // ================= 16x16x128 shape =================
+        // accumulator (a, f, r): corpus row 32 g + 16 a + 4 (lane >> 4) + r, query 16 f + (lane & 15)
+        const uint32_t l15 = lane & 15, lq = lane >> 4;
+        f32x4 init16[2];
+        if (vnorm) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) init16[a][r] = -0.5f * __shfl(vn_mine, 16 * a + 4 * (int)lq + r);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) init16[a][r] = (32 * g + 16 * a + 4 * lq + r) < N ? 0.0f : -__builtin_inff();
+        }
+        f32x4 acc16[2][16];
+        const unsigned char *cur = uniform_ptr(Vf + (size_t)g * gbytes);
+        const unsigned char *nxt = uniform_ptr(Vf + (size_t)min(g + F7_NW, g_last) * gbytes);
+        // sub-step (J, QD): 4 query fragments x 2 row fragments = 8 MFMAs of 16 cycles; the B quarter sets ping-pong
+        static_for<K128 * 4>([&](auto sc) {
+            constexpr int SS = decltype(sc)::value, J = SS / 4, QD = SS % 4;
+            constexpr int SN = (SS + 2) % (K128 * 4), JN = SN / 4, QN = SN % 4;  // the set freed now is needed two sub-steps on
+            constexpr int SLOT = (J % RD16) * 2;                                // ring: RD16 k-steps x 2 row fragments
+            auto &BS = (SS & 1) ? BY : BX;
+            i32x8 wa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const i32x4 xa = __builtin_bit_cast(i32x4, A[SLOT + a]);
+                wa[a] = i32x8{xa.x, xa.y, xa.z, xa.w, 0, 0, 0, 0};
+            }
+            wait4(BS);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const i32x4 xb = __builtin_bit_cast(i32x4, BS[f]);
+                const i32x8 wb = {xb.x, xb.y, xb.z, xb.w, 0, 0, 0, 0};
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc16[a][4 * QD + f] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        wa[a], wb, J == 0 ? init16[a] : acc16[a][4 * QD + f], 4, 4, 0, scale1, 0, scale1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(dbg & 4)) rd4s(BS, std::integral_constant<int, JN>{}, std::integral_constant<int, QN>{});
+            if constexpr (QD == 3 && !(dbg & 2)) {  // both row fragments of k-step J are consumed: refill with k-step J + RD16
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if constexpr (J + RD16 < K128) A[SLOT + a] = *reinterpret_cast<const u32x4 *>(cur + lane16 + ((J + RD16) * 2 + a) * 1024);
+                    else A[SLOT + a] = *reinterpret_cast<const u32x4 *>(nxt + lane16 + ((J + RD16 - K128) * 2 + a) * 1024);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (dbg & 1) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) asm volatile("" :: "v"(acc16[0][f]), "v"(acc16[1][f]));
+            continue;
+        }
+        if constexpr (MOM) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc16[a][f][r] > -3.0e38f ? acc16[a][f][r] : 0.0f;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                m1[f] += s1;
+                m2[f] += s2;
+            }
+            mrows += min(32u, N - 32 * g);
+            continue;
+        }
+        // bounds of my 16 queries (one per fragment): tau[16 f + (lane & 15)], read in two batches of 8 through ONE address
+        // register + immediates (hipcc otherwise keeps 16 invariant addresses live across the whole step loop)
+        const uint32_t tau_l = (uint32_t)(size_t)(lptr_t)tau + l15 * 4;
+        unsigned long long any16 = 0;
+        uint32_t fmask = 0;  // query fragments in which some lane passed
+#pragma unroll
+        for (int H = 0; H < 2; ++H) {
+            float th8[8];  // (the rare path re-reads its bound: only 8 bounds are live at a time)
+            lds_read8_f32(th8, tau_l + H * 512);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int f = 8 * H + i;
+                const float m = fmaxf(fmaxf(fmaxf(acc16[0][f][0], acc16[0][f][1]), fmaxf(acc16[0][f][2], acc16[0][f][3])),
+                                      fmaxf(fmaxf(acc16[1][f][0], acc16[1][f][1]), fmaxf(acc16[1][f][2], acc16[1][f][3])));
+                const unsigned long long bal = __ballot(m > -th8[i]);
+                any16 |= bal;
+                fmask |= (bal != 0 ? 1u : 0u) << f;
+            }
+        }
+        if (any16) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                if (!((fmask >> f) & 1u)) continue;
+                const float thr_f = -tau[f * 16 + l15];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (acc16[a][f][r] > thr_f) {
+                            uint32_t q = (uint32_t)f * 16 + l15;
+                            asm volatile("" : "+v"(q));
+                            const uint32_t slot = atomicAdd(cnt + q, 1u);
+                            const uint32_t id = 32 * g + 16 * a + 4 * lq + r;
+                            if (slot < (uint32_t)F7_CAP) subs[(size_t)q * F7_CAP + slot] = ((uint64_t)f32_key(-acc16[a][f][r]) << 32) | id;
+                            if (slot == (uint32_t)F7_HW) ctl[0] = 1;
+                        }
+                    }
+            }
+        }
+        }
     }
 
     if constexpr (MOM) {  // fixed slots, no atomics: the reduction order (and so the thresholds) is deterministic
         float *slot = mom + (size_t)(b * F7_NW + wave) * (T2 * 2);
+        if constexpr (SH == 32) {
 #pragma unroll
-        for (int f = 0; f < F7_NF; ++f) {
-            const float a1 = m1[f] + __shfl_xor(m1[f], 32), a2 = m2[f] + __shfl_xor(m2[f], 32);
-            if (lane < 32) {
-                slot[(f * 32 + fr) * 2 + 0] = a1;
-                slot[(f * 32 + fr) * 2 + 1] = a2;
+            for (int f = 0; f < F7_NF; ++f) {
+                const float a1 = m1[f] + __shfl_xor(m1[f], 32), a2 = m2[f] + __shfl_xor(m2[f], 32);
+                if (lane < 32) {
+                    slot[(f * 32 + fr) * 2 + 0] = a1;
+                    slot[(f * 32 + fr) * 2 + 1] = a2;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {  // the 4 lanes lane & 15 + {0, 16, 32, 48} hold one query's row quarters
+                float a1 = m1[f] + __shfl_xor(m1[f], 16), a2 = m2[f] + __shfl_xor(m2[f], 16);
+                a1 += __shfl_xor(a1, 32);
+                a2 += __shfl_xor(a2, 32);
+                if (lane < 16) {
+                    slot[(f * 16 + lane) * 2 + 0] = a1;
+                    slot[(f * 16 + lane) * 2 + 1] = a2;
+                }
             }
         }
         if (lane == 0) mom[(size_t)gridDim.x * F7_NW * (T2 * 2) + b * F7_NW + wave] = (float)mrows;
@@ -373,16 +546,25 @@ __global__ __launch_bounds__(64) void k_fp4_guess(const float *__restrict__ mom,
 
 // rows (fp32, row-major) -> fp4 fragment order: unit (group g, k-step j, lane l) = 16 bytes = the 32 codes of
 // row 32 g + (l & 31), elements 64 j + 32 (l >> 5) + [0, 32), low nibble first.  Rows >= n and elements >= dim are 0.
+// layout 1 / 2 (16x16x128 shape): a 1-KiB block = 16 rows x 128 elements, lane l = row (l & 15), elements 32 (l >> 4) +
+// [0, 32); a 32-row group holds its KS blocks as [k-step][row half] (1: corpus, the order the stream consumes them) or
+// [row half][k-step] (2: queries, so that a 16-query fragment's k-steps are contiguous in the resident tile).
 __global__ __launch_bounds__(256) void k_fp4_pack_frag(const float *__restrict__ src, uint32_t dim, uint32_t ld,
                                                        uint64_t n, uint64_t units, uint32_t KS, float mid, float scale,
-                                                       unsigned char *__restrict__ out) {
+                                                       unsigned char *__restrict__ out, int layout) {
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= units) return;
     const uint32_t l = (uint32_t)(u & 63);
     const uint64_t gj = u >> 6;
     const uint32_t j = (uint32_t)(gj % KS);
-    const uint64_t row = (gj / KS) * 32 + (l & 31);
-    const uint32_t k0 = 64 * j + 32 * (l >> 5);
+    uint64_t row = (gj / KS) * 32 + (l & 31);
+    uint32_t k0 = 64 * j + 32 * (l >> 5);
+    if (layout != 0) {
+        const uint32_t K128 = KS / 2;
+        const uint32_t a = layout == 1 ? (j & 1) : j / K128, j128 = layout == 1 ? (j >> 1) : j % K128;
+        row = (gj / KS) * 32 + 16 * a + (l & 15);
+        k0 = 128 * j128 + 32 * (l >> 4);
+    }
     u32x4 w = {0, 0, 0, 0};
     if (row < n) {
         const float *v = src + row * ld;
@@ -418,6 +600,16 @@ __global__ __launch_bounds__(256) void k_fp4_norms(const float *__restrict__ row
 
 uint32_t fp4s_ksteps(uint32_t dim) { return round_up((dim + 63) / 64, F7_KC); }
 
+// MFMA shape of the stream kernel (fixed per process: the mirror is packed for it).  Default 32x32x64.
+// ZVDB_BF_FP4_SHAPE=16 selects the 16x16x128 form: the bare instruction sustains 7.6 vs 6.7 PFLOP/s on random operands
+// (tools/mfma_peak_bench.hip), but in this kernel it measured 9 % SLOWER (3.76 vs 3.42 ms per 10M x 768 batch): a
+// 16-cycle MFMA holds the SIMD's vector issue for half of its cycles, which starves the partner wave's selection
+// epilogue and LDS reads.  Kept as a tested A/B variant.
+int fp4s_shape() {
+    static const int v = [] { const char *e = getenv("ZVDB_BF_FP4_SHAPE"); return (e && e[0] == '1') ? 16 : 32; }();
+    return v;
+}
+
 bool fp4s_eligible(const zvdb_hip_index *h) {
     static const bool off = [] { const char *e = getenv("ZVDB_BF_FP4_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 0 && fp4s_ksteps(h->dim) <= 12;  // instantiated: KS = 6 (dim <= 384), 12 (dim <= 768)
@@ -442,7 +634,7 @@ int ensure_fp4_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     ZV_CHECK(fp4_range(h, s));
     const uint64_t units = rows_pad / 32 * KS * 64;
     hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, h->rows, h->dim, h->ld,
-                       h->count, units, KS, h->p_mid, h->p_scale, h->rows_pf);
+                       h->count, units, KS, h->p_mid, h->p_scale, h->rows_pf, fp4s_shape() == 16 ? 1 : 0);
     hipLaunchKernelGGL(k_fp4_norms, dim3((uint32_t)((rows_pad + 3) / 4)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count,
                        rows_pad, h->p_mid, h->p_scale, h->norm_pf);
     ZV_HIP(hipGetLastError());
@@ -455,7 +647,7 @@ int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
     const uint32_t KS = fp4s_ksteps(h->dim);
     const uint64_t units = (uint64_t)nq_pad / 32 * KS * 64;
     hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim,
-                       (uint64_t)nq, units, KS, h->p_mid, h->p_scale, q_op);
+                       (uint64_t)nq, units, KS, h->p_mid, h->p_scale, q_op, fp4s_shape() == 16 ? 2 : 0);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }
@@ -474,8 +666,13 @@ int launch_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t n
                            partial, tau_g, kp, t_first, list_base, Stot, pcnt, max_tiles, gate, mom);
         return ZVDB_OK;
     };
-    if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, DBG == 8 ? 8 : 0>));
-    else ZV_CHECK(go(k_fp4_stream<12, DBG>));
+    if (fp4s_shape() == 16) {
+        if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, DBG == 8 ? 8 : 0, 16>));
+        else ZV_CHECK(go(k_fp4_stream<12, DBG, 16>));
+    } else {
+        if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, DBG == 8 ? 8 : 0, 32>));
+        else ZV_CHECK(go(k_fp4_stream<12, DBG, 32>));
+    }
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }
