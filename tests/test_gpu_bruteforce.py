@@ -158,6 +158,51 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
         assert np.array_equal(res[name]["c"], base["c"]), name
 
 
+def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):
+    """Stream kernel + guessed thresholds on a corpus that is not a multiple of anything (rows, queries), searched,
+    GROWN (the lazy fp4 mirror and its value range are rebuilt) and searched again; k = 48 (the mode's maximum).
+    Checks: recall against the exact route, exact ascending distances, no id past the row count, counts."""
+    n0, d, nq = 530_003, 200, 261
+    idx = zv.Index()
+    idx.add_synthetic(n0, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    for n, k in ((n0, 10), (n0 + 70_001, 48)):
+        if n > n0:
+            idx.add_synthetic(n - n0, d, 0x5EED, first_row=n0)
+        assert idx.count() == n
+        ei, ed, _ = idx.search_bruteforce(Q, k, zv.BF_F32)
+        ai, ad, ac = idx.search_bruteforce(Q, k, zv.BF_FP4)
+        assert np.all(ac == k) and np.all(ai < n)
+        rec = np.mean([len(set(ai[i]) & set(ei[i])) / k for i in range(nq)])
+        assert rec >= (0.95 if k == 10 else 0.80), (n, k, rec)  # (k = 48 of the 64 survivors leaves little slack: 0.87 measured)
+        assert np.all(np.diff(ad, axis=1) >= 0)
+        for qi in (0, nq - 1):
+            for j in range(0, k, 7):
+                assert oracle.distance(Q[qi], idx.get_vector(int(ai[qi, j]))) == ad[qi, j]
+
+
+@pytest.mark.parametrize("metric", ["dot", "cosine"])
+def test_bruteforce_fp4_dot_and_cosine(zv, oracle, metric):
+    """fp4 screen under the inner-product metrics (symmetric range, no norm term): whatever it returns is exactly what
+    the exact route computes for those ids; recall is reported against the exact route (bar 0.8: an inner product of
+    zero-centred data has less spread per unit of quantisation noise than an L2 distance)."""
+    m = zv.METRIC_DOT if metric == "dot" else zv.METRIC_COSINE
+    V = oracle.uniform_rows(5, 0, 40_000, 128) - 0.5
+    Q = oracle.uniform_rows(6, 0, 64, 128) - 0.5
+    idx = zv.Index(metric=m)
+    idx.add(V)
+    ei, ed, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)
+    ai, ad, ac = idx.search_bruteforce(Q, 10, zv.BF_FP4)
+    assert np.all(ac == 10) and np.all(np.diff(ad, axis=1) >= 0)
+    rec = np.mean([len(set(ai[i]) & set(ei[i])) / 10 for i in range(64)])
+    assert rec >= 0.8, rec
+    for qi in range(64):  # every id both routes return carries the same exact distance
+        e = {int(i): float(x) for i, x in zip(ei[qi], ed[qi])}
+        for i, x in zip(ai[qi], ad[qi]):
+            if int(i) in e:
+                assert e[int(i)] == float(x)
+
+
 def test_bruteforce_dot_metric(zv, oracle):
     V = oracle.uniform_rows(5, 0, 3000, 64) - 0.5
     Q = oracle.uniform_rows(6, 0, 32, 64) - 0.5
