@@ -498,14 +498,37 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     }
     __syncthreads();
 
-    for (int q = wave; q < T2; q += F7_NW) {
+    // ---- stream end: the k' best of every query -> partial[q][list][KP] -----------------------------------------
+    // Common case (guessed thresholds): a query holds a handful of new entries and kept + new <= KP, so there is
+    // nothing to select: ONE lane per query copies them (32 queries of a wave in flight together; the wave-per-query
+    // select below costs ~3 us of dependent round trips per query, ~100 us per workgroup).  The rest (floods, repair
+    // scans) go through the exact radix select.
+    {
+        const uint32_t q = (uint32_t)wave + F7_NW * fr;  // lanes 0-31 <-> my 32 queries (lanes 32-63 idle)
         const uint32_t qg = qt * T2 + q;
-        if (qg >= nq) continue;
-        const uint32_t c = min(lds_load_u32(cnt + q), (uint32_t)F7_CAP);
-        if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-        const uint64_t best = prune_query<false, true>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
-        partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
-        if (lane == 0) pcnt[(size_t)qg * Stot + list_base + s] = nkept[q];
+        const bool mine = lane < 32 && qg < nq;
+        const uint32_t c = mine ? min(lds_load_u32(cnt + q), (uint32_t)F7_CAP) : 0u;
+        const uint32_t nk = mine ? nkept[q] : 0u;
+        const bool simple = mine && nk + c <= (uint32_t)KP;
+        if (simple) {
+            uint64_t *dst = partial + ((size_t)qg * Stot + list_base + s) * KP;
+            for (uint32_t e = 0; e < nk; ++e) dst[e] = kept[(size_t)q * KP + e];
+            for (uint32_t e = 0; e < c; ++e) dst[nk + e] = subs[(size_t)q * F7_CAP + e];
+            for (uint32_t e = nk + c; e < (uint32_t)KP; ++e) dst[e] = ~0ull;
+            pcnt[(size_t)qg * Stot + list_base + s] = nk + c;
+        }
+        unsigned long long todo = __ballot(mine && !simple);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t q2 = (uint32_t)wave + F7_NW * (uint32_t)l;
+            const uint32_t qg2 = qt * T2 + q2;
+            const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)F7_CAP);
+            if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
+            const uint64_t best = prune_query<false, true>(kept, subs, tau, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
+            partial[((size_t)qg2 * Stot + list_base + s) * KP + lane] = best;
+            if (lane == 0) pcnt[(size_t)qg2 * Stot + list_base + s] = nkept[q2];
+        }
     }
 }
 
