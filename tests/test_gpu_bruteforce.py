@@ -126,7 +126,8 @@ def test_bruteforce_fp4_recall_and_exact_distances(zv, oracle, n, d, nq):
             assert oracle.distance(Q[qi], idx.get_vector(int(ai[qi, j]))) == ad[qi, j]
 
 
-def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp_path):
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp_path, metric):
     """Large corpus, fp4 stream kernel: ONE scan against thresholds GUESSED from sample moments, verified by the
     merge, repaired by a gated exact re-scan.  All of these must return the same ids and distances, because each
     ends with the exact k' best (fp4 key, id) pairs per query before the exact re-rank:
@@ -136,7 +137,7 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
     import subprocess, sys, os
     code = (
         "import sys, numpy as np, oracle, zvdb_amd as zv\n"
-        "idx = zv.Index(); idx.add_synthetic(600_000, 96, 0x5EED)\n"
+        "idx = zv.Index(metric=zv.METRIC_DOT if sys.argv[2] == 'dot' else zv.METRIC_L2SQ); idx.add_synthetic(600_000, 96, 0x5EED)\n"
         "Q = oracle.uniform_rows(0xC0FFEE, 0, 300, 96)\n"
         "i, d, c = idx.search_bruteforce(Q, 10, zv.BF_FP4)\n"
         "e, ed, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)\n"
@@ -146,12 +147,12 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
     for name, env in {"guess": {}, "cascade": {"ZVDB_BF_GUESS": "0"}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"}, "shape16": {"ZVDB_BF_FP4_SHAPE": "16"},
                       "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2"}}.items():
         out = tmp_path / (name + ".npz")
-        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", code, str(out), metric], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
         assert r.returncode == 0, name + ": " + r.stdout + r.stderr
         res[name] = np.load(out)
     base = res["cascade"]
     rec = np.mean([len(set(base["i"][q]) & set(base["e"][q])) / 10 for q in range(300)])
-    assert rec >= 0.95, rec
+    assert rec >= (0.95 if metric == "l2" else 0.5), rec  # (dot on all-positive U[0,1) data ranks by norm: a hard case for 4 bits)
     for name in ("guess", "staged", "shape16", "tight", "loose"):
         assert np.array_equal(res[name]["i"], base["i"]), name
         assert np.array_equal(res[name]["d"], base["d"]), name

@@ -1183,7 +1183,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         // is too loose is self-correcting (the append buffers fill and the prune rounds tighten the bound).
         static const int guess_off = [] { const char *e = getenv("ZVDB_BF_GUESS"); return e && e[0] == '0'; }();
         if (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) {
-            static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 512.0; }();
+            static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
             static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
             const double tail = std::min(0.25, target / (double)N);
             const float z = (float)(norm_quantile(tail) + zshift);
