@@ -35,6 +35,7 @@ constexpr int F7_CAP = NSUB * SUBCAP;     // append-buffer entries per (workgrou
 constexpr int F7_HW = 384;                // an append at this slot requests a prune round (CAP - HW > 8 waves x 2 steps x 32 rows)
 constexpr int F7_MARK = 64;               // a round merges the queries holding more than this many new entries
 constexpr int F7_NW = 8;                  // waves per workgroup
+constexpr bool kPrioMfma = true;          // the wave inside its MFMA section wins issue arbitration over its partner's epilogue
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
         f32x16 acc[F7_NF];
         const unsigned char *cur = uniform_ptr(Vf + (size_t)g * gbytes);                      // wave-uniform bases
         const unsigned char *nxt = uniform_ptr(Vf + (size_t)min(g + F7_NW, g_last) * gbytes);  // past the end: a re-read, never used
+        if constexpr (kPrioMfma) __builtin_amdgcn_s_setprio(1);
         static_for<KS>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             constexpr int JN = (J + 1) % KS;    // the query tile is resident: the read-ahead wraps into the next step
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             __builtin_amdgcn_sched_barrier(0);
         });
 
+        if constexpr (kPrioMfma) __builtin_amdgcn_s_setprio(0);
         // this step's bounds, one query per fragment per lane (read here, not before the MFMAs: 8 fewer live registers)
         if constexpr (dbg & 1) {
 #pragma unroll
