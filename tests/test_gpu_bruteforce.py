@@ -141,10 +141,12 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
         "Q = oracle.uniform_rows(0xC0FFEE, 0, 300, 96)\n"
         "i, d, c = idx.search_bruteforce(Q, 10, zv.BF_FP4)\n"
         "e, ed, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)\n"
-        "np.savez(sys.argv[1], i=i, d=d, c=c, e=e)\n")
+        "i8, d8, _ = idx.search_bruteforce(Q, 10, zv.BF_I8)\n"
+        "np.savez(sys.argv[1], i=i, d=d, c=c, e=e, ed=ed, i8=i8, d8=d8)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for name, env in {"guess": {}, "cascade": {"ZVDB_BF_GUESS": "0"}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"}, "shape16": {"ZVDB_BF_FP4_SHAPE": "16"},
+                      "i8staged": {"ZVDB_BF_I8_KERNEL": "v6"},
                       "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2"}}.items():
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, "-c", code, str(out), metric], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
@@ -157,6 +159,12 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
         assert np.array_equal(res[name]["i"], base["i"]), name
         assert np.array_equal(res[name]["d"], base["d"]), name
         assert np.array_equal(res[name]["c"], base["c"]), name
+    # the int8 route rides the same pipeline (stream kernel + guessed thresholds; "cascade" and "i8staged" = the staged
+    # kernel with learned thresholds): every variant must return the EXACT top-k
+    if metric == "l2":
+        for name in res:
+            assert np.array_equal(res[name]["i8"], base["e"]), name
+            assert np.array_equal(res[name]["d8"], base["ed"]), name
 
 
 def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):

@@ -210,6 +210,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->rows_p);
     (void)hipFree(h->norm_p);
     (void)hipFree(h->rows_pf);
+    (void)hipFree(h->rows_qf);
+    (void)hipFree(h->norm_qf);
     (void)hipFree(h->norm_pf);
     (void)hipFree(h->q_range);
     if (h->pin.ptr) (void)hipHostFree(h->pin.ptr);

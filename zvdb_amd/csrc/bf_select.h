@@ -68,7 +68,8 @@ __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, con
         if (ncarry == kp) {
             if (INTKEY) {
                 int32_t *ti = reinterpret_cast<int32_t *>(tau);
-                const int32_t nt = (int32_t)((uint32_t)(last >> 32) ^ 0x80000000u);
+                int32_t nt = (int32_t)((uint32_t)(last >> 32) ^ 0x80000000u);
+                if (INCL && nt != 0x7FFFFFFF) nt += 1;
                 if (nt < ti[q]) ti[q] = nt;
             } else {
                 const float nt = f32_unkey((uint32_t)(last >> 32) + (INCL ? 1u : 0u));

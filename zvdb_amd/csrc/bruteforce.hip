@@ -963,6 +963,7 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
 struct BfPlan {
     uint32_t tile, cap, nq_pad, QT, S, NT, KT, row_bytes, row_elems;
     uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_verify, off_pcnt, total;
+    uint32_t QT8, S8;  // int8 stream kernel: tiles of 128 queries, streams
 };
 
 int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v4 | v6 (default): older generations kept for A/B.
@@ -1005,12 +1006,18 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     uint32_t S = std::max(8u, (resident / p.QT) / 8 * 8);
     while (S > 8 && S > p.NT) S -= 8;  // do not create streams with no tiles
     p.S = S;
+    p.QT8 = p.nq_pad / 128;
+    p.S8 = std::max(8u, (resident / p.QT8) / 8 * 8);
+    while (p.S8 > 8 && p.S8 > p.NT) p.S8 -= 8;
+    p.S8 = std::min(p.S8, p.S);  // (lists and counters are sized by S)
     uint64_t off = 0;
     p.off_q = off;
     off += round_up64(std::max<uint64_t>((uint64_t)p.nq_pad * p.row_bytes,
-                                         mode == ZVDB_BF_FP4 && fp4s_eligible(h) ? fp4s_query_bytes(h, p.nq_pad) : 0), 256);
+                                         mode == ZVDB_BF_FP4 && fp4s_eligible(h) ? fp4s_query_bytes(h, p.nq_pad)
+                                         : mode == ZVDB_BF_I8 && i8s_eligible(h) ? i8s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
-    off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap, (uint64_t)p.QT * p.S * BLK4_ENTRIES) * 8;
+    off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap,
+                              (uint64_t)std::max(p.QT * p.S, p.QT8 * p.S8) * BLK4_ENTRIES) * 8;
     p.off_partial = off;
     off += (uint64_t)p.nq_pad * 3 * p.S * KP * 8;  // lists of up to three passes
     p.off_ids = off;
@@ -1093,11 +1100,15 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         set_error("shard too large");
         return ZVDB_ERR_UNSUPPORTED;
     }
-    if (mode == ZVDB_BF_I8) ZV_CHECK(ensure_i8_mirror(h, s));
+    const BfPlan p = make_plan(h, nq, mode);
+    static const int guess_off = [] { const char *e = getenv("ZVDB_BF_GUESS"); return e && e[0] == '0'; }();
     // fp4: barrier-free stream kernel over the fragment-order mirror when the query tile fits LDS, else the staged scan
     const bool f7 = mode == ZVDB_BF_FP4 && fp4s_eligible(h);
+    // int8: the stream kernel serves large shards (one scan against guessed + verified thresholds); small ones stay on the
+    // staged kernel and its threshold cascade
+    const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
+    if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK(f7 ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
-    const BfPlan p = make_plan(h, nq, mode);
     if (ws_bytes < p.total) {
         set_error("workspace too small: need %llu bytes, got %llu", (unsigned long long)p.total,
                   (unsigned long long)ws_bytes);
@@ -1112,6 +1123,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
     if (f7) {
         ZV_CHECK(launch_fp4s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
+    } else if (s8) {
+        ZV_CHECK(launch_i8s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else {
         const uint64_t total = (uint64_t)p.nq_pad * p.row_elems;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);
@@ -1181,8 +1194,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         // than kp candidates has no proof that it holds the kp best -> (4) gated repair scan + merge re-read the corpus
         // for those queries with no bound (exact; no-ops when the guess held, which is the common case).  A guess that
         // is too loose is self-correcting (the append buffers fill and the prune rounds tighten the bound).
-        static const int guess_off = [] { const char *e = getenv("ZVDB_BF_GUESS"); return e && e[0] == '0'; }();
-        if (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) {
+        if ((f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || s8) {
             static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
             static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
             const double tail = std::min(0.25, target / (double)N);
@@ -1191,14 +1203,22 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
             uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
             ZV_HIP(hipMemsetAsync(vflag, 0, 256, s));
-            ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, p.S, p.NT, reinterpret_cast<float *>(cand), z, tau_g, s));  // (cand is free until the scan)
-            ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, p.S, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, s));
+            const uint32_t SS = s8 ? p.S8 : p.S;  // streams = lists per query and scan
+            float *mom = reinterpret_cast<float *>(cand);  // (cand is free until the scan)
+            if (s8) {
+                ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, s));
+                ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, s));
+            } else {
+                ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, SS, p.NT, mom, z, tau_g, s));
+                ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, s));
+            }
             const uint32_t cap = kp + 64 * KP;
-            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep,
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
                                kp, cap, 0u, 1, vflag, defq);
-            ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, p.S, p.NT, cand, partial, tau_rep, kp, 0, p.S, Stot, pcnt, vflag, s));
-            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, p.S, Stot, cand_ids,
-                               (uint32_t *)nullptr, kp, cap, p.S, 2, vflag, defq);
+            if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, s));
+            else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, s));
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids,
+                               (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
             return launch_rerank(h, d_queries, nq, cand_ids, KP, k, id_offset, d_ids, d_dist, d_count, s);

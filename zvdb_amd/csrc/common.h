@@ -116,6 +116,11 @@ struct zvdb_hip_index {
     uint32_t ldq = 0;
     uint64_t cap_q = 0, count_q = 0;
     float q_lo = 0.0f, q_inv = 1.0f;  // q = clamp(rint((x - q_lo) * q_inv) - 128) (L2) / rint(x * q_inv) (dot)
+    // the same int8 codes in MFMA fragment order for the barrier-free stream kernel (bf_i8_stream.hip):
+    // [group of 32 rows][k-step of 32 elements][lane 0..63][16 B]; rows padded to a multiple of 256
+    unsigned char *rows_qf = nullptr;
+    int32_t *norm_qf = nullptr;  // [cap_qf], INT_MAX past count
+    uint64_t cap_qf = 0, count_qf = 0;
     // fp4 (E2M1) scalar-quantised mirror for ZVDB_BF_FP4 (lazy, like the int8 one)
     unsigned char *rows_p = nullptr;  // [cap_p][ldp] bytes, 2 codes per byte (low nibble = even element), ldp = round_up(dim, 256) / 2
     float *norm_p = nullptr;          // [cap_p] sum of the squared fp4 VALUES (exact in fp32)
@@ -181,6 +186,20 @@ int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t
 int launch_merge_topk_strided(const uint64_t *d_ids, uint64_t rs_ids, const float *d_dist, uint64_t rs_dist,
                               const uint32_t *d_count, uint64_t rs_cnt, uint32_t G, uint32_t nq, uint32_t k,
                               uint64_t *o_ids, float *o_dist, uint32_t *o_count, hipStream_t s);
+
+// ---- bf_i8_stream.hip --------------------------------------------------------
+bool i8s_eligible(const zvdb_hip_index *h);
+uint32_t i8s_ksteps(uint32_t dim);
+uint64_t i8s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad);
+int i8_range(zvdb_hip_index *h, hipStream_t s);  // sets q_lo / q_inv from the rows' value range (data_kernels.hip)
+int ensure_i8_frag_mirror(zvdb_hip_index *h, hipStream_t s);
+int launch_i8s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op,
+                            hipStream_t s);
+int launch_i8s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                    uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
+                    uint32_t *pcnt, const uint32_t *gate, hipStream_t s);
+int launch_i8s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt, float *mom,
+                     float z, uint32_t *tau_g, hipStream_t s);
 
 // ---- bf_fp4_stream.hip -------------------------------------------------------
 bool fp4s_eligible(const zvdb_hip_index *h);

@@ -204,19 +204,7 @@ __global__ __launch_bounds__(256) void k_quantize_rows(const float *__restrict__
     if (lane == 0) norm_q[r] = s;
 }
 
-int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
-    if (h->rows_q && h->count_q == h->count) return ZVDB_OK;
-    if (h->count == 0) return ZVDB_OK;
-    h->ldq = round_up(h->dim, 128);
-    if (h->cap_q < h->count) {
-        if (h->rows_q) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_q)); ZV_HIP(hipFree(h->norm_q)); }
-        h->rows_q = nullptr;
-        h->norm_q = nullptr;
-        const uint64_t ncap = std::max<uint64_t>(h->count, h->cap);
-        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->rows_q), ncap * h->ldq));
-        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->norm_q), ncap * sizeof(int32_t)));
-        h->cap_q = ncap;
-    }
+int i8_range(zvdb_hip_index *h, hipStream_t s) {
     if (!h->q_range) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->q_range), 8));
     const uint32_t init[2] = {0xFFFFFFFFu, 0u};
     ZV_HIP(hipMemcpyAsync(h->q_range, init, 8, hipMemcpyHostToDevice, s));
@@ -237,6 +225,24 @@ int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
         h->q_lo = 0.0f;
         h->q_inv = m > 0.0f ? 127.0f / m : 1.0f;
     }
+    return ZVDB_OK;
+}
+
+int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
+    if (h->rows_q && h->count_q == h->count) return ZVDB_OK;
+    if (h->count == 0) return ZVDB_OK;
+    h->ldq = round_up(h->dim, 128);
+    if (h->cap_q < h->count) {
+        if (h->rows_q) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_q)); ZV_HIP(hipFree(h->norm_q)); }
+        h->rows_q = nullptr;
+        h->norm_q = nullptr;
+        const uint64_t ncap = std::max<uint64_t>(h->count, h->cap);
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->rows_q), ncap * h->ldq));
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->norm_q), ncap * sizeof(int32_t)));
+        h->cap_q = ncap;
+    }
+    ZV_CHECK(i8_range(h, s));
+    const bool affine = h->metric == ZVDB_METRIC_L2SQ;
     hipLaunchKernelGGL(k_quantize_rows, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
                        h->ld, h->rows_q, h->ldq, h->norm_q, h->count, h->q_lo, h->q_inv, affine ? 1 : 0);
     ZV_HIP(hipGetLastError());
