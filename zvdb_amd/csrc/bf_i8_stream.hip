@@ -18,7 +18,7 @@ namespace {
 
 constexpr int I8_NF = 4;                  // query fragments per step (128 queries per workgroup)
 constexpr int I8_TQ = 32 * I8_NF;
-constexpr int I8_RING = 6;                // A prefetch ring (k-steps)
+constexpr int I8_RING_MAX = 12;           // A prefetch ring (k-steps): min(KS, this); 6 -> 12 measured +3.5 %
 constexpr int I8_CAP = NSUB * SUBCAP;     // append-buffer entries per (workgroup, query)
 constexpr int I8_HW = 384, I8_MARK = 64, I8_NW = 8;
 
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t list_base, uint32_t Stot,
     uint32_t *__restrict__ pcnt, uint32_t max_tiles, const uint32_t *__restrict__ gate, float *__restrict__ mom) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
+    constexpr int I8_RING = KS % I8_RING_MAX == 0 ? I8_RING_MAX : 6;
     static_assert(KS % I8_RING == 0 && KS % 2 == 0, "ring wrap / set parity");
     static_assert((2 * KS - 1) * 1024 <= 65535, "ds_read immediate offsets");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
