@@ -188,6 +188,9 @@ def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):
         for qi in (0, nq - 1):
             for j in range(0, k, 7):
                 assert oracle.distance(Q[qi], idx.get_vector(int(ai[qi, j]))) == ad[qi, j]
+        # the int8 stream kernel (KS = 12 at d = 200) on the same ragged / grown corpus: the exact top-k
+        i8, d8, c8 = idx.search_bruteforce(Q, k, zv.BF_I8)
+        assert np.array_equal(i8, ei) and np.array_equal(d8, ed) and np.all(c8 == k)
 
 
 @pytest.mark.parametrize("metric", ["dot", "cosine"])

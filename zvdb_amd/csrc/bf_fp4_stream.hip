@@ -539,7 +539,9 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
 // (target candidates) / N.  One wave per query; fixed summation order in fp64.  A GUESS: the scan verifies it (a
 // query that ends with fewer than k' candidates is re-scanned exactly), so a bad guess costs time, never results.
 __global__ __launch_bounds__(64) void k_fp4_guess(const float *__restrict__ mom, uint32_t nblocks, uint32_t QT, uint32_t S,
-                                                  uint32_t nq, float z, uint32_t *__restrict__ tau_g) {
+                                                  uint32_t nq, float z, uint32_t *__restrict__ tau_g,
+        uint32_t *__restrict__ verify_flag /* cleared here: saves a memset launch */) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
     const int lane = threadIdx.x;
     const uint32_t qg = blockIdx.x, qt = qg / T2, q = qg % T2;
     double s1 = 0.0, s2 = 0.0, n = 0.0;
@@ -722,9 +724,9 @@ int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
 uint64_t fp4s_moment_bytes(uint32_t QT, uint32_t S) { return ((uint64_t)QT * S * F7_NW * (T2 * 2) + (uint64_t)QT * S * F7_NW) * sizeof(float); }
 
 int launch_fp4s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
-                      float *mom, float z, uint32_t *tau_g, hipStream_t s) {
+                      float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
     ZV_CHECK(launch_stream<8>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s));
-    hipLaunchKernelGGL(k_fp4_guess, dim3(QT * T2), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, tau_g);
+    hipLaunchKernelGGL(k_fp4_guess, dim3(QT * T2), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, tau_g, verify_flag);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

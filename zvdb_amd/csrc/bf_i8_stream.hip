@@ -301,7 +301,9 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
 
 // moments -> guessed int threshold (see k_fp4_guess): key domain = int32 stored as key ^ 0x80000000
 __global__ __launch_bounds__(64) void k_i8_guess(const float *__restrict__ mom, uint32_t nblocks, uint32_t QT, uint32_t S, uint32_t nq,
-                                                 float z, uint32_t *__restrict__ tau_g) {
+                                                 float z, uint32_t *__restrict__ tau_g,
+        uint32_t *__restrict__ verify_flag /* cleared here: saves a memset launch */) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
     const int lane = threadIdx.x;
     const uint32_t qg = blockIdx.x, qt = qg / I8_TQ, q = qg % I8_TQ;
     double s1 = 0.0, s2 = 0.0, n = 0.0;
@@ -462,9 +464,9 @@ int launch_i8s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t
 }
 
 int launch_i8s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt, float *mom,
-                     float z, uint32_t *tau_g, hipStream_t s) {
+                     float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
     ZV_CHECK(launch_i8_stream<true>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s));
-    hipLaunchKernelGGL(k_i8_guess, dim3(QT * I8_TQ), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, tau_g);
+    hipLaunchKernelGGL(k_i8_guess, dim3(QT * I8_TQ), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, tau_g, verify_flag);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

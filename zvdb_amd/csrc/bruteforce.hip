@@ -1136,7 +1136,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const int alpha_i = l2 ? -2 : -1;
     const uint32_t N = (uint32_t)h->count;
     uint32_t nlists = p.S, stot_lists = p.S;
-    ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
+    // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
+    // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || s8;
+    if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
     if (p.tile == BM) {  // v1 (kept for A/B: ZVDB_BF_KERNEL=v1)
@@ -1194,7 +1197,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         // than kp candidates has no proof that it holds the kp best -> (4) gated repair scan + merge re-read the corpus
         // for those queries with no bound (exact; no-ops when the guess held, which is the common case).  A guess that
         // is too loose is self-correcting (the append buffers fill and the prune rounds tighten the bound).
-        if ((f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || s8) {
+        if (guess_pipe) {
             static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
             static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
             const double tail = std::min(0.25, target / (double)N);
@@ -1202,14 +1205,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
             uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
             uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
-            ZV_HIP(hipMemsetAsync(vflag, 0, 256, s));
             const uint32_t SS = s8 ? p.S8 : p.S;  // streams = lists per query and scan
             float *mom = reinterpret_cast<float *>(cand);  // (cand is free until the scan)
             if (s8) {
-                ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, s));
+                ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, s));
             } else {
-                ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, SS, p.NT, mom, z, tau_g, s));
+                ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, s));
             }
             const uint32_t cap = kp + 64 * KP;
