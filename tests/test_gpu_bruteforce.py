@@ -161,10 +161,11 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
         assert np.array_equal(res[name]["c"], base["c"]), name
     # the int8 route rides the same pipeline (stream kernel + guessed thresholds; "cascade" and "i8staged" = the staged
     # kernel with learned thresholds): every variant must return the EXACT top-k
+    for name in res:  # (both metrics: stream kernel == staged kernel, bit for bit)
+        assert np.array_equal(res[name]["i8"], base["i8"]), name
+        assert np.array_equal(res[name]["d8"], base["d8"]), name
     if metric == "l2":
-        for name in res:
-            assert np.array_equal(res[name]["i8"], base["e"]), name
-            assert np.array_equal(res[name]["d8"], base["ed"]), name
+        assert np.array_equal(base["i8"], base["e"]) and np.array_equal(base["d8"], base["ed"])
 
 
 def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):
