@@ -141,6 +141,10 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
                      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
                      : "v"(b0), "v"(b1), "n"((0 * KS + J) * 1024), "n"((1 * KS + J) * 1024));
     };
+    // HAZARD of the hand-written reads: hipcc believes the registers written by rd4 are valid when the asm statement ends, but
+    // they land only behind wait4's lgkmcnt.  The build must therefore not spill or copy them in between: this holds while the
+    // kernel has no VGPR spill inside the step loop (checked in the ISA: tools/cc_f7.sh; an experimental 12-wave build of the
+    // int8 kernel that spilled 60 VGPRs returned wrong neighbours), and the bit-exact stream == staged tests would catch it.
     auto wait4 = [&](u32x4 (&d)[4]) {
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
     };
