@@ -63,10 +63,13 @@ __device__ __forceinline__ void lds_read8_f32(float *d, uint32_t a) {
 }
 
 // tell the compiler a pointer is wave-uniform (SGPR pair): loads become saddr + 32-bit lane offset
-__device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char *p) {
+typedef const __attribute__((address_space(1))) unsigned char *gbytes_t;  // GLOBAL address space: a generic pointer
+                                                                           // would turn the stream loads into flat_load
+                                                                           // (counted in lgkmcnt as well as vmcnt)
+__device__ __forceinline__ gbytes_t uniform_ptr(const unsigned char *p) {
     const uint64_t v = (uint64_t)(size_t)p;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return reinterpret_cast<const unsigned char *>((size_t)(((uint64_t)hi << 32) | lo));
+    return (gbytes_t)(size_t)(((uint64_t)hi << 32) | lo);
 }
 
 __device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) {
@@ -173,9 +176,9 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const uint32_t lane16 = (uint32_t)lane * 16;  // uniform 64-bit base + this 32-bit offset: saddr-form loads, no 64-bit VGPR pointers
     u32x4 A[NRING];  // SH 32: 6 k-steps of 64; SH 16: 2 (3) k-steps of 128 x 2 row fragments
     if (nsteps > 0) {
-        const unsigned char *p0 = uniform_ptr(Vf + (size_t)min(g_begin + (uint32_t)wave, g_last) * gbytes);
+        const gbytes_t p0 = uniform_ptr(Vf + (size_t)min(g_begin + (uint32_t)wave, g_last) * gbytes);
 #pragma unroll
-        for (int i = 0; i < NRING; ++i) A[i] = *reinterpret_cast<const u32x4 *>(p0 + lane16 + i * 1024);
+        for (int i = 0; i < NRING; ++i) A[i] = *(const __attribute__((address_space(1))) u32x4 *)(p0 + lane16 + i * 1024);
     }
     const uint32_t qlds = (uint32_t)(size_t)(lptr_t)smem + (uint32_t)lane * 16;
     const uint32_t scale1 = 0x7F7F7F7Fu;  // E8M0 127 = 2^0 for every 32-element block
@@ -257,8 +260,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
         // and their waits are hand-written (LDS returns in order: lgkmcnt(4) = "all but the 4 younger reads"), and
         // sched_barriers pin the order read -> MFMA -> read, otherwise hipcc hoists all 48 reads of a chunk.
         f32x16 acc[F7_NF];
-        const unsigned char *cur = uniform_ptr(Vf + (size_t)g * gbytes);                      // wave-uniform bases
-        const unsigned char *nxt = uniform_ptr(Vf + (size_t)min(g + F7_NW, g_last) * gbytes);  // past the end: a re-read, never used
+        const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes);                      // wave-uniform bases
+        const gbytes_t nxt = uniform_ptr(Vf + (size_t)min(g + F7_NW, g_last) * gbytes);  // past the end: a re-read, never used
         if constexpr (kPrioMfma) __builtin_amdgcn_s_setprio(1);
         static_for<KS>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
@@ -287,8 +290,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             if constexpr (!(dbg & 4)) rd4(BY, std::integral_constant<int, JN>{}, c1_t{});
             // the ring slot is free again: k-step J + 6 of my stream (KS is a multiple of the ring depth)
             if constexpr (!(dbg & 2)) {
-                if constexpr (J + F7_KC < KS) A[SLOT] = *reinterpret_cast<const u32x4 *>(cur + lane16 + (J + F7_KC) * 1024);
-                else A[SLOT] = *reinterpret_cast<const u32x4 *>(nxt + lane16 + (J + F7_KC - KS) * 1024);
+                if constexpr (J + F7_KC < KS) A[SLOT] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + (J + F7_KC) * 1024);
+                else A[SLOT] = *(const __attribute__((address_space(1))) u32x4 *)(nxt + lane16 + (J + F7_KC - KS) * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -363,8 +366,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
                 for (int r = 0; r < 4; ++r) init16[a][r] = (32 * g + 16 * a + 4 * lq + r) < N ? 0.0f : -__builtin_inff();
         }
         f32x4 acc16[2][16];
-        const unsigned char *cur = uniform_ptr(Vf + (size_t)g * gbytes);
-        const unsigned char *nxt = uniform_ptr(Vf + (size_t)min(g + F7_NW, g_last) * gbytes);
+        const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes);
+        const gbytes_t nxt = uniform_ptr(Vf + (size_t)min(g + F7_NW, g_last) * gbytes);
         // sub-step (J, QD): 4 query fragments x 2 row fragments = 8 MFMAs of 16 cycles; the B quarter sets ping-pong
         static_for<K128 * 4>([&](auto sc) {
             constexpr int SS = decltype(sc)::value, J = SS / 4, QD = SS % 4;
@@ -393,8 +396,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             if constexpr (QD == 3 && !(dbg & 2)) {  // both row fragments of k-step J are consumed: refill with k-step J + RD16
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    if constexpr (J + RD16 < K128) A[SLOT + a] = *reinterpret_cast<const u32x4 *>(cur + lane16 + ((J + RD16) * 2 + a) * 1024);
-                    else A[SLOT + a] = *reinterpret_cast<const u32x4 *>(nxt + lane16 + ((J + RD16 - K128) * 2 + a) * 1024);
+                    if constexpr (J + RD16 < K128) A[SLOT + a] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + ((J + RD16) * 2 + a) * 1024);
+                    else A[SLOT + a] = *(const __attribute__((address_space(1))) u32x4 *)(nxt + lane16 + ((J + RD16 - K128) * 2 + a) * 1024);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

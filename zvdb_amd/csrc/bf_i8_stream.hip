@@ -35,10 +35,13 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
-__device__ __forceinline__ const unsigned char *uniform_ptr(const unsigned char *p) {
+typedef const __attribute__((address_space(1))) unsigned char *gbytes_t;  // GLOBAL address space: a generic pointer
+                                                                           // would turn the stream loads into flat_load
+                                                                           // (counted in lgkmcnt as well as vmcnt)
+__device__ __forceinline__ gbytes_t uniform_ptr(const unsigned char *p) {
     const uint64_t v = (uint64_t)(size_t)p;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return reinterpret_cast<const unsigned char *>((size_t)(((uint64_t)hi << 32) | lo));
+    return (gbytes_t)(size_t)(((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -125,9 +128,9 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
     const uint32_t lane16 = (uint32_t)lane * 16;
     u32x4 A[I8_RING];
     if (nsteps > 0) {
-        const unsigned char *p0 = uniform_ptr(Vf + (size_t)min(g_begin + (uint32_t)wave, g_last) * gbytes);
+        const gbytes_t p0 = uniform_ptr(Vf + (size_t)min(g_begin + (uint32_t)wave, g_last) * gbytes);
 #pragma unroll
-        for (int i = 0; i < I8_RING; ++i) A[i] = *reinterpret_cast<const u32x4 *>(p0 + lane16 + i * 1024);
+        for (int i = 0; i < I8_RING; ++i) A[i] = *(const __attribute__((address_space(1))) u32x4 *)(p0 + lane16 + i * 1024);
     }
     const uint32_t qlds = (uint32_t)(size_t)(lptr_t)smem + lane16;
     const uint32_t qb0 = qlds, qb1 = qlds + 2 * KS * 1024;
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
         }
 
         i32x16 acc[I8_NF];
-        const unsigned char *cur = uniform_ptr(Vf + (size_t)g * gbytes);
-        const unsigned char *nxt = uniform_ptr(Vf + (size_t)min(g + I8_NW, g_last) * gbytes);
+        const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes);
+        const gbytes_t nxt = uniform_ptr(Vf + (size_t)min(g + I8_NW, g_last) * gbytes);
         __builtin_amdgcn_s_setprio(1);
         // one sub-step per k-step: 4 fragments / 4 MFMAs; the two B sets alternate by k-step parity
         static_for<KS>([&](auto jc) {
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
                 acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, BS[f]), J == 0 ? init : acc[f], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             rd4(BS, std::integral_constant<int, JN>{});
-            if constexpr (J + I8_RING < KS) A[SLOT] = *reinterpret_cast<const u32x4 *>(cur + lane16 + (J + I8_RING) * 1024);
-            else A[SLOT] = *reinterpret_cast<const u32x4 *>(nxt + lane16 + (J + I8_RING - KS) * 1024);
+            if constexpr (J + I8_RING < KS) A[SLOT] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + (J + I8_RING) * 1024);
+            else A[SLOT] = *(const __attribute__((address_space(1))) u32x4 *)(nxt + lane16 + (J + I8_RING - KS) * 1024);
             __builtin_amdgcn_sched_barrier(0);
         });
         __builtin_amdgcn_s_setprio(0);
