@@ -209,6 +209,7 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->norm_q);
     (void)hipFree(h->rows_p);
     (void)hipFree(h->norm_p);
+    if (h->guess_flag_host) (void)hipHostFree(h->guess_flag_host);
     (void)hipFree(h->rows_pf);
     (void)hipFree(h->rows_qf);
     (void)hipFree(h->norm_qf);

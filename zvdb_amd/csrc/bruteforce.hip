@@ -845,7 +845,8 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
                                                      const uint32_t *__restrict__ pcnt, uint32_t S, uint32_t Stot,
                                                      uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
                                                      uint32_t kp, uint32_t cap, uint32_t l0 = 0, int vmode = 0,
-                                                     uint32_t *__restrict__ flag = nullptr, uint32_t *__restrict__ defq = nullptr) {
+                                                     uint32_t *__restrict__ flag = nullptr, uint32_t *__restrict__ defq = nullptr,
+                                                     uint32_t *__restrict__ host_flag = nullptr /* mapped host memory */) {
     if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
@@ -898,7 +899,10 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
             const bool deficient = n < kp;
             defq[q] = deficient ? 1u : 0u;
             tau_out[q] = deficient ? 0xFFFFFFFFu : 0u;
-            if (deficient) atomicOr(flag, 1u);
+            if (deficient) {
+                atomicOr(flag, 1u);
+                if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     } else if (tau_out) {
         uint64_t mx = wave_max64((uint32_t)lane < n ? pool[lane] : 0ull);
@@ -1201,7 +1205,18 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
             static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
             const double tail = std::min(0.25, target / (double)N);
-            const float z = (float)(norm_quantile(tail) + zshift);
+            // adaptive part: a batch that needed a repair (keys not Gaussian enough, e.g. low dimensions) loosens the guess of
+            // the following batches by half a standard deviation, up to +2 (too loose is self-correcting, only slower)
+            if (!h->guess_flag_host) {
+                ZV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->guess_flag_host), 64, hipHostMallocMapped));
+                h->guess_flag_host[0] = 0;
+                ZV_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->guess_flag_dev), h->guess_flag_host, 0));
+            }
+            if (__atomic_load_n(h->guess_flag_host, __ATOMIC_RELAXED) != 0) {
+                __atomic_store_n(h->guess_flag_host, 0u, __ATOMIC_RELAXED);
+                h->guess_adapt = std::min(2.0f, h->guess_adapt + 0.5f);
+            }
+            const float z = (float)(norm_quantile(tail) + zshift + (zshift == 0.0 ? (double)h->guess_adapt : 0.0));
             uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
             uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
             uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
@@ -1216,7 +1231,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             }
             const uint32_t cap = kp + 64 * KP;
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
-                               kp, cap, 0u, 1, vflag, defq);
+                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev);
             if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids,

@@ -132,6 +132,11 @@ struct zvdb_hip_index {
     unsigned char *rows_pf = nullptr;
     float *norm_pf = nullptr;         // [cap_pf], +inf past count
     uint64_t cap_pf = 0, count_pf = 0;
+    // guessed-threshold pipeline: a repair (guess too tight for some query) raises a flag in host-mapped memory; the next
+    // calls loosen the guess by guess_adapt standard deviations (no synchronisation: the flag is read whenever it has arrived)
+    uint32_t *guess_flag_host = nullptr;  // hipHostMalloc'ed, mapped
+    uint32_t *guess_flag_dev = nullptr;   // its device alias
+    float guess_adapt = 0.0f;
     hipStream_t stream = nullptr;
     // pinned host staging + device scratch for the host-pointer entry points
     zvdb::PinnedBuf pin;
