@@ -79,9 +79,9 @@ __host__ __device__ inline float fp4_e2m1_sq(uint32_t code) {  // value^2 of a c
     const float v = m < 4u ? 0.5f * (float)m : m == 4u ? 2.0f : m == 5u ? 3.0f : m == 6u ? 4.0f : 6.0f;
     return v * v;
 }
-// the shard's value range is mapped onto [-kFp4Amax, kFp4Amax]: |y| > 5 would round to 6, (3.5, 5] to 4; with
-// 4.5 the coarse top step is unused and the quantisation error of uniformly spread data is smallest
-// (DESIGN.md "fp4 screen": recall sweep)
+// the shard's elements are mapped so that mean +- sqrt(3) sigma (= the whole range of uniformly spread data) lands on
+// [-kFp4Amax, kFp4Amax]: |y| > 5 rounds to 6, (3.5, 5] to 4; with 4.5 the quantisation error of uniformly spread data is
+// smallest (DESIGN.md "fp4 screen": recall sweep), and bell-shaped data uses all 15 values (data_kernels.hip:fp4_range)
 constexpr float kFp4Amax = 4.5f;
 
 struct PinnedBuf {

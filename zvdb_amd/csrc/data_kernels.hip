@@ -302,25 +302,57 @@ int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s) {
     return ZVDB_OK;
 }
 
+// sum and sum of squares of all (unpadded) elements: one fp64 pair of atomics per wave
+__global__ __launch_bounds__(256) void k_moments_all(const float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
+                                                     double *__restrict__ out /* [2] */) {
+    double s1 = 0.0, s2 = 0.0;
+    const uint64_t total = n * ld;
+    for (uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total; t += (uint64_t)gridDim.x * blockDim.x * 4) {
+        const uint32_t c = (uint32_t)(t % ld);
+        const float4 v = *reinterpret_cast<const float4 *>(rows + t);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < dim) { s1 += (double)e[j]; s2 += (double)e[j] * (double)e[j]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], s1);
+        atomicAdd(&out[1], s2);
+    }
+}
+
+// The fp4 map is placed by the MEAN and STANDARD DEVIATION of the shard's elements, not by their extremes: sigma maps to
+// kFp4Amax / sqrt(3) = 2.6 units.  For uniformly spread data this is exactly "range -> [-4.5, 4.5]" (the measured optimum
+// for the benchmark's generator); for bell-shaped data it keeps the 15 values busy (the extremes clip to +-6 at 2.3 sigma)
+// where a min/max map would leave most elements in the 7 innermost values (recall@10 on N(0,1) data, 1M x 128:
+// 0.93 with the min/max map).  L2 centres on the mean (offsets cancel in q - v); dot / cosine scale around 0 by the RMS.
 int fp4_range(zvdb_hip_index *h, hipStream_t s) {
-    if (!h->q_range) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->q_range), 8));
-    const uint32_t init[2] = {0xFFFFFFFFu, 0u};
-    ZV_HIP(hipMemcpyAsync(h->q_range, init, 8, hipMemcpyHostToDevice, s));
+    double *d_mom = nullptr;
+    ZV_HIP(hipMalloc(reinterpret_cast<void **>(&d_mom), 16));
+    ZV_HIP(hipMemsetAsync(d_mom, 0, 16, s));
     const uint64_t total4 = h->count * h->ld / 4;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((total4 + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_minmax, dim3(grid), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, h->q_range);
+    hipLaunchKernelGGL(k_moments_all, dim3(grid), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, d_mom);
     ZV_HIP(hipGetLastError());
-    uint32_t got[2];
-    ZV_HIP(hipMemcpyAsync(got, h->q_range, 8, hipMemcpyDeviceToHost, s));
+    double got[2];
+    ZV_HIP(hipMemcpyAsync(got, d_mom, 16, hipMemcpyDeviceToHost, s));
     ZV_HIP(hipStreamSynchronize(s));  // (lazy one-off build; not on the steady-state search path)
-    const float lo = f32_unkey(got[0]), hi = f32_unkey(got[1]);
+    ZV_HIP(hipFree(d_mom));
+    const double cnt = (double)h->count * (double)h->dim;
+    const double mean = got[0] / cnt, ms = got[1] / cnt;
+    const double unit = (double)kFp4Amax / 1.7320508075688772;  // fp4 units per standard deviation
     if (h->metric == ZVDB_METRIC_L2SQ) {
-        h->p_mid = 0.5f * (lo + hi);
-        h->p_scale = hi > lo ? kFp4Amax / (0.5f * (hi - lo)) : 1.0f;
+        const double var = ms - mean * mean;
+        h->p_mid = (float)mean;
+        h->p_scale = var > 0.0 ? (float)(unit / std::sqrt(var)) : 1.0f;
     } else {
-        const float m = std::max(std::fabs(lo), std::fabs(hi));
         h->p_mid = 0.0f;
-        h->p_scale = m > 0.0f ? kFp4Amax / m : 1.0f;
+        h->p_scale = ms > 0.0 ? (float)(unit / std::sqrt(ms)) : 1.0f;
     }
     return ZVDB_OK;
 }
