@@ -24,6 +24,7 @@
 #include "common.h"
 #include "wave_select.h"
 #include "bf_select.h"
+#include "stream_common.h"
 
 namespace zvdb {
 
@@ -41,17 +42,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using i32x8 = __attribute__((ext_vector_type(8))) int;
-typedef const __attribute__((address_space(1))) void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
-
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int, i>) for i = 0 .. N-1: i usable as an asm immediate
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
 
 // 8 floats at LDS byte address a + {0, 64, ..., 448}: one address register, immediates, one wait
 __device__ __forceinline__ void lds_read8_f32(float *d, uint32_t a) {
@@ -60,20 +50,6 @@ __device__ __forceinline__ void lds_read8_f32(float *d, uint32_t a) {
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
                  : "v"(a));
-}
-
-// tell the compiler a pointer is wave-uniform (SGPR pair): loads become saddr + 32-bit lane offset
-typedef const __attribute__((address_space(1))) unsigned char *gbytes_t;  // GLOBAL address space: a generic pointer
-                                                                           // would turn the stream loads into flat_load
-                                                                           // (counted in lgkmcnt as well as vmcnt)
-__device__ __forceinline__ gbytes_t uniform_ptr(const unsigned char *p) {
-    const uint64_t v = (uint64_t)(size_t)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (gbytes_t)(size_t)(((uint64_t)hi << 32) | lo);
-}
-
-__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // LDS map (dynamic): [Q tile: 8 * KS KiB][tau 256 f32][cnt 256][nkept 256][subcnt 1024][ctl 4][select scratch 8 waves]

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "wave_select.h"
 #include "bf_select.h"
+#include "stream_common.h"
 
 namespace zvdb {
 
@@ -24,28 +25,7 @@ constexpr int I8_HW = 384, I8_MARK = 64, I8_NW = 8;
 
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
-typedef const __attribute__((address_space(1))) void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-typedef const __attribute__((address_space(1))) unsigned char *gbytes_t;  // GLOBAL address space: a generic pointer
-                                                                           // would turn the stream loads into flat_load
-                                                                           // (counted in lgkmcnt as well as vmcnt)
-__device__ __forceinline__ gbytes_t uniform_ptr(const unsigned char *p) {
-    const uint64_t v = (uint64_t)(size_t)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (gbytes_t)(size_t)(((uint64_t)hi << 32) | lo);
-}
-__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 __host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS) {
     return I8_NF * KS * 1024 + T2 * 4 * 3 + T2 * NSUB * 4 + 16 + I8_NW * SEL_SCRATCH;
