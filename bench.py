@@ -396,7 +396,8 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_fp4_stream<12>" if args.mode == "fp4" else f"k_bf_scan5<{args.mode}>",
+                "kernel": {"fp4": "k_fp4_stream<12,0,32>", "i8": "k_i8_stream<24> (shards >= 16 tiles per stream; else k_bf_scan5<i8>)"}.get(
+                    args.mode, f"k_bf_scan5<{args.mode}>"),
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s" if args.mode != "i8" else "TOP/s",
@@ -407,8 +408,8 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel_ms_avg": kavg * 1e3,
                 "timed_regions": kern_n,
-                "region": ("per step: sample-moments launch + threshold guess + ONE scan of the whole shard (k_fp4_stream) + verifying merge "
-                           "+ gated repair scan/merge (no-ops when the guess held)" if args.mode == "fp4" else
+                "region": ("per step: sample-moments launch + threshold guess + ONE scan of the whole shard (stream kernel) + verifying merge "
+                           "+ gated repair scan/merge (no-ops when the guess held)" if args.mode in ("fp4", "i8") else
                            "per step: 3 launches of the scan kernel (threshold cascade passes A/B/C) + 2 threshold merges"),
                 "peak_note": ("spec dense fp4 MFMA peak; tools/mfma_peak_bench.hip measures 6.7 PFLOP/s for back-to-back "
                               "v_mfma_scale_f32_32x32x64_f8f6f4 on random operands (the chip lowers its clock under load)" if args.mode == "fp4" else None),
