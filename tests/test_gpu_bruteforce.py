@@ -194,6 +194,33 @@ def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):
         assert np.array_equal(i8, ei) and np.array_equal(d8, ed) and np.all(c8 == k)
 
 
+@pytest.mark.parametrize("d", [1024, 1536])
+def test_bruteforce_fp4_wide_rows_stream_equals_staged(zv, oracle, tmp_path, d):
+    """768 < dim <= 1536: the fp4 screen runs on the 128-query stream kernel (bf_i8_stream.hip, MODE 3; KS = 18 / 24) with
+    guessed + verified thresholds.  It must return exactly what the staged fp4 kernel returns (both end with the exact k'
+    best (fp4 key, id) pairs), and hold the recall bar against the exact route."""
+    import subprocess, sys, os
+    code = (
+        "import sys, numpy as np, oracle, zvdb_amd as zv\n"
+        "d = int(sys.argv[2]); idx = zv.Index(); idx.add_synthetic(560_000, d, 0x5EED)\n"
+        "Q = oracle.uniform_rows(0xC0FFEE, 0, 70, d)\n"
+        "i, dd, c = idx.search_bruteforce(Q, 10, zv.BF_FP4)\n"
+        "e, ed, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)\n"
+        "np.savez(sys.argv[1], i=i, d=dd, c=c, e=e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env in {"stream": {}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"}, "repair": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}}.items():
+        out = tmp_path / (name + ".npz")
+        r = subprocess.run([sys.executable, "-c", code, str(out), str(d)], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, name + ": " + r.stdout + r.stderr
+        res[name] = np.load(out)
+    base = res["staged"]
+    rec = np.mean([len(set(base["i"][q]) & set(base["e"][q])) / 10 for q in range(70)])
+    assert rec >= 0.95, rec
+    for name in ("stream", "repair"):
+        assert np.array_equal(res[name]["i"], base["i"]) and np.array_equal(res[name]["d"], base["d"]), name
+
+
 @pytest.mark.parametrize("metric", ["dot", "cosine"])
 def test_bruteforce_fp4_dot_and_cosine(zv, oracle, metric):
     """fp4 screen under the inner-product metrics (symmetric range, no norm term): whatever it returns is exactly what

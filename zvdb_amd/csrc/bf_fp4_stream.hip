@@ -609,7 +609,12 @@ __global__ __launch_bounds__(256) void k_fp4_norms(const float *__restrict__ row
 
 }  // namespace
 
-uint32_t fp4s_ksteps(uint32_t dim) { return round_up((dim + 63) / 64, F7_KC); }
+// k-steps of 64 elements per row of the fragment-order mirror: 6 / 12 (256-query kernel here), 18 / 24 (768 < dim <= 1536:
+// the 128-query kernel in bf_i8_stream.hip)
+uint32_t fp4s_ksteps(uint32_t dim) {
+    const uint32_t k = (dim + 63) / 64;
+    return k <= 12 ? round_up(k, F7_KC) : fp4s128_ksteps(dim);
+}
 
 // MFMA shape of the stream kernel (fixed per process: the mirror is packed for it).  Default 32x32x64.
 // ZVDB_BF_FP4_SHAPE=16 selects the 16x16x128 form: the bare instruction sustains 7.6 vs 6.7 PFLOP/s on random operands
@@ -645,7 +650,7 @@ int ensure_fp4_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     ZV_CHECK(fp4_range(h, s));
     const uint64_t units = rows_pad / 32 * KS * 64;
     hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, h->rows, h->dim, h->ld,
-                       h->count, units, KS, h->p_mid, h->p_scale, h->rows_pf, fp4s_shape() == 16 ? 1 : 0);
+                       h->count, units, KS, h->p_mid, h->p_scale, h->rows_pf, (fp4s_shape() == 16 && KS <= 12) ? 1 : 0);
     hipLaunchKernelGGL(k_fp4_norms, dim3((uint32_t)((rows_pad + 3) / 4)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count,
                        rows_pad, h->p_mid, h->p_scale, h->norm_pf);
     ZV_HIP(hipGetLastError());
@@ -658,7 +663,7 @@ int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
     const uint32_t KS = fp4s_ksteps(h->dim);
     const uint64_t units = (uint64_t)nq_pad / 32 * KS * 64;
     hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim,
-                       (uint64_t)nq, units, KS, h->p_mid, h->p_scale, q_op, fp4s_shape() == 16 ? 2 : 0);
+                       (uint64_t)nq, units, KS, h->p_mid, h->p_scale, q_op, (fp4s_shape() == 16 && KS <= 12) ? 2 : 0);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

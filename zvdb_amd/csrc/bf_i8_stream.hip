@@ -8,6 +8,10 @@
 // i32 registers, 96 MFMAs.  Keys are exact integers (the staged kernel's int path): key = (|v'|^2 >> 1) - q'.v';
 // the (key, id) radix select is shared (bf_select.h).  The result is the exact k' best by int8 key -- identical to
 // the staged kernel's (tested) -- so with k' >= k + margin the final top-k is the exact one (recall 1.0 in bench.py).
+//
+// MODE 3 instantiates the same 128-query geometry for the fp4 screen (v_mfma_scale_f32_32x32x64_f8f6f4, fp32 keys): a
+// 32-byte k-step then covers 64 elements, so KS = 24 is a 1536-d row -- the dimensions the 256-query fp4 kernel
+// (bf_fp4_stream.hip, KS <= 12) cannot keep resident.  It reads the fp4 fragment-order mirror built there.
 #include "common.h"
 #include "wave_select.h"
 #include "bf_select.h"
@@ -25,6 +29,10 @@ constexpr int I8_HW = 384, I8_MARK = 64, I8_NW = 8;
 
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+template <int MODE> struct Acc128 { using type = i32x16; };
+template <> struct Acc128<3> { using type = f32x16; };
 
 
 __host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS) {
@@ -32,16 +40,20 @@ __host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS) {
 }
 
 // KS = 32-byte (32-element) k-steps per row; MOM: moments mode (sum of key, key^2 per query instead of selecting)
-template <int KS, bool MOM>
+// MODE: 2 = int8 (int keys), 3 = fp4 (fp32 keys)
+template <int MODE, int KS, bool MOM>
 __global__ __launch_bounds__(512, 2) void k_i8_stream(
     const unsigned char *__restrict__ Qf /* [query group of 32][KS][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
-    const int32_t *__restrict__ vnorm /* sum q^2 per row, padded to groups with INT_MAX; nullptr: dot / cosine */, uint32_t N,
+    const void *__restrict__ vnorm_v /* int8: sum q^2 (i32, INT_MAX past N); fp4: sum v'^2 (f32, +inf past N); nullptr: dot / cosine */, uint32_t N,
     uint32_t nq, uint32_t QT /* tiles of 128 queries */, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t list_base, uint32_t Stot,
     uint32_t *__restrict__ pcnt, uint32_t max_tiles, const uint32_t *__restrict__ gate, float *__restrict__ mom) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
     constexpr int I8_RING = KS % I8_RING_MAX == 0 ? I8_RING_MAX : 6;
     static_assert(KS % I8_RING == 0 && KS % 2 == 0, "ring wrap / set parity");
+    constexpr bool INT = MODE == 2;
+    using acc_t = typename Acc128<MODE>::type;
+    const int32_t *vnorm = reinterpret_cast<const int32_t *>(vnorm_v);  // (read as raw 32-bit words; fp4 reinterprets)
     static_assert((2 * KS - 1) * 1024 <= 65535, "ds_read immediate offsets");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t qbytes = I8_NF * KS * 1024;
@@ -75,9 +87,15 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
         const bool live = (qt * I8_TQ + tq) < nq;
         const uint32_t g = (tau_g && live) ? __hip_atomic_load(tau_g + tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
         // live rows satisfy acc >= -2^29 (dim <= 16384), rows past N start near -2^30: 0x30000000 admits every live row
-        int32_t t0 = live ? 0x30000000 : -0x7FFFFFFF;
-        if (g != 0xFFFFFFFFu) { const int32_t gv = (int32_t)(g ^ 0x80000000u); t0 = min(t0, gv == 0x7FFFFFFF ? gv : gv + 1); }
-        tau[tq] = t0;
+        if constexpr (INT) {
+            int32_t t0 = live ? 0x30000000 : -0x7FFFFFFF;
+            if (g != 0xFFFFFFFFu) { const int32_t gv = (int32_t)(g ^ 0x80000000u); t0 = min(t0, gv == 0x7FFFFFFF ? gv : gv + 1); }
+            tau[tq] = t0;
+        } else {
+            float t0 = live ? __builtin_inff() : -__builtin_inff();
+            if (g != 0xFFFFFFFFu) t0 = fminf(t0, f32_unkey(g + 1));
+            tau_f[tq] = t0;
+        }
         cnt[tq] = 0;
         nkept[tq] = 0;
     }
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             if (c > (uint32_t)I8_MARK) {
                 if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
                 if (lane == 0) cnt[q] = 0;
-                prune_query<true, true>(kept, subs, tau_f, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
+                prune_query<INT, true>(kept, subs, tau_f, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
             }
         }
         __syncthreads();
@@ -148,17 +166,16 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
         const int32_t vn_mine = vn_next;  // loaded one step ahead (see bf_fp4_stream.hip)
         if (vnorm) vn_next = vnorm[(size_t)32 * min(g + I8_NW, g_last) + fr];
         // accumulator start = -(|v'|^2 >> 1) of the register's corpus row; rows past N: INT_MAX >> 1 ~ 2^30, never pass
-        i32x16 init;
-        if (vnorm) {
+        acc_t init;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) init[r] = -(__shfl(vn_mine, (r & 3) + 8 * (r >> 2) + 4 * (int)fh) >> 1);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                init[r] = (32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh) < N ? 0 : -0x40000000;
+        for (int r = 0; r < 16; ++r) {
+            const int src = (r & 3) + 8 * (r >> 2) + 4 * (int)fh;
+            const bool in = (32 * g + (uint32_t)src) < N;
+            if constexpr (INT) init[r] = vnorm ? -(__shfl(vn_mine, src) >> 1) : (in ? 0 : -0x40000000);
+            else init[r] = vnorm ? -0.5f * __int_as_float(__shfl(vn_mine, src)) : (in ? 0.0f : -__builtin_inff());
         }
 
-        i32x16 acc[I8_NF];
+        acc_t acc[I8_NF];
         const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes);
         const gbytes_t nxt = uniform_ptr(Vf + (size_t)min(g + I8_NW, g_last) * gbytes);
         __builtin_amdgcn_s_setprio(1);
@@ -172,8 +189,15 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             wait4(BS);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int f = 0; f < I8_NF; ++f)
-                acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, __builtin_bit_cast(i32x4, BS[f]), J == 0 ? init : acc[f], 0, 0, 0);
+            for (int f = 0; f < I8_NF; ++f) {
+                const i32x4 xb = __builtin_bit_cast(i32x4, BS[f]);
+                if constexpr (INT) {
+                    acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, xb, J == 0 ? init : acc[f], 0, 0, 0);
+                } else {
+                    const i32x8 wa = {xa.x, xa.y, xa.z, xa.w, 0, 0, 0, 0}, wb = {xb.x, xb.y, xb.z, xb.w, 0, 0, 0, 0};
+                    acc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, wb, J == 0 ? init : acc[f], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             rd4(BS, std::integral_constant<int, JN>{});
             if constexpr (J + I8_RING < KS) A[SLOT] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + (J + I8_RING) * 1024);
@@ -188,7 +212,9 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
                 float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float a = acc[f][r] > -0x30000000 ? (float)acc[f][r] : 0.0f;
+                    float a;
+                    if constexpr (INT) a = acc[f][r] > -0x30000000 ? (float)acc[f][r] : 0.0f;
+                    else a = acc[f][r] > -3.0e38f ? acc[f][r] : 0.0f;
                     s1 += a;
                     s2 += a * a;
                 }
@@ -198,16 +224,23 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             mrows += min(32u, N - 32 * g);
             continue;
         }
-        int thr[I8_NF];
+        using thr_t = std::conditional_t<INT, int, float>;
+        thr_t thr[I8_NF];
 #pragma unroll
-        for (int f = 0; f < I8_NF; ++f) thr[f] = -tau[f * 32 + fr];
+        for (int f = 0; f < I8_NF; ++f) {
+            if constexpr (INT) thr[f] = -tau[f * 32 + fr];
+            else thr[f] = -tau_f[f * 32 + fr];
+        }
         unsigned long long fany[I8_NF];
         unsigned long long any = 0;
 #pragma unroll
         for (int f = 0; f < I8_NF; ++f) {
-            int m = acc[f][0];
+            auto m = acc[f][0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = max(m, acc[f][r]);
+            for (int r = 1; r < 16; ++r) {
+                if constexpr (INT) m = max(m, acc[f][r]);
+                else m = fmaxf(m, acc[f][r]);
+            }
             fany[f] = __ballot(m > thr[f]);
             any |= fany[f];
         }
@@ -222,8 +255,10 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
                         asm volatile("" : "+v"(q));
                         const uint32_t slot = atomicAdd(cnt + q, 1u);
                         const uint32_t id = 32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
-                        if (slot < (uint32_t)I8_CAP)
-                            subs[(size_t)q * I8_CAP + slot] = ((uint64_t)((uint32_t)(-acc[f][r]) ^ 0x80000000u) << 32) | id;
+                        uint32_t keyhi;
+                        if constexpr (INT) keyhi = (uint32_t)(-acc[f][r]) ^ 0x80000000u;
+                        else keyhi = f32_key(-acc[f][r]);
+                        if (slot < (uint32_t)I8_CAP) subs[(size_t)q * I8_CAP + slot] = ((uint64_t)keyhi << 32) | id;
                         if (slot == (uint32_t)I8_HW) ctl[0] = 1;
                     }
                 }
@@ -279,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             const uint32_t qg2 = qt * I8_TQ + q2;
             const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)I8_CAP);
             if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-            const uint64_t best = prune_query<true, true>(kept, subs, tau_f, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
+            const uint64_t best = prune_query<INT, true>(kept, subs, tau_f, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
             partial[((size_t)qg2 * Stot + list_base + s) * KP + lane] = best;
             if (lane == 0) pcnt[(size_t)qg2 * Stot + list_base + s] = nkept[q2];
         }
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
 
 // moments -> guessed int threshold (see k_fp4_guess): key domain = int32 stored as key ^ 0x80000000
 __global__ __launch_bounds__(64) void k_i8_guess(const float *__restrict__ mom, uint32_t nblocks, uint32_t QT, uint32_t S, uint32_t nq,
-                                                 float z, uint32_t *__restrict__ tau_g,
+                                                 float z, int int_keys, uint32_t *__restrict__ tau_g,
         uint32_t *__restrict__ verify_flag /* cleared here: saves a memset launch */) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
     const int lane = threadIdx.x;
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(64) void k_i8_guess(const float *__restrict__ mom, 
             const double mu = s1 / n, var = s2 / n - mu * mu;
             if (var > 0.0) {
                 const double tk = -mu + (double)z * sqrt(var);
-                if (tk == tk && fabs(tk) < 1.0e9) out = (uint32_t)(int32_t)floor(tk) ^ 0x80000000u;
+                if (tk == tk && fabs(tk) < 1.0e9) out = int_keys ? ((uint32_t)(int32_t)floor(tk) ^ 0x80000000u) : f32_key((float)tk);
             }
         }
         tau_g[qg] = out;
@@ -371,22 +406,29 @@ __global__ __launch_bounds__(256) void k_i8_norms(const float *__restrict__ rows
     if (lane == 0) norm[r] = s;
 }
 
-template <bool MOM>
+template <int MODE, bool MOM>
 int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
                      uint32_t *pcnt, uint32_t max_tiles, const uint32_t *gate, float *mom, hipStream_t s) {
-    const uint32_t KS = i8s_ksteps(h->dim);
+    const uint32_t KS = MODE == 2 ? i8s_ksteps(h->dim) : fp4s128_ksteps(h->dim);
     const uint32_t lds = i8s_lds_bytes(KS);
-    const int32_t *vn = h->metric == ZVDB_METRIC_L2SQ ? h->norm_qf : (const int32_t *)nullptr;
+    const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
+    const void *vn = !l2 ? nullptr : MODE == 2 ? (const void *)h->norm_qf : (const void *)h->norm_pf;
+    const unsigned char *rows = MODE == 2 ? h->rows_qf : h->rows_pf;
     auto go = [&](auto kern) -> int {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_qf, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
+        hipLaunchKernelGGL(kern, dim3(QT * S), dim3(512), lds, s, q_op, rows, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
                            partial, tau_g, kp, list_base, Stot, pcnt, max_tiles, gate, mom);
         return ZVDB_OK;
     };
-    if (KS == 6) ZV_CHECK(go(k_i8_stream<6, MOM>));
-    else if (KS == 12) ZV_CHECK(go(k_i8_stream<12, MOM>));
-    else ZV_CHECK(go(k_i8_stream<24, MOM>));
+    if constexpr (MODE == 2) {
+        if (KS == 6) ZV_CHECK(go(k_i8_stream<2, 6, MOM>));
+        else if (KS == 12) ZV_CHECK(go(k_i8_stream<2, 12, MOM>));
+        else ZV_CHECK(go(k_i8_stream<2, 24, MOM>));
+    } else {
+        if (KS == 18) ZV_CHECK(go(k_i8_stream<3, 18, MOM>));
+        else ZV_CHECK(go(k_i8_stream<3, 24, MOM>));
+    }
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }
@@ -447,13 +489,32 @@ int launch_i8s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uin
 int launch_i8s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
                     uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
-    return launch_i8_stream<false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+    return launch_i8_stream<2, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
 
 int launch_i8s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt, float *mom,
                      float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
-    ZV_CHECK(launch_i8_stream<true>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s));
-    hipLaunchKernelGGL(k_i8_guess, dim3(QT * I8_TQ), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, tau_g, verify_flag);
+    ZV_CHECK((launch_i8_stream<2, true>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s)));
+    hipLaunchKernelGGL(k_i8_guess, dim3(QT * I8_TQ), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, 1, tau_g, verify_flag);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+// ---- the same 128-query kernel on the fp4 fragment-order mirror: 768 < dim <= 1536 (KS = 18, 24) -------------------------
+uint32_t fp4s128_ksteps(uint32_t dim) { return (dim + 63) / 64 <= 18 ? 18 : 24; }
+bool fp4s128_eligible(const zvdb_hip_index *h) {
+    static const bool off = [] { const char *e = getenv("ZVDB_BF_FP4_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    return !off && h->dim > 768 && h->dim <= 1536;
+}
+int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                        uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
+                        uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
+    return launch_i8_stream<3, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+}
+int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                         float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
+    ZV_CHECK((launch_i8_stream<3, true>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s)));
+    hipLaunchKernelGGL(k_i8_guess, dim3(QT * I8_TQ), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, 0, tau_g, verify_flag);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

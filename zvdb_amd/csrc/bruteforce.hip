@@ -1017,7 +1017,7 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     uint64_t off = 0;
     p.off_q = off;
     off += round_up64(std::max<uint64_t>((uint64_t)p.nq_pad * p.row_bytes,
-                                         mode == ZVDB_BF_FP4 && fp4s_eligible(h) ? fp4s_query_bytes(h, p.nq_pad)
+                                         mode == ZVDB_BF_FP4 && (fp4s_eligible(h) || fp4s128_eligible(h)) ? fp4s_query_bytes(h, p.nq_pad)
                                          : mode == ZVDB_BF_I8 && i8s_eligible(h) ? i8s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
     off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap,
@@ -1111,8 +1111,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // int8: the stream kernel serves large shards (one scan against guessed + verified thresholds); small ones stay on the
     // staged kernel and its threshold cascade
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
+    // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
+    const bool s4 = mode == ZVDB_BF_FP4 && !f7 && fp4s128_eligible(h) && !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
-    if (mode == ZVDB_BF_FP4) ZV_CHECK(f7 ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
+    if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
     if (ws_bytes < p.total) {
         set_error("workspace too small: need %llu bytes, got %llu", (unsigned long long)p.total,
                   (unsigned long long)ws_bytes);
@@ -1125,7 +1127,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t *cand_ids = reinterpret_cast<uint32_t *>(ws + p.off_ids);
 
     const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
-    if (f7) {
+    if (f7 || s4) {
         ZV_CHECK(launch_fp4s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else if (s8) {
         ZV_CHECK(launch_i8s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
@@ -1142,7 +1144,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t nlists = p.S, stot_lists = p.S;
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
-    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || s8;
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || s8 || s4;
     if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
@@ -1220,11 +1222,15 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
             uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
             uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
-            const uint32_t SS = s8 ? p.S8 : p.S;  // streams = lists per query and scan
+            const bool t128 = s8 || s4;               // 128-query tiles (QT8 x S8 workgroups)
+            const uint32_t SS = t128 ? p.S8 : p.S;  // streams = lists per query and scan
             float *mom = reinterpret_cast<float *>(cand);  // (cand is free until the scan)
             if (s8) {
                 ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, s));
+            } else if (s4) {
+                ZV_CHECK(launch_fp4s128_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
+                ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, s));
             } else {
                 ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, s));
@@ -1233,6 +1239,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
                                kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev);
             if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, s));
+            else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids,
                                (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq);
