@@ -167,12 +167,20 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
         if (vnorm) vn_next = vnorm[(size_t)32 * min(g + I8_NW, g_last) + fr];
         // accumulator start = -(|v'|^2 >> 1) of the register's corpus row; rows past N: INT_MAX >> 1 ~ 2^30, never pass
         acc_t init;
+        if (vnorm) {  // (one uniform branch around 16 shuffles: per-register selects on `vnorm` cost 11 % of the scan)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int src = (r & 3) + 8 * (r >> 2) + 4 * (int)fh;
-            const bool in = (32 * g + (uint32_t)src) < N;
-            if constexpr (INT) init[r] = vnorm ? -(__shfl(vn_mine, src) >> 1) : (in ? 0 : -0x40000000);
-            else init[r] = vnorm ? -0.5f * __int_as_float(__shfl(vn_mine, src)) : (in ? 0.0f : -__builtin_inff());
+            for (int r = 0; r < 16; ++r) {
+                const int w = __shfl(vn_mine, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
+                if constexpr (INT) init[r] = -(w >> 1);
+                else init[r] = -0.5f * __int_as_float(w);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool in = (32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh) < N;
+                if constexpr (INT) init[r] = in ? 0 : -0x40000000;
+                else init[r] = in ? 0.0f : -__builtin_inff();
+            }
         }
 
         acc_t acc[I8_NF];
