@@ -227,6 +227,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
 #pragma unroll
             for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn_mine, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
         } else {  // dot / cosine: no norm term; rows past N must still never pass
+            asm volatile("");  // (keeps this path a real branch: if-converted, its 48 VALU ops ran on every L2 step)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 init[r] = (32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh) < N ? 0.0f : -__builtin_inff();
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) init16[a][r] = -0.5f * __shfl(vn_mine, 16 * a + 4 * (int)lq + r);
         } else {
+            asm volatile("");  // (keeps this path a real branch)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll

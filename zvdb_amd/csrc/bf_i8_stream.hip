@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
                 else init[r] = -0.5f * __int_as_float(w);
             }
         } else {
+            asm volatile("");  // (keeps this path a real branch: if-converted, its VALU ops would run on every L2 step)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool in = (32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh) < N;
