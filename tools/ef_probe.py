@@ -20,4 +20,6 @@ for ef in (64, 128, 256):
         g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, 0, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, s)
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / 3
-    print(f"ef {ef}: {el*1e3:.2f} ms/batch, evals/q {st[0].item()/BG:.0f}, pops/q {st[1].item()/BG:.0f}, overflow {st[2].item()}, cyc/pop A(min+adj+hash) {st[4].item()/st[1].item():.0f} B(dist) {st[5].item()/st[1].item():.0f} C(nofit) {st[6].item()/st[1].item():.0f} D(update) {st[7].item()/st[1].item():.0f}, us per pop {el*1e6/(st[1].item()/BG):.2f}")
+    ev, pp = st[0].item(), st[1].item()
+    print(f"ef {ef}: {el*1e3:.2f} ms/batch = {BG/el:,.0f} QPS, evals/q {ev/BG:.0f}, pops/q {pp/BG:.0f}, visited-set overflows {st[2].item()}, "
+          f"{ev*DG*4/el/1e12:.2f} TB/s algorithmic ({ev*DG*4/el/8e12:.2f} of 8 TB/s), {el*1e6/(pp/BG):.2f} us per pop")
