@@ -194,6 +194,34 @@ def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):
         assert np.array_equal(i8, ei) and np.array_equal(d8, ed) and np.all(c8 == k)
 
 
+@pytest.mark.parametrize("k", [64, 100, 112])
+def test_bruteforce_k_up_to_112_on_the_stream_pipelines(zv, oracle, k):
+    """k > 48 (the reference's own benchmark goes to k = 100: single_threaded_benchmarks.zig:28-33): the stream pipelines
+    switch to k' = 128 survivors (two entries per lane in the selects, 128-wide lists / merge / re-rank).  int8 route:
+    the exact top-k, bit for bit against the oracle; fp4 route: measured recall, exact ascending distances."""
+    n, d, nq = 600_000, 96, 300
+    idx = zv.Index()
+    idx.add_synthetic(n, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    i8, d8, c8 = idx.search_bruteforce(Q, k, zv.BF_I8)
+    assert np.all(c8 == k) and np.all(np.diff(d8, axis=1) >= 0)
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    sel = [0, 1, 150, 298, 299]
+    ri, rd, _ = oracle.bruteforce_topk(V, Q[sel], k)
+    assert np.array_equal(i8[sel], ri) and np.array_equal(d8[sel], rd)
+    a4, d4, c4 = idx.search_bruteforce(Q, k, zv.BF_FP4)
+    assert np.all(c4 == k) and np.all(np.diff(d4, axis=1) >= 0)
+    rec = np.mean([len(set(a4[i]) & set(i8[i])) / k for i in range(nq)])
+    assert rec >= 0.75, rec  # (k of k' = 128 survivors: little slack for a 4-bit screen)
+    for qi in sel:
+        for j in range(0, k, 9):
+            assert oracle.distance(Q[qi], V[int(a4[qi, j])]) == d4[qi, j]
+    with pytest.raises(zv.ZvdbError):
+        idx.search_bruteforce(Q, 113, zv.BF_I8)
+    with pytest.raises(zv.ZvdbError):
+        idx.search_bruteforce(Q, 64, zv.BF_F32)  # the staged routes stay at k' = 64
+
+
 @pytest.mark.parametrize("d", [1024, 1536])
 def test_bruteforce_fp4_wide_rows_stream_equals_staged(zv, oracle, tmp_path, d):
     """768 < dim <= 1536: the fp4 screen runs on the 128-query stream kernel (bf_i8_stream.hip, MODE 3; KS = 18 / 24) with

@@ -66,7 +66,8 @@ __host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS) {
 // v_mfma_scale_f32_16x16x128 (2 x 16 accumulators of 4 registers): same bytes, same cadence (4 ds_read_b128 per 128
 // MFMA cycles), but the chip holds a higher clock on the 16x16 shape (tools/mfma_peak_bench.hip, random operands:
 // 7.6 vs 6.7 PFLOP/s).  The operand layouts differ (fragment = 16 rows x 128 k), so the mirror is packed per shape.
-template <int KS, int DBG, int SH>
+// KPV = width of the kept lists / output lists: 64, or 128 (two entries per lane in the selects) for k > 48.
+template <int KS, int DBG, int SH, int KPV = KP>
 __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const unsigned char *__restrict__ Qf /* [query group][KS][64][16 B] */,
     const unsigned char *__restrict__ Vf /* [row group][KS][64][16 B] */, const float *__restrict__ vnorm /* padded to groups, +inf past N */,
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const uint32_t g_begin = 8 * t_begin, g_end = min(8 * t_end, (N + 31) / 32);  // row groups of 32
     const uint32_t nsteps = g_end > g_begin ? (g_end - g_begin + F7_NW - 1) / F7_NW : 0;  // the same for every wave
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
-    uint64_t *kept = cand + (size_t)b * BLK4_ENTRIES;
-    uint64_t *subs = kept + BLK4_KEPT;
+    uint64_t *kept = cand + (size_t)b * BLKV_ENTRIES;  // (regions are sized for the widest list)
+    uint64_t *subs = kept + (size_t)T2 * KPMAX;
 
     for (int tq = tid; tq < T2; tq += 512) {
         const bool live = (qt * T2 + tq) < nq;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             if (c > (uint32_t)F7_MARK) {
                 if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
                 if (lane == 0) cnt[q] = 0;
-                prune_query<false, true>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
+                prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
             }
         }
         __syncthreads();
@@ -497,12 +498,12 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
         const bool mine = lane < 32 && qg < nq;
         const uint32_t c = mine ? min(lds_load_u32(cnt + q), (uint32_t)F7_CAP) : 0u;
         const uint32_t nk = mine ? nkept[q] : 0u;
-        const bool simple = mine && nk + c <= (uint32_t)KP;
+        const bool simple = mine && nk + c <= (uint32_t)KPV;
         if (simple) {
-            uint64_t *dst = partial + ((size_t)qg * Stot + list_base + s) * KP;
-            for (uint32_t e = 0; e < nk; ++e) dst[e] = kept[(size_t)q * KP + e];
+            uint64_t *dst = partial + ((size_t)qg * Stot + list_base + s) * KPV;
+            for (uint32_t e = 0; e < nk; ++e) dst[e] = kept[(size_t)q * KPV + e];
             for (uint32_t e = 0; e < c; ++e) dst[nk + e] = subs[(size_t)q * F7_CAP + e];
-            for (uint32_t e = nk + c; e < (uint32_t)KP; ++e) dst[e] = ~0ull;
+            for (uint32_t e = nk + c; e < (uint32_t)KPV; ++e) dst[e] = ~0ull;
             pcnt[(size_t)qg * Stot + list_base + s] = nk + c;
         }
         unsigned long long todo = __ballot(mine && !simple);
@@ -513,8 +514,10 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             const uint32_t qg2 = qt * T2 + q2;
             const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)F7_CAP);
             if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-            const uint64_t best = prune_query<false, true>(kept, subs, tau, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
-            partial[((size_t)qg2 * Stot + list_base + s) * KP + lane] = best;
+            prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
+#pragma unroll
+            for (int c2i = 0; c2i < KPV / 64; ++c2i)  // (the list as prune_query left it: compacted, ~0 padded)
+                partial[((size_t)qg2 * Stot + list_base + s) * KPV + lane + 64 * c2i] = kept[(size_t)q2 * KPV + lane + 64 * c2i];
             if (lane == 0) pcnt[(size_t)qg2 * Stot + list_base + s] = nkept[q2];
         }
     }
@@ -671,7 +674,7 @@ int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
 }
 
 namespace {
-template <int DBG>
+template <int DBG, int KPV = KP>
 int launch_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                   uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
                   uint32_t Stot, uint32_t *pcnt, uint32_t max_tiles, const uint32_t *gate, float *mom, hipStream_t s) {
@@ -684,7 +687,10 @@ int launch_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t n
                            partial, tau_g, kp, t_first, list_base, Stot, pcnt, max_tiles, gate, mom);
         return ZVDB_OK;
     };
-    if (fp4s_shape() == 16) {
+    if constexpr (KPV != KP) {  // wide lists: production instantiations of the 32x32 shape only
+        if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, 0, 32, KPV>));
+        else ZV_CHECK(go(k_fp4_stream<12, 0, 32, KPV>));
+    } else if (fp4s_shape() == 16) {
         if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, DBG == 8 ? 8 : 0, 16>));
         else ZV_CHECK(go(k_fp4_stream<12, DBG, 16>));
     } else {
@@ -698,7 +704,9 @@ int launch_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t n
 
 int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
-                     uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
+                     uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s) {
+    if (kpv == (uint32_t)KPMAX)
+        return launch_stream<0, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     static const uint32_t dbg = [] { const char *e = getenv("ZVDB_BF_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
 #define ZV_F7_ARGS h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, (float *)nullptr, s
     if (dbg == 1) return launch_stream<1>(ZV_F7_ARGS);

@@ -41,7 +41,7 @@ __host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS) {
 
 // KS = 32-byte (32-element) k-steps per row; MOM: moments mode (sum of key, key^2 per query instead of selecting)
 // MODE: 2 = int8 (int keys), 3 = fp4 (fp32 keys)
-template <int MODE, int KS, bool MOM>
+template <int MODE, int KS, bool MOM, int KPV = KP>
 __global__ __launch_bounds__(512, 2) void k_i8_stream(
     const unsigned char *__restrict__ Qf /* [query group of 32][KS][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
     const void *__restrict__ vnorm_v /* int8: sum q^2 (i32, INT_MAX past N); fp4: sum v'^2 (f32, +inf past N); nullptr: dot / cosine */, uint32_t N,
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
     const uint32_t g_begin = 8 * t_begin, g_end = min(8 * t_end, (N + 31) / 32);
     const uint32_t nsteps = g_end > g_begin ? (g_end - g_begin + I8_NW - 1) / I8_NW : 0;
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * I8_TQ : nullptr;
-    uint64_t *kept = cand + (size_t)b * BLK4_ENTRIES;
-    uint64_t *subs = kept + BLK4_KEPT;
+    uint64_t *kept = cand + (size_t)b * BLKV_ENTRIES;  // (regions are sized for the widest list)
+    uint64_t *subs = kept + (size_t)T2 * KPMAX;
 
     for (int tq = tid; tq < I8_TQ; tq += 512) {
         const bool live = (qt * I8_TQ + tq) < nq;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             if (c > (uint32_t)I8_MARK) {
                 if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
                 if (lane == 0) cnt[q] = 0;
-                prune_query<INT, true>(kept, subs, tau_f, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
+                prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
             }
         }
         __syncthreads();
@@ -307,12 +307,12 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
         const bool mine = lane < 16 && qg < nq;
         const uint32_t c = mine ? min(lds_load_u32(cnt + q), (uint32_t)I8_CAP) : 0u;
         const uint32_t nk = mine ? nkept[q] : 0u;
-        const bool simple = mine && nk + c <= (uint32_t)KP;
+        const bool simple = mine && nk + c <= (uint32_t)KPV;
         if (simple) {
-            uint64_t *dst = partial + ((size_t)qg * Stot + list_base + s) * KP;
-            for (uint32_t e = 0; e < nk; ++e) dst[e] = kept[(size_t)q * KP + e];
+            uint64_t *dst = partial + ((size_t)qg * Stot + list_base + s) * KPV;
+            for (uint32_t e = 0; e < nk; ++e) dst[e] = kept[(size_t)q * KPV + e];
             for (uint32_t e = 0; e < c; ++e) dst[nk + e] = subs[(size_t)q * I8_CAP + e];
-            for (uint32_t e = nk + c; e < (uint32_t)KP; ++e) dst[e] = ~0ull;
+            for (uint32_t e = nk + c; e < (uint32_t)KPV; ++e) dst[e] = ~0ull;
             pcnt[(size_t)qg * Stot + list_base + s] = nk + c;
         }
         unsigned long long todo = __ballot(mine && !simple);
@@ -323,8 +323,10 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             const uint32_t qg2 = qt * I8_TQ + q2;
             const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)I8_CAP);
             if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-            const uint64_t best = prune_query<INT, true>(kept, subs, tau_f, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
-            partial[((size_t)qg2 * Stot + list_base + s) * KP + lane] = best;
+            prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
+#pragma unroll
+            for (int c2i = 0; c2i < KPV / 64; ++c2i)
+                partial[((size_t)qg2 * Stot + list_base + s) * KPV + lane + 64 * c2i] = kept[(size_t)q2 * KPV + lane + 64 * c2i];
             if (lane == 0) pcnt[(size_t)qg2 * Stot + list_base + s] = nkept[q2];
         }
     }
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void k_i8_norms(const float *__restrict__ rows
     if (lane == 0) norm[r] = s;
 }
 
-template <int MODE, bool MOM>
+template <int MODE, bool MOM, int KPV = KP>
 int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
                      uint32_t *pcnt, uint32_t max_tiles, const uint32_t *gate, float *mom, hipStream_t s) {
@@ -431,12 +433,12 @@ int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
         return ZVDB_OK;
     };
     if constexpr (MODE == 2) {
-        if (KS == 6) ZV_CHECK(go(k_i8_stream<2, 6, MOM>));
-        else if (KS == 12) ZV_CHECK(go(k_i8_stream<2, 12, MOM>));
-        else ZV_CHECK(go(k_i8_stream<2, 24, MOM>));
+        if (KS == 6) ZV_CHECK(go(k_i8_stream<2, 6, MOM, KPV>));
+        else if (KS == 12) ZV_CHECK(go(k_i8_stream<2, 12, MOM, KPV>));
+        else ZV_CHECK(go(k_i8_stream<2, 24, MOM, KPV>));
     } else {
-        if (KS == 18) ZV_CHECK(go(k_i8_stream<3, 18, MOM>));
-        else ZV_CHECK(go(k_i8_stream<3, 24, MOM>));
+        if (KS == 18) ZV_CHECK(go(k_i8_stream<3, 18, MOM, KPV>));
+        else ZV_CHECK(go(k_i8_stream<3, 24, MOM, KPV>));
     }
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
@@ -497,7 +499,9 @@ int launch_i8s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uin
 // QT = tiles of 128 queries; S = streams (QT * S workgroups)
 int launch_i8s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
-                    uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
+                    uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s) {
+    if (kpv == (uint32_t)KPMAX)
+        return launch_i8_stream<2, false, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     return launch_i8_stream<2, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
 
@@ -517,7 +521,9 @@ bool fp4s128_eligible(const zvdb_hip_index *h) {
 }
 int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                         uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
-                        uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
+                        uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s) {
+    if (kpv == (uint32_t)KPMAX)
+        return launch_i8_stream<3, false, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     return launch_i8_stream<3, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
 int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,

@@ -13,55 +13,70 @@ constexpr int SUBCAP = 256, SUBHW = 48, SUBURG = 192, NSUB = 4;  // capacity, so
 constexpr size_t BLK4_KEPT = (size_t)T2 * KP;                 // u64 entries
 constexpr size_t BLK4_ENTRIES = BLK4_KEPT + (size_t)T2 * NSUB * SUBCAP;
 
+constexpr int KPMAX = 128;  // widest kept list (2 entries per lane): k <= 112 on the stream pipelines
+constexpr size_t BLKV_ENTRIES = (size_t)T2 * KPMAX + (size_t)T2 * NSUB * SUBCAP;  // per-workgroup region sized for KPMAX
+
 // merge query q's kept list with its sub-buffers -> exact best kp (UNSORTED, compacted to the front of
-// kept[q]); resets the sub-buffers.  Rounds of <= 64 carried + 256 new keys, radix-selected.
+// kept[q]); resets the sub-buffers.  Rounds of <= KPV carried + 256 new keys, radix-selected.
 // INCL: tau becomes next_up(k'-th key), i.e. later keys EQUAL to the k'-th best still pass (needed when rows do not
-// arrive in id order).
-template <bool INTKEY, bool INCL = false>
+// arrive in id order).  KPV = capacity (and row stride) of the kept lists: 64 (one entry per lane) or 128 (two).
+// Returns the lane's first kept entry (KPV = 64: the whole list, one per lane).
+template <bool INTKEY, bool INCL = false, int KPV = KP>
 __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, const uint64_t *__restrict__ sub,
                                                 float *tau, uint32_t *nkept, uint32_t *subcnt, int q, int lane,
                                                 uint32_t kp, uint32_t *tau_g, unsigned char *scratch) {
+    constexpr int EPL = KPV / kWave;  // kept entries per lane
+    static_assert(KPV == 64 || KPV == 128, "kept list width");
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch);
-    uint64_t *stage = reinterpret_cast<uint64_t *>(scratch + SEL_HIST_BYTES);
+    uint64_t *stage = reinterpret_cast<uint64_t *>(scratch + SEL_HIST_BYTES);  // [KPV]
     const uint32_t n0 = min(subcnt[q * NSUB + 0], (uint32_t)SUBCAP), n1 = min(subcnt[q * NSUB + 1], (uint32_t)SUBCAP);
     const uint32_t n2 = min(subcnt[q * NSUB + 2], (uint32_t)SUBCAP), n3 = min(subcnt[q * NSUB + 3], (uint32_t)SUBCAP);
     const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, total = p3 + n3;
     uint32_t ncarry = nkept[q];
-    uint64_t carry = (uint32_t)lane < ncarry ? kept[(size_t)q * KP + lane] : ~0ull;
+    uint64_t carry[EPL];
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) carry[c] = (uint32_t)(lane + kWave * c) < ncarry ? kept[(size_t)q * KPV + lane + kWave * c] : ~0ull;
     uint32_t done = 0;
     while (done < total) {
-        uint64_t k[5];
-        k[0] = carry;
+        uint64_t k[EPL + 4];
 #pragma unroll
-        for (int e = 1; e < 5; ++e) {
-            const uint32_t i = done + (e - 1) * kWave + lane;
+        for (int c = 0; c < EPL; ++c) k[c] = carry[c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = done + e * kWave + lane;
             uint64_t v = ~0ull;
             if (i < total) {
                 const uint32_t si = (i >= p1) + (i >= p2) + (i >= p3);
                 const uint32_t off = i - (si == 0 ? 0u : si == 1 ? p1 : si == 2 ? p2 : p3);
                 v = sub[((size_t)q * NSUB + si) * SUBCAP + off];
             }
-            k[e] = v;
+            k[EPL + e] = v;
         }
         const uint32_t nnew = min(256u, total - done);
         done += nnew;
         const uint32_t nvalid = ncarry + nnew;
         uint64_t T = ~0ull - 1;  // everything valid passes
-        if (nvalid > kp) T = wave_kth_key<5>([&](uint32_t e) { return k[e]; }, 5, kp, hist, lane);
+        if (nvalid > kp) T = wave_kth_key<EPL + 4>([&](uint32_t e) { return k[e]; }, EPL + 4, kp, hist, lane);
         uint32_t base = 0;
 #pragma unroll
-        for (int e = 0; e < 5; ++e) {
+        for (int e = 0; e < EPL + 4; ++e) {
             const bool selv = k[e] <= T;
             const unsigned long long m = __ballot(selv);
             const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (selv && pos < (uint32_t)KP) stage[pos] = k[e];
+            if (selv && pos < (uint32_t)KPV) stage[pos] = k[e];
             base += (uint32_t)__popcll(m);
         }
         ncarry = min(nvalid, kp);
-        carry = (uint32_t)lane < ncarry ? stage[lane] : ~0ull;
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) carry[c] = (uint32_t)(lane + kWave * c) < ncarry ? stage[lane + kWave * c] : ~0ull;
     }
-    kept[(size_t)q * KP + lane] = carry;
-    const uint64_t last = ncarry == kp ? wave_max64((uint32_t)lane < ncarry ? carry : 0ull) : ~0ull;
+    uint64_t mx = 0;
+#pragma unroll
+    for (int c = 0; c < EPL; ++c) {
+        kept[(size_t)q * KPV + lane + kWave * c] = carry[c];
+        if ((uint32_t)(lane + kWave * c) < ncarry) mx = umax64(mx, carry[c]);
+    }
+    const uint64_t last = ncarry == kp ? wave_max64(mx) : ~0ull;
     if (lane == 0) {
         nkept[q] = ncarry;
         subcnt[q * NSUB + 0] = 0; subcnt[q * NSUB + 1] = 0; subcnt[q * NSUB + 2] = 0; subcnt[q * NSUB + 3] = 0;
@@ -78,7 +93,7 @@ __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, con
             if (tau_g) atomicMin(tau_g + q, (uint32_t)(last >> 32));
         }
     }
-    return carry;
+    return carry[0];
 }
 
 

@@ -846,7 +846,8 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
                                                      uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
                                                      uint32_t kp, uint32_t cap, uint32_t l0 = 0, int vmode = 0,
                                                      uint32_t *__restrict__ flag = nullptr, uint32_t *__restrict__ defq = nullptr,
-                                                     uint32_t *__restrict__ host_flag = nullptr /* mapped host memory */) {
+                                                     uint32_t *__restrict__ host_flag = nullptr /* mapped host memory */,
+                                                     uint32_t lkp = KP /* width (stride) of the lists and of cand_ids: 64 or 128 */) {
     if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
@@ -854,7 +855,7 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
     uint64_t *pool = reinterpret_cast<uint64_t *>(smem + SEL_SCRATCH);  // [cap]
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
-    const uint64_t *p = partial + ((size_t)q * Stot + l0) * KP;
+    const uint64_t *p = partial + ((size_t)q * Stot + l0) * lkp;
     uint32_t n = 0;       // keys in the pool (wave-uniform)
     uint64_t T = ~0ull - 1;
     auto reduce_pool = [&]() {  // pool -> its kp best, compacted to the front
@@ -868,22 +869,22 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
             const bool selv = k <= T;
             const unsigned long long m = __ballot(selv);
             const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (selv && pos < (uint32_t)KP) stage[pos] = k;
+            if (selv && pos < lkp) stage[pos] = k;
             base += (uint32_t)__popcll(m);
         }
         __syncthreads();
-        if ((uint32_t)lane < kp) pool[lane] = stage[lane];
+        for (uint32_t i = lane; i < kp; i += kWave) pool[i] = stage[i];
         n = kp;
         __syncthreads();
     };
     for (uint32_t s0 = 0; s0 < S; s0 += kWave) {
         // one lane per list; its valid-entry count was written by the scan
         const uint32_t li = s0 + lane;
-        const uint64_t *lp = p + (size_t)li * KP;
-        const uint32_t cnt = li < S ? min(pcnt[(size_t)q * Stot + l0 + li], (uint32_t)KP) : 0u;
+        const uint64_t *lp = p + (size_t)li * lkp;
+        const uint32_t cnt = li < S ? min(pcnt[(size_t)q * Stot + l0 + li], lkp) : 0u;
         const uint32_t inc = wave_incl_scan(cnt, lane);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-        if (n + tot > cap) reduce_pool();  // make room (cap >= kp + 64 * KP)
+        if (n + tot > cap) reduce_pool();  // make room (cap >= kp + 64 * lkp)
         const uint32_t off = n + inc - cnt;
         for (uint32_t j2 = 0; j2 < cnt; ++j2) pool[off + j2] = lp[j2];
         n += tot;
@@ -891,8 +892,10 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
     }
     reduce_pool();
     if (cand_ids) {
-        const uint64_t k = (uint32_t)lane < n ? pool[lane] : ~0ull;
-        cand_ids[(size_t)q * KP + lane] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
+        for (uint32_t i = lane; i < lkp; i += kWave) {
+            const uint64_t k = i < n ? pool[i] : ~0ull;
+            cand_ids[(size_t)q * lkp + i] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
+        }
     }
     if (vmode == 1) {
         if (lane == 0) {
@@ -905,7 +908,9 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
             }
         }
     } else if (tau_out) {
-        uint64_t mx = wave_max64((uint32_t)lane < n ? pool[lane] : 0ull);
+        uint64_t mxl = 0;
+        for (uint32_t i = lane; i < n; i += kWave) mxl = umax64(mxl, pool[i]);
+        uint64_t mx = wave_max64(mxl);
         if (lane == 0) tau_out[q] = n >= kp ? (uint32_t)(mx >> 32) : 0xFFFFFFFFu;
     }
 }
@@ -1021,11 +1026,11 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
                                          : mode == ZVDB_BF_I8 && i8s_eligible(h) ? i8s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
     off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap,
-                              (uint64_t)std::max(p.QT * p.S, p.QT8 * p.S8) * BLK4_ENTRIES) * 8;
+                              (uint64_t)std::max(p.QT * p.S, p.QT8 * p.S8) * BLKV_ENTRIES) * 8;
     p.off_partial = off;
-    off += (uint64_t)p.nq_pad * 3 * p.S * KP * 8;  // lists of up to three passes
+    off += (uint64_t)p.nq_pad * 3 * p.S * KPMAX * 8;  // lists of up to three passes (widest list)
     p.off_ids = off;
-    off += (uint64_t)p.nq_pad * KP * 4;
+    off += (uint64_t)p.nq_pad * KPMAX * 4;
     p.off_taug = off;
     off += round_up64((uint64_t)p.nq_pad * 4, 256) + 256;  // + debug counters
     p.off_verify = off;  // guessed-threshold pipeline: [flag 256 B][defq nq_pad][tau_rep nq_pad]
@@ -1091,11 +1096,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     if (nq == 0) return ZVDB_OK;
     // the screen keeps k' = 64 candidates per query; the exact re-rank needs a margin over k to
     // absorb the screen's rounding (reduced-precision inputs: wider margin).  TODO: 2 keys/lane.
-    const uint32_t kmax = mode == ZVDB_BF_F32 ? KP - 8 : KP - 16;
-    if (k > kmax) {
-        set_error("brute force supports k <= %u in this mode (k' = %d candidates are re-ranked exactly)", kmax, KP);
-        return ZVDB_ERR_UNSUPPORTED;
-    }
+    const uint32_t kmax = mode == ZVDB_BF_F32 ? KP - 8 : KP - 16;  // (checked below, once the route is known)
     if (mode == ZVDB_BF_BF16 && !(h->flags & ZVDB_FLAG_BF16_MIRROR)) {
         set_error("ZVDB_BF_BF16 needs an index created with ZVDB_FLAG_BF16_MIRROR");
         return ZVDB_ERR_INVALID;
@@ -1145,6 +1146,14 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
     const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || s8 || s4;
+    // k' = 64 survivors per query (one per lane of the selects) carry k <= 48 (56 with the exact fp32 screen); the stream
+    // pipelines also run with k' = 128 (two entries per lane), which carries k <= 112
+    const uint32_t kpv = (k > kmax && guess_pipe) ? (uint32_t)KPMAX : (uint32_t)KP;
+    if (k > (kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX - 16 : kmax)) {
+        set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d needs the int8 / fp4 stream "
+                  "pipeline: dim <= 768 (fp4: 1536) and a shard of >= 16 tiles per stream)", kpv == (uint32_t)KPMAX ? KPMAX - 16 : kmax, kpv, KPMAX - 16);
+        return ZVDB_ERR_UNSUPPORTED;
+    }
     if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
@@ -1175,7 +1184,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         uint32_t *pcnt = reinterpret_cast<uint32_t *>(ws + p.off_pcnt);
         // survivors per query: 32 suffice for k <= 16 with the (near-)exact screens; the 4-bit screen keeps 64
         static const uint32_t fp4_kp = [] { const char *e = getenv("ZVDB_BF_FP4_KP"); return e ? (uint32_t)atoi(e) : (uint32_t)KP; }();  // tuning
-        const uint32_t kp = mode == ZVDB_BF_FP4 ? std::min<uint32_t>(std::max<uint32_t>(fp4_kp, k + 16), KP)
+        const uint32_t kp = kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX
+                            : mode == ZVDB_BF_FP4 ? std::min<uint32_t>(std::max<uint32_t>(fp4_kp, k + 16), KP)
                                                 : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
                                     : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
@@ -1206,7 +1216,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         if (guess_pipe) {
             static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
             static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
-            const double tail = std::min(0.25, target / (double)N);
+            const double tail = std::min(0.25, std::max(target, 4.0 * kp) / (double)N);
             // adaptive part: a batch that needed a repair (keys not Gaussian enough, e.g. low dimensions) loosens the guess of
             // the following batches by half a standard deviation, up to +2 (too loose is self-correcting, only slower)
             if (!h->guess_flag_host) {
@@ -1227,25 +1237,28 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             float *mom = reinterpret_cast<float *>(cand);  // (cand is free until the scan)
             if (s8) {
                 ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
-                ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, s));
+                ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             } else if (s4) {
                 ZV_CHECK(launch_fp4s128_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
-                ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, s));
+                ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             } else {
                 ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, SS, p.NT, mom, z, tau_g, vflag, s));
-                ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, s));
+                ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
             }
-            const uint32_t cap = kp + 64 * KP;
-            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
-                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev);
-            if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, s));
-            else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, s));
-            else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, s));
-            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, SS, Stot, cand_ids,
-                               (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq);
+            const uint32_t cap = kp + 64 * kpv;
+            const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+            if (mlds > 64 * 1024)
+                ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
+                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv);
+            if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
+            else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
+            else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, kpv, s));
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids,
+                               (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries, nq, cand_ids, KP, k, id_offset, d_ids, d_dist, d_count, s);
+            return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
         }
         if (p.NT >= 4 * p.S && !(debug_flags() & 64)) {
             // pass A streams: every workgroup of pass A floods one tile (256 candidates per query, 8-byte
@@ -1267,7 +1280,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         auto scan = [&](const Pass &ps, uint32_t list_base) -> int {
             BfPlan q = p;
             q.S = ps.S;
-            if (f7) return launch_fp4s_scan(h, q_op, nq, q.QT, ps.S, ps.nt, cand, partial, tau_g, kp, ps.t0, list_base, Stot, pcnt, nullptr, s);
+            if (f7) return launch_fp4s_scan(h, q_op, nq, q.QT, ps.S, ps.nt, cand, partial, tau_g, kp, ps.t0, list_base, Stot, pcnt, nullptr, (uint32_t)KP, s);
             if (mode == ZVDB_BF_FP4 && !is_v6())  // A/B: 64-byte slices, 4-stage ring (3 slices in flight)
                 return launch_scan5<3, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             if (mode == ZVDB_BF_FP4)  // default: full-line pieces, 128-byte (256-element) slices

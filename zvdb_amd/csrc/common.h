@@ -202,7 +202,7 @@ int launch_i8s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uin
                             hipStream_t s);
 int launch_i8s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
-                    uint32_t *pcnt, const uint32_t *gate, hipStream_t s);
+                    uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s);
 int launch_i8s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt, float *mom,
                      float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
 
@@ -210,7 +210,7 @@ uint32_t fp4s128_ksteps(uint32_t dim);
 bool fp4s128_eligible(const zvdb_hip_index *h);
 int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                         uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
-                        uint32_t *pcnt, const uint32_t *gate, hipStream_t s);
+                        uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s);
 int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                          float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
 
@@ -223,7 +223,7 @@ int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
                              unsigned char *q_op, hipStream_t s);
 int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
-                     uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, hipStream_t s);
+                     uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, uint32_t kpv /* list width: 64 or 128 */, hipStream_t s);
 uint64_t fp4s_moment_bytes(uint32_t QT, uint32_t S);
 int launch_fp4s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                       float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);

@@ -755,12 +755,15 @@ typedef const __attribute__((address_space(1))) void *rr_gptr_t;
 typedef __attribute__((address_space(3))) void *rr_lptr_t;
 constexpr int RR_CH = 64;  // floats per chunk (256 B)
 
+// KC = 64 or 128 candidates per query (KC / 64 batches of 64 rows through the same two stage buffers)
+template <int KC>
 __global__ __launch_bounds__(64) void k_rerank_staged(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
                                                       const float *__restrict__ queries, const uint32_t *__restrict__ cand,
                                                       uint32_t k, uint64_t id_offset, uint64_t *__restrict__ out_ids,
                                                       float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
                                                       uint32_t dim_pad /* multiple of 64 */) {
-    constexpr uint32_t kc = 64;
+    constexpr uint32_t kc = KC;
+    constexpr int NB = KC / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *stage = smem;                                              // [2][64 rows][256 B]
     float *q = reinterpret_cast<float *>(smem + 2 * 64 * 256);               // [dim_pad], zero padded
@@ -770,86 +773,103 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const float *__restrict__ 
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
-    ci[lane] = cand[(size_t)qi * kc + lane];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) ci[lane + 64 * bt] = cand[(size_t)qi * kc + lane + 64 * bt];
     __syncthreads();
     {   // drop duplicate ids (keep the first copy)
-        bool dup = false;
-        const uint32_t ii = ci[lane];
-        if (ii != 0xFFFFFFFFu)
-            for (int j = 0; j < lane; ++j)
-                if (ci[j] == ii) { dup = true; break; }
+        bool dup[NB];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            dup[bt] = false;
+            const int me = lane + 64 * bt;
+            const uint32_t ii = ci[me];
+            if (ii != 0xFFFFFFFFu)
+                for (int j = 0; j < me; ++j)
+                    if (ci[j] == ii) { dup[bt] = true; break; }
+        }
         __syncthreads();
-        if (dup) ci[lane] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+            if (dup[bt]) ci[lane + 64 * bt] = 0xFFFFFFFFu;
         __syncthreads();
     }
-    // DMA side: instruction t fills rows 4t .. 4t+3; this lane serves row 4t + (lane >> 4), position lane & 15
     const uint32_t nch = (ld + RR_CH - 1) / RR_CH;
     const uint32_t row_bytes = ld * 4;
-    uint32_t src_off[16];  // byte offset of my piece inside a chunk of row (4t + lane/16), before the chunk offset
-    const float *src_row[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const uint32_t r = 4 * t + (lane >> 4);
-        const uint32_t id = ci[r];
-        src_row[t] = rows + (size_t)(id == 0xFFFFFFFFu ? 0u : id) * ld;
-        src_off[t] = (((uint32_t)lane & 15u) ^ (r & 15u)) << 4;
-    }
-    auto issue = [&](uint32_t c, uint32_t buf) {
+#pragma unroll 1
+    for (int bt = 0; bt < NB; ++bt) {
+        // DMA side: instruction t fills rows 4t .. 4t+3 of this batch; this lane serves row 4t + (lane >> 4), position lane & 15
+        uint32_t src_off[16];  // byte offset of my piece inside a chunk of row (4t + lane/16), before the chunk offset
+        const float *src_row[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            // the row's last chunk may be short (ld is a multiple of 32 floats): stay inside the row
-            const uint32_t off = min(c * (RR_CH * 4) + src_off[t], row_bytes - 16);
-            __builtin_amdgcn_global_load_lds((rr_gptr_t)(reinterpret_cast<const unsigned char *>(src_row[t]) + off),
-                                             (rr_lptr_t)(stage + buf * (64 * 256) + t * 1024), 16, 0, 0);
+            const uint32_t r = 4 * t + (lane >> 4);
+            const uint32_t id = ci[64 * bt + r];
+            src_row[t] = rows + (size_t)(id == 0xFFFFFFFFu ? 0u : id) * ld;
+            src_off[t] = (((uint32_t)lane & 15u) ^ (r & 15u)) << 4;
         }
-    };
-    const uint32_t my_id = ci[lane];
-    float sum = 0.0f;
-    issue(0, 0);
-    for (uint32_t c = 0; c < nch; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c has landed (single wave: no barrier needed)
-        if (c + 1 < nch) issue(c + 1, (c + 1) & 1);
-        const unsigned char *mine = stage + (c & 1) * (64 * 256) + lane * 256;
-        const uint32_t k0 = c * RR_CH;
-        const uint32_t kend = min(dim, k0 + RR_CH);
+        auto issue = [&](uint32_t c, uint32_t buf) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const uint32_t kk = k0 + 4 * p;
-            if (kk >= kend) break;
-            const float4 v = *reinterpret_cast<const float4 *>(mine + ((p ^ (lane & 15)) << 4));
-            const float4 a = *reinterpret_cast<const float4 *>(q + kk);
-            const float vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a.x, a.y, a.z, a.w};
+            for (int t = 0; t < 16; ++t) {
+                // the row's last chunk may be short (ld is a multiple of 32 floats): stay inside the row
+                const uint32_t off = min(c * (RR_CH * 4) + src_off[t], row_bytes - 16);
+                __builtin_amdgcn_global_load_lds((rr_gptr_t)(reinterpret_cast<const unsigned char *>(src_row[t]) + off),
+                                                 (rr_lptr_t)(stage + buf * (64 * 256) + t * 1024), 16, 0, 0);
+            }
+        };
+        const uint32_t my_id = ci[64 * bt + lane];
+        float sum = 0.0f;
+        issue(0, 0);
+        for (uint32_t c = 0; c < nch; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c has landed (single wave: no barrier needed)
+            if (c + 1 < nch) issue(c + 1, (c + 1) & 1);
+            const unsigned char *mine = stage + (c & 1) * (64 * 256) + lane * 256;
+            const uint32_t k0 = c * RR_CH;
+            const uint32_t kend = min(dim, k0 + RR_CH);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (kk + e < kend) {
-                    if (metric == ZVDB_METRIC_L2SQ) {
-                        float t = aa[e] - vv[e];
-                        t = t * t;
-                        sum = sum + t;
-                    } else {
-                        const float t = aa[e] * vv[e];
-                        sum = sum + t;
+            for (int p = 0; p < 16; ++p) {
+                const uint32_t kk = k0 + 4 * p;
+                if (kk >= kend) break;
+                const float4 v = *reinterpret_cast<const float4 *>(mine + ((p ^ (lane & 15)) << 4));
+                const float4 a = *reinterpret_cast<const float4 *>(q + kk);
+                const float vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (kk + e < kend) {
+                        if (metric == ZVDB_METRIC_L2SQ) {
+                            float t = aa[e] - vv[e];
+                            t = t * t;
+                            sum = sum + t;
+                        } else {
+                            const float t = aa[e] * vv[e];
+                            sum = sum + t;
+                        }
                     }
                 }
             }
         }
+        cd[64 * bt + lane] = my_id == 0xFFFFFFFFu ? __builtin_inff() : (metric == ZVDB_METRIC_L2SQ ? sum : -sum);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads of the stage are done before the next batch refills it
     }
-    cd[lane] = my_id == 0xFFFFFFFFu ? __builtin_inff() : (metric == ZVDB_METRIC_L2SQ ? sum : -sum);
     __syncthreads();
-    const bool valid = my_id != 0xFFFFFFFFu;
-    uint32_t rank = 0;
-    if (valid) {
-        const float di = cd[lane];
-        for (uint32_t j = 0; j < kc; ++j) {
-            const uint32_t ij = ci[j];
-            if (ij != 0xFFFFFFFFu && lex_less(cd[j], ij, di, my_id)) ++rank;
+    uint32_t total = 0;
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        const uint32_t my_id = ci[64 * bt + lane];
+        const bool valid = my_id != 0xFFFFFFFFu;
+        if (valid) {
+            const float di = cd[64 * bt + lane];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < kc; ++j) {
+                const uint32_t ij = ci[j];
+                if (ij != 0xFFFFFFFFu && lex_less(cd[j], ij, di, my_id)) ++rank;
+            }
+            if (rank < k) {
+                out_ids[(size_t)qi * k + rank] = (uint64_t)my_id + id_offset;
+                out_dist[(size_t)qi * k + rank] = di;
+            }
         }
-        if (rank < k) {
-            out_ids[(size_t)qi * k + rank] = (uint64_t)my_id + id_offset;
-            out_dist[(size_t)qi * k + rank] = di;
-        }
+        total += (uint32_t)__popcll(__ballot(valid));
     }
-    const uint32_t total = (uint32_t)__popcll(__ballot(valid));
     const uint32_t nres = total < k ? total : k;
     for (uint32_t i = nres + lane; i < k; i += kWave) {
         out_ids[(size_t)qi * k + i] = ~0ull;
@@ -864,12 +884,18 @@ int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, 
     if (nq == 0) return ZVDB_OK;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool staged_off = [] { const char *e = getenv("ZVDB_RERANK"); return e && e[0] == 'v' && e[1] == '1'; }();
-    if (kc == 64 && h->ld >= 64 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
+    if ((kc == 64 || kc == 128) && h->ld >= 64 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
         const uint32_t dp = round_up(h->dim, 64);
         const size_t lds2 = 2 * 64 * 256 + 4ull * (dp + 2ull * kc);
-        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged), lds2));
-        hipLaunchKernelGGL(k_rerank_staged, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
-                           id_offset, d_ids, d_dist, d_count, dp);
+        if (kc == 64) {
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<64>), lds2));
+            hipLaunchKernelGGL(k_rerank_staged<64>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
+                               id_offset, d_ids, d_dist, d_count, dp);
+        } else {
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<128>), lds2));
+            hipLaunchKernelGGL(k_rerank_staged<128>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
+                               id_offset, d_ids, d_dist, d_count, dp);
+        }
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
     }

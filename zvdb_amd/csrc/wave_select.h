@@ -24,7 +24,7 @@ __device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a < 
 // the chosen bin holds one candidate).  Replaces the bitonic sort/merge networks (21 + 7
 // dependent ds_bpermute stages per 64 keys) in the prune rounds and the list merges.
 // =====================================================================================
-constexpr int SEL_HIST_BYTES = 1024, SEL_STAGE_BYTES = 512;
+constexpr int SEL_HIST_BYTES = 1024, SEL_STAGE_BYTES = 1024;  // stage: up to 128 keys (the widest kept list)
 constexpr int SEL_SCRATCH = SEL_HIST_BYTES + SEL_STAGE_BYTES;  // per wave
 
 // inclusive prefix sum across the wave on DPP (row_shr 1/2/4/8 + row_bcast15/31): 6 VALU ops, no LDS
