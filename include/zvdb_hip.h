@@ -206,7 +206,9 @@ int zvdb_hip_merge_topk_packed_dev(const void *d_packed, uint64_t rank_stride_by
 /* Kernel timing hook for bench.py's roofline object: the library records HIP
  * events around the dominant kernel of the last *_dev brute-force/graph call
  * on the stream it was launched on; this returns the elapsed ms of the last
- * `n` recorded launches (synchronises on the events). */
+ * `n` recorded launches (synchronises on the events).
+ * enable: 1 = start a new measurement, 2 = resume (sampled timing: an event
+ * pair costs two ~6 us bubbles in the launch chain), 0 = pause (samples kept). */
 int zvdb_hip_timing_enable(zvdb_hip_index *h, int enable);
 int zvdb_hip_timing_read(zvdb_hip_index *h, double *out_total_ms, uint32_t *out_launches);
 

@@ -712,7 +712,7 @@ int zvdb_hip_timing_enable(zvdb_hip_index *h, int enable) {
     ZV_ARG(h, "null argument");
     std::lock_guard<std::mutex> g(h->mu);
     h->timing = enable != 0;
-    h->events_used = 0;
+    if (enable == 1) h->events_used = 0;  // 1: start a new measurement; 2: resume (sampled timing); 0: pause, keep the samples
     return ZVDB_OK;
 }
 

@@ -171,8 +171,9 @@ class Index:
         check(self._L.zvdb_hip_search_graph_dev(self._h, q_ptr, nq, dim, k, ef, entry, id_offset, ids_ptr,
                                                 dist_ptr, cnt_ptr, stats_ptr, stream))
 
-    def timing_enable(self, on: bool = True) -> None:
-        check(self._L.zvdb_hip_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on=True) -> None:
+        """True / 1: start a new measurement; 2: resume (sampled timing); False / 0: pause (samples stay readable)."""
+        check(self._L.zvdb_hip_timing_enable(self._h, int(on)))
 
     def timing_read(self) -> Tuple[float, int]:
         ms, n = C.c_double(0), C.c_uint32(0)
