@@ -222,6 +222,30 @@ def test_bruteforce_k_up_to_112_on_the_stream_pipelines(zv, oracle, k):
         idx.search_bruteforce(Q, 64, zv.BF_F32)  # the staged routes stay at k' = 64
 
 
+@pytest.mark.parametrize("n,d,nq,k", [(5000, 64, 40, 100), (129, 200, 3, 112), (70, 32, 5, 100), (30000, 96, 300, 64)])
+def test_bruteforce_k_up_to_112_on_small_shards(zv, oracle, n, d, nq, k):
+    """k > 48 on shards too small for the guessed-threshold pipeline: one flooding scan of the stream kernel with 128-wide lists
+    (no bound to start with; the prune rounds learn it).  int8 route: bit-exact vs the oracle, also when k > N."""
+    V = oracle.uniform_rows(7000 + n, 0, n, d)
+    Q = oracle.uniform_rows(8000 + n, 0, nq, d)
+    idx = _index(zv, V)
+    ids, dist, cnt = idx.search_bruteforce(Q, k, zv.BF_I8)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
+    assert np.array_equal(cnt, rc)
+    for qi in range(nq):
+        c = int(rc[qi])
+        assert np.array_equal(ids[qi, :c], ri[qi, :c]), (qi, ids[qi][:8], ri[qi][:8])
+        assert np.array_equal(dist[qi, :c], rd[qi, :c])
+        assert np.all(ids[qi, c:] == np.uint64(0xFFFFFFFFFFFFFFFF))
+    a4, d4, c4 = idx.search_bruteforce(Q, k, zv.BF_FP4)  # fp4: counts, order, exact distances of whatever it returns
+    assert np.array_equal(c4, rc)
+    for qi in range(nq):
+        c = int(rc[qi])
+        assert np.all(np.diff(d4[qi, :c]) >= 0)
+        for j in range(0, c, 11):
+            assert oracle.distance(Q[qi], V[int(a4[qi, j])]) == d4[qi, j]
+
+
 @pytest.mark.parametrize("d", [1024, 1536])
 def test_bruteforce_fp4_wide_rows_stream_equals_staged(zv, oracle, tmp_path, d):
     """768 < dim <= 1536: the fp4 screen runs on the 128-query stream kernel (bf_i8_stream.hip, MODE 3; KS = 18 / 24) with

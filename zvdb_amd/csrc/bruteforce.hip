@@ -1111,9 +1111,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool f7 = mode == ZVDB_BF_FP4 && fp4s_eligible(h);
     // int8: the stream kernel serves large shards (one scan against guessed + verified thresholds); small ones stay on the
     // staged kernel and its threshold cascade
-    const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
+    const bool wide_k = k > kmax;  // needs the 128-wide lists, which only the stream kernels have
+    const bool big8 = !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
+    const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
-    const bool s4 = mode == ZVDB_BF_FP4 && !f7 && fp4s128_eligible(h) && !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
+    const bool s4 = mode == ZVDB_BF_FP4 && !f7 && fp4s128_eligible(h) && (big8 || wide_k);
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
     if (ws_bytes < p.total) {
@@ -1145,13 +1147,15 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t nlists = p.S, stot_lists = p.S;
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
-    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || s8 || s4;
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4) && big8);
     // k' = 64 survivors per query (one per lane of the selects) carry k <= 48 (56 with the exact fp32 screen); the stream
-    // pipelines also run with k' = 128 (two entries per lane), which carries k <= 112
-    const uint32_t kpv = (k > kmax && guess_pipe) ? (uint32_t)KPMAX : (uint32_t)KP;
+    // kernels also run with k' = 128 (two entries per lane), which carries k <= 112 -- on large shards inside the guessed-
+    // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
+    const bool stream_route = f7 || s8 || s4;
+    const uint32_t kpv = (wide_k && stream_route) ? (uint32_t)KPMAX : (uint32_t)KP;
     if (k > (kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX - 16 : kmax)) {
-        set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d needs the int8 / fp4 stream "
-                  "pipeline: dim <= 768 (fp4: 1536) and a shard of >= 16 tiles per stream)", kpv == (uint32_t)KPMAX ? KPMAX - 16 : kmax, kpv, KPMAX - 16);
+        set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d needs ZVDB_BF_I8 with "
+                  "dim <= 768 or ZVDB_BF_FP4 with dim <= 1536)", kpv == (uint32_t)KPMAX ? KPMAX - 16 : kmax, kpv, KPMAX - 16);
         return ZVDB_ERR_UNSUPPORTED;
     }
     if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
@@ -1256,6 +1260,21 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, kpv, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids,
                                (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv);
+            timing_end(h, s);
+            ZV_HIP(hipGetLastError());
+            return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+        }
+        if (kpv == (uint32_t)KPMAX) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
+            const bool t128 = s8 || s4;
+            const uint32_t SS = t128 ? p.S8 : p.S;
+            if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
+            const uint32_t cap = kp + 64 * kpv;
+            const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, (uint32_t *)nullptr, kp, cap,
+                               0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
             return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
