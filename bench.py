@@ -227,6 +227,36 @@ def extras(args, zv, torch):
                                 "dist_evals_per_query": ev / BG, "algorithmic_GBps": ev * DG * 4 / el / 1e9,
                                 "hbm_frac_of_8TBps": ev * DG * 4 / el / 8e12}
     out["graph_route_ef_mode"] = graph
+    del g, ws
+
+    # ---- k sweep of the reference's benchmark (single_threaded_benchmarks.zig:28-33: k in {10, 25, 50, 100}) on the brute-force
+    # routes: int8 = exact top-k (k' = 64 survivors up to k = 48, 128 beyond), fp4 = approximate, recall measured against int8 ----
+    NK, DK, BK = 2_000_000, 768, 1024
+    kidx = zv.Index(dim=DK, capacity=NK)
+    kidx.add_synthetic(NK, DK, CORPUS_SEED)
+    qk = torch.empty((BK, DK), dtype=torch.float32, device=dev)
+    zv.fill_synthetic_dev(qk.data_ptr(), BK, DK, QUERY_SEED, 0, stream)
+    sweep = {"rows": NK, "dim": DK, "batch": BK, "k": {}}
+    for kk in (10, 25, 50, 100):
+        wsb = max(kidx.bruteforce_workspace(BK, kk, m) for m in (zv.BF_I8, zv.BF_FP4))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        ids = torch.empty((BK, kk), dtype=torch.int64, device=dev)
+        dd = torch.empty((BK, kk), dtype=torch.float32, device=dev)
+        cnt = torch.empty((BK,), dtype=torch.int32, device=dev)
+        res = {}
+        for name, m in (("i8", zv.BF_I8), ("fp4", zv.BF_FP4)):
+            for _ in range(3):
+                kidx.search_bruteforce_dev(qk.data_ptr(), BK, DK, kk, m, 0, ws.data_ptr(), wsb, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                kidx.search_bruteforce_dev(qk.data_ptr(), BK, DK, kk, m, 0, ws.data_ptr(), wsb, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), stream)
+            torch.cuda.synchronize()
+            res[name] = {"qps": BK * 5 / (time.perf_counter() - t0), "ids": ids.cpu().numpy().copy()}
+        rec = float(np.mean([len(set(res["fp4"]["ids"][i]) & set(res["i8"]["ids"][i])) / kk for i in range(BK)]))
+        sweep["k"][str(kk)] = {"i8_qps": res["i8"]["qps"], "fp4_qps": res["fp4"]["qps"], "fp4_recall_at_k_vs_i8": rec}
+        del ws
+    out["bruteforce_k_sweep"] = sweep
     return out
 
 

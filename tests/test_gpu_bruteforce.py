@@ -184,7 +184,7 @@ def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):
         ai, ad, ac = idx.search_bruteforce(Q, k, zv.BF_FP4)
         assert np.all(ac == k) and np.all(ai < n)
         rec = np.mean([len(set(ai[i]) & set(ei[i])) / k for i in range(nq)])
-        assert rec >= (0.95 if k == 10 else 0.80), (n, k, rec)  # (k = 48 of the 64 survivors leaves little slack: 0.87 measured)
+        assert rec >= (0.95 if k == 10 else 0.93), (n, k, rec)  # (k = 48 runs with k' = 128 survivors: 0.97 measured; 0.87 with 64)
         assert np.all(np.diff(ad, axis=1) >= 0)
         for qi in (0, nq - 1):
             for j in range(0, k, 7):

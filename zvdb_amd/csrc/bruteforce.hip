@@ -1111,7 +1111,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool f7 = mode == ZVDB_BF_FP4 && fp4s_eligible(h);
     // int8: the stream kernel serves large shards (one scan against guessed + verified thresholds); small ones stay on the
     // staged kernel and its threshold cascade
-    const bool wide_k = k > kmax;  // needs the 128-wide lists, which only the stream kernels have
+    // needs the 128-wide lists, which only the stream kernels have.  The approximate fp4 screen switches earlier (k > 32):
+    // k of its k' survivors are asked for, and recall@k falls with the slack (k = 48: 0.83 with k' = 64, 0.97 with 128)
+    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32 && (fp4s_eligible(h) || fp4s128_eligible(h)));
     const bool big8 = !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
