@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--extras-points", type=int, default=100_000)
     ap.add_argument("--extras-graph-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-shard-of", type=int, default=0, metavar="G",
+                    help="(experiments, 1 GPU) time ONE shard of a G-way run: rows/G rows, the shard's survivor share")
     ap.add_argument("--same-queries", action="store_true", help="(experiments) every step answers the same query batch")
     ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=16)
@@ -278,12 +280,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    # ZVDB_BENCH_FORCE_DIST=1: rehearse the N > 1 step (RCCL all-gather + packed merge) at world size 1
+    dist_on = world > 1 or os.environ.get("ZVDB_BENCH_FORCE_DIST") == "1"
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.rehearse_shard_of > 1 and world == 1:
+        args.rows //= args.rehearse_shard_of
     N, D, B, K = args.rows, args.dim, args.batch, args.k
     lo = rank * N // world
     hi = (rank + 1) * N // world
@@ -297,6 +302,8 @@ def main():
     # ---- resident inputs -------------------------------------------------------------------
     idx = zv.Index(dim=D, capacity=n_local, device=local_rank, flags=zv.FLAG_BF16_MIRROR)
     idx.add_synthetic(n_local, D, CORPUS_SEED, first_row=lo)  # rows [lo, hi) of the global stream
+    if world > 1 or args.rehearse_shard_of > 1:
+        idx.set_shard_count(world if world > 1 else args.rehearse_shard_of)  # the approximate screen keeps this shard's share of the survivor budget
     total_steps = args.warmup + args.steps
     queries = torch.empty((total_steps + 1, B, D), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream

@@ -196,6 +196,15 @@ int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d
                             uint32_t G, uint32_t nq, uint32_t k,
                             void *d_out_ids, void *d_out_dist, void *d_out_count, void *stream);
 
+/* Declares that this index holds ONE of `shards` id-range shards whose per-shard results are merged by
+ * zvdb_hip_merge_topk*_dev (no reference counterpart: zvdb is single-node).  The approximate 4-bit screen
+ * (ZVDB_BF_FP4, k <= 32) then keeps this shard's SHARE of the 64 survivors per query instead of all 64 --
+ * ceil(64/G + 6 sqrt(64 (1/G)(1 - 1/G))), at least k + 8: a true neighbour inside the global 64 best screen keys is
+ * lost only if its shard holds more than that many of them (a 6-sigma event for uniformly spread ids) -- which
+ * shortens the fixed per-batch work (appends, merge, exact re-rank) that bounds strong scaling.  Exact screens are
+ * unaffected.  shards = 1 (default) restores the full budget. */
+int zvdb_hip_index_set_shard_count(zvdb_hip_index *h, uint32_t shards);
+
 /* Same merge over ONE all-gathered byte buffer: rank g's chunk starts at g * rank_stride_bytes and
  * holds ids u64[nq*k] at offset 0, dist f32[nq*k] at nq*k*8, count u32[nq] at nq*k*12 (so a rank
  * sends its three result arrays with a single collective). */

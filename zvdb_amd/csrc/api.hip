@@ -708,6 +708,14 @@ int zvdb_hip_merge_topk_packed_dev(const void *d_packed, uint64_t rank_stride_by
                                      static_cast<uint32_t *>(d_out_count), static_cast<hipStream_t>(stream));
 }
 
+int zvdb_hip_index_set_shard_count(zvdb_hip_index *h, uint32_t shards) {
+    ZV_ARG(h, "null argument");
+    ZV_ARG(shards >= 1, "shard count must be >= 1");
+    std::lock_guard<std::mutex> g(h->mu);
+    h->shard_count = shards;
+    return ZVDB_OK;
+}
+
 int zvdb_hip_timing_enable(zvdb_hip_index *h, int enable) {
     ZV_ARG(h, "null argument");
     std::lock_guard<std::mutex> g(h->mu);

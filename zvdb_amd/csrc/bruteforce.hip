@@ -1190,8 +1190,15 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         uint32_t *pcnt = reinterpret_cast<uint32_t *>(ws + p.off_pcnt);
         // survivors per query: 32 suffice for k <= 16 with the (near-)exact screens; the 4-bit screen keeps 64
         static const uint32_t fp4_kp = [] { const char *e = getenv("ZVDB_BF_FP4_KP"); return e ? (uint32_t)atoi(e) : (uint32_t)KP; }();  // tuning
+        // one of G id-range shards: its share of the global 64 best screen keys is Binomial(64, 1/G) -> mean + 6 sigma
+        // (zvdb_hip_index_set_shard_count; G = 8: 24 survivors instead of 64)
+        uint32_t fp4_share = fp4_kp;
+        if (h->shard_count > 1) {
+            const double pg = 1.0 / (double)h->shard_count, mean = (double)fp4_kp * pg;
+            fp4_share = std::max<uint32_t>((uint32_t)std::ceil(mean + 6.0 * std::sqrt(mean * (1.0 - pg))), k + 8);
+        }
         const uint32_t kp = kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX
-                            : mode == ZVDB_BF_FP4 ? std::min<uint32_t>(std::max<uint32_t>(fp4_kp, k + 16), KP)
+                            : mode == ZVDB_BF_FP4 ? std::min<uint32_t>(h->shard_count > 1 ? fp4_share : std::max<uint32_t>(fp4_kp, k + 16), KP)
                                                 : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
                                     : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
@@ -1222,7 +1229,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         if (guess_pipe) {
             static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
             static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
-            const double tail = std::min(0.25, std::max(target, 4.0 * kp) / (double)N);
+            // candidates admitted per query: 6 per survivor wanted (384 for the usual 64; fewer survivors, fewer appends)
+            const double tail = std::min(0.25, std::max(std::min(target, target * kp / 64.0), 4.0 * kp) / (double)N);
             // adaptive part: a batch that needed a repair (keys not Gaussian enough, e.g. low dimensions) loosens the guess of
             // the following batches by half a standard deviation, up to +2 (too loose is self-correcting, only slower)
             if (!h->guess_flag_host) {

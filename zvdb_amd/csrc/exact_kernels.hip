@@ -807,9 +807,14 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const float *__restrict__ 
             src_row[t] = rows + (size_t)(id == 0xFFFFFFFFu ? 0u : id) * ld;
             src_off[t] = (((uint32_t)lane & 15u) ^ (r & 15u)) << 4;
         }
+        // slots past the last valid candidate of the batch (lists are compacted to the front: a shard that keeps fewer than
+        // 64 survivors leaves a ~0 tail) are not fetched at all: whole DMA instructions drop out, wave-uniformly
+        const unsigned long long vmask = __ballot(ci[64 * bt + lane] != 0xFFFFFFFFu);
+        const int nt_used = vmask ? (64 - __builtin_clzll(vmask) + 3) / 4 : 0;
         auto issue = [&](uint32_t c, uint32_t buf) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
+                if (t >= nt_used) break;
                 // the row's last chunk may be short (ld is a multiple of 32 floats): stay inside the row
                 const uint32_t off = min(c * (RR_CH * 4) + src_off[t], row_bytes - 16);
                 __builtin_amdgcn_global_load_lds((rr_gptr_t)(reinterpret_cast<const unsigned char *>(src_row[t]) + off),

@@ -171,6 +171,11 @@ class Index:
         check(self._L.zvdb_hip_search_graph_dev(self._h, q_ptr, nq, dim, k, ef, entry, id_offset, ids_ptr,
                                                 dist_ptr, cnt_ptr, stats_ptr, stream))
 
+    def set_shard_count(self, shards: int) -> None:
+        """This index is one of `shards` id-range shards (zvdb_hip_index_set_shard_count): the fp4 screen keeps its
+        share of the survivor budget."""
+        check(self._L.zvdb_hip_index_set_shard_count(self._h, int(shards)))
+
     def timing_enable(self, on=True) -> None:
         """True / 1: start a new measurement; 2: resume (sampled timing); False / 0: pause (samples stay readable)."""
         check(self._L.zvdb_hip_timing_enable(self._h, int(on)))
