@@ -82,6 +82,12 @@ typedef struct zvdb_hip_config {
 } zvdb_hip_config;
 
 #define ZVDB_FLAG_BF16_MIRROR 1u /* keep a bf16 copy of the rows for ZVDB_BF_BF16 */
+/* bf16 STORAGE semantics ("bf16 = storage type with fp32 accumulate"): every element is
+ * rounded to bf16 (round-to-nearest-even) when it is added -- after the cosine normalisation -- so get_vector, every
+ * exact distance and every re-rank is the reference's fp32 arithmetic (hnsw.zig:182-192) over bf16-representable values,
+ * and the bf16 mirror is lossless.  Round 1 holds the rounded values in fp32 containers (the footprint is not halved
+ * yet).  Queries are never rounded. */
+#define ZVDB_FLAG_BF16_ROWS 2u
 
 typedef struct zvdb_hip_search_stats {
     uint64_t dist_evals; /* E of SURVEY 8d: hnsw.zig:208 + :219 evaluations */

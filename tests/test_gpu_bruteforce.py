@@ -336,3 +336,38 @@ def test_bruteforce_limits(zv, oracle):
     empty = zv.Index(dim=8)
     ids, dist, cnt = empty.search_bruteforce(oracle.uniform_rows(2, 0, 2, 8), 5)
     assert np.all(cnt == 0)
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot", "cosine"])
+def test_bf16_rows_storage_semantics(zv, oracle, metric):
+    """ZVDB_FLAG_BF16_ROWS: elements are rounded to bf16 (RNE) when added, after the cosine
+    normalisation; everything downstream is the exact fp32 arithmetic over the rounded values -- bit-exact against the
+    oracle fed with oracle.bf16_round(rows), on every screen (the bf16 mirror of such rows is lossless)."""
+    m = {"l2": zv.METRIC_L2SQ, "dot": zv.METRIC_DOT, "cosine": zv.METRIC_COSINE}[metric]
+    n, d, nq, k = 6000, 96, 40, 10
+    V = oracle.uniform_rows(21, 0, n, d) - (0.0 if metric == "l2" else 0.5)
+    Q = oracle.uniform_rows(22, 0, nq, d) - (0.0 if metric == "l2" else 0.5)
+    idx = zv.Index(metric=m, flags=zv.FLAG_BF16_MIRROR | zv.FLAG_BF16_ROWS)
+    idx.add(V[:4000])
+    idx.add(V[4000:])  # incremental adds round too
+    stored = np.stack([idx.get_vector(i) for i in range(n)])
+    assert not np.any(stored.view(np.uint32) & 0xFFFF)  # bf16-representable
+    if metric == "cosine":
+        plain = zv.Index(metric=m)
+        plain.add(V)
+        want = oracle.bf16_round(np.stack([plain.get_vector(i) for i in range(n)]))  # normalise first, then round
+    else:
+        want = oracle.bf16_round(V)
+    assert np.array_equal(stored, want)
+    ri, rd, _ = oracle.bruteforce_topk(want, Q, k, metric={"l2": 0, "dot": 1, "cosine": 1}[metric])
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+        ids, dist, cnt = idx.search_bruteforce(Q, k, mode)
+        if metric == "cosine":  # (queries are normalised by the index: compare the neighbours it ranks by -q.v / |q|)
+            if mode == zv.BF_I8:  # 8-bit screen of unit-norm 96-d rows: approximate (32 survivors for k = 10)
+                assert np.mean([len(set(ids[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.95
+            else:
+                assert np.array_equal(ids, ri), mode
+        else:
+            assert np.array_equal(ids, ri) and np.array_equal(dist, rd), mode
+    ai, ad, _ = idx.search_bruteforce(Q, k, zv.BF_FP4)
+    assert np.mean([len(set(ai[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.8

@@ -13,6 +13,7 @@ OK, ERR_INVALID, ERR_DIM_MISMATCH, ERR_OOM, ERR_NODE_NOT_FOUND, ERR_HIP, ERR_UNS
 METRIC_L2SQ, METRIC_DOT, METRIC_COSINE = 0, 1, 2
 BF_F32, BF_BF16, BF_I8, BF_FP4 = 0, 1, 2, 3
 FLAG_BF16_MIRROR = 1
+FLAG_BF16_ROWS = 2
 ABI_VERSION = 1
 
 

@@ -118,6 +118,7 @@ static int use_device(zvdb_hip_index *h) {
 static int finish_rows(zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s) {
     if (h->metric == ZVDB_METRIC_COSINE)
         ZV_CHECK(launch_normalize_rows(h->rows + first * h->ld, h->dim, h->ld, n, s));
+    if (h->flags & ZVDB_FLAG_BF16_ROWS) ZV_CHECK(launch_round_rows_bf16(h->rows + first * h->ld, h->dim, h->ld, n, s));
     ZV_CHECK(launch_finalize_rows(h, first, n, s));
     return ZVDB_OK;
 }

@@ -179,6 +179,7 @@ int launch_fill_synthetic(float *d_out, uint64_t nrows, uint32_t dim, uint32_t l
 int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld, uint64_t n,
                      hipStream_t s);
 int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
+int launch_round_rows_bf16(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);  // ZVDB_FLAG_BF16_ROWS
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
 int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
 int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s);

@@ -97,6 +97,21 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// ZVDB_FLAG_BF16_ROWS: v <- bf16(v) held in an fp32 container (padding columns stay 0)
+__global__ __launch_bounds__(256) void k_round_rows_bf16(float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n) {
+    const uint64_t total = n * ld;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+        if ((uint32_t)(i % ld) < dim) rows[i] = __uint_as_float((uint32_t)f32_to_bf16_rne(rows[i]) << 16);
+}
+
+int launch_round_rows_bf16(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n * ld + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_round_rows_bf16, dim3(grid), dim3(256), 0, s, d_rows, dim, ld, n);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 // per row: norm = sum v^2 (fp32), bf16 mirror row + its own norm.  One wave per row.
 __global__ __launch_bounds__(256) void k_finalize_rows(const float *__restrict__ rows, uint32_t dim,
                                                        uint32_t ld, uint16_t *__restrict__ rows_h,
