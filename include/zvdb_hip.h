@@ -174,9 +174,9 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
 /* ---- a10: brute-force Q x V^T + fused top-k (no reference symbol) --------- */
 /* For each query the k smallest distances over all rows, ascending, ties by
  * lower id; final distances are recomputed in exact reference arithmetic.
- * k <= 48 (56 with ZVDB_BF_F32) on every route; k <= 112 with ZVDB_BF_I8
- * (dim <= 768) and ZVDB_BF_FP4 (dim <= 1536), whose stream kernels keep
- * k' = 128 survivors per query; else ZVDB_ERR_UNSUPPORTED. */
+ * k <= 112 on every route and dimension (k <= 48, 56 with ZVDB_BF_F32, keep
+ * k' = 64 survivors per query; larger k -- the approximate ZVDB_BF_FP4 screen
+ * from k > 32 -- keep k' = 128); else ZVDB_ERR_UNSUPPORTED. */
 int zvdb_hip_search_bruteforce(zvdb_hip_index *h, const float *queries, uint32_t nq, uint32_t dim,
                                uint32_t k, uint32_t mode,
                                uint64_t *out_ids, float *out_dist, uint32_t *out_count);

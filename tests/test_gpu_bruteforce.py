@@ -218,8 +218,34 @@ def test_bruteforce_k_up_to_112_on_the_stream_pipelines(zv, oracle, k):
             assert oracle.distance(Q[qi], V[int(a4[qi, j])]) == d4[qi, j]
     with pytest.raises(zv.ZvdbError):
         idx.search_bruteforce(Q, 113, zv.BF_I8)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(40_000, 96, 70, 100), (300_000, 1024, 40, 100), (9000, 40, 17, 57), (70, 32, 5, 112), (2000, 2048, 9, 64)])
+def test_bruteforce_k_up_to_112_on_the_staged_routes(zv, oracle, n, d, nq, k):
+    """k > 48 (56) on the staged kernel (fp32 / bf16 screens, int8 beyond 768 dimensions, fp4 beyond 1536): the same
+    k' = 128 lists (KPV = 128 instantiation of the staged scan + the cascade's merges).  The reference's benchmark grid
+    holds dims up to 1024 x k up to 100.  Exact screens: bit for bit against the oracle on sampled queries."""
+    V = oracle.uniform_rows(9000 + n, 0, n, d)
+    Q = oracle.uniform_rows(9500 + n, 0, nq, d)
+    idx = _index(zv, V)
+    sel = sorted(set([0, nq // 2, nq - 1]))
+    ri, rd, rc = oracle.bruteforce_topk(V, Q[sel], k)
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+        ids, dist, cnt = idx.search_bruteforce(Q, k, mode)
+        assert np.all(cnt == min(k, n))
+        for j, qi in enumerate(sel):
+            c = int(rc[j])
+            assert np.array_equal(ids[qi, :c], ri[j, :c]), (mode, qi)
+            assert np.array_equal(dist[qi, :c], rd[j, :c]), (mode, qi)
+    a4, d4, c4 = idx.search_bruteforce(Q, k, zv.BF_FP4)
+    assert np.all(c4 == min(k, n))
+    for j, qi in enumerate(sel):
+        c = int(rc[j])
+        assert np.all(np.diff(d4[qi, :c]) >= 0)
+        for e in range(0, c, 13):
+            assert oracle.distance(Q[qi], V[int(a4[qi, e])]) == d4[qi, e]
     with pytest.raises(zv.ZvdbError):
-        idx.search_bruteforce(Q, 64, zv.BF_F32)  # the staged routes stay at k' = 64
+        idx.search_bruteforce(Q, 113, zv.BF_F32)
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(5000, 64, 40, 100), (129, 200, 3, 112), (70, 32, 5, 100), (30000, 96, 300, 64)])
@@ -330,7 +356,7 @@ def test_bruteforce_limits(zv, oracle):
     idx = zv.Index()
     idx.add(oracle.uniform_rows(1, 0, 10, 8))
     with pytest.raises(zv.ZvdbError):
-        idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 57)        # k > k' - margin
+        idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 113)       # k > k' - margin (k' = 128)
     with pytest.raises(zv.ZvdbError):
         idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 5, zv.BF_BF16)  # no mirror
     empty = zv.Index(dim=8)

@@ -327,7 +327,8 @@ constexpr int LDS4 = LDS4_SEL + 8 * SEL_SCRATCH;
 // k_bf_scan5: the v4 kernel generalised over the wave tile: NI = 2 -> 8 waves of 128 x 64 (two per
 // SIMD); NI = 4 -> 4 waves of 128 x 128, ONE per SIMD with the whole 512-register file (256 accumulators):
 // a third fewer LDS fragment bytes per MFMA and half the barrier participants.
-template <int MODE, bool DBG, int NI, int KBV>
+// KPV: width of the kept lists (64; 128 = two entries per lane, carries k <= 112).
+template <int MODE, bool DBG, int NI, int KBV, int KPV = KP>
 __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_scan5(
     const unsigned char *__restrict__ Q /* query operand */, const unsigned char *__restrict__ V /* corpus operand */,
     uint32_t row_bytes, uint32_t KT /* KBV-byte slices per row */, const void *__restrict__ vnorm, uint32_t N,
@@ -370,8 +371,8 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
     const uint32_t ntiles = t_end - t_begin;
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
 
-    uint64_t *kept = cand + (size_t)b * BLK4_ENTRIES;
-    uint64_t *subs = kept + BLK4_KEPT;
+    uint64_t *kept = cand + (size_t)b * (KPV == KP ? BLK4_ENTRIES : BLKV_ENTRIES);
+    uint64_t *subs = kept + (size_t)T2 * KPV;
     for (int tq = tid; tq < T2; tq += NW * 64) {
         const int tid_q = tq;
         const bool live = (qt * T2 + tid_q) < nq;
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
                         const u32x4 c4 = *reinterpret_cast<const u32x4 *>(subcnt + q * NSUB);
                         if (max(max(c4.x, c4.y), max(c4.z, c4.w)) > (uint32_t)SUBHW) {
                             if ((dbg & 16) && lane == 0) atomicAdd(&dbgbuf[2], 1ull);
-                            prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, smem + LDS4_SEL + wave * SEL_SCRATCH);
+                            prune_query<INT, false, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, smem + LDS4_SEL + wave * SEL_SCRATCH);
                         }
                     }
                     __syncthreads();
@@ -803,8 +804,11 @@ uint32_t ncross = 0;
     for (int q = wave; q < T2; q += NW) {
         const uint32_t qg = qt * T2 + q;
         if (qg >= nq) continue;
-        const uint64_t best = prune_query<INT>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
-        partial[((size_t)qg * Stot + list_base + s) * KP + lane] = best;
+        const uint64_t best = prune_query<INT, false, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
+        partial[((size_t)qg * Stot + list_base + s) * KPV + lane] = best;
+#pragma unroll
+        for (int c = 1; c < KPV / 64; ++c)  // (the rest of the list as prune_query left it: compacted, ~0 padded)
+            partial[((size_t)qg * Stot + list_base + s) * KPV + lane + 64 * c] = kept[(size_t)q * KPV + lane + 64 * c];
         if (lane == 0) pcnt[(size_t)qg * Stot + list_base + s] = nkept[q];  // valid entries (compacted to the front)
     }
 }
@@ -1059,12 +1063,20 @@ int slice_bytes() {
     return v;
 }
 
-template <int MODE, int NI, int KBV>
+template <int MODE, int NI, int KBV, int KPV = KP>
 int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
                  uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
                  uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, uint32_t *pcnt,
                  hipStream_t s) {
     unsigned long long *dbgbuf = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);
+    if constexpr (KPV != KP) {  // wide lists: production build only
+        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, false, NI, KBV, KPV>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
+        hipLaunchKernelGGL((k_bf_scan5<MODE, false, NI, KBV, KPV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
+                           p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
+                           list_base, Stot, pcnt, rot_table(p.row_bytes / KBV), 0u, dbgbuf);
+        return ZVDB_OK;
+    }
     if (debug_flags()) {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, true, NI, KBV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
@@ -1111,9 +1123,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool f7 = mode == ZVDB_BF_FP4 && fp4s_eligible(h);
     // int8: the stream kernel serves large shards (one scan against guessed + verified thresholds); small ones stay on the
     // staged kernel and its threshold cascade
-    // needs the 128-wide lists, which only the stream kernels have.  The approximate fp4 screen switches earlier (k > 32):
+    // needs the 128-wide lists.  The approximate fp4 screen switches earlier (k > 32):
     // k of its k' survivors are asked for, and recall@k falls with the slack (k = 48: 0.83 with k' = 64, 0.97 with 128)
-    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32 && (fp4s_eligible(h) || fp4s128_eligible(h)));
+    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32);
     const bool big8 = !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
@@ -1154,10 +1166,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // kernels also run with k' = 128 (two entries per lane), which carries k <= 112 -- on large shards inside the guessed-
     // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
     const bool stream_route = f7 || s8 || s4;
-    const uint32_t kpv = (wide_k && stream_route) ? (uint32_t)KPMAX : (uint32_t)KP;
+    // (the staged kernel has the same two list widths; the v1 kernel kept for A/B has only k' = 64)
+    const uint32_t kpv = (wide_k && (stream_route || p.tile != BM)) ? (uint32_t)KPMAX : (uint32_t)KP;
     if (k > (kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX - 16 : kmax)) {
-        set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d needs ZVDB_BF_I8 with "
-                  "dim <= 768 or ZVDB_BF_FP4 with dim <= 1536)", kpv == (uint32_t)KPMAX ? KPMAX - 16 : kmax, kpv, KPMAX - 16);
+        set_error("brute force supports k <= %u (k' = %u candidates are re-ranked exactly)", kpv == (uint32_t)KPMAX ? KPMAX - 16 : kmax, kpv);
         return ZVDB_ERR_UNSUPPORTED;
     }
     if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
@@ -1274,7 +1286,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             ZV_HIP(hipGetLastError());
             return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
         }
-        if (kpv == (uint32_t)KPMAX) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
+        if (kpv == (uint32_t)KPMAX && stream_route) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
             const bool t128 = s8 || s4;
             const uint32_t SS = t128 ? p.S8 : p.S;
             if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
@@ -1310,6 +1322,12 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             BfPlan q = p;
             q.S = ps.S;
             if (f7) return launch_fp4s_scan(h, q_op, nq, q.QT, ps.S, ps.nt, cand, partial, tau_g, kp, ps.t0, list_base, Stot, pcnt, nullptr, (uint32_t)KP, s);
+            if (kpv == (uint32_t)KPMAX) {  // k > 48 (56) on the staged routes: the default tiling with 128-wide lists
+                if (mode == ZVDB_BF_FP4) return launch_scan5<3, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                return launch_scan5<0, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            }
             if (mode == ZVDB_BF_FP4 && !is_v6())  // A/B: 64-byte slices, 4-stage ring (3 slices in flight)
                 return launch_scan5<3, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             if (mode == ZVDB_BF_FP4)  // default: full-line pieces, 128-byte (256-element) slices
@@ -1347,9 +1365,12 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             }
             if (i + 1 < np)
                 {
-                    const uint32_t cap = kp + 64 * KP;
-                    hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial, pcnt, lists, Stot,
-                                       (uint32_t *)nullptr, tau_g, kp, cap);
+                    const uint32_t cap = kp + 64 * kpv;
+                    const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+                    if (mlds > 64 * 1024)
+                        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+                    hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, lists, Stot,
+                                       (uint32_t *)nullptr, tau_g, kp, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
                 }
         }
         nlists = lists;
@@ -1367,16 +1388,20 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 (double)c[8] / (p.QT * p.S), (double)c[6] / (p.QT * p.S), (double)c[7] / (p.QT * p.S));
     }
     if (p.tile != BM && kernel_version() == 4) {
-        const uint32_t kpf = mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
-        const uint32_t cap = kpf + 64 * KP;
-        hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), SEL_SCRATCH + cap * 8, s, partial,
+        const uint32_t kpf = kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX
+                             : mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+        const uint32_t cap = kpf + 64 * kpv;
+        const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+        if (mlds > 64 * 1024)
+            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial,
                            reinterpret_cast<const uint32_t *>(ws + p.off_pcnt), nlists, stot_lists, cand_ids,
-                           (uint32_t *)nullptr, kpf, cap);
+                           (uint32_t *)nullptr, kpf, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
     } else {
         hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, nlists, stot_lists, cand_ids, (uint32_t *)nullptr, (uint32_t)KP);
     }
     ZV_HIP(hipGetLastError());
-    return launch_rerank(h, d_queries, nq, cand_ids, KP, k, id_offset, d_ids, d_dist, d_count, s);
+    return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
 }
 
 }  // namespace zvdb
