@@ -53,8 +53,8 @@ __device__ __forceinline__ void lds_read8_f32(float *d, uint32_t a) {
 }
 
 // LDS map (dynamic): [Q tile: 8 * KS KiB][tau 256 f32][cnt 256][nkept 256][subcnt 1024][ctl 4][select scratch 8 waves]
-__host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS) {
-    return F7_NF * KS * 1024 + T2 * 4 * 3 + T2 * NSUB * 4 + 16 + F7_NW * SEL_SCRATCH;
+__host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS, uint32_t sel_bytes = SEL_SCRATCH) {
+    return F7_NF * KS * 1024 + T2 * 4 * 3 + T2 * NSUB * 4 + 16 + F7_NW * sel_bytes;
 }
 
 // KS = 64-element k-steps per row (compile time: every LDS offset of the resident tile is an instruction immediate)
@@ -66,7 +66,7 @@ __host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS) {
 // v_mfma_scale_f32_16x16x128 (2 x 16 accumulators of 4 registers): same bytes, same cadence (4 ds_read_b128 per 128
 // MFMA cycles), but the chip holds a higher clock on the 16x16 shape (tools/mfma_peak_bench.hip, random operands:
 // 7.6 vs 6.7 PFLOP/s).  The operand layouts differ (fragment = 16 rows x 128 k), so the mirror is packed per shape.
-// KPV = width of the kept lists / output lists: 64, or 128 (two entries per lane in the selects) for k > 48.
+// KPV = width of the kept lists / output lists: 64, or 128 / 256 (two / four entries per lane in the selects) for k > 48 / 112.
 template <int KS, int DBG, int SH, int KPV = KP>
 __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const unsigned char *__restrict__ Qf /* [query group][KS][64][16 B] */,
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             if (c > (uint32_t)F7_MARK) {
                 if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
                 if (lane == 0) cnt[q] = 0;
-                prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
+                prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, sel + wave * sel_scratch_bytes<KPV>());
             }
         }
         __syncthreads();
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             const uint32_t qg2 = qt * T2 + q2;
             const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)F7_CAP);
             if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-            prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
+            prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * sel_scratch_bytes<KPV>());
 #pragma unroll
             for (int c2i = 0; c2i < KPV / 64; ++c2i)  // (the list as prune_query left it: compacted, ~0 padded)
                 partial[((size_t)qg2 * Stot + list_base + s) * KPV + lane + 64 * c2i] = kept[(size_t)q2 * KPV + lane + 64 * c2i];
@@ -679,7 +679,7 @@ int launch_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t n
                   uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t t_first, uint32_t list_base,
                   uint32_t Stot, uint32_t *pcnt, uint32_t max_tiles, const uint32_t *gate, float *mom, hipStream_t s) {
     const uint32_t KS = fp4s_ksteps(h->dim);
-    const uint32_t lds = f7_lds_bytes(KS);
+    const uint32_t lds = f7_lds_bytes(KS, (uint32_t)sel_scratch_bytes<KPV>());
     const float *vn = h->metric == ZVDB_METRIC_L2SQ ? h->norm_pf : (const float *)nullptr;
     auto go = [&](auto kern) -> int {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -707,6 +707,8 @@ int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
                      uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s) {
     if (kpv == (uint32_t)KPMAX)
         return launch_stream<0, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+    if (kpv == (uint32_t)KPW)
+        return launch_stream<0, KPW>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     static const uint32_t dbg = [] { const char *e = getenv("ZVDB_BF_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
 #define ZV_F7_ARGS h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, (float *)nullptr, s
     if (dbg == 1) return launch_stream<1>(ZV_F7_ARGS);

@@ -35,8 +35,8 @@ template <int MODE> struct Acc128 { using type = i32x16; };
 template <> struct Acc128<3> { using type = f32x16; };
 
 
-__host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS) {
-    return I8_NF * KS * 1024 + T2 * 4 * 3 + T2 * NSUB * 4 + 16 + I8_NW * SEL_SCRATCH;
+__host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS, uint32_t sel_bytes = SEL_SCRATCH) {
+    return I8_NF * KS * 1024 + T2 * 4 * 3 + T2 * NSUB * 4 + 16 + I8_NW * sel_bytes;
 }
 
 // KS = 32-byte (32-element) k-steps per row; MOM: moments mode (sum of key, key^2 per query instead of selecting)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             if (c > (uint32_t)I8_MARK) {
                 if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
                 if (lane == 0) cnt[q] = 0;
-                prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q, lane, kp, tau_g, sel + wave * SEL_SCRATCH);
+                prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q, lane, kp, tau_g, sel + wave * sel_scratch_bytes<KPV>());
             }
         }
         __syncthreads();
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             const uint32_t qg2 = qt * I8_TQ + q2;
             const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)I8_CAP);
             if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-            prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * SEL_SCRATCH);
+            prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * sel_scratch_bytes<KPV>());
 #pragma unroll
             for (int c2i = 0; c2i < KPV / 64; ++c2i)
                 partial[((size_t)qg2 * Stot + list_base + s) * KPV + lane + 64 * c2i] = kept[(size_t)q2 * KPV + lane + 64 * c2i];
@@ -422,7 +422,7 @@ int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
                      uint32_t *pcnt, uint32_t max_tiles, const uint32_t *gate, float *mom, hipStream_t s) {
     const uint32_t KS = MODE == 2 ? i8s_ksteps(h->dim) : fp4s128_ksteps(h->dim);
-    const uint32_t lds = i8s_lds_bytes(KS);
+    const uint32_t lds = i8s_lds_bytes(KS, (uint32_t)sel_scratch_bytes<KPV>());
     const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
     const void *vn = !l2 ? nullptr : MODE == 2 ? (const void *)h->norm_qf : (const void *)h->norm_pf;
     const unsigned char *rows = MODE == 2 ? h->rows_qf : h->rows_pf;
@@ -502,6 +502,8 @@ int launch_i8s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t
                     uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s) {
     if (kpv == (uint32_t)KPMAX)
         return launch_i8_stream<2, false, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+    if (kpv == (uint32_t)KPW)
+        return launch_i8_stream<2, false, KPW>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     return launch_i8_stream<2, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
 
@@ -524,6 +526,8 @@ int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint
                         uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s) {
     if (kpv == (uint32_t)KPMAX)
         return launch_i8_stream<3, false, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+    if (kpv == (uint32_t)KPW)
+        return launch_i8_stream<3, false, KPW>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     return launch_i8_stream<3, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
 int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,

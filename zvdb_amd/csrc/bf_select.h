@@ -13,20 +13,24 @@ constexpr int SUBCAP = 256, SUBHW = 48, SUBURG = 192, NSUB = 4;  // capacity, so
 constexpr size_t BLK4_KEPT = (size_t)T2 * KP;                 // u64 entries
 constexpr size_t BLK4_ENTRIES = BLK4_KEPT + (size_t)T2 * NSUB * SUBCAP;
 
-constexpr int KPMAX = 128;  // widest kept list (2 entries per lane): k <= 112 on the stream pipelines
+constexpr int KPW = 128;    // wide kept list (2 entries per lane): k <= 112, every route
+constexpr int KPMAX = 256;  // widest kept list (4 entries per lane): k <= 240 on the stream pipelines
 constexpr size_t BLKV_ENTRIES = (size_t)T2 * KPMAX + (size_t)T2 * NSUB * SUBCAP;  // per-workgroup region sized for KPMAX
+// per-wave scratch of prune_query: radix histogram + compaction stage of KPV keys
+template <int KPV> constexpr int sel_scratch_bytes() { return SEL_HIST_BYTES + (KPV * 8 > SEL_STAGE_BYTES ? KPV * 8 : SEL_STAGE_BYTES); }
 
 // merge query q's kept list with its sub-buffers -> exact best kp (UNSORTED, compacted to the front of
 // kept[q]); resets the sub-buffers.  Rounds of <= KPV carried + 256 new keys, radix-selected.
 // INCL: tau becomes next_up(k'-th key), i.e. later keys EQUAL to the k'-th best still pass (needed when rows do not
-// arrive in id order).  KPV = capacity (and row stride) of the kept lists: 64 (one entry per lane) or 128 (two).
+// arrive in id order).  KPV = capacity (and row stride) of the kept lists: 64 (one entry per lane), 128 (two) or 256
+// (four; scratch must then hold sel_scratch_bytes<KPV>()).
 // Returns the lane's first kept entry (KPV = 64: the whole list, one per lane).
 template <bool INTKEY, bool INCL = false, int KPV = KP>
 __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, const uint64_t *__restrict__ sub,
                                                 float *tau, uint32_t *nkept, uint32_t *subcnt, int q, int lane,
                                                 uint32_t kp, uint32_t *tau_g, unsigned char *scratch) {
     constexpr int EPL = KPV / kWave;  // kept entries per lane
-    static_assert(KPV == 64 || KPV == 128, "kept list width");
+    static_assert(KPV == 64 || KPV == 128 || KPV == 256, "kept list width");
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch);
     uint64_t *stage = reinterpret_cast<uint64_t *>(scratch + SEL_HIST_BYTES);  // [KPV]
     const uint32_t n0 = min(subcnt[q * NSUB + 0], (uint32_t)SUBCAP), n1 = min(subcnt[q * NSUB + 1], (uint32_t)SUBCAP);

@@ -851,12 +851,12 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
                                                      uint32_t kp, uint32_t cap, uint32_t l0 = 0, int vmode = 0,
                                                      uint32_t *__restrict__ flag = nullptr, uint32_t *__restrict__ defq = nullptr,
                                                      uint32_t *__restrict__ host_flag = nullptr /* mapped host memory */,
-                                                     uint32_t lkp = KP /* width (stride) of the lists and of cand_ids: 64 or 128 */) {
+                                                     uint32_t lkp = KP /* width (stride) of the lists and of cand_ids: 64, 128 or 256 */) {
     if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     uint64_t *stage = reinterpret_cast<uint64_t *>(smem + SEL_HIST_BYTES);
-    uint64_t *pool = reinterpret_cast<uint64_t *>(smem + SEL_SCRATCH);  // [cap]
+    uint64_t *pool = reinterpret_cast<uint64_t *>(smem + SEL_HIST_BYTES + max(lkp * 8u, (uint32_t)SEL_STAGE_BYTES));  // [cap]
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x;
     const uint64_t *p = partial + ((size_t)q * Stot + l0) * lkp;
@@ -1167,9 +1167,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
     const bool stream_route = f7 || s8 || s4;
     // (the staged kernel has the same two list widths; the v1 kernel kept for A/B has only k' = 64)
-    const uint32_t kpv = (wide_k && (stream_route || p.tile != BM)) ? (uint32_t)KPMAX : (uint32_t)KP;
-    if (k > (kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX - 16 : kmax)) {
-        set_error("brute force supports k <= %u (k' = %u candidates are re-ranked exactly)", kpv == (uint32_t)KPMAX ? KPMAX - 16 : kmax, kpv);
+    // The stream kernels go on to k' = 256 (four entries per lane): k <= 240, and the fp4 screen uses it from k > 64
+    // (recall@100: 0.84 with 128 survivors).
+    const bool widest = stream_route && (k > (uint32_t)KPW - 16 || (mode == ZVDB_BF_FP4 && k > 64));
+    const uint32_t kpv = !(wide_k && (stream_route || p.tile != BM)) ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
+    if (k > (kpv != (uint32_t)KP ? kpv - 16 : kmax)) {
+        set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d on the stream routes: "
+                  "ZVDB_BF_I8 with dim <= 768, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
         return ZVDB_ERR_UNSUPPORTED;
     }
     if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
@@ -1209,7 +1213,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             const double pg = 1.0 / (double)h->shard_count, mean = (double)fp4_kp * pg;
             fp4_share = std::max<uint32_t>((uint32_t)std::ceil(mean + 6.0 * std::sqrt(mean * (1.0 - pg))), k + 8);
         }
-        const uint32_t kp = kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX
+        const uint32_t kp = kpv != (uint32_t)KP ? kpv
                             : mode == ZVDB_BF_FP4 ? std::min<uint32_t>(h->shard_count > 1 ? fp4_share : std::max<uint32_t>(fp4_kp, k + 16), KP)
                                                 : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
@@ -1272,7 +1276,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
             }
             const uint32_t cap = kp + 64 * kpv;
-            const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+            const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
@@ -1286,14 +1290,14 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             ZV_HIP(hipGetLastError());
             return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
         }
-        if (kpv == (uint32_t)KPMAX && stream_route) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
+        if (kpv != (uint32_t)KP && stream_route) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
             const bool t128 = s8 || s4;
             const uint32_t SS = t128 ? p.S8 : p.S;
             if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
             const uint32_t cap = kp + 64 * kpv;
-            const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+            const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, (uint32_t *)nullptr, kp, cap,
                                0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
@@ -1322,11 +1326,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             BfPlan q = p;
             q.S = ps.S;
             if (f7) return launch_fp4s_scan(h, q_op, nq, q.QT, ps.S, ps.nt, cand, partial, tau_g, kp, ps.t0, list_base, Stot, pcnt, nullptr, (uint32_t)KP, s);
-            if (kpv == (uint32_t)KPMAX) {  // k > 48 (56) on the staged routes: the default tiling with 128-wide lists
-                if (mode == ZVDB_BF_FP4) return launch_scan5<3, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-                if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-                return launch_scan5<0, 2, 128, KPMAX>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            if (kpv == (uint32_t)KPW) {  // k > 48 (56) on the staged routes: the default tiling with 128-wide lists
+                if (mode == ZVDB_BF_FP4) return launch_scan5<3, 2, 128, KPW>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128, KPW>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128, KPW>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+                return launch_scan5<0, 2, 128, KPW>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             }
             if (mode == ZVDB_BF_FP4 && !is_v6())  // A/B: 64-byte slices, 4-stage ring (3 slices in flight)
                 return launch_scan5<3, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
@@ -1366,7 +1370,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             if (i + 1 < np)
                 {
                     const uint32_t cap = kp + 64 * kpv;
-                    const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+                    const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
                     if (mlds > 64 * 1024)
                         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
                     hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, lists, Stot,
@@ -1388,10 +1392,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 (double)c[8] / (p.QT * p.S), (double)c[6] / (p.QT * p.S), (double)c[7] / (p.QT * p.S));
     }
     if (p.tile != BM && kernel_version() == 4) {
-        const uint32_t kpf = kpv == (uint32_t)KPMAX ? (uint32_t)KPMAX
+        const uint32_t kpf = kpv != (uint32_t)KP ? kpv
                              : mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const uint32_t cap = kpf + 64 * kpv;
-        const size_t mlds = SEL_SCRATCH + (size_t)cap * 8;
+        const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
         if (mlds > 64 * 1024)
             ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial,

@@ -889,16 +889,20 @@ int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, 
     if (nq == 0) return ZVDB_OK;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool staged_off = [] { const char *e = getenv("ZVDB_RERANK"); return e && e[0] == 'v' && e[1] == '1'; }();
-    if ((kc == 64 || kc == 128) && h->ld >= 64 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
+    if ((kc == 64 || kc == 128 || kc == 256) && h->ld >= 64 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
         const uint32_t dp = round_up(h->dim, 64);
         const size_t lds2 = 2 * 64 * 256 + 4ull * (dp + 2ull * kc);
         if (kc == 64) {
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<64>), lds2));
             hipLaunchKernelGGL(k_rerank_staged<64>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
                                id_offset, d_ids, d_dist, d_count, dp);
-        } else {
+        } else if (kc == 128) {
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<128>), lds2));
             hipLaunchKernelGGL(k_rerank_staged<128>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
+                               id_offset, d_ids, d_dist, d_count, dp);
+        } else {
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<256>), lds2));
+            hipLaunchKernelGGL(k_rerank_staged<256>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
                                id_offset, d_ids, d_dist, d_count, dp);
         }
         ZV_HIP(hipGetLastError());
