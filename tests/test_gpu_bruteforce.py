@@ -305,8 +305,9 @@ def test_bruteforce_fp4_wide_rows_stream_equals_staged(zv, oracle, tmp_path, d):
 @pytest.mark.parametrize("metric", ["dot", "cosine"])
 def test_bruteforce_fp4_dot_and_cosine(zv, oracle, metric):
     """fp4 screen under the inner-product metrics (symmetric range, no norm term): whatever it returns is exactly what
-    the exact route computes for those ids; recall is reported against the exact route (bar 0.8: an inner product of
-    zero-centred data has less spread per unit of quantisation noise than an L2 distance)."""
+    the exact route computes for those ids; recall against the exact route.  The ranking does not depend on the query's
+    length but the quantiser does: queries are rescaled to the rows' spread before they are quantised, so queries of any
+    scale (cosine rows are normalised at insert, queries arrive as they are) screen equally well."""
     m = zv.METRIC_DOT if metric == "dot" else zv.METRIC_COSINE
     V = oracle.uniform_rows(5, 0, 40_000, 128) - 0.5
     Q = oracle.uniform_rows(6, 0, 64, 128) - 0.5
@@ -316,7 +317,12 @@ def test_bruteforce_fp4_dot_and_cosine(zv, oracle, metric):
     ai, ad, ac = idx.search_bruteforce(Q, 10, zv.BF_FP4)
     assert np.all(ac == 10) and np.all(np.diff(ad, axis=1) >= 0)
     rec = np.mean([len(set(ai[i]) & set(ei[i])) / 10 for i in range(64)])
-    assert rec >= 0.8, rec
+    assert rec >= 0.97, rec
+    for scale in (1e-3, 37.0):  # the same neighbours whatever the queries' length (fp4 and int8 screens)
+        si, _, _ = idx.search_bruteforce(Q * np.float32(scale), 10, zv.BF_FP4)
+        assert np.mean([len(set(si[i]) & set(ei[i])) / 10 for i in range(64)]) >= 0.97, scale
+        s8, _, _ = idx.search_bruteforce(Q * np.float32(scale), 10, zv.BF_I8)
+        assert np.mean([len(set(s8[i]) & set(ei[i])) / 10 for i in range(64)]) >= 0.99, scale
     for qi in range(64):  # every id both routes return carries the same exact distance
         e = {int(i): float(x) for i, x in zip(ei[qi], ed[qi])}
         for i, x in zip(ai[qi], ad[qi]):
@@ -392,11 +398,11 @@ def test_bf16_rows_storage_semantics(zv, oracle, metric):
     for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
         ids, dist, cnt = idx.search_bruteforce(Q, k, mode)
         if metric == "cosine":  # (queries are normalised by the index: compare the neighbours it ranks by -q.v / |q|)
-            if mode == zv.BF_I8:  # 8-bit screen of unit-norm 96-d rows: approximate (32 survivors for k = 10)
-                assert np.mean([len(set(ids[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.95
+            if mode == zv.BF_I8:  # 8-bit screen under an inner-product metric: near-exact, not guaranteed
+                assert np.mean([len(set(ids[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.99
             else:
                 assert np.array_equal(ids, ri), mode
         else:
             assert np.array_equal(ids, ri) and np.array_equal(dist, rd), mode
     ai, ad, _ = idx.search_bruteforce(Q, k, zv.BF_FP4)
-    assert np.mean([len(set(ai[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.8
+    assert np.mean([len(set(ai[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.95

@@ -973,9 +973,32 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
     }
 }
 
+// dot / cosine with a quantised screen (int8, fp4): the ranking does not depend on the query's length, the quantiser does --
+// its step was placed by the ROWS' spread (fp4: RMS, int8: largest magnitude), and a query of another scale (cosine rows
+// are normalised at insert, queries arrive as they are) would clip or vanish.  One wave per query: out = q * target / stat(q).
+__global__ __launch_bounds__(64) void k_rescale_queries(const float *__restrict__ q, uint32_t nq, uint32_t dim, int use_absmax,
+                                                        float target, float *__restrict__ out) {
+    const uint32_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (r >= nq) return;
+    float acc = 0.0f;
+    for (uint32_t c = lane; c < dim; c += kWave) {
+        const float v = q[(size_t)r * dim + c];
+        acc = use_absmax ? fmaxf(acc, fabsf(v)) : acc + v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(acc, off);
+        acc = use_absmax ? fmaxf(acc, o) : acc + o;
+    }
+    const float stat = use_absmax ? acc : sqrtf(acc / (float)dim);
+    const float f = (stat > 0.0f && stat < __builtin_inff()) ? target / stat : 1.0f;
+    for (uint32_t c = lane; c < dim; c += kWave) out[(size_t)r * dim + c] = q[(size_t)r * dim + c] * f;
+}
+
 struct BfPlan {
     uint32_t tile, cap, nq_pad, QT, S, NT, KT, row_bytes, row_elems;
-    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_verify, off_pcnt, total;
+    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_verify, off_pcnt, off_qs, total;
     uint32_t QT8, S8;  // int8 stream kernel: tiles of 128 queries, streams
 };
 
@@ -1041,6 +1064,8 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     off += 256 + 2 * round_up64((uint64_t)p.nq_pad * 4, 256);
     p.off_pcnt = off;
     off += round_up64((uint64_t)p.nq_pad * 3 * p.S * 4, 256);  // valid-entry count of every list
+    p.off_qs = off;  // rescaled fp32 queries (dot / cosine with a quantised screen)
+    if (h->metric != ZVDB_METRIC_L2SQ && (mode == ZVDB_BF_I8 || mode == ZVDB_BF_FP4)) off += round_up64((uint64_t)p.nq_pad * h->dim * 4, 256);
     p.total = off;
     return p;
 }
@@ -1144,6 +1169,14 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t *cand_ids = reinterpret_cast<uint32_t *>(ws + p.off_ids);
 
     const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
+    const float *d_queries_exact = d_queries;  // the exact re-rank always reads the caller's queries
+    if (!l2 && (mode == ZVDB_BF_I8 || mode == ZVDB_BF_FP4)) {
+        float *qs = reinterpret_cast<float *>(ws + p.off_qs);
+        const bool i8m = mode == ZVDB_BF_I8;
+        const float target = i8m ? 127.0f / h->q_inv : (kFp4Amax / 1.7320508f) / h->p_scale;  // rows' |max| / RMS
+        hipLaunchKernelGGL(k_rescale_queries, dim3(nq), dim3(64), 0, s, d_queries, nq, h->dim, i8m ? 1 : 0, target, qs);
+        d_queries = qs;
+    }
     if (f7 || s4) {
         ZV_CHECK(launch_fp4s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else if (s8) {
@@ -1288,7 +1321,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
         }
         if (kpv != (uint32_t)KP && stream_route) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
             const bool t128 = s8 || s4;
@@ -1303,7 +1336,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
         }
         if (p.NT >= 4 * p.S && !(debug_flags() & 64)) {
             // pass A streams: every workgroup of pass A floods one tile (256 candidates per query, 8-byte
@@ -1405,7 +1438,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, nlists, stot_lists, cand_ids, (uint32_t *)nullptr, (uint32_t)KP);
     }
     ZV_HIP(hipGetLastError());
-    return launch_rerank(h, d_queries, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+    return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
 }
 
 }  // namespace zvdb
