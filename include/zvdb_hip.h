@@ -213,6 +213,12 @@ int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d
  * unaffected.  shards = 1 (default) restores the full budget. */
 int zvdb_hip_index_set_shard_count(zvdb_hip_index *h, uint32_t shards);
 
+/* Survivors of the approximate ZVDB_BF_FP4 screen that are re-ranked exactly, per query: 0 = chosen from k (64 for
+ * k <= 32, 128 for k <= 64, 256 above), or at least 64 / 128 / 256.  More survivors buy recall on data whose neighbours
+ * differ by less than the 4-bit step resolves (e.g. tight clusters far apart), for a longer re-rank; recall is measured,
+ * never guaranteed, on this route -- ZVDB_BF_I8 / _BF16 / _F32 are the exact ones. */
+int zvdb_hip_index_set_screen_survivors(zvdb_hip_index *h, uint32_t survivors);
+
 /* Same merge over ONE all-gathered byte buffer: rank g's chunk starts at g * rank_stride_bytes and
  * holds ids u64[nq*k] at offset 0, dist f32[nq*k] at nq*k*8, count u32[nq] at nq*k*12 (so a rank
  * sends its three result arrays with a single collective). */

@@ -406,3 +406,27 @@ def test_bf16_rows_storage_semantics(zv, oracle, metric):
             assert np.array_equal(ids, ri) and np.array_equal(dist, rd), mode
     ai, ad, _ = idx.search_bruteforce(Q, k, zv.BF_FP4)
     assert np.mean([len(set(ai[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.95
+
+
+def test_fp4_screen_survivors_knob(zv, oracle):
+    """zvdb_hip_index_set_screen_survivors: more fp4 survivors re-ranked -> recall can only grow; tight clusters far apart
+    (neighbours differ by less than the 4-bit step resolves) are the case it is for.  Returned distances stay exact."""
+    rng = np.random.default_rng(7)
+    n, d, nq, k = 200_000, 64, 128, 10
+    C = rng.standard_normal((32, d), dtype=np.float32) * 3
+    V = (C[rng.integers(0, 32, n)] + rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    Q = (C[rng.integers(0, 32, nq)] + rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    idx = zv.Index()
+    idx.add(V)
+    ei, ed, _ = idx.search_bruteforce(Q, k, zv.BF_I8)
+    recs = []
+    for sv in (0, 128, 256):
+        idx.set_screen_survivors(sv)
+        ai, ad, ac = idx.search_bruteforce(Q, k, zv.BF_FP4)
+        assert np.all(ac == k) and np.all(np.diff(ad, axis=1) >= 0)
+        recs.append(np.mean([len(set(ai[i]) & set(ei[i])) / k for i in range(nq)]))
+        for qi in (0, nq - 1):
+            assert oracle.distance(Q[qi], V[int(ai[qi, 0])]) == ad[qi, 0]
+    assert recs[0] <= recs[1] + 0.01 and recs[1] <= recs[2] + 0.01 and recs[2] >= 0.9, recs
+    with pytest.raises(zv.ZvdbError):
+        idx.set_screen_survivors(100)

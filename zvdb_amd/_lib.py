@@ -61,6 +61,7 @@ HIP_SYMBOLS = [
     ("zvdb_hip_merge_topk_dev", _i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_merge_topk_packed_dev", _i32, [_vp, _u64, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_index_set_shard_count", _i32, [_vp, _u32]),
+    ("zvdb_hip_index_set_screen_survivors", _i32, [_vp, _u32]),
     ("zvdb_hip_timing_enable", _i32, [_vp, _i32]),
     ("zvdb_hip_timing_read", _i32, [_vp, C.POINTER(C.c_double), _u32p]),
 ]

@@ -709,6 +709,14 @@ int zvdb_hip_merge_topk_packed_dev(const void *d_packed, uint64_t rank_stride_by
                                      static_cast<uint32_t *>(d_out_count), static_cast<hipStream_t>(stream));
 }
 
+int zvdb_hip_index_set_screen_survivors(zvdb_hip_index *h, uint32_t survivors) {
+    ZV_ARG(h, "null argument");
+    ZV_ARG(survivors == 0 || survivors == 64 || survivors == 128 || survivors == 256, "survivors must be 0, 64, 128 or 256");
+    std::lock_guard<std::mutex> g(h->mu);
+    h->screen_survivors = survivors;
+    return ZVDB_OK;
+}
+
 int zvdb_hip_index_set_shard_count(zvdb_hip_index *h, uint32_t shards) {
     ZV_ARG(h, "null argument");
     ZV_ARG(shards >= 1, "shard count must be >= 1");

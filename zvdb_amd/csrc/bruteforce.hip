@@ -1150,7 +1150,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // staged kernel and its threshold cascade
     // needs the 128-wide lists.  The approximate fp4 screen switches earlier (k > 32):
     // k of its k' survivors are asked for, and recall@k falls with the slack (k = 48: 0.83 with k' = 64, 0.97 with 128)
-    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32);
+    const uint32_t want = mode == ZVDB_BF_FP4 ? h->screen_survivors : 0u;  // zvdb_hip_index_set_screen_survivors
+    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32) || want > (uint32_t)KP;
     const bool big8 = !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
@@ -1202,7 +1203,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // (the staged kernel has the same two list widths; the v1 kernel kept for A/B has only k' = 64)
     // The stream kernels go on to k' = 256 (four entries per lane): k <= 240, and the fp4 screen uses it from k > 64
     // (recall@100: 0.84 with 128 survivors).
-    const bool widest = stream_route && (k > (uint32_t)KPW - 16 || (mode == ZVDB_BF_FP4 && k > 64));
+    const bool widest = stream_route && (k > (uint32_t)KPW - 16 || (mode == ZVDB_BF_FP4 && k > 64) || want > (uint32_t)KPW);
     const uint32_t kpv = !(wide_k && (stream_route || p.tile != BM)) ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
     if (k > (kpv != (uint32_t)KP ? kpv - 16 : kmax)) {
         set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d on the stream routes: "

@@ -137,6 +137,7 @@ struct zvdb_hip_index {
     uint32_t *guess_flag_host = nullptr;  // hipHostMalloc'ed, mapped
     uint32_t *guess_flag_dev = nullptr;   // its device alias
     float guess_adapt = 0.0f;
+    uint32_t screen_survivors = 0;  // zvdb_hip_index_set_screen_survivors: minimum k' of the fp4 screen (0 = from k)
     uint32_t shard_count = 1;  // zvdb_hip_index_set_shard_count: the approximate screen keeps its share of the survivors
     hipStream_t stream = nullptr;
     // pinned host staging + device scratch for the host-pointer entry points

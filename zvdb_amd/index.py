@@ -176,6 +176,10 @@ class Index:
         share of the survivor budget."""
         check(self._L.zvdb_hip_index_set_shard_count(self._h, int(shards)))
 
+    def set_screen_survivors(self, survivors: int) -> None:
+        """Minimum number of fp4-screen survivors re-ranked exactly per query (0 = from k; 64, 128 or 256)."""
+        check(self._L.zvdb_hip_index_set_screen_survivors(self._h, int(survivors)))
+
     def timing_enable(self, on=True) -> None:
         """True / 1: start a new measurement; 2: resume (sampled timing); False / 0: pause (samples stay readable)."""
         check(self._L.zvdb_hip_timing_enable(self._h, int(on)))
