@@ -122,3 +122,63 @@ def test_fp4_shards_keep_their_share_of_the_survivors(oracle):
         for j, v in enumerate(sharded[i]):
             if int(v) in pos:
                 assert sd[i, j] == ed[i, pos[int(v)]]
+
+
+def _hip_rank(rank, world, port, n, d, nq, k, ret):
+    """One rank of the product path: HipShard (HIP search + HIP merge) under ShardedSearch, collectives over gloo (RCCL wants
+    one GPU per rank; the box has one, so both ranks share cuda:0)."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    import zvdb_amd as zv
+    from zvdb_amd.sharded import HipShard, ShardedSearch
+    shard = HipShard(n, d, rank, world, 0)
+    shard.add_synthetic(0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    q_t = torch.from_numpy(Q).to(shard.device)
+
+    class Gloo(ShardedSearch):  # gloo moves host memory: stage the three result arrays through the CPU
+        def search(self, queries, k, mode=0):
+            ids, dd, cnt = self.backend.local_search(queries, k, mode)
+            parts = []
+            for t in (ids, dd, cnt):
+                c = t.cpu().contiguous()
+                g = torch.empty((self.world * c.shape[0],) + tuple(c.shape[1:]), dtype=c.dtype)
+                dist.all_gather_into_tensor(g, c)
+                parts.append(g.to(ids.device))
+            nq_ = ids.shape[0]
+            return self.backend.merge(parts[0].view(self.world, nq_, k), parts[1].view(self.world, nq_, k), parts[2].view(self.world, nq_), k)
+
+    ss = Gloo(shard)
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
+    ok = True
+    for mode in (zv.BF_F32, zv.BF_I8):
+        ids, dd, cnt = ss.search(q_t, k, mode)
+        torch.cuda.synchronize()
+        ok = ok and np.array_equal(ids.cpu().numpy().astype(np.uint64), ri) and np.array_equal(dd.cpu().numpy(), rd)
+    ids, dd, cnt = ss.search(q_t, k, zv.BF_FP4)  # approximate screen with the shard's survivor share
+    torch.cuda.synchronize()
+    a = ids.cpu().numpy().astype(np.uint64)
+    rec = np.mean([len(set(a[i]) & set(ri[i])) / k for i in range(nq)])
+    ret[rank] = bool(ok) and rec >= 0.95
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_processes_on_the_hip_backend(oracle):
+    """world_size 2, one PROCESS per rank (both on cuda:0): HipShard + ShardedSearch's gather layout + the HIP merge give
+    the oracle's global top-k on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hip_rank, args=(2, port, 20_001, 64, 33, 10, ret), nprocs=2, join=True)
+    assert all(ret.get(r, False) for r in range(2)), dict(ret)

@@ -31,6 +31,7 @@ class HipShard:
         self.dim = dim
         self.device = torch.device("cuda", device_index)
         self.index = Index(dim=dim, capacity=self.hi - self.lo, device=device_index, flags=flags)
+        self.index.set_shard_count(world)  # the approximate screen keeps this shard's share of the survivor budget
         self._ws = None
 
     def add_synthetic(self, seed: int) -> None:
