@@ -143,17 +143,11 @@ def _hip_rank(rank, world, port, n, d, nq, k, ret):
     Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
     q_t = torch.from_numpy(Q).to(shard.device)
 
-    class Gloo(ShardedSearch):  # gloo moves host memory: stage the three result arrays through the CPU
-        def search(self, queries, k, mode=0):
-            ids, dd, cnt = self.backend.local_search(queries, k, mode)
-            parts = []
-            for t in (ids, dd, cnt):
-                c = t.cpu().contiguous()
-                g = torch.empty((self.world * c.shape[0],) + tuple(c.shape[1:]), dtype=c.dtype)
-                dist.all_gather_into_tensor(g, c)
-                parts.append(g.to(ids.device))
-            nq_ = ids.shape[0]
-            return self.backend.merge(parts[0].view(self.world, nq_, k), parts[1].view(self.world, nq_, k), parts[2].view(self.world, nq_), k)
+    class Gloo(ShardedSearch):  # gloo moves host memory: stage the rank's byte buffer through the CPU
+        def _gather(self, mine):
+            g = torch.empty((self.world, mine.numel()), dtype=torch.uint8)
+            dist.all_gather_into_tensor(g.view(-1), mine.cpu())
+            return g.to(mine.device)
 
     ss = Gloo(shard)
     V = oracle.uniform_rows(0x5EED, 0, n, d)

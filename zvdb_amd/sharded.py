@@ -73,17 +73,24 @@ class ShardedSearch:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+    def _gather(self, mine: torch.Tensor) -> torch.Tensor:
+        """[world][bytes] <- every rank's byte buffer (RCCL on device memory; gloo on host memory)."""
+        gathered = torch.empty((self.world, mine.numel()), dtype=torch.uint8, device=mine.device)
+        dist.all_gather_into_tensor(gathered.view(-1), mine, group=self.group)
+        return gathered
+
     def search(self, queries: torch.Tensor, k: int, mode: int = 0):
         ids, dd, cnt = self.backend.local_search(queries, k, mode)
         if self.world == 1:
             return ids, dd, cnt
         nq = ids.shape[0]
-        # concatenation along dim 0 == [G][nq][k] row-major (the layout merge_topk consumes)
-        g_ids = torch.empty((self.world * nq, k), dtype=ids.dtype, device=ids.device)
-        g_dist = torch.empty((self.world * nq, k), dtype=dd.dtype, device=dd.device)
-        g_cnt = torch.empty((self.world * nq,), dtype=cnt.dtype, device=cnt.device)
-        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_dist, dd.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(g_cnt, cnt.contiguous(), group=self.group)
-        return self.backend.merge(g_ids.view(self.world, nq, k), g_dist.view(self.world, nq, k),
-                                  g_cnt.view(self.world, nq), k)
+        # ONE collective per batch: the three result arrays travel as one byte buffer per rank (ids | dist | count)
+        parts = [t.contiguous().view(torch.uint8).reshape(-1) for t in (ids, dd, cnt)]
+        mine = torch.cat(parts)
+        gathered = self._gather(mine)
+        b0, b1 = parts[0].numel(), parts[0].numel() + parts[1].numel()
+        # [G][nq][k] row-major (the layout merge_topk consumes)
+        g_ids = gathered[:, :b0].contiguous().view(ids.dtype).view(self.world, nq, k)
+        g_dist = gathered[:, b0:b1].contiguous().view(dd.dtype).view(self.world, nq, k)
+        g_cnt = gathered[:, b1:].contiguous().view(cnt.dtype).view(self.world, nq)
+        return self.backend.merge(g_ids, g_dist, g_cnt, k)
