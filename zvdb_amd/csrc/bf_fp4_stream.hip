@@ -67,7 +67,9 @@ __host__ __device__ inline uint32_t f7_lds_bytes(uint32_t KS, uint32_t sel_bytes
 // MFMA cycles), but the chip holds a higher clock on the 16x16 shape (tools/mfma_peak_bench.hip, random operands:
 // 7.6 vs 6.7 PFLOP/s).  The operand layouts differ (fragment = 16 rows x 128 k), so the mirror is packed per shape.
 // KPV = width of the kept lists / output lists: 64, or 128 / 256 (two / four entries per lane in the selects) for k > 48 / 112.
-template <int KS, int DBG, int SH, int KPV = KP>
+// GATED = 1: the same code under its own symbol for the gated repair launch (a no-op unless the verification failed), so
+// that per-kernel profiler statistics do not average 5-us no-ops into the scan.
+template <int KS, int DBG, int SH, int KPV = KP, int GATED = 0>
 __global__ __launch_bounds__(512, 2) void k_fp4_stream(
     const unsigned char *__restrict__ Qf /* [query group][KS][64][16 B] */,
     const unsigned char *__restrict__ Vf /* [row group][KS][64][16 B] */, const float *__restrict__ vnorm /* padded to groups, +inf past N */,
@@ -693,6 +695,9 @@ int launch_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t n
     } else if (fp4s_shape() == 16) {
         if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, DBG == 8 ? 8 : 0, 16>));
         else ZV_CHECK(go(k_fp4_stream<12, DBG, 16>));
+    } else if (DBG == 0 && gate) {
+        if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, 0, 32, KP, 1>));
+        else ZV_CHECK(go(k_fp4_stream<12, 0, 32, KP, 1>));
     } else {
         if (KS == 6) ZV_CHECK(go(k_fp4_stream<6, DBG == 8 ? 8 : 0, 32>));
         else ZV_CHECK(go(k_fp4_stream<12, DBG, 32>));

@@ -41,7 +41,8 @@ __host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS, uint32_t sel_byte
 
 // KS = 32-byte (32-element) k-steps per row; MOM: moments mode (sum of key, key^2 per query instead of selecting)
 // MODE: 2 = int8 (int keys), 3 = fp4 (fp32 keys)
-template <int MODE, int KS, bool MOM, int KPV = KP>
+// GATED = 1: the same code under its own symbol for the gated repair launch (see k_fp4_stream)
+template <int MODE, int KS, bool MOM, int KPV = KP, int GATED = 0>
 __global__ __launch_bounds__(512, 2) void k_i8_stream(
     const unsigned char *__restrict__ Qf /* [query group of 32][KS][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
     const void *__restrict__ vnorm_v /* int8: sum q^2 (i32, INT_MAX past N); fp4: sum v'^2 (f32, +inf past N); nullptr: dot / cosine */, uint32_t N,
@@ -432,6 +433,13 @@ int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
                            partial, tau_g, kp, list_base, Stot, pcnt, max_tiles, gate, mom);
         return ZVDB_OK;
     };
+    if constexpr (MODE == 2 && !MOM && KPV == KP) {
+        if (gate && KS == 24) {  // (the headline shape only: 768 dimensions)
+            ZV_CHECK(go(k_i8_stream<2, 24, false, KP, 1>));
+            ZV_HIP(hipGetLastError());
+            return ZVDB_OK;
+        }
+    }
     if constexpr (MODE == 2) {
         if (KS == 6) ZV_CHECK(go(k_i8_stream<2, 6, MOM, KPV>));
         else if (KS == 12) ZV_CHECK(go(k_i8_stream<2, 12, MOM, KPV>));
