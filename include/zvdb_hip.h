@@ -154,6 +154,15 @@ int zvdb_hip_distances_from(zvdb_hip_index *h, uint64_t owner, const uint64_t *i
 /* a2: the whole layer-0 greedy descent of insert (hnsw.zig:88-104 at layer 0)
  * for query row `owner`, starting at (*ep, *ep_dist); returns the final pair
  * and the number of distance evaluations. */
+/* insert's device work for layer 0, fused into ONE launch and one synchronisation (the separate calls above cost a
+ * synchronous launch each): appends `point` (hnsw.zig:77-82; id = count), then, unless entry == UINT64_MAX (first node),
+ * distance(point, entry) (:86), the greedy scan at layer 0 (:88-104) and connect(id, ep, 0) (:106-108, :119-141) with
+ * shrinkConnections (:143-170) of both lists, on the device mirror of layer 0.  Outputs what the host mirror adopts:
+ * the arg-min ep and its distance (the ep the upper layers continue from), ep's list after the connect (out_ep_list:
+ * room for m ids) and the length of the new node's own list ([ep] unless m == 0). */
+int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, uint64_t entry, uint64_t *out_id,
+                           uint64_t *out_ep, float *out_ep_dist, uint64_t *out_ep_list, uint32_t *out_ep_n,
+                           uint32_t *out_owner_n, uint64_t *out_evals);
 int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, float *ep_dist,
                            uint64_t *out_evals);
 

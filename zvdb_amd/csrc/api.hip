@@ -211,6 +211,7 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->rows_p);
     (void)hipFree(h->norm_p);
     if (h->guess_flag_host) (void)hipHostFree(h->guess_flag_host);
+    if (h->ins_host) (void)hipHostFree(h->ins_host);
     (void)hipFree(h->rows_pf);
     (void)hipFree(h->rows_qf);
     (void)hipFree(h->norm_qf);
@@ -484,6 +485,73 @@ int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, floa
     *ep = p->ep;
     *ep_dist = p->dist;
     if (out_evals) *out_evals = p->evals;
+    return ZVDB_OK;
+}
+
+// insert's device work for layer 0 in one launch and one synchronisation: append the point (hnsw.zig:77-82), then -- unless
+// it is the first node -- :86, :88-104 at layer 0 and connect(id, ep, 0) (:106-108, :119-141 with :143-170) on the device
+// mirror.  See k_insert_layer0.
+int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, uint64_t entry, uint64_t *out_id,
+                           uint64_t *out_ep, float *out_ep_dist, uint64_t *out_ep_list, uint32_t *out_ep_n,
+                           uint32_t *out_owner_n, uint64_t *out_evals) {
+    ZV_ARG(h && point, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(set_dim(h, dim));
+    const bool first = entry == ~0ull;
+    if (!first && entry >= h->count) {
+        set_error("NodeNotFound: entry %llu", (unsigned long long)entry);
+        return ZVDB_ERR_NODE_NOT_FOUND;
+    }
+    ZV_ARG(first || (out_ep && out_ep_dist && out_ep_list && out_ep_n), "null argument");
+    ZV_CHECK(ensure_capacity(h, h->count + 1));
+    const uint64_t id = h->count;
+    const size_t row_bytes = round_up64((uint64_t)dim * sizeof(float), 256), ob = insert_l0_out_bytes(h);
+    if (h->ins_bytes < row_bytes + ob) {  // host-mapped [row | result] block
+        if (h->ins_host) { ZV_HIP(hipStreamSynchronize(h->stream)); ZV_HIP(hipHostFree(h->ins_host)); h->ins_host = nullptr; h->ins_bytes = 0; }
+        const size_t nb = round_up64(row_bytes + ob, 4096);
+        ZV_HIP(hipHostMalloc(&h->ins_host, nb, hipHostMallocMapped));
+        ZV_HIP(hipHostGetDevicePointer(&h->ins_dev, h->ins_host, 0));
+        h->ins_bytes = nb;
+    }
+    std::memcpy(h->ins_host, point, (size_t)dim * sizeof(float));
+    // plain fp32 L2 rows (the reference's only case): the insert kernel copies the point itself and the row's norm / mirror
+    // entries are computed BEHIND it in the stream (nothing on the insert path reads them): one launch on the critical path
+    const bool fast = !first && h->metric == ZVDB_METRIC_L2SQ && !(h->flags & ZVDB_FLAG_BF16_ROWS) && (size_t)dim * 4 <= 96 * 1024;
+    if (!fast) {
+        ZV_CHECK(launch_copy_row(static_cast<const float *>(h->ins_dev), h->rows + id * h->ld, dim, h->stream));
+        ZV_CHECK(finish_rows(h, id, 1, h->stream));
+    }
+    unsigned char *res = static_cast<unsigned char *>(h->ins_host) + row_bytes;
+    if (!first) {
+        const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;  // never 0 (a fresh block reads 0)
+        volatile uint32_t *flag = &reinterpret_cast<InsertL0Out *>(res)->seq;
+        *flag = 0;
+        ZV_CHECK(launch_insert_layer0(h, (uint32_t)id, (uint32_t)entry, static_cast<unsigned char *>(h->ins_dev) + row_bytes, seq,
+                                      fast ? static_cast<const float *>(h->ins_dev) : nullptr, h->stream));
+        if (fast) ZV_CHECK(finish_rows(h, id, 1, h->stream));
+        // the kernel's last store is the sequence number: poll it (a stream synchronise costs a ~10 us wake-up per insert);
+        // bounded -- after ~200 us, or on any doubt, fall back to the synchronise, which also surfaces launch errors
+        for (int spin = 0; spin < 20000 && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) __builtin_ia32_pause();
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) ZV_HIP(hipStreamSynchronize(h->stream));
+    } else {
+        ZV_HIP(hipStreamSynchronize(h->stream));
+    }
+    h->count += 1;
+    if (out_id) *out_id = id;
+    if (first) return ZVDB_OK;
+    const InsertL0Out *hd = reinterpret_cast<const InsertL0Out *>(res);
+    if (hd->error) {
+        set_error("layer-0 list exceeds the device stride %u (m = %u)", h->gstride, h->m);
+        return ZVDB_ERR_INVALID;
+    }
+    const uint32_t *lst = reinterpret_cast<const uint32_t *>(res + sizeof(InsertL0Out));
+    *out_ep = hd->ep;
+    *out_ep_dist = hd->ep_dist;
+    *out_ep_n = hd->ep_n;
+    for (uint32_t i = 0; i < hd->ep_n; ++i) out_ep_list[i] = lst[i];
+    if (out_owner_n) *out_owner_n = hd->owner_n;
+    if (out_evals) *out_evals = hd->evals;
     return ZVDB_OK;
 }
 

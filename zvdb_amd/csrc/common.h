@@ -137,6 +137,11 @@ struct zvdb_hip_index {
     uint32_t *guess_flag_host = nullptr;  // hipHostMalloc'ed, mapped
     uint32_t *guess_flag_dev = nullptr;   // its device alias
     float guess_adapt = 0.0f;
+    // zvdb_hip_insert_layer0: host-mapped [row | result] block -- the kernels read the point and write the result through
+    // it, so an insert submits no copy-engine transfers (each costs ~10 us for a few hundred bytes)
+    void *ins_host = nullptr, *ins_dev = nullptr;
+    size_t ins_bytes = 0;
+    uint32_t ins_seq = 0;
     uint32_t screen_survivors = 0;  // zvdb_hip_index_set_screen_survivors: minimum k' of the fp4 screen (0 = from k)
     uint32_t shard_count = 1;  // zvdb_hip_index_set_shard_count: the approximate screen keeps its share of the survivors
     hipStream_t stream = nullptr;
@@ -161,6 +166,21 @@ void timing_end(zvdb_hip_index *h, hipStream_t s);
 // ---- exact_kernels.hip (compiled with -ffp-contract=off) -------------------
 int launch_exact_distances(const zvdb_hip_index *h, const float *d_query, const uint32_t *d_ids,
                            uint32_t n, float *d_out, hipStream_t s);
+// result block of k_insert_layer0 (device scratch -> pinned host memory)
+struct InsertL0Out {
+    uint32_t ep;        // layer-0 arg-min the new node was connected to
+    float ep_dist;
+    uint32_t owner_n;   // length of the new node's list after the connect (0 or 1 unless it already had entries)
+    uint32_t ep_n;      // length of ep's list after connect + shrink
+    unsigned long long evals;  // distance evaluations of the greedy scan (the counter zvdb_hip_greedy_layer0 reports)
+    uint32_t error;     // 1: a list does not fit the device stride
+    uint32_t seq;       // written LAST (system scope): the host polls it instead of paying a stream-synchronise wake-up
+    // followed by uint32_t ep_list[gstride], owner_list[gstride]
+};
+size_t insert_l0_out_bytes(const zvdb_hip_index *h);
+int launch_copy_row(const float *src, float *dst, uint32_t dim, hipStream_t s);
+int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
+                         hipStream_t s);
 int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep_io,
                          float *d_dist_io, unsigned long long *d_evals, hipStream_t s);
 int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,

@@ -148,6 +148,144 @@ __global__ __launch_bounds__(64) void k_greedy_layer0(const float *__restrict__ 
     }
 }
 
+// ---- a2 + a4 + a3 at layer 0, fused (one wave, one launch per insert) -----------------------------------------------
+// hnsw.zig:86 (distance of the new point to the entry point), :88-104 at layer 0 (the greedy scan above), :106-108 ->
+// connect(owner, ep, 0) :119-141: append each node to the other's layer-0 list, then shrinkConnections :143-170 of both
+// (only when a list exceeds m: distances to its owner, one lane per entry; the reference's stable insertion sort with a
+// strict '<' is reproduced by ranks -- rank(i) = #{d_j < d_i} + #{j < i : d_j == d_i}; the first m stay).  All on the
+// device mirror of layer 0; `out` receives what the host mirror must adopt.
+
+__global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+                                                      uint32_t *__restrict__ adj, uint32_t *__restrict__ deg, uint32_t gstride,
+                                                      uint32_t m, uint32_t owner, uint32_t ep_in, InsertL0Out *__restrict__ out, uint32_t seq,
+                                                      const float *__restrict__ point_src /* optional: host-mapped new point */,
+                                                      float *__restrict__ rows_w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t cap = gstride + 1;                       // a list holds at most gstride entries before the append
+    uint32_t *lst = reinterpret_cast<uint32_t *>(smem);     // [cap]
+    float *dst = reinterpret_cast<float *>(lst + cap);      // [cap]
+    uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
+    uint32_t *out_ep_list = reinterpret_cast<uint32_t *>(out + 1);
+    uint32_t *out_owner_list = out_ep_list + gstride;
+    const float *q = rows + (size_t)owner * ld;
+    if (point_src) {  // Node.init's copy (:24-26) done here: the point goes to its row AND to LDS, which the walks below read
+        float *ql = reinterpret_cast<float *>(srt + cap);
+        for (uint32_t i = lane; i < dim; i += kWave) {
+            const float v = point_src[i];
+            rows_w[(size_t)owner * ld + i] = v;
+            ql[i] = v;
+        }
+        __syncthreads();
+        q = ql;
+    }
+    // :86 -- one lane walks the row (the only bit-exact order), the wave adopts its value
+    float cur = 0.0f;
+    if (lane == 0) cur = exact_dist_rt(metric, q, rows + (size_t)ep_in * ld, dim);
+    cur = __shfl(cur, 0);
+    uint32_t ep = ep_in;
+    unsigned long long evals = 0;
+    bool changed = true;
+    while (changed) {  // :90-104 (same scan as k_greedy_layer0)
+        changed = false;
+        const uint32_t dg = deg[ep];
+        float best_d = cur;
+        uint32_t best_j = 0xFFFFFFFFu, best_id = ep;
+        for (uint32_t base = 0; base < dg; base += kWave) {
+            const uint32_t j = base + lane;
+            float d = 0.0f;
+            uint32_t nb = 0;
+            const bool act = j < dg;
+            if (act) {
+                nb = adj[(size_t)ep * gstride + j];
+                d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
+            }
+            float md = act ? d : __builtin_inff();
+            uint32_t mj = act ? j : 0xFFFFFFFFu, mid = nb;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(md, off);
+                const uint32_t oj = __shfl_xor(mj, off), oid = __shfl_xor(mid, off);
+                if (od < md || (od == md && oj < mj)) { md = od; mj = oj; mid = oid; }
+            }
+            if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
+        }
+        evals += dg;
+        if (best_j != 0xFFFFFFFFu) { ep = best_id; cur = best_d; changed = true; }
+    }
+    // connect(owner, ep, 0): lists are read before either is written (the two nodes differ)
+    uint32_t err = 0;
+    auto link = [&](uint32_t node, uint32_t other, uint32_t *out_list) -> uint32_t {
+        const uint32_t n0 = min(deg[node], gstride);
+        for (uint32_t i = lane; i < n0; i += kWave) lst[i] = adj[(size_t)node * gstride + i];
+        if (lane == 0) lst[n0] = other;                      // :128-133 append
+        uint32_t n = n0 + 1;
+        __syncthreads();
+        if (n > m) {                                          // :146 shrink
+            const float *o = rows + (size_t)node * ld;
+            for (uint32_t i = lane; i < n; i += kWave) dst[i] = exact_dist_rt(metric, o, rows + (size_t)lst[i] * ld, dim);  // :160-161
+            __syncthreads();
+            for (uint32_t i = lane; i < n; i += kWave) {
+                const float di = dst[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const float dj = dst[j];
+                    rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+                }
+                srt[rank] = lst[i];
+            }
+            __syncthreads();
+            n = m;                                            // :168-169
+            for (uint32_t i = lane; i < n; i += kWave) lst[i] = srt[i];
+            __syncthreads();
+        }
+        if (n > gstride) { err = 1; n = gstride; }
+        for (uint32_t i = lane; i < n; i += kWave) {
+            adj[(size_t)node * gstride + i] = lst[i];
+            out_list[i] = lst[i];
+        }
+        if (lane == 0) deg[node] = n;
+        __syncthreads();
+        return n;
+    };
+    const uint32_t owner_n = link(owner, ep, out_owner_list);
+    const uint32_t ep_n = link(ep, owner, out_ep_list);
+    if (lane == 0) {
+        out->ep = ep;
+        out->ep_dist = cur;
+        out->owner_n = owner_n;
+        out->ep_n = ep_n;
+        out->evals = evals;
+        out->error = err;
+    }
+    __threadfence_system();  // `out` is host-mapped memory: everything above is visible to the host before the sequence number
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void k_copy_row(const float *__restrict__ src, float *__restrict__ dst, uint32_t dim) {
+    for (uint32_t i = threadIdx.x; i < dim; i += 256) dst[i] = src[i];
+}
+
+int launch_copy_row(const float *src, float *dst, uint32_t dim, hipStream_t s) {
+    hipLaunchKernelGGL(k_copy_row, dim3(1), dim3(256), 0, s, src, dst, dim);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+size_t insert_l0_out_bytes(const zvdb_hip_index *h) { return sizeof(InsertL0Out) + 2ull * h->gstride * sizeof(uint32_t); }
+
+int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
+                         hipStream_t s) {
+    const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
+    const size_t lds = 3ull * (h->gstride + 1) * sizeof(uint32_t) + (point_src ? (size_t)h->dim * sizeof(float) : 0);
+    if (lds > 48 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_layer0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_insert_layer0, dim3(1), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj, h->deg, h->gstride,
+                       h->m, owner, ep, static_cast<InsertL0Out *>(d_out), seq, point_src, h->rows);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep_io,
                          float *d_dist_io, unsigned long long *d_evals, hipStream_t s) {
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;

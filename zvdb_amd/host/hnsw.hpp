@@ -108,8 +108,15 @@ class HNSW<float> {
         const size_t id = points_.size();                                      // :77
         const size_t level = forced_level_ >= 0 ? (size_t)forced_level_ : random_level();  // :78
         forced_level_ = -1;
-        uint64_t dev_id = 0;
-        check(zvdb_hip_add(h_, point, 1, (uint32_t)len, &dev_id));             // Node.init copy :24-26
+        // ONE launch + one synchronisation for everything layer 0 needs: Node.init copy (:24-26), distance to the entry
+        // point (:86), the while(changed) scan at layer 0 (:90-104) and connect(id, ep, 0) (:106-108) incl. both
+        // shrinkConnections, on the device mirror; the lists it settled on are adopted below
+        uint64_t dev_id = 0, ep = entry_point ? *entry_point : ~0ull;          // :85
+        float curr_dist = 0.0f;
+        uint32_t ep_n = 0, owner_n = 0;
+        ids_.resize(m + 1);
+        check(zvdb_hip_insert_layer0(h_, point, (uint32_t)len, ep, &dev_id, &ep, &curr_dist, ids_.data(), &ep_n, &owner_n,
+                                     nullptr));
         if (dev_id != id) throw Error(ZVDB_ERR_INVALID, "device id out of step with host id");
         std::unique_ptr<float[]> owned(new float[len ? len : 1]);
         std::memcpy(owned.get(), point, len * sizeof(float));
@@ -117,13 +124,12 @@ class HNSW<float> {
         conns_.emplace_back(level + 1);                                        // :19-23
 
         if (entry_point) {                                                     // :84
-            uint64_t ep = *entry_point;                                        // :85
-            float curr_dist = 0.0f;
-            check(zvdb_hip_distances_from(h_, id, &ep, 1, &curr_dist));        // :86
             for (size_t layer = 0; layer <= max_level; ++layer) {              // :88 (pre-insert max_level)
                 if (layer == 0) {
-                    // whole while(changed) loop on the device mirror of layer 0 (:90-104)
-                    check(zvdb_hip_greedy_layer0(h_, id, &ep, &curr_dist, nullptr));
+                    // host mirror of what the device did: id's list = [ep] (shrunk to m), ep's list as returned
+                    conns_[id][0].assign(owner_n ? 1 : 0, (size_t)ep);
+                    conns_[(size_t)ep][0].assign(ids_.begin(), ids_.begin() + ep_n);
+                    continue;
                 } else {
                     bool changed = true;
                     while (changed) {                                          // :90
@@ -226,10 +232,7 @@ class HNSW<float> {
         if (level < t.size()) t[level].push_back(source);                      // :131-133
         if (level < s.size()) shrink_connections(source, level);               // :135-137
         if (level < t.size()) shrink_connections(target, level);               // :138-140
-        if (level == 0) {  // device mirror of connections[0]
-            mirror(source);
-            mirror(target);
-        }
+        // (layer 0 never comes through here: zvdb_hip_insert_layer0 connects it on the device mirror)
     }
 
     // shrinkConnections -- hnsw.zig:143-170
@@ -252,12 +255,6 @@ class HNSW<float> {
         }
         lst.resize(m);                                                         // :168
         for (size_t i = 0; i < m; ++i) lst[i] = (size_t)ids_[i];               // :169
-    }
-
-    void mirror(size_t node) {
-        const auto &l0 = conns_[node][0];
-        ids_.assign(l0.begin(), l0.end());
-        check(zvdb_hip_set_neighbors(h_, node, ids_.data(), (uint32_t)ids_.size()));
     }
 
     mutable std::mutex mu_;  // hnsw.zig:50
