@@ -31,6 +31,16 @@ int ensure_pin(zvdb_hip_index *h, size_t bytes) {
     return ZVDB_OK;
 }
 
+int ensure_ins_block(zvdb_hip_index *h, size_t bytes) {
+    if (h->ins_bytes >= bytes) return ZVDB_OK;
+    if (h->ins_host) { ZV_HIP(hipStreamSynchronize(h->stream)); ZV_HIP(hipHostFree(h->ins_host)); h->ins_host = nullptr; h->ins_bytes = 0; }
+    const size_t nb = round_up64(bytes, 4096);
+    ZV_HIP(hipHostMalloc(&h->ins_host, nb, hipHostMallocMapped));
+    ZV_HIP(hipHostGetDevicePointer(&h->ins_dev, h->ins_host, 0));
+    h->ins_bytes = nb;
+    return ZVDB_OK;
+}
+
 int ensure_scratch(zvdb_hip_index *h, size_t bytes) {
     if (h->scratch_bytes >= bytes) return ZVDB_OK;
     if (h->scratch) {
@@ -507,13 +517,7 @@ int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, 
     ZV_CHECK(ensure_capacity(h, h->count + 1));
     const uint64_t id = h->count;
     const size_t row_bytes = round_up64((uint64_t)dim * sizeof(float), 256), ob = insert_l0_out_bytes(h);
-    if (h->ins_bytes < row_bytes + ob) {  // host-mapped [row | result] block
-        if (h->ins_host) { ZV_HIP(hipStreamSynchronize(h->stream)); ZV_HIP(hipHostFree(h->ins_host)); h->ins_host = nullptr; h->ins_bytes = 0; }
-        const size_t nb = round_up64(row_bytes + ob, 4096);
-        ZV_HIP(hipHostMalloc(&h->ins_host, nb, hipHostMallocMapped));
-        ZV_HIP(hipHostGetDevicePointer(&h->ins_dev, h->ins_host, 0));
-        h->ins_bytes = nb;
-    }
+    ZV_CHECK(ensure_ins_block(h, row_bytes + ob));  // host-mapped [row | result] block
     std::memcpy(h->ins_host, point, (size_t)dim * sizeof(float));
     // plain fp32 L2 rows (the reference's only case): the insert kernel copies the point itself and the row's norm / mirror
     // entries are computed BEHIND it in the stream (nothing on the insert path reads them): one launch on the critical path
@@ -623,6 +627,42 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
         const size_t db = round_up64((size_t)nq * k * 4, 256);
         const size_t cb = round_up64((size_t)nq * 4, 256);
         const size_t total = qb + ib + db + cb + 64;
+        if (nq == 1 && ef == 0 && total <= (1u << 20)) {
+            // The reference's calling pattern -- ONE query per search() (hnsw.zig:194) -- is all latency: the query and the
+            // results travel through host-mapped memory (the kernel stages the query in LDS once and writes each result
+            // once), no copy-engine transfers, and the host polls a sequence number published behind the search kernel
+            // instead of paying a stream-synchronise wake-up.
+            if (entry >= h->count) {
+                set_error("NodeNotFound: entry %llu", (unsigned long long)entry);
+                return ZVDB_ERR_NODE_NOT_FOUND;
+            }
+            ZV_CHECK(ensure_ins_block(h, total + 64));
+            ZV_CHECK(ensure_scratch(h, 64));
+            unsigned char *hb = static_cast<unsigned char *>(h->ins_host), *dbs = static_cast<unsigned char *>(h->ins_dev);
+            std::memcpy(hb, queries, (size_t)dim * 4);
+            const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;
+            volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(hb + total);
+            *flag = 0;
+            ZV_HIP(hipMemsetAsync(h->scratch, 0, 64, h->stream));
+            ZV_CHECK(launch_search_compat(h, reinterpret_cast<const float *>(dbs), 1, k, (uint32_t)entry, 0,
+                                          reinterpret_cast<uint64_t *>(dbs + qb), reinterpret_cast<float *>(dbs + qb + ib),
+                                          reinterpret_cast<uint32_t *>(dbs + qb + ib + db),
+                                          static_cast<unsigned long long *>(h->scratch), h->stream));
+            ZV_CHECK(launch_publish(reinterpret_cast<unsigned long long *>(dbs + qb + ib + db + cb),
+                                    static_cast<const unsigned long long *>(h->scratch), 8,
+                                    reinterpret_cast<uint32_t *>(dbs + total), seq, h->stream));
+            for (int spin = 0; spin < 40000 && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) __builtin_ia32_pause();
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) ZV_HIP(hipStreamSynchronize(h->stream));
+            std::memcpy(out_ids, hb + qb, (size_t)k * 8);
+            std::memcpy(out_dist, hb + qb + ib, (size_t)k * 4);
+            std::memcpy(out_count, hb + qb + ib + db, 4);
+            const unsigned long long *st = reinterpret_cast<const unsigned long long *>(hb + qb + ib + db + cb);
+            if (stats) {
+                stats->dist_evals = st[0];
+                stats->pops = st[1];
+            }
+            return ZVDB_OK;
+        }
         ZV_CHECK(ensure_scratch(h, total));
         ZV_CHECK(ensure_pin(h, total));
         unsigned char *scr = static_cast<unsigned char *>(h->scratch);

@@ -179,6 +179,9 @@ struct InsertL0Out {
 };
 size_t insert_l0_out_bytes(const zvdb_hip_index *h);
 int launch_copy_row(const float *src, float *dst, uint32_t dim, hipStream_t s);
+// dst[0..n) <- src[0..n) (64-bit words), then *seq_dst = seq at system scope: publishes a result block to a polling host
+int launch_publish(unsigned long long *dst, const unsigned long long *src, uint32_t n, uint32_t *seq_dst, uint32_t seq, hipStream_t s);
+int ensure_ins_block(zvdb_hip_index *h, size_t bytes);
 int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
                          hipStream_t s);
 int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep_io,

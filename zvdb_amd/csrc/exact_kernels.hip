@@ -273,6 +273,20 @@ int launch_copy_row(const float *src, float *dst, uint32_t dim, hipStream_t s) {
     return ZVDB_OK;
 }
 
+__global__ __launch_bounds__(64) void k_publish(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src,
+                                                uint32_t n, uint32_t *__restrict__ seq_dst, uint32_t seq) {
+    for (uint32_t i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seq_dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int launch_publish(unsigned long long *dst, const unsigned long long *src, uint32_t n, uint32_t *seq_dst, uint32_t seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, dst, src, n, seq_dst, seq);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 size_t insert_l0_out_bytes(const zvdb_hip_index *h) { return sizeof(InsertL0Out) + 2ull * h->gstride * sizeof(uint32_t); }
 
 int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
