@@ -124,6 +124,17 @@ static int use_device(zvdb_hip_index *h) {
     return ZVDB_OK;
 }
 
+// Every host-api call ends with its work complete, except the fused insert, which returns while the new row's norm /
+// mirror kernel is still queued on h->stream.  Calls on h->stream are ordered behind it; calls that launch on a CALLER's
+// stream (the *_dev entry points) settle it first.
+static int settle_own_stream(zvdb_hip_index *h) {
+    if (h->own_stream_busy) {
+        ZV_HIP(hipStreamSynchronize(h->stream));
+        h->own_stream_busy = false;
+    }
+    return ZVDB_OK;
+}
+
 // rows [first, first+n) are in place in h->rows: normalise (cosine), norms, bf16 mirror
 static int finish_rows(zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s) {
     if (h->metric == ZVDB_METRIC_COSINE)
@@ -281,6 +292,7 @@ int zvdb_hip_add_dev(zvdb_hip_index *h, const void *d_rows, uint64_t n, uint32_t
     ZV_ARG(h && (d_rows || n == 0), "null argument");
     std::lock_guard<std::mutex> g(h->mu);
     ZV_CHECK(use_device(h));
+    ZV_CHECK(settle_own_stream(h));
     ZV_CHECK(set_dim(h, dim));
     if (first_id) *first_id = h->count;
     if (n == 0) return ZVDB_OK;
@@ -533,7 +545,10 @@ int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, 
         *flag = 0;
         ZV_CHECK(launch_insert_layer0(h, (uint32_t)id, (uint32_t)entry, static_cast<unsigned char *>(h->ins_dev) + row_bytes, seq,
                                       fast ? static_cast<const float *>(h->ins_dev) : nullptr, h->stream));
-        if (fast) ZV_CHECK(finish_rows(h, id, 1, h->stream));
+        if (fast) {
+            ZV_CHECK(finish_rows(h, id, 1, h->stream));
+            h->own_stream_busy = true;
+        }
         // the kernel's last store is the sequence number: poll it (a stream synchronise costs a ~10 us wake-up per insert);
         // bounded -- after ~200 us, or on any doubt, fall back to the synchronise, which also surfaces launch errors
         for (int spin = 0; spin < 20000 && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) __builtin_ia32_pause();
@@ -585,6 +600,7 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
     ZV_ARG(h && d_queries && d_ids && d_dist && d_count, "null argument");
     std::lock_guard<std::mutex> g(h->mu);
     ZV_CHECK(use_device(h));
+    ZV_CHECK(settle_own_stream(h));
     ZV_CHECK(check_query_args(h, dim, k));
     ZV_ARG(h->count > 0 && k > 0, "search_graph_dev needs a non-empty index and k > 0");
     if (entry >= h->count) {
@@ -717,6 +733,7 @@ int zvdb_hip_search_bruteforce_dev(zvdb_hip_index *h, const void *d_queries, uin
     ZV_ARG(h && d_queries && d_ids && d_dist && d_count && d_workspace, "null argument");
     std::lock_guard<std::mutex> g(h->mu);
     ZV_CHECK(use_device(h));
+    ZV_CHECK(settle_own_stream(h));
     ZV_CHECK(check_query_args(h, dim, k));
     ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
     ZV_ARG(h->count > 0 && k > 0, "search_bruteforce_dev needs a non-empty index and k > 0");

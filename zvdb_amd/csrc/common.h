@@ -142,6 +142,7 @@ struct zvdb_hip_index {
     void *ins_host = nullptr, *ins_dev = nullptr;
     size_t ins_bytes = 0;
     uint32_t ins_seq = 0;
+    bool own_stream_busy = false;  // a fused insert left its finalize kernel running on h->stream (see settle_own_stream)
     uint32_t screen_survivors = 0;  // zvdb_hip_index_set_screen_survivors: minimum k' of the fp4 screen (0 = from k)
     uint32_t shard_count = 1;  // zvdb_hip_index_set_shard_count: the approximate screen keeps its share of the survivors
     hipStream_t stream = nullptr;
