@@ -266,3 +266,27 @@ def test_gpu_knn_graph_build_and_ef_search(zv, oracle):
         assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)
         hits += len(set(ri.tolist()) & set(gt[qi].tolist()))
     assert hits / (10 * len(Q)) > 0.6
+
+
+@pytest.mark.parametrize("n,d,m", [(500, 2, 3), (400, 3, 1), (300, 4, 16), (64, 1, 2)])
+def test_fused_insert_under_exact_ties(zv, oracle, n, d, m):
+    """zvdb_hip_insert_layer0 (a2 + a4 + a3 in one launch) on data made of ties: points on a 3-wide integer grid with many
+    duplicates, tiny m (every connect shrinks).  Strict '<' in the scan (earliest wins), stable shrink order: the graphs must
+    equal the oracle's on every layer, and so must every search."""
+    rng = np.random.default_rng(n)
+    V = np.floor(rng.random((n, d), dtype=np.float32) * 3).astype(np.float32)
+    ref = oracle.HNSW(m, 200, level_seed=3)
+    got = zv.HNSW(m, 200)
+    for i, r in enumerate(V):
+        ref.insert(r)
+        got.insert(r, _level=ref.node_level(i))
+    assert got.max_level == ref.max_level
+    for i in range(n):
+        for layer in range(ref.node_level(i) + 1):
+            assert np.array_equal(ref.neighbors(i, layer), got.connections(i, layer)), (i, layer)
+        assert np.array_equal(got.index.get_neighbors(i), ref.neighbors(i, 0))
+    for q in V[:20] + np.float32(0.25):
+        for k in (1, 7, 40):
+            ri, rd = ref.search(q, k)
+            gi, gd = got.search_ids(q, k)
+            assert np.array_equal(ri, gi) and np.array_equal(rd, gd)
