@@ -163,6 +163,12 @@ def extras(args, zv, torch):
     for r in V:
         h.insert(r, _level=0)
     t_ins_gpu = time.perf_counter() - t0
+    hb = zv.HNSW(16, 200)                     # the same inserts as ONE bulk call (chunks of 8192 inside one launch each)
+    t0 = time.perf_counter()
+    hb.insert_many(V, np.zeros(P, dtype=np.int32))
+    t_ins_many = time.perf_counter() - t0
+    same_graph = all(np.array_equal(hb.connections(i, 0), h.connections(i, 0)) for i in range(0, P, 97))
+    del hb
     ref = oracle.HNSW(16, 200)
     t0 = time.perf_counter()
     for r in V:
@@ -182,7 +188,8 @@ def extras(args, zv, torch):
     out["reference_shape_compat_search"] = {
         "points": P, "dim": D3, "queries": NQ, "k": K, "m": 16,
         "gpu_qps_batched_host_api": NQ / t_gpu, "cpu_oracle_qps_1thread": NQ / t_cpu,
-        "gpu_insert_pts_per_s": P / t_ins_gpu, "cpu_oracle_insert_pts_per_s": P / t_ins_cpu,
+        "gpu_insert_pts_per_s": P / t_ins_gpu, "gpu_insert_many_pts_per_s": P / t_ins_many,
+        "insert_many_graph_equals_sequential": bool(same_graph), "cpu_oracle_insert_pts_per_s": P / t_ins_cpu,
         "dist_evals_per_query": ev / NQ, "pops_per_query": pp / NQ,
         "bit_exact_vs_oracle_first_500": same,
         "reference_published": {"search_qps": 2678.13, "insert_pts_per_s": 8392.22, "source": "benchmarks/benchmark.md:102-113 (100k x 128, unstated CPU)"},

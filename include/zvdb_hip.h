@@ -163,6 +163,13 @@ int zvdb_hip_distances_from(zvdb_hip_index *h, uint64_t owner, const uint64_t *i
 int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, uint64_t entry, uint64_t *out_id,
                            uint64_t *out_ep, float *out_ep_dist, uint64_t *out_ep_list, uint32_t *out_ep_n,
                            uint32_t *out_owner_n, uint64_t *out_evals);
+/* n of the above in ONE launch (extension: the reference inserts one point per call): the inserts run one after the
+ * other on the device, each seeing the lists its predecessors left -- the result of n single calls, without their
+ * launches and host round trips.  Needs a non-empty index (entry = its entry point).  Outputs are arrays of n
+ * (out_ep_lists: n x m ids, row i holds out_ep_n[i] entries). */
+int zvdb_hip_insert_batch_layer0(zvdb_hip_index *h, const float *points, uint32_t dim, uint64_t n, uint64_t entry,
+                                 uint64_t *out_first_id, uint64_t *out_ep, float *out_ep_dist, uint64_t *out_ep_lists,
+                                 uint32_t *out_ep_n, uint32_t *out_owner_n);
 int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, float *ep_dist,
                            uint64_t *out_evals);
 

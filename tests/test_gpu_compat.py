@@ -290,3 +290,41 @@ def test_fused_insert_under_exact_ties(zv, oracle, n, d, m):
             ri, rd = ref.search(q, k)
             gi, gd = got.search_ids(q, k)
             assert np.array_equal(ri, gi) and np.array_equal(rd, gd)
+
+
+@pytest.mark.parametrize("n,d,m,ties", [(3000, 32, 16, False), (700, 2, 3, True), (9000, 8, 4, False)])
+def test_insert_many_equals_sequential_inserts(zv, oracle, n, d, m, ties):
+    """HNSW.insert_many (zvdb_hip_insert_batch_layer0: a chunk of inserts inside ONE launch, each seeing the lists its
+    predecessors left) builds the graph of n insert() calls: identical to the oracle's on every layer, device mirror
+    included; also when the index already holds points and when a chunk boundary (8192) falls inside the batch."""
+    rng = np.random.default_rng(n)
+    V = rng.random((n, d), dtype=np.float32)
+    if ties:
+        V = np.floor(V * 3).astype(np.float32)
+    ref = oracle.HNSW(m, 200, level_seed=11)
+    for r in V:
+        ref.insert(r)
+    levels = np.array([ref.node_level(i) for i in range(n)], dtype=np.int32)
+    got = zv.HNSW(m, 200)
+    head = 5
+    for i in range(head):  # a few single inserts first, then the rest in two batches
+        got.insert(V[i], _level=int(levels[i]))
+    got.insert_many(V[head:n // 2], levels[head:n // 2])
+    got.insert_many(V[n // 2:], levels[n // 2:])
+    assert got.count() == n and got.max_level == ref.max_level
+    for i in range(n):
+        for layer in range(ref.node_level(i) + 1):
+            assert np.array_equal(ref.neighbors(i, layer), got.connections(i, layer)), (i, layer)
+        if i % 7 == 0:
+            assert np.array_equal(got.index.get_neighbors(i), ref.neighbors(i, 0))
+    fresh = zv.HNSW(m, 200)  # an empty index: the first node goes through the single-insert path
+    fresh.insert_many(V[:300], levels[:300])
+    ref2 = oracle.HNSW(m, 200, level_seed=11)
+    for r in V[:300]:
+        ref2.insert(r)
+    for i in range(300):
+        assert np.array_equal(ref2.neighbors(i, 0), fresh.connections(i, 0))
+    for q in V[:10] + np.float32(0.125):
+        ri, rd = ref.search(q, 10)
+        gi, gd = got.search_ids(q, 10)
+        assert np.array_equal(ri, gi) and np.array_equal(rd, gd)

@@ -50,6 +50,7 @@ HIP_SYMBOLS = [
     ("zvdb_hip_distances", _i32, [_vp, _f32p, _u32, _u64p, _u32, _f32p]),
     ("zvdb_hip_distances_from", _i32, [_vp, _u64, _u64p, _u32, _f32p]),
     ("zvdb_hip_greedy_layer0", _i32, [_vp, _u64, _u64p, _f32p, _u64p]),
+    ("zvdb_hip_insert_batch_layer0", _i32, [_vp, _f32p, _u32, _u64, _u64, _u64p, _u64p, _f32p, _u64p, _u32p, _u32p]),
     ("zvdb_hip_insert_layer0", _i32, [_vp, _f32p, _u32, _u64, _u64p, _u64p, _f32p, _u64p, _u32p, _u32p, _u64p]),
     ("zvdb_hip_search_graph", _i32, [_vp, _f32p, _u32, _u32, _u32, _u32, _u64, _u64p, _f32p, _u32p,
                                       C.POINTER(SearchStats)]),
@@ -72,6 +73,7 @@ HOST_SYMBOLS = [
     ("zvdb_host_hnsw_init", _vp, [C.c_size_t, C.c_size_t, _i32, _u32]),
     ("zvdb_host_hnsw_deinit", None, [_vp]),
     ("zvdb_host_hnsw_insert", _i32, [_vp, _f32p, C.c_size_t, _i32]),
+    ("zvdb_host_hnsw_insert_many", _i32, [_vp, _f32p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]),
     ("zvdb_host_hnsw_search", _i32, [_vp, _f32p, C.c_size_t, C.c_size_t, _u64p, _f32p,
                                       C.POINTER(C.c_size_t), _u64p, _u64p]),
     ("zvdb_host_hnsw_count", C.c_size_t, [_vp]),

@@ -423,6 +423,31 @@ int zvdb_hip_get_neighbors(zvdb_hip_index *h, uint64_t node, uint64_t *out_ids, 
 static int distances_impl(zvdb_hip_index *h, const float *host_query, uint64_t owner,
                           const uint64_t *ids, uint32_t n, float *out) {
     if (n == 0) return ZVDB_OK;
+    if (!host_query && n <= 1024) {
+        // insert's upper layers and shrinks call this once per step with a handful of ids: ids and distances travel through
+        // host-mapped memory and completion is polled (no copy-engine transfers, no stream-synchronise wake-up)
+        const size_t ib = round_up64((size_t)n * 4, 64), need2 = 2 * ib + 64;
+        ZV_CHECK(ensure_ins_block(h, need2));
+        unsigned char *hb = static_cast<unsigned char *>(h->ins_host), *db = static_cast<unsigned char *>(h->ins_dev);
+        uint32_t *m_ids = reinterpret_cast<uint32_t *>(hb);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (ids[i] >= h->count) {
+                set_error("NodeNotFound: id %llu", (unsigned long long)ids[i]);
+                return ZVDB_ERR_NODE_NOT_FOUND;
+            }
+            m_ids[i] = (uint32_t)ids[i];
+        }
+        const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(hb + 2 * ib);
+        *flag = 0;
+        ZV_CHECK(launch_exact_distances(h, h->rows + owner * h->ld, reinterpret_cast<const uint32_t *>(db), n,
+                                        reinterpret_cast<float *>(db + ib), h->stream));
+        ZV_CHECK(launch_publish(nullptr, nullptr, 0, reinterpret_cast<uint32_t *>(db + 2 * ib), seq, h->stream));
+        for (int spin = 0; spin < 40000 && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) __builtin_ia32_pause();
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) ZV_HIP(hipStreamSynchronize(h->stream));
+        std::memcpy(out, hb + ib, (size_t)n * 4);
+        return ZVDB_OK;
+    }
     const size_t qb = (size_t)h->ld * sizeof(float);
     const size_t need = qb + (size_t)n * 8;
     ZV_CHECK(ensure_scratch(h, need));
@@ -571,6 +596,74 @@ int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, 
     for (uint32_t i = 0; i < hd->ep_n; ++i) out_ep_list[i] = lst[i];
     if (out_owner_n) *out_owner_n = hd->owner_n;
     if (out_evals) *out_evals = hd->evals;
+    return ZVDB_OK;
+}
+
+// n inserts' layer-0 work inside ONE launch: the wave of k_insert_layer0 runs them one after the other, so the result is
+// that of n zvdb_hip_insert_layer0 calls (every insert sees the lists its predecessors left) without their launches and
+// host round trips.  Plain fp32 L2 rows only (the reference's case); other configurations loop over the single call.
+int zvdb_hip_insert_batch_layer0(zvdb_hip_index *h, const float *points, uint32_t dim, uint64_t n, uint64_t entry,
+                                 uint64_t *out_first_id, uint64_t *out_ep, float *out_ep_dist, uint64_t *out_ep_lists,
+                                 uint32_t *out_ep_n, uint32_t *out_owner_n) {
+    ZV_ARG(h && (points || n == 0) && out_ep && out_ep_dist && out_ep_lists && out_ep_n, "null argument");
+    if (n == 0) return ZVDB_OK;
+    uint32_t m = 0;
+    bool fast = false;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        ZV_CHECK(use_device(h));
+        ZV_CHECK(set_dim(h, dim));
+        m = h->m;
+        if (entry >= h->count) {
+            set_error("NodeNotFound: entry %llu", (unsigned long long)entry);
+            return ZVDB_ERR_NODE_NOT_FOUND;
+        }
+        fast = h->metric == ZVDB_METRIC_L2SQ && !(h->flags & ZVDB_FLAG_BF16_ROWS) && (size_t)dim * 4 <= 96 * 1024;
+        if (fast) {
+            if (out_first_id) *out_first_id = h->count;
+            const size_t ob = insert_l0_out_bytes(h);
+            const uint64_t chunk_max = 8192;
+            for (uint64_t c0 = 0; c0 < n; c0 += chunk_max) {
+                const uint64_t nc = std::min<uint64_t>(chunk_max, n - c0);
+                ZV_CHECK(ensure_capacity(h, h->count + nc));
+                const size_t pb = round_up64(nc * dim * sizeof(float), 256), rb = nc * ob;
+                ZV_CHECK(ensure_pin(h, pb + rb));
+                ZV_CHECK(ensure_scratch(h, pb + rb));
+                unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr), *scr = static_cast<unsigned char *>(h->scratch);
+                std::memcpy(pin, points + c0 * dim, nc * dim * sizeof(float));
+                ZV_HIP(hipMemcpyAsync(scr, pin, nc * dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+                const uint64_t id0 = h->count;
+                ZV_CHECK(launch_insert_layer0(h, (uint32_t)id0, (uint32_t)entry, scr + pb, 1u, reinterpret_cast<const float *>(scr),
+                                              h->stream, (uint32_t)nc, (uint32_t)ob));
+                ZV_CHECK(finish_rows(h, id0, nc, h->stream));
+                ZV_HIP(hipMemcpyAsync(pin + pb, scr + pb, rb, hipMemcpyDeviceToHost, h->stream));
+                ZV_HIP(hipStreamSynchronize(h->stream));
+                h->count += nc;
+                for (uint64_t i = 0; i < nc; ++i) {
+                    const InsertL0Out *hd = reinterpret_cast<const InsertL0Out *>(pin + pb + i * ob);
+                    if (hd->error) {
+                        set_error("layer-0 list exceeds the device stride %u (m = %u)", h->gstride, h->m);
+                        return ZVDB_ERR_INVALID;
+                    }
+                    const uint32_t *lst = reinterpret_cast<const uint32_t *>(hd + 1);
+                    out_ep[c0 + i] = hd->ep;
+                    out_ep_dist[c0 + i] = hd->ep_dist;
+                    out_ep_n[c0 + i] = hd->ep_n;
+                    for (uint32_t j = 0; j < hd->ep_n; ++j) out_ep_lists[(c0 + i) * m + j] = lst[j];
+                    if (out_owner_n) out_owner_n[c0 + i] = hd->owner_n;
+                }
+            }
+            return ZVDB_OK;
+        }
+    }
+    for (uint64_t i = 0; i < n; ++i) {  // (cosine / dot / bf16-valued rows: one call per insert)
+        uint64_t id = 0;
+        uint32_t on = 0;
+        ZV_CHECK(zvdb_hip_insert_layer0(h, points + i * dim, dim, entry, &id, out_ep + i, out_ep_dist + i, out_ep_lists + i * m,
+                                        out_ep_n + i, &on, nullptr));
+        if (i == 0 && out_first_id) *out_first_id = id;
+        if (out_owner_n) out_owner_n[i] = on;
+    }
     return ZVDB_OK;
 }
 

@@ -184,7 +184,7 @@ int launch_copy_row(const float *src, float *dst, uint32_t dim, hipStream_t s);
 int launch_publish(unsigned long long *dst, const unsigned long long *src, uint32_t n, uint32_t *seq_dst, uint32_t seq, hipStream_t s);
 int ensure_ins_block(zvdb_hip_index *h, size_t bytes);
 int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
-                         hipStream_t s);
+                         hipStream_t s, uint32_t n_batch = 1, uint32_t out_stride = 0);
 int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep_io,
                          float *d_dist_io, unsigned long long *d_evals, hipStream_t s);
 int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,

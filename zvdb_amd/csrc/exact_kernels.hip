@@ -156,23 +156,30 @@ __global__ __launch_bounds__(64) void k_greedy_layer0(const float *__restrict__ 
 // device mirror of layer 0; `out` receives what the host mirror must adopt.
 
 __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
-                                                      uint32_t *__restrict__ adj, uint32_t *__restrict__ deg, uint32_t gstride,
-                                                      uint32_t m, uint32_t owner, uint32_t ep_in, InsertL0Out *__restrict__ out, uint32_t seq,
-                                                      const float *__restrict__ point_src /* optional: host-mapped new point */,
-                                                      float *__restrict__ rows_w) {
+                                                      uint32_t *adj, uint32_t *deg, uint32_t gstride,
+                                                      uint32_t m, uint32_t first_owner, uint32_t ep_in, unsigned char *__restrict__ out_base,
+                                                      uint32_t seq, const float *__restrict__ point_src /* optional: [n][dim] new points */,
+                                                      float *__restrict__ rows_w, uint32_t n_batch, uint32_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t cap = gstride + 1;                       // a list holds at most gstride entries before the append
     uint32_t *lst = reinterpret_cast<uint32_t *>(smem);     // [cap]
     float *dst = reinterpret_cast<float *>(lst + cap);      // [cap]
     uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
+    float *ql = reinterpret_cast<float *>(srt + cap);       // [dim] (only with point_src)
+    // A BATCH is n_batch inserts executed one after the other by this one wave (insert i + 1 sees the lists insert i left:
+    // the same result as n_batch separate calls, without their launches).  The lists are re-read through L2 (agent-scope
+    // loads) because this CU's vector L1 may still hold what an earlier iteration read.
+    auto ld_u32 = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (uint32_t b = 0; b < n_batch; ++b) {
+    const uint32_t owner = first_owner + b;
+    InsertL0Out *out = reinterpret_cast<InsertL0Out *>(out_base + (size_t)b * out_stride);
     uint32_t *out_ep_list = reinterpret_cast<uint32_t *>(out + 1);
     uint32_t *out_owner_list = out_ep_list + gstride;
     const float *q = rows + (size_t)owner * ld;
     if (point_src) {  // Node.init's copy (:24-26) done here: the point goes to its row AND to LDS, which the walks below read
-        float *ql = reinterpret_cast<float *>(srt + cap);
         for (uint32_t i = lane; i < dim; i += kWave) {
-            const float v = point_src[i];
+            const float v = point_src[(size_t)b * dim + i];
             rows_w[(size_t)owner * ld + i] = v;
             ql[i] = v;
         }
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ 
     bool changed = true;
     while (changed) {  // :90-104 (same scan as k_greedy_layer0)
         changed = false;
-        const uint32_t dg = deg[ep];
+        const uint32_t dg = min(ld_u32(deg + ep), gstride);
         float best_d = cur;
         uint32_t best_j = 0xFFFFFFFFu, best_id = ep;
         for (uint32_t base = 0; base < dg; base += kWave) {
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ 
             uint32_t nb = 0;
             const bool act = j < dg;
             if (act) {
-                nb = adj[(size_t)ep * gstride + j];
+                nb = ld_u32(adj + (size_t)ep * gstride + j);
                 d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
             }
             float md = act ? d : __builtin_inff();
@@ -216,13 +223,13 @@ __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ 
     // connect(owner, ep, 0): lists are read before either is written (the two nodes differ)
     uint32_t err = 0;
     auto link = [&](uint32_t node, uint32_t other, uint32_t *out_list) -> uint32_t {
-        const uint32_t n0 = min(deg[node], gstride);
-        for (uint32_t i = lane; i < n0; i += kWave) lst[i] = adj[(size_t)node * gstride + i];
+        const uint32_t n0 = min(ld_u32(deg + node), gstride);
+        for (uint32_t i = lane; i < n0; i += kWave) lst[i] = ld_u32(adj + (size_t)node * gstride + i);
         if (lane == 0) lst[n0] = other;                      // :128-133 append
         uint32_t n = n0 + 1;
         __syncthreads();
         if (n > m) {                                          // :146 shrink
-            const float *o = rows + (size_t)node * ld;
+            const float *o = (node == owner) ? q : rows + (size_t)node * ld;
             for (uint32_t i = lane; i < n; i += kWave) dst[i] = exact_dist_rt(metric, o, rows + (size_t)lst[i] * ld, dim);  // :160-161
             __syncthreads();
             for (uint32_t i = lane; i < n; i += kWave) {
@@ -258,9 +265,15 @@ __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ 
         out->evals = evals;
         out->error = err;
     }
-    __threadfence_system();  // `out` is host-mapped memory: everything above is visible to the host before the sequence number
+    __threadfence();  // the row and both lists are in L2 before the next insert of the batch (or anybody else) reads them
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();  // `out` may be host-mapped memory: everything above is visible to the host before the sequence number
+    __syncthreads();
+    if (lane == 0) {
+        InsertL0Out *last = reinterpret_cast<InsertL0Out *>(out_base + (size_t)(n_batch - 1) * out_stride);
+        __hip_atomic_store(&last->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_copy_row(const float *__restrict__ src, float *__restrict__ dst, uint32_t dim) {
@@ -287,15 +300,16 @@ int launch_publish(unsigned long long *dst, const unsigned long long *src, uint3
     return ZVDB_OK;
 }
 
-size_t insert_l0_out_bytes(const zvdb_hip_index *h) { return sizeof(InsertL0Out) + 2ull * h->gstride * sizeof(uint32_t); }
+size_t insert_l0_out_bytes(const zvdb_hip_index *h) { return round_up64(sizeof(InsertL0Out) + 2ull * h->gstride * sizeof(uint32_t), 8); }
 
 int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
-                         hipStream_t s) {
+                         hipStream_t s, uint32_t n_batch, uint32_t out_stride) {
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     const size_t lds = 3ull * (h->gstride + 1) * sizeof(uint32_t) + (point_src ? (size_t)h->dim * sizeof(float) : 0);
     if (lds > 48 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_layer0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_insert_layer0, dim3(1), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj, h->deg, h->gstride,
-                       h->m, owner, ep, static_cast<InsertL0Out *>(d_out), seq, point_src, h->rows);
+                       h->m, owner, ep, static_cast<unsigned char *>(d_out), seq, point_src, h->rows, n_batch,
+                       out_stride ? out_stride : (uint32_t)insert_l0_out_bytes(h));
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

@@ -61,6 +61,17 @@ class HNSW:
         self._check(self._L.zvdb_host_hnsw_insert(self._p, p.ctypes.data_as(C.POINTER(C.c_float)), p.size,
                                                   _level))
 
+    def insert_many(self, points, levels=None) -> None:
+        """n inserts with the result of n insert() calls in this order; the layer-0 work of a chunk is one device launch
+        (zvdb_hip_insert_batch_layer0).  Extension: the reference inserts one point per call."""
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        if pts.ndim != 2:
+            raise ValueError("points must be [n][dim]")
+        lv = None if levels is None else np.ascontiguousarray(levels, dtype=np.int32)
+        self._check(self._L.zvdb_host_hnsw_insert_many(
+            self._p, pts.ctypes.data_as(C.POINTER(C.c_float)), pts.shape[0], pts.shape[1],
+            None if lv is None else lv.ctypes.data_as(C.POINTER(C.c_int))))
+
     def search(self, query, k: int) -> List[Node]:
         q = np.ascontiguousarray(query, dtype=np.float32).reshape(-1)
         ids = np.zeros(max(k, 1), dtype=np.uint64)

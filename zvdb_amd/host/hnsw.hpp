@@ -103,6 +103,39 @@ class HNSW<float> {
     // insert -- hnsw.zig:73-117
     void insert(const float *point, size_t len) {
         std::lock_guard<std::mutex> g(mu_);                                   // :74-75
+        insert_locked(point, len);
+    }
+
+    // n inserts, same result as n insert() calls in this order (extension: the reference has no bulk call).  The layer-0
+    // work of a whole chunk runs inside ONE device launch (zvdb_hip_insert_batch_layer0); the host bookkeeping (levels, the
+    // layer-0 lists the device settled on, the upper layers) follows in the same order.  levels: optional forced levels.
+    void insert_many(const float *points, size_t n, size_t len, const int *levels = nullptr) {
+        std::lock_guard<std::mutex> g(mu_);
+        size_t i = 0;
+        if (n && !entry_point) {  // the first node of an index has nothing to scan or connect to
+            if (levels) forced_level_ = levels[0];
+            insert_locked(points, len);
+            i = 1;
+        }
+        if (i < n && len != dim_) throw Panic("Mismatched dimensions in distance calculation");
+        const size_t chunk_max = 8192;
+        while (i < n) {
+            const size_t nc = std::min(chunk_max, n - i);
+            b_ep_.resize(nc); b_dist_.resize(nc); b_lists_.resize(nc * (m ? m : 1)); b_epn_.resize(nc); b_on_.resize(nc);
+            uint64_t first = 0;
+            check(zvdb_hip_insert_batch_layer0(h_, points + i * len, (uint32_t)len, nc, *entry_point, &first, b_ep_.data(),
+                                               b_dist_.data(), b_lists_.data(), b_epn_.data(), b_on_.data()));
+            if (first != points_.size()) throw Error(ZVDB_ERR_INVALID, "device id out of step with host id");
+            for (size_t j = 0; j < nc; ++j) {
+                const size_t level = levels ? (size_t)levels[i + j] : random_level();
+                adopt(points + (i + j) * len, len, level, b_ep_[j], b_dist_[j], b_lists_.data() + j * m, b_epn_[j], b_on_[j]);
+            }
+            i += nc;
+        }
+    }
+
+  private:
+    void insert_locked(const float *point, size_t len) {
         if (!h_) create_device_index(len);
         if (len != dim_) throw Panic("Mismatched dimensions in distance calculation");
         const size_t id = points_.size();                                      // :77
@@ -118,6 +151,15 @@ class HNSW<float> {
         check(zvdb_hip_insert_layer0(h_, point, (uint32_t)len, ep, &dev_id, &ep, &curr_dist, ids_.data(), &ep_n, &owner_n,
                                      nullptr));
         if (dev_id != id) throw Error(ZVDB_ERR_INVALID, "device id out of step with host id");
+        l0_.assign(ids_.begin(), ids_.begin() + ep_n);
+        adopt(point, len, level, ep, curr_dist, l0_.data(), ep_n, owner_n);
+    }
+
+    // host bookkeeping of one insert whose layer-0 work the device has done: the owned copy of the point, the node's
+    // lists, the layer-0 lists the device settled on, then the upper layers (hnsw.zig:88-108 for layer >= 1) and :110-116
+    void adopt(const float *point, size_t len, size_t level, uint64_t ep, float curr_dist, const uint64_t *ep_list,
+               uint32_t ep_n, uint32_t owner_n) {
+        const size_t id = points_.size();
         std::unique_ptr<float[]> owned(new float[len ? len : 1]);
         std::memcpy(owned.get(), point, len * sizeof(float));
         points_.push_back(std::move(owned));                                   // :82
@@ -128,7 +170,7 @@ class HNSW<float> {
                 if (layer == 0) {
                     // host mirror of what the device did: id's list = [ep] (shrunk to m), ep's list as returned
                     conns_[id][0].assign(owner_n ? 1 : 0, (size_t)ep);
-                    conns_[(size_t)ep][0].assign(ids_.begin(), ids_.begin() + ep_n);
+                    conns_[(size_t)ep][0].assign(ep_list, ep_list + ep_n);
                     continue;
                 } else {
                     bool changed = true;
@@ -158,6 +200,8 @@ class HNSW<float> {
         }
         if (level > max_level) max_level = level;                              // :114-116
     }
+
+  public:
     void insert(const std::vector<float> &p) { insert(p.data(), p.size()); }
 
     // search -- hnsw.zig:194-236.  Caller owns the returned vector (the reference returns a
@@ -266,7 +310,9 @@ class HNSW<float> {
     std::mt19937_64 rng_;
     std::vector<std::unique_ptr<float[]>> points_;           // Node.point (host copy: results alias it)
     std::vector<std::vector<std::vector<size_t>>> conns_;    // Node.connections
-    std::vector<uint64_t> ids_, out_ids_;
+    std::vector<uint64_t> ids_, out_ids_, l0_, b_ep_, b_lists_;
+    std::vector<uint32_t> b_epn_, b_on_;
+    std::vector<float> b_dist_;
     std::vector<float> dist_, out_dist_, last_dist_;
     zvdb_hip_search_stats last_stats_{};
 };

@@ -49,6 +49,10 @@ int zvdb_host_hnsw_insert(void *p, const float *point, size_t len, int level) {
     });
 }
 
+int zvdb_host_hnsw_insert_many(void *p, const float *points, size_t n, size_t len, const int *levels) {
+    return guard([&] { static_cast<H *>(p)->insert_many(points, n, len, levels); });
+}
+
 int zvdb_host_hnsw_search(void *p, const float *query, size_t len, size_t k, uint64_t *out_ids,
                           float *out_dist, size_t *out_n, uint64_t *out_evals, uint64_t *out_pops) {
     return guard([&] {
