@@ -170,6 +170,18 @@ int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, 
 int zvdb_hip_insert_batch_layer0(zvdb_hip_index *h, const float *points, uint32_t dim, uint64_t n, uint64_t entry,
                                  uint64_t *out_first_id, uint64_t *out_ep, float *out_ep_dist, uint64_t *out_ep_lists,
                                  uint32_t *out_ep_n, uint32_t *out_owner_n);
+/* The WHOLE of insert (hnsw.zig:73-117), every layer, for n points per call: the device holds each node's level and all
+ * of its lists, and one launch per chunk of 8,192 points runs the inserts one after the other -- append the point, then
+ * per layer 0..max_level the greedy scan (:90-104) and, up to the point's own level, connect (:106-108) with both
+ * shrinkConnections -- each insert seeing what its predecessors left: the graph of n reference inserts in this order.
+ * levels[i] = the level randomLevel() (:172-180) drew for point i (the caller draws it: the binding owns the RNG).
+ * The entry point is the first node (:84, :111).  For the host mirror: out_nrec[i] records for point i, one per layer
+ * 0..min(level, max_level before it), each 4 + m words {ep, owner_n, ep_n, ep_has_layer, ep's list after the connect}:
+ * connections[layer] of the new node becomes [ep] (empty if owner_n == 0), and, if ep_has_layer, that of ep becomes the
+ * list.  recs_cap (in records) >= sum(levels[i] + 1).  An index fed through this call must be fed ONLY through it
+ * (the step-by-step calls above keep upper layers on the host).  Plain fp32 L2 rows, m <= graph_stride. */
+int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, uint64_t n, const uint32_t *levels,
+                          uint64_t *out_first_id, uint32_t *out_nrec, uint32_t *out_recs, uint64_t recs_cap);
 int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, float *ep_dist,
                            uint64_t *out_evals);
 

@@ -328,3 +328,32 @@ def test_insert_many_equals_sequential_inserts(zv, oracle, n, d, m, ties):
         ri, rd = ref.search(q, 10)
         gi, gd = got.search_ids(q, 10)
         assert np.array_equal(ri, gi) and np.array_equal(rd, gd)
+
+
+def test_step_by_step_binding_still_bit_exact(oracle):
+    """ZVDB_HOST_INSERT=steps: the host mirror drives the insert the way INTEGRATION.md's Zig binding does (layer 0 fused on
+    the device through zvdb_hip_insert_layer0 / _batch_layer0, upper layers a host loop over zvdb_hip_distances_from) --
+    the same graphs as the whole-insert-on-device default, i.e. the oracle's."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, oracle, zvdb_amd as zv\n"
+        "n, d, m = 1200, 16, 4\n"
+        "V = oracle.uniform_rows(5, 0, n, d)\n"
+        "ref = oracle.HNSW(m, 200, level_seed=9)\n"
+        "for r in V: ref.insert(r)\n"
+        "lv = np.array([ref.node_level(i) for i in range(n)], dtype=np.int32)\n"
+        "a = zv.HNSW(m, 200)\n"
+        "for i in range(400): a.insert(V[i], _level=int(lv[i]))\n"
+        "a.insert_many(V[400:], lv[400:])\n"
+        "for i in range(n):\n"
+        "    for layer in range(ref.node_level(i) + 1):\n"
+        "        assert np.array_equal(ref.neighbors(i, layer), a.connections(i, layer)), (i, layer)\n"
+        "    assert np.array_equal(a.index.get_neighbors(i), ref.neighbors(i, 0))\n"
+        "for q in V[:8] + np.float32(0.5):\n"
+        "    ri, rd = ref.search(q, 10); gi, gd = a.search_ids(q, 10)\n"
+        "    assert np.array_equal(ri, gi) and np.array_equal(rd, gd)\n"
+        "print('steps ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZVDB_HOST_INSERT="steps"), cwd=root,
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "steps ok" in out.stdout, out.stdout + out.stderr

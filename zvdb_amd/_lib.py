@@ -50,6 +50,7 @@ HIP_SYMBOLS = [
     ("zvdb_hip_distances", _i32, [_vp, _f32p, _u32, _u64p, _u32, _f32p]),
     ("zvdb_hip_distances_from", _i32, [_vp, _u64, _u64p, _u32, _f32p]),
     ("zvdb_hip_greedy_layer0", _i32, [_vp, _u64, _u64p, _f32p, _u64p]),
+    ("zvdb_hip_insert_batch", _i32, [_vp, _f32p, _u32, _u64, _u32p, _u64p, _u32p, _u32p, _u64]),
     ("zvdb_hip_insert_batch_layer0", _i32, [_vp, _f32p, _u32, _u64, _u64, _u64p, _u64p, _f32p, _u64p, _u32p, _u32p]),
     ("zvdb_hip_insert_layer0", _i32, [_vp, _f32p, _u32, _u64, _u64p, _u64p, _f32p, _u64p, _u32p, _u32p, _u64p]),
     ("zvdb_hip_search_graph", _i32, [_vp, _f32p, _u32, _u32, _u32, _u32, _u64, _u64p, _f32p, _u32p,

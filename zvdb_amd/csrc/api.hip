@@ -83,7 +83,19 @@ int ensure_capacity(zvdb_hip_index *h, uint64_t want) {
     }
     ZV_CHECK(regrow(&h->adj, h->count * h->gstride, ncap * h->gstride, h->stream));
     ZV_CHECK(regrow(&h->deg, h->count, ncap, h->stream));
+    ZV_CHECK(regrow(&h->lvl, h->count, ncap, h->stream));
+    ZV_CHECK(regrow(&h->slot, h->count, ncap, h->stream));
     h->cap = ncap;
+    return ZVDB_OK;
+}
+
+// upper-layer lists (one slot per (node, layer >= 1)); new slots are zeroed (empty lists)
+static int ensure_upper(zvdb_hip_index *h, uint64_t want) {
+    if (want <= h->up_cap) return ZVDB_OK;
+    const uint64_t ncap = std::max<uint64_t>({want, h->up_cap * 2, 1024});
+    ZV_CHECK(regrow(&h->adj_up, h->up_count * h->gstride, ncap * h->gstride, h->stream));
+    ZV_CHECK(regrow(&h->deg_up, h->up_count, ncap, h->stream));
+    h->up_cap = ncap;
     return ZVDB_OK;
 }
 
@@ -226,6 +238,10 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->norm_h);
     (void)hipFree(h->adj);
     (void)hipFree(h->deg);
+    (void)hipFree(h->lvl);
+    (void)hipFree(h->slot);
+    (void)hipFree(h->adj_up);
+    (void)hipFree(h->deg_up);
     (void)hipFree(h->scratch);
     (void)hipFree(h->rows_q);
     (void)hipFree(h->norm_q);
@@ -663,6 +679,116 @@ int zvdb_hip_insert_batch_layer0(zvdb_hip_index *h, const float *points, uint32_
                                         out_ep_n + i, &on, nullptr));
         if (i == 0 && out_first_id) *out_first_id = id;
         if (out_owner_n) out_owner_n[i] = on;
+    }
+    return ZVDB_OK;
+}
+
+// The whole of insert (hnsw.zig:73-117), every layer, for n points in one launch per chunk: see k_insert_full.
+int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, uint64_t n, const uint32_t *levels,
+                          uint64_t *out_first_id, uint32_t *out_nrec, uint32_t *out_recs, uint64_t recs_cap) {
+    ZV_ARG(h && (points || n == 0) && (levels || n == 0) && out_nrec && out_recs, "null argument");
+    if (n == 0) return ZVDB_OK;
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(set_dim(h, dim));
+    if (h->metric != ZVDB_METRIC_L2SQ || (h->flags & ZVDB_FLAG_BF16_ROWS) || (size_t)dim * 4 > 96 * 1024 || h->m > h->gstride) {
+        set_error("zvdb_hip_insert_batch serves plain fp32 L2 rows with m <= graph_stride (the reference's case)");
+        return ZVDB_ERR_UNSUPPORTED;
+    }
+    for (uint64_t i = 0; i < n; ++i) ZV_ARG(levels[i] <= 31, "level above the reference's cap of 31 (hnsw.zig:177)");
+    if (out_first_id) *out_first_id = h->count;
+    const uint32_t m = h->m, rw = 4 + h->gstride, ow = 4 + m;
+    uint64_t done = 0, rec_out = 0;
+    if (h->count == 0) {  // the first node: nothing to scan or connect to (:110-112)
+        ZV_CHECK(ensure_capacity(h, 1));
+        ZV_CHECK(ensure_upper(h, levels[0]));
+        ZV_CHECK(ensure_pin(h, (size_t)dim * 4 + 64));
+        std::memcpy(h->pin.ptr, points, (size_t)dim * 4);
+        uint32_t *w = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(h->pin.ptr) + round_up64((size_t)dim * 4, 8));
+        w[0] = levels[0];
+        w[1] = 0;
+        ZV_HIP(hipMemcpyAsync(h->rows, h->pin.ptr, (size_t)dim * 4, hipMemcpyHostToDevice, h->stream));
+        ZV_HIP(hipMemcpyAsync(h->lvl, w, 4, hipMemcpyHostToDevice, h->stream));
+        ZV_HIP(hipMemcpyAsync(h->slot, w + 1, 4, hipMemcpyHostToDevice, h->stream));
+        ZV_CHECK(finish_rows(h, 0, 1, h->stream));
+        ZV_HIP(hipStreamSynchronize(h->stream));
+        h->count = 1;
+        h->max_level = levels[0];
+        h->up_count = levels[0];
+        out_nrec[0] = 0;
+        done = 1;
+    }
+    const uint64_t chunk_max = 8192;
+    while (done < n) {
+        const uint64_t nc = std::min<uint64_t>(chunk_max, n - done);
+        // host-side schedule of the chunk: slots, record offsets, max_level before each insert
+        std::vector<InsertParam> prm(nc);
+        uint64_t up = h->up_count, totrec = 0;
+        uint32_t maxlev = h->max_level;
+        for (uint64_t b = 0; b < nc; ++b) {
+            const uint32_t level = levels[done + b];
+            prm[b] = {level, (uint32_t)up, (uint32_t)totrec, maxlev};
+            up += level;
+            totrec += std::min(level, maxlev) + 1;
+            maxlev = std::max(maxlev, level);
+        }
+        if (rec_out + totrec > recs_cap) {
+            set_error("record buffer too small: need %llu records", (unsigned long long)(rec_out + totrec));
+            return ZVDB_ERR_INVALID;
+        }
+        ZV_CHECK(ensure_capacity(h, h->count + nc));
+        ZV_CHECK(ensure_upper(h, up));
+        const size_t pb = round_up64(nc * dim * sizeof(float), 256), qb = round_up64(nc * sizeof(InsertParam), 256),
+                     rb = round_up64(totrec * rw * 4, 256);
+        const uint64_t id0 = h->count;
+        const unsigned char *res = nullptr;
+        if (nc <= 4) {  // a call or two per point: everything through host-mapped memory, completion polled
+            ZV_CHECK(ensure_ins_block(h, pb + qb + rb + 64));
+            unsigned char *hb = static_cast<unsigned char *>(h->ins_host), *db = static_cast<unsigned char *>(h->ins_dev);
+            std::memcpy(hb, points + done * dim, nc * dim * sizeof(float));
+            std::memcpy(hb + pb, prm.data(), nc * sizeof(InsertParam));
+            const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;
+            volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(hb + pb + qb + rb);
+            *flag = 0;
+            ZV_CHECK(launch_insert_full(h, (uint32_t)id0, (uint32_t)nc, reinterpret_cast<const float *>(db),
+                                        reinterpret_cast<const InsertParam *>(db + pb), reinterpret_cast<uint32_t *>(db + pb + qb),
+                                        reinterpret_cast<uint32_t *>(db + pb + qb + rb), seq, h->stream));
+            ZV_CHECK(finish_rows(h, id0, nc, h->stream));
+            h->own_stream_busy = true;
+            for (int spin = 0; spin < 40000 && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) __builtin_ia32_pause();
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) ZV_HIP(hipStreamSynchronize(h->stream));
+            res = hb + pb + qb;
+        } else {
+            ZV_CHECK(ensure_pin(h, pb + qb + rb));
+            ZV_CHECK(ensure_scratch(h, pb + qb + rb));
+            unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr), *scr = static_cast<unsigned char *>(h->scratch);
+            std::memcpy(pin, points + done * dim, nc * dim * sizeof(float));
+            std::memcpy(pin + pb, prm.data(), nc * sizeof(InsertParam));
+            ZV_HIP(hipMemcpyAsync(scr, pin, pb + qb, hipMemcpyHostToDevice, h->stream));
+            ZV_CHECK(launch_insert_full(h, (uint32_t)id0, (uint32_t)nc, reinterpret_cast<const float *>(scr),
+                                        reinterpret_cast<const InsertParam *>(scr + pb), reinterpret_cast<uint32_t *>(scr + pb + qb),
+                                        nullptr, 0u, h->stream));
+            ZV_CHECK(finish_rows(h, id0, nc, h->stream));
+            ZV_HIP(hipMemcpyAsync(pin + pb + qb, scr + pb + qb, totrec * rw * 4, hipMemcpyDeviceToHost, h->stream));
+            ZV_HIP(hipStreamSynchronize(h->stream));
+            res = pin + pb + qb;
+        }
+        h->count += nc;
+        h->up_count = up;
+        h->max_level = maxlev;
+        const uint32_t *rr = reinterpret_cast<const uint32_t *>(res);
+        for (uint64_t b = 0; b < nc; ++b) {
+            const uint32_t nrec = std::min(prm[b].level, prm[b].maxlev_pre) + 1;
+            out_nrec[done + b] = nrec;
+            for (uint32_t l = 0; l < nrec; ++l) {
+                const uint32_t *src = rr + (size_t)(prm[b].rec_off + l) * rw;
+                uint32_t *dstp = out_recs + (rec_out + prm[b].rec_off + l) * ow;
+                dstp[0] = src[0]; dstp[1] = src[1]; dstp[2] = src[2]; dstp[3] = src[3];
+                for (uint32_t j = 0; j < std::min(src[2], m); ++j) dstp[4 + j] = src[4 + j];
+            }
+        }
+        rec_out += totrec;
+        done += nc;
     }
     return ZVDB_OK;
 }

@@ -109,6 +109,12 @@ struct zvdb_hip_index {
     float *norm_h = nullptr;
     uint32_t *adj = nullptr;
     uint32_t *deg = nullptr;
+    // EVERY layer on the device (zvdb_hip_insert_batch): each node's level and first upper-layer list slot, and the
+    // upper-layer lists themselves -- node's layer L >= 1 list is row slot[node] + L - 1 of adj_up [up_cap][gstride]
+    uint32_t *lvl = nullptr, *slot = nullptr;       // [cap]
+    uint32_t *adj_up = nullptr, *deg_up = nullptr;  // [up_cap][gstride], [up_cap]
+    uint64_t up_cap = 0, up_count = 0;
+    uint32_t max_level = 0;  // over the nodes inserted through zvdb_hip_insert_batch
     // int8 scalar-quantised mirror for ZVDB_BF_I8 (lazy; rebuilt when rows were added)
     int8_t *rows_q = nullptr;   // [cap_q][ldq], ldq = round_up(dim, 128)
     int32_t *norm_q = nullptr;  // [cap_q] sum q^2
@@ -179,6 +185,10 @@ struct InsertL0Out {
     // followed by uint32_t ep_list[gstride], owner_list[gstride]
 };
 size_t insert_l0_out_bytes(const zvdb_hip_index *h);
+// k_insert_full: per-insert parameters (host-computed) and per-(insert, layer) result records of 4 + gstride words
+struct InsertParam { uint32_t level, slot, rec_off, maxlev_pre; };
+int launch_insert_full(const zvdb_hip_index *h, uint32_t first_owner, uint32_t n, const float *points, const InsertParam *params,
+                       uint32_t *recs, uint32_t *seq_dst, uint32_t seq, hipStream_t s);
 int launch_copy_row(const float *src, float *dst, uint32_t dim, hipStream_t s);
 // dst[0..n) <- src[0..n) (64-bit words), then *seq_dst = seq at system scope: publishes a result block to a polling host
 int launch_publish(unsigned long long *dst, const unsigned long long *src, uint32_t n, uint32_t *seq_dst, uint32_t seq, hipStream_t s);

@@ -276,6 +276,158 @@ __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ 
     }
 }
 
+// ---- the whole insert, every layer, n inserts per launch (hnsw.zig:73-117) -----------------------------------------
+// As k_insert_layer0, with the upper layers on the device too: per layer 0..max_level (ascending, :88) the greedy scan
+// over connections[layer] of the current node (:90-104; a node has the layer iff its level reaches it, :93) and, while
+// layer <= the new node's level, connect (:106-108) with both shrinks.  Per (insert, layer <= min(level, max_level)) one
+// record {ep, owner_n, ep_n, ep_has_layer, ep's list} tells the host mirror what to adopt.  Parameters per insert are
+// computed by the host (level, first upper-layer slot, record offset, max_level before the insert).
+__global__ __launch_bounds__(64) void k_insert_full(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+                                                    uint32_t *adj, uint32_t *deg, uint32_t *adj_up, uint32_t *deg_up,
+                                                    uint32_t *lvl, uint32_t *slot, uint32_t gstride, uint32_t m,
+                                                    uint32_t first_owner, uint32_t n_batch, const float *__restrict__ points,
+                                                    const InsertParam *__restrict__ params, float *__restrict__ rows_w,
+                                                    uint32_t *__restrict__ recs, uint32_t *seq_dst, uint32_t seq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t cap = gstride + 1;
+    uint32_t *lst = reinterpret_cast<uint32_t *>(smem);       // [cap]
+    float *dst = reinterpret_cast<float *>(lst + cap);        // [cap]
+    uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
+    float *q = reinterpret_cast<float *>(srt + cap);          // [dim]
+    const uint32_t rec_words = 4 + gstride;
+    auto ld_u32 = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    for (uint32_t b = 0; b < n_batch; ++b) {
+        const uint32_t owner = first_owner + b;
+        const uint32_t level = params[b].level, my_slot = params[b].slot, rec0 = params[b].rec_off, maxlev = params[b].maxlev_pre;
+        if (lane == 0) { lvl[owner] = level; slot[owner] = my_slot; }
+        for (uint32_t i = lane; i < dim; i += kWave) {  // Node.init's copy (:24-26): to the row and to LDS
+            const float v = points[(size_t)b * dim + i];
+            rows_w[(size_t)owner * ld + i] = v;
+            q[i] = v;
+        }
+        __syncthreads();
+        // list of `node` at `layer` (nullptr: the node does not reach the layer)
+        // (the level / slot of the current ep are kept in registers: most upper layers of most inserts are empty, and
+        // asking memory for lvl[ep] once per layer would cost more than the layers' work)
+        uint32_t ep_cached = 0xFFFFFFFFu, ep_lvl = 0, ep_slot = 0;
+        auto list_of = [&](uint32_t node, uint32_t layer, uint32_t *&dg) -> uint32_t * {
+            if (layer == 0) { dg = deg + node; return adj + (size_t)node * gstride; }
+            uint32_t nl, ns;
+            if (node == owner) { nl = level; ns = my_slot; }
+            else {
+                if (node != ep_cached) { ep_cached = node; ep_lvl = ld_u32(lvl + node); ep_slot = ep_lvl ? ld_u32(slot + node) : 0u; }
+                nl = ep_lvl; ns = ep_slot;
+            }
+            if (nl < layer) return nullptr;
+            const uint32_t sl = ns + layer - 1;
+            dg = deg_up + sl;
+            return adj_up + (size_t)sl * gstride;
+        };
+        uint32_t ep = 0;  // the entry point is the first node, always (hnsw.zig:84, :111)
+        float cur = 0.0f;
+        if (lane == 0) cur = exact_dist_rt(metric, q, rows + (size_t)ep * ld, dim);  // :86
+        cur = __shfl(cur, 0);
+        for (uint32_t layer = 0; layer <= maxlev; ++layer) {  // :88
+            bool changed = true;
+            while (changed) {  // :90-104
+                changed = false;
+                uint32_t *dgp = nullptr;
+                const uint32_t *al = list_of(ep, layer, dgp);
+                if (!al) break;
+                const uint32_t dg = min(ld_u32(dgp), gstride);
+                float best_d = cur;
+                uint32_t best_j = 0xFFFFFFFFu, best_id = ep;
+                for (uint32_t base = 0; base < dg; base += kWave) {
+                    const uint32_t j = base + lane;
+                    float d = 0.0f;
+                    uint32_t nb = 0;
+                    const bool act = j < dg;
+                    if (act) {
+                        nb = ld_u32(al + j);
+                        d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
+                    }
+                    float md = act ? d : __builtin_inff();
+                    uint32_t mj = act ? j : 0xFFFFFFFFu, mid = nb;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const float od = __shfl_xor(md, off);
+                        const uint32_t oj = __shfl_xor(mj, off), oid = __shfl_xor(mid, off);
+                        if (od < md || (od == md && oj < mj)) { md = od; mj = oj; mid = oid; }
+                    }
+                    if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
+                }
+                if (best_j != 0xFFFFFFFFu) { ep = best_id; cur = best_d; changed = true; }
+            }
+            if (layer > level) continue;  // :106 -- above the new node's level only the scan runs
+            uint32_t *rec = recs + (size_t)(rec0 + layer) * rec_words;
+            // connect(owner, ep, layer) :119-141
+            auto link = [&](uint32_t node, uint32_t other, uint32_t *out_list) -> uint32_t {
+                uint32_t *dgp = nullptr;
+                uint32_t *al = list_of(node, layer, dgp);
+                if (!al) return 0xFFFFFFFFu;                       // :128 / :131 the node lacks the layer
+                const uint32_t n0 = min(ld_u32(dgp), gstride);
+                for (uint32_t i = lane; i < n0; i += kWave) lst[i] = ld_u32(al + i);
+                if (lane == 0) lst[n0] = other;                    // append
+                uint32_t n = n0 + 1;
+                __syncthreads();
+                if (n > m) {                                        // shrinkConnections :143-170
+                    const float *o = (node == owner) ? q : rows + (size_t)node * ld;
+                    for (uint32_t i = lane; i < n; i += kWave) dst[i] = exact_dist_rt(metric, o, rows + (size_t)lst[i] * ld, dim);
+                    __syncthreads();
+                    for (uint32_t i = lane; i < n; i += kWave) {
+                        const float di = dst[i];
+                        uint32_t rank = 0;
+                        for (uint32_t j = 0; j < n; ++j) {
+                            const float dj = dst[j];
+                            rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+                        }
+                        srt[rank] = lst[i];
+                    }
+                    __syncthreads();
+                    n = m;
+                    for (uint32_t i = lane; i < n; i += kWave) lst[i] = srt[i];
+                    __syncthreads();
+                }
+                if (n > gstride) n = gstride;  // (m <= gstride is checked on the host)
+                for (uint32_t i = lane; i < n; i += kWave) {
+                    al[i] = lst[i];
+                    if (out_list) out_list[i] = lst[i];
+                }
+                if (lane == 0) *dgp = n;
+                __syncthreads();
+                return n;
+            };
+            const uint32_t owner_n = link(owner, ep, nullptr);
+            const uint32_t ep_n = link(ep, owner, rec + 4);
+            if (lane == 0) {
+                rec[0] = ep;
+                rec[1] = owner_n;
+                rec[2] = ep_n == 0xFFFFFFFFu ? 0u : ep_n;
+                rec[3] = ep_n == 0xFFFFFFFFu ? 0u : 1u;
+            }
+            __threadfence();  // both lists are in L2 before the next layer / insert reads them
+            __syncthreads();
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    __threadfence_system();  // recs may be host-mapped memory
+    __syncthreads();
+    if (lane == 0 && seq_dst) __hip_atomic_store(seq_dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int launch_insert_full(const zvdb_hip_index *h, uint32_t first_owner, uint32_t n, const float *points, const InsertParam *params,
+                       uint32_t *recs, uint32_t *seq_dst, uint32_t seq, hipStream_t s) {
+    const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
+    const size_t lds = 3ull * (h->gstride + 1) * sizeof(uint32_t) + (size_t)h->dim * sizeof(float);
+    if (lds > 48 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_insert_full, dim3(1), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj, h->deg, h->adj_up, h->deg_up,
+                       h->lvl, h->slot, h->gstride, h->m, first_owner, n, points, params, h->rows, recs, seq_dst, seq);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 __global__ __launch_bounds__(256) void k_copy_row(const float *__restrict__ src, float *__restrict__ dst, uint32_t dim) {
     for (uint32_t i = threadIdx.x; i < dim; i += 256) dst[i] = src[i];
 }

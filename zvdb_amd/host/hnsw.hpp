@@ -24,6 +24,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -111,6 +112,10 @@ class HNSW<float> {
     // layer-0 lists the device settled on, the upper layers) follows in the same order.  levels: optional forced levels.
     void insert_many(const float *points, size_t n, size_t len, const int *levels = nullptr) {
         std::lock_guard<std::mutex> g(mu_);
+        if (device_layers_) {
+            insert_full(points, n, len, levels);
+            return;
+        }
         size_t i = 0;
         if (n && !entry_point) {  // the first node of an index has nothing to scan or connect to
             if (levels) forced_level_ = levels[0];
@@ -134,8 +139,58 @@ class HNSW<float> {
         }
     }
 
+    // false: the step-by-step binding (layer 0 fused on the device, upper layers a host loop over distances_from);
+    // true (default; ZVDB_HOST_INSERT=steps selects the other): the whole insert on the device, zvdb_hip_insert_batch.
+    // Fixed at the first insert: an index is fed through one of the two only.
+    void use_device_layers(bool on) { if (!h_) device_layers_ = on; }
+
   private:
+    // the whole insert on the device: levels drawn here (the binding owns the RNG, hnsw.zig:172-180), one call for the n
+    // points, then the host mirror adopts, per point and layer, the lists the device settled on
+    void insert_full(const float *points, size_t n, size_t len, const int *levels) {
+        if (n == 0) return;
+        if (!h_) create_device_index(len);
+        if (len != dim_) throw Panic("Mismatched dimensions in distance calculation");
+        lv_.resize(n);
+        uint64_t total = 0;
+        for (size_t i = 0; i < n; ++i) {
+            size_t level = levels ? (size_t)levels[i] : random_level();
+            if (i == 0 && forced_level_ >= 0) level = (size_t)forced_level_;
+            lv_[i] = (uint32_t)level;
+            total += level + 1;
+        }
+        forced_level_ = -1;
+        const size_t rw = 4 + m;
+        nrec_.resize(n);
+        recs_.resize(total * rw);
+        uint64_t first = 0;
+        check(zvdb_hip_insert_batch(h_, points, (uint32_t)len, n, lv_.data(), &first, nrec_.data(), recs_.data(), total));
+        if (first != points_.size()) throw Error(ZVDB_ERR_INVALID, "device id out of step with host id");
+        const uint32_t *r = recs_.data();
+        for (size_t i = 0; i < n; ++i) {
+            const size_t id = points_.size(), level = lv_[i];                  // :77-78
+            std::unique_ptr<float[]> owned(new float[len ? len : 1]);
+            std::memcpy(owned.get(), points + i * len, len * sizeof(float));
+            points_.push_back(std::move(owned));                               // :82
+            conns_.emplace_back(level + 1);                                    // :19-23
+            if (entry_point) {                                                 // :84
+                for (uint32_t l = 0; l < nrec_[i]; ++l, r += rw) {             // layers 0..min(level, max_level) (:106)
+                    const size_t ep = r[0];
+                    conns_[id][l].assign(r[1] ? 1 : 0, ep);
+                    if (r[3]) conns_[ep][l].assign(r + 4, r + 4 + r[2]);
+                }
+            } else {
+                entry_point = id;                                              // :110-112
+            }
+            if (level > max_level) max_level = level;                          // :114-116
+        }
+    }
+
     void insert_locked(const float *point, size_t len) {
+        if (device_layers_) {
+            insert_full(point, 1, len, nullptr);
+            return;
+        }
         if (!h_) create_device_index(len);
         if (len != dim_) throw Panic("Mismatched dimensions in distance calculation");
         const size_t id = points_.size();                                      // :77
@@ -311,7 +366,8 @@ class HNSW<float> {
     std::vector<std::unique_ptr<float[]>> points_;           // Node.point (host copy: results alias it)
     std::vector<std::vector<std::vector<size_t>>> conns_;    // Node.connections
     std::vector<uint64_t> ids_, out_ids_, l0_, b_ep_, b_lists_;
-    std::vector<uint32_t> b_epn_, b_on_;
+    std::vector<uint32_t> b_epn_, b_on_, lv_, nrec_, recs_;
+    bool device_layers_ = [] { const char *e = std::getenv("ZVDB_HOST_INSERT"); return !(e && e[0] == 's'); }();
     std::vector<float> b_dist_;
     std::vector<float> dist_, out_dist_, last_dist_;
     zvdb_hip_search_stats last_stats_{};
