@@ -89,6 +89,15 @@ int ensure_capacity(zvdb_hip_index *h, uint64_t want) {
     return ZVDB_OK;
 }
 
+static int ensure_tie(zvdb_hip_index *h, uint64_t nq) {
+    if (nq <= h->tie_cap) return ZVDB_OK;
+    if (h->tie_buf) { ZV_HIP(hipDeviceSynchronize()); ZV_HIP(hipFree(h->tie_buf)); h->tie_buf = nullptr; h->tie_cap = 0; }
+    const uint64_t ncap = std::max<uint64_t>(nq, 4096);
+    ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->tie_buf), ncap * sizeof(uint32_t)));
+    h->tie_cap = ncap;
+    return ZVDB_OK;
+}
+
 // upper-layer lists (one slot per (node, layer >= 1)); new slots are zeroed (empty lists)
 static int ensure_upper(zvdb_hip_index *h, uint64_t want) {
     if (want <= h->up_cap) return ZVDB_OK;
@@ -242,6 +251,7 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->slot);
     (void)hipFree(h->adj_up);
     (void)hipFree(h->deg_up);
+    (void)hipFree(h->tie_buf);
     (void)hipFree(h->scratch);
     (void)hipFree(h->rows_q);
     (void)hipFree(h->norm_q);
@@ -827,13 +837,14 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
         return ZVDB_ERR_NODE_NOT_FOUND;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ef == 0) ZV_CHECK(ensure_tie(h, nq));
     timing_begin(h, s);
     int rc;
     if (ef == 0)
         rc = launch_search_compat(h, static_cast<const float *>(d_queries), nq, k, (uint32_t)entry,
                                   id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
                                   static_cast<uint32_t *>(d_count),
-                                  static_cast<unsigned long long *>(d_stats), s);
+                                  static_cast<unsigned long long *>(d_stats), s, h->tie_buf);
     else
         rc = launch_search_ef(h, static_cast<const float *>(d_queries), nq, k, ef, (uint32_t)entry,
                               id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
@@ -873,6 +884,7 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
             }
             ZV_CHECK(ensure_ins_block(h, total + 64));
             ZV_CHECK(ensure_scratch(h, 64));
+            ZV_CHECK(ensure_tie(h, 1));
             unsigned char *hb = static_cast<unsigned char *>(h->ins_host), *dbs = static_cast<unsigned char *>(h->ins_dev);
             std::memcpy(hb, queries, (size_t)dim * 4);
             const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;
@@ -882,7 +894,7 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
             ZV_CHECK(launch_search_compat(h, reinterpret_cast<const float *>(dbs), 1, k, (uint32_t)entry, 0,
                                           reinterpret_cast<uint64_t *>(dbs + qb), reinterpret_cast<float *>(dbs + qb + ib),
                                           reinterpret_cast<uint32_t *>(dbs + qb + ib + db),
-                                          static_cast<unsigned long long *>(h->scratch), h->stream));
+                                          static_cast<unsigned long long *>(h->scratch), h->stream, h->tie_buf));
             ZV_CHECK(launch_publish(reinterpret_cast<unsigned long long *>(dbs + qb + ib + db + cb),
                                     static_cast<const unsigned long long *>(h->scratch), 8,
                                     reinterpret_cast<uint32_t *>(dbs + total), seq, h->stream));
@@ -912,8 +924,9 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
         float *d_dist = reinterpret_cast<float *>(scr + qb + ib);
         uint32_t *d_cnt = reinterpret_cast<uint32_t *>(scr + qb + ib + db);
         unsigned long long *d_st = reinterpret_cast<unsigned long long *>(scr + qb + ib + db + cb);
+        if (ef == 0) ZV_CHECK(ensure_tie(h, nq));
         int rc = ef == 0 ? launch_search_compat(h, reinterpret_cast<float *>(scr), nq, k, (uint32_t)entry, 0,
-                                                d_ids, d_dist, d_cnt, d_st, h->stream)
+                                                d_ids, d_dist, d_cnt, d_st, h->stream, h->tie_buf)
                          : launch_search_ef(h, reinterpret_cast<float *>(scr), nq, k, ef, (uint32_t)entry,
                                             0, d_ids, d_dist, d_cnt, d_st, h->stream);
         ZV_CHECK(rc);

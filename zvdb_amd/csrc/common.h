@@ -115,6 +115,8 @@ struct zvdb_hip_index {
     uint32_t *adj_up = nullptr, *deg_up = nullptr;  // [up_cap][gstride], [up_cap]
     uint64_t up_cap = 0, up_count = 0;
     uint32_t max_level = 0;  // over the nodes inserted through zvdb_hip_insert_batch
+    uint32_t *tie_buf = nullptr;  // [tie_cap] per-query "equal minima" flags of k_search_compat_fast
+    uint64_t tie_cap = 0;
     // int8 scalar-quantised mirror for ZVDB_BF_I8 (lazy; rebuilt when rows were added)
     int8_t *rows_q = nullptr;   // [cap_q][ldq], ldq = round_up(dim, 128)
     int32_t *norm_q = nullptr;  // [cap_q] sum q^2
@@ -199,7 +201,7 @@ int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep
                          float *d_dist_io, unsigned long long *d_evals, hipStream_t s);
 int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                          uint32_t entry, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
-                         uint32_t *d_count, unsigned long long *d_stats, hipStream_t s);
+                         uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, uint32_t *d_tie = nullptr /* [nq] scratch: enables the unordered-frontier kernel */);
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
                      float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s);

@@ -568,7 +568,8 @@ __global__ __launch_bounds__(64) void k_search_compat(
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
     uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
     unsigned long long *__restrict__ stats, uint32_t dim_pad, uint32_t heap_cap, uint32_t hash_bits,
-    uint32_t rcap) {
+    uint32_t rcap, const uint32_t *__restrict__ gate /* optional: run only the queries the fast kernel gave up on */) {
+    if (gate && gate[blockIdx.x] == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *q = reinterpret_cast<float *>(smem);
     float *heap_d = q + dim_pad;
@@ -656,6 +657,135 @@ __global__ __launch_bounds__(64) void k_search_compat(
     }
 }
 
+// The same search with the frontier as an UNORDERED set: add = one LDS write per neighbour (all neighbours of a pop in
+// parallel), pop = wave arg-min.  A binary heap's remove-min returns THE minimum whenever it is unique, so the pop sequence,
+// the results and the evaluation counts are those of the PriorityQueue emulation above -- the heap's layout only decides
+// among EQUAL minima.  When the minimum is not unique at a pop, this kernel gives the query up (tie[qi] = 1) and the exact
+// emulation runs it instead (gated launch right behind this one): identical results either way, ~10x fewer dependent LDS
+// round trips in the common case.
+__global__ __launch_bounds__(64) void k_search_compat_fast(
+    const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
+    uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
+    uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
+    unsigned long long *__restrict__ stats, uint32_t dim_pad, uint32_t heap_cap, uint32_t hash_bits,
+    uint32_t rcap, uint32_t *__restrict__ tie) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);
+    float *fr_d = q + dim_pad;
+    uint32_t *fr_i = reinterpret_cast<uint32_t *>(fr_d + heap_cap);
+    uint32_t *hash = fr_i + heap_cap;
+    float *res_d = reinterpret_cast<float *>(hash + (1u << hash_bits));
+    uint32_t *res_i = reinterpret_cast<uint32_t *>(res_d + rcap);
+
+    const int lane = threadIdx.x;
+    const uint32_t qi = blockIdx.x;
+    const float *qg = queries + (size_t)qi * dim;
+    for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
+    for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
+    __syncthreads();
+
+    uint32_t nres = 0, n = 0;
+    unsigned long long evals = 0, pops = 0;
+    bool gave_up = false;
+    if (N > 0 && k > 0) {
+        float d0 = 0.0f;
+        if (lane == 0) {
+            d0 = exact_dist_rt(metric, q, rows + (size_t)entry * ld, dim);  // :208
+            fr_d[0] = d0;
+            fr_i[0] = entry;
+            hash_insert_atomic(hash, hash_bits, entry);                     // :209
+        }
+        n = 1;
+        evals = 1;
+        __syncthreads();
+        while (n > 0 && nres < k) {                                         // :211
+            // pop: the minimum and how many entries hold it
+            float bd = __builtin_inff();
+            uint32_t bp = 0xFFFFFFFFu;
+            for (uint32_t i = lane; i < n; i += kWave) {
+                const float d = fr_d[i];
+                if (d < bd || bp == 0xFFFFFFFFu) { bd = d; bp = i; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(bd, off);
+                const uint32_t op = __shfl_xor(bp, off);
+                if (op != 0xFFFFFFFFu && (bp == 0xFFFFFFFFu || od < bd || (od == bd && op < bp))) { bd = od; bp = op; }
+            }
+            uint32_t same = 0;
+            for (uint32_t i = lane; i < n; i += kWave) same += fr_d[i] == bd ? 1u : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) same += __shfl_xor(same, off);
+            if (same != 1) { gave_up = true; break; }  // equal minima (or a NaN): the heap's layout decides -> exact emulation
+            const uint32_t cid = fr_i[bp];
+            __syncthreads();
+            if (lane == 0) {
+                fr_d[bp] = fr_d[n - 1];
+                fr_i[bp] = fr_i[n - 1];
+                res_i[nres] = cid;                                          // :213-214
+                res_d[nres] = bd;
+            }
+            n -= 1;
+            nres += 1;
+            pops += 1;
+            __syncthreads();
+            const uint32_t dg = deg[cid];                                   // :216 layer 0
+            for (uint32_t base = 0; base < dg; base += kWave) {
+                const uint32_t j = base + lane;
+                bool fresh = false;
+                uint32_t nb = 0;
+                float d = 0.0f;
+                if (j < dg) {
+                    nb = adj[(size_t)cid * gstride + j];
+                    if (!hash_contains(hash, hash_bits, nb)) {              // :217
+                        d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);  // :219
+                        fresh = hash_insert_atomic(hash, hash_bits, nb);    // :221 (one owner per id)
+                    }
+                }
+                const unsigned long long fm = __ballot(fresh);
+                if (fresh) {
+                    const uint32_t pos = n + (uint32_t)__popcll(fm & ((1ull << lane) - 1));
+                    fr_d[pos] = d;                                          // :220
+                    fr_i[pos] = nb;
+                }
+                n += (uint32_t)__popcll(fm);
+                evals += (unsigned long long)__popcll(fm);
+                __syncthreads();
+            }
+        }
+    }
+    if (gave_up) {
+        if (lane == 0) tie[qi] = 1;
+        return;
+    }
+    if (lane == 0) tie[qi] = 0;
+    __syncthreads();
+    // stable sort by distance (hnsw.zig:227-233) by ranks: #{d_j < d_i} + #{j < i : d_j == d_i}
+    for (uint32_t i = lane; i < k; i += kWave) {
+        out_ids[(size_t)qi * k + i] = ~0ull;
+        out_dist[(size_t)qi * k + i] = __builtin_inff();
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < nres; i += kWave) {
+        const float di = res_d[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nres; ++j) {
+            const float dj = res_d[j];
+            rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+        }
+        out_ids[(size_t)qi * k + rank] = (uint64_t)res_i[i] + id_offset;
+        out_dist[(size_t)qi * k + rank] = di;
+    }
+    if (lane == 0) {
+        out_count[qi] = nres;
+        if (stats) {
+            atomicAdd(&stats[0], evals);
+            atomicAdd(&stats[1], pops);
+        }
+    }
+}
+
 static int set_dyn_lds(const void *fn, size_t bytes) {
     if (bytes > 160 * 1024) {
         set_error("per-query search state needs %zu B of LDS (> 160 KiB): k*m too large", bytes);
@@ -675,7 +805,7 @@ static uint32_t bits_for(uint64_t entries) {  // table with >= 2x entries, at le
 
 int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                          uint32_t entry, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
-                         uint32_t *d_count, unsigned long long *d_stats, hipStream_t s) {
+                         uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, uint32_t *d_tie) {
     if (nq == 0) return ZVDB_OK;
     const uint64_t N = h->count;
     const uint32_t rcap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(k, N));
@@ -686,9 +816,18 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
     const size_t lds = 4ull * (dim_pad + 2ull * heap_cap + (1ull << hash_bits) + 2ull * rcap + 2 * kWave);
     ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat), lds));
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
+    static const bool fast_off = [] { const char *e = getenv("ZVDB_COMPAT_SEARCH"); return e && e[0] == 'h'; }();  // "heap": emulation only
+    if (d_tie && !fast_off) {  // unordered-frontier kernel first; the exact emulation serves the queries it gave up on
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat_fast), lds));
+        hipLaunchKernelGGL(k_search_compat_fast, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric,
+                           h->adj, h->deg, h->gstride, (uint32_t)N, d_queries, k, entry, id_offset, d_ids,
+                           d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, d_tie);
+    } else {
+        d_tie = nullptr;
+    }
     hipLaunchKernelGGL(k_search_compat, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric,
                        h->adj, h->deg, h->gstride, (uint32_t)N, d_queries, k, entry, id_offset, d_ids,
-                       d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap);
+                       d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, d_tie);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }
