@@ -335,6 +335,9 @@ __global__ __launch_bounds__(64) void k_insert_full(const float *__restrict__ ro
                 uint32_t *dgp = nullptr;
                 const uint32_t *al = list_of(ep, layer, dgp);
                 if (!al) break;
+                // the degree and the first 64 list slots are requested TOGETHER (both depend on ep only): one memory round
+                // trip per hop instead of two before the rows can be fetched (slots past the degree hold stale or zero ids)
+                const uint32_t nb0 = (uint32_t)lane < gstride ? ld_u32(al + lane) : 0u;
                 const uint32_t dg = min(ld_u32(dgp), gstride);
                 float best_d = cur;
                 uint32_t best_j = 0xFFFFFFFFu, best_id = ep;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(64) void k_insert_full(const float *__restrict__ ro
                     uint32_t nb = 0;
                     const bool act = j < dg;
                     if (act) {
-                        nb = ld_u32(al + j);
+                        nb = base == 0 ? nb0 : ld_u32(al + j);
                         d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
                     }
                     float md = act ? d : __builtin_inff();
@@ -730,6 +733,8 @@ __global__ __launch_bounds__(64) void k_search_compat_fast(
             nres += 1;
             pops += 1;
             __syncthreads();
+            // (the degree and the first 64 list slots are requested together: both depend on cid only)
+            const uint32_t nb0 = (uint32_t)lane < gstride ? adj[(size_t)cid * gstride + lane] : 0u;
             const uint32_t dg = deg[cid];                                   // :216 layer 0
             for (uint32_t base = 0; base < dg; base += kWave) {
                 const uint32_t j = base + lane;
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(64) void k_search_compat_fast(
                 uint32_t nb = 0;
                 float d = 0.0f;
                 if (j < dg) {
-                    nb = adj[(size_t)cid * gstride + j];
+                    nb = base == 0 ? nb0 : adj[(size_t)cid * gstride + j];
                     if (!hash_contains(hash, hash_bits, nb)) {              // :217
                         d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);  // :219
                         fresh = hash_insert_atomic(hash, hash_bits, nb);    // :221 (one owner per id)
