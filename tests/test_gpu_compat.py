@@ -357,3 +357,30 @@ def test_step_by_step_binding_still_bit_exact(oracle):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZVDB_HOST_INSERT="steps"), cwd=root,
                          capture_output=True, text=True)
     assert out.returncode == 0 and "steps ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_heap_emulation_alone_equals_the_two_kernel_search(zv, oracle):
+    """ZVDB_COMPAT_SEARCH=heap (every query on the PriorityQueue emulation) returns what the default (unordered-frontier
+    kernel + gated emulation for equal minima) returns, on distinct AND on tie-heavy data, counters included."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, oracle, zvdb_amd as zv\n"
+        "rng = np.random.default_rng(3)\n"
+        "out = []\n"
+        "for ties in (False, True):\n"
+        "    V = rng.random((3000, 6), dtype=np.float32)\n"
+        "    if ties: V = np.floor(V * 3).astype(np.float32)\n"
+        "    h = zv.HNSW(8, 200)\n"
+        "    h.insert_many(V, np.zeros(len(V), dtype=np.int32))\n"
+        "    Q = V[:200] + np.float32(0.0 if ties else 0.01)\n"
+        "    ids, dist, cnt, (ev, pp) = h.index.search_graph(Q, 12, with_stats=True)\n"
+        "    out.append((ids, dist, cnt, ev, pp))\n"
+        "np.save('/tmp/zvdb_compat_' + ('heap' if __import__('os').environ.get('ZVDB_COMPAT_SEARCH') else 'fast') + '.npy',\n"
+        "        np.array([np.concatenate([o[0].ravel().astype(np.float64), o[1].ravel().astype(np.float64), o[2].ravel().astype(np.float64), [o[3], o[4]]]) for o in out]))\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({}, {"ZVDB_COMPAT_SEARCH": "heap"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    a, b = np.load("/tmp/zvdb_compat_fast.npy"), np.load("/tmp/zvdb_compat_heap.npy")
+    assert np.array_equal(a, b)
