@@ -631,25 +631,23 @@ __global__ __launch_bounds__(64) void k_search_compat(
             }
         }
         __syncthreads();
-        // stable insertion sort by distance (hnsw.zig:227-233); the comparator's recomputed
-        // distance is bit-identical to the stored one.
-        for (uint32_t i = 1; i < nres; ++i) {
-            uint32_t j = i;
-            while (j > 0) {
-                const float a = res_d[j], b = res_d[j - 1];
-                if (!(a < b)) break;
-                const uint32_t ia = res_i[j], ib = res_i[j - 1];
-                res_d[j] = b; res_d[j - 1] = a;
-                res_i[j] = ib; res_i[j - 1] = ia;
-                --j;
-            }
-        }
-        __syncthreads();
     }
+    // stable insertion sort by distance (hnsw.zig:227-233; the comparator's recomputed distance is bit-identical to the
+    // stored one), done by ranks -- #{d_j < d_i} + #{j < i : d_j == d_i} is the position a stable sort gives entry i
     for (uint32_t i = lane; i < k; i += kWave) {
-        const bool ok = i < nres;
-        out_ids[(size_t)qi * k + i] = ok ? (uint64_t)res_i[i] + id_offset : ~0ull;
-        out_dist[(size_t)qi * k + i] = ok ? res_d[i] : __builtin_inff();
+        out_ids[(size_t)qi * k + i] = ~0ull;
+        out_dist[(size_t)qi * k + i] = __builtin_inff();
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < nres; i += kWave) {
+        const float di = res_d[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nres; ++j) {
+            const float dj = res_d[j];
+            rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+        }
+        out_ids[(size_t)qi * k + rank] = (uint64_t)res_i[i] + id_offset;
+        out_dist[(size_t)qi * k + rank] = di;
     }
     if (lane == 0) {
         out_count[qi] = nres;
