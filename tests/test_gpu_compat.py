@@ -384,3 +384,23 @@ def test_heap_emulation_alone_equals_the_two_kernel_search(zv, oracle):
         assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
     a, b = np.load("/tmp/zvdb_compat_fast.npy"), np.load("/tmp/zvdb_compat_heap.npy")
     assert np.array_equal(a, b)
+
+
+def test_hnsw_with_bf16_valued_rows_uses_the_step_binding(zv, oracle):
+    """An index whose rows are rounded to bf16 on insert (ZVDB_FLAG_BF16_ROWS) is outside zvdb_hip_insert_batch's case; the
+    host mirror then drives the insert step by step.  The graph equals the oracle's built from the rounded points."""
+    n, d, m = 500, 20, 4
+    V = oracle.uniform_rows(77, 0, n, d)
+    R = oracle.bf16_round(V)
+    ref = oracle.HNSW(m, 200, level_seed=5)
+    got = zv.HNSW(m, 200, flags=zv.FLAG_BF16_ROWS)
+    for i in range(n):
+        ref.insert(R[i])
+        got.insert(V[i], _level=ref.node_level(i))
+    for i in range(n):
+        for layer in range(ref.node_level(i) + 1):
+            assert np.array_equal(ref.neighbors(i, layer), got.connections(i, layer)), (i, layer)
+    q = V[3] + np.float32(0.05)
+    ri, rd = ref.search(q, 10)
+    gi, gd = got.search_ids(q, 10)
+    assert np.array_equal(ri, gi) and np.array_equal(rd, gd)

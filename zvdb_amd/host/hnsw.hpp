@@ -112,6 +112,7 @@ class HNSW<float> {
     // layer-0 lists the device settled on, the upper layers) follows in the same order.  levels: optional forced levels.
     void insert_many(const float *points, size_t n, size_t len, const int *levels = nullptr) {
         std::lock_guard<std::mutex> g(mu_);
+        if (n && !h_) create_device_index(len);  // (settles which of the two insert paths this index uses)
         if (device_layers_) {
             insert_full(points, n, len, levels);
             return;
@@ -187,6 +188,7 @@ class HNSW<float> {
     }
 
     void insert_locked(const float *point, size_t len) {
+        if (!h_) create_device_index(len);  // (settles which of the two insert paths this index uses)
         if (device_layers_) {
             insert_full(point, 1, len, nullptr);
             return;
@@ -311,6 +313,8 @@ class HNSW<float> {
         cfg.graph_stride = (uint32_t)m;  // m caps every layer incl. 0 (hnsw.zig:146)
         check(zvdb_hip_create(&cfg, &h_));
         dim_ = len;
+        // zvdb_hip_insert_batch serves plain fp32 rows that fit a wave's LDS; anything else goes step by step
+        if ((flags_ & ZVDB_FLAG_BF16_ROWS) || len * sizeof(float) > 96 * 1024) device_layers_ = false;
     }
 
     // randomLevel -- hnsw.zig:172-180: geometric(p = 0.5), capped at 31
