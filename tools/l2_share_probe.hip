@@ -13,9 +13,10 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 template <int RING>
 __global__ __launch_bounds__(512) void k_read(const unsigned char *__restrict__ buf, size_t region_bytes, int readers, int skew_kb,
                                               unsigned *__restrict__ sink) {
-    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;  // r-th reader of this XCD's region
+    // blockIdx = ((stream * readers) + r) * 8 + xcd: `readers` workgroups read the region of (xcd, stream)
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3, r = jb % readers, stream = jb / readers;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const unsigned char *base = buf + (size_t)xcd * region_bytes;
+    const unsigned char *base = buf + ((size_t)stream * 8 + xcd) * region_bytes;
     const size_t steps = region_bytes / (8 * 1024);  // one step = 8 waves x 1 KB
     const size_t skew = ((size_t)skew_kb * 1024 / (8 * 1024)) * (size_t)r;  // reader r starts `skew` steps into the region (wraps)
     u32x4 ring[RING];
@@ -37,25 +38,27 @@ __global__ __launch_bounds__(512) void k_read(const unsigned char *__restrict__ 
 }
 
 int main() {
-    const size_t region = 96ull << 20;  // per XCD: 96 MB (past the 4-MB L2; 8 regions = 768 MB, past the 256-MB Infinity Cache)
+    const size_t region = 96ull << 20;  // per (XCD, stream): 96 MB (past the 4-MB L2; the whole buffer past the 256-MB Infinity Cache)
     unsigned char *buf = nullptr;
     unsigned *sink = nullptr;
-    hipMalloc(&buf, region * 8);
+    hipMalloc(&buf, region * 8 * 8);
     hipMalloc(&sink, 64);
-    hipMemset(buf, 1, region * 8);
-    for (int readers : {1, 2, 4, 8}) {
-        for (int skew_kb : {0, 256, 2048}) {
-            hipEvent_t a, b;
-            hipEventCreate(&a); hipEventCreate(&b);
-            hipEventRecord(a);
-            hipLaunchKernelGGL(k_read<6>, dim3(8 * readers), dim3(512), 0, 0, buf, region, readers, skew_kb, sink);
-            hipEventRecord(b);
-            hipEventSynchronize(b);
-            float ms = 0;
-            hipEventElapsedTime(&ms, a, b);
-            printf("readers/XCD %d, start skew %4d KB between readers: unique bytes %.1f MB, read bytes %.1f MB, %.3f ms\n", readers, skew_kb,
-                   region * 8 / 1e6, region * 8.0 * readers / 1e6, ms);
-        }
-    }
+    hipMemset(buf, 1, region * 8 * 8);
+    auto run = [&](int streams, int readers, int skew_kb) {
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a);
+        hipLaunchKernelGGL(k_read<6>, dim3(8 * streams * readers), dim3(512), 0, 0, buf, region, readers, skew_kb, sink);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms = 0;
+        hipEventElapsedTime(&ms, a, b);
+        printf("streams/XCD %d x readers %d, start skew %4d KB between readers: unique bytes %.1f MB, read bytes %.1f MB, %.3f ms\n", streams,
+               readers, skew_kb, region * 8.0 * streams / 1e6, region * 8.0 * streams * readers / 1e6, ms);
+    };
+    for (int readers : {1, 2, 4, 8})
+        for (int skew_kb : {0, 256, 2048}) run(1, readers, skew_kb);
+    // the scan's occupancy of an XCD: 8 streams x 4 readers = 32 workgroups, one per CU
+    for (int skew_kb : {0, 96, 256, 512}) run(8, 4, skew_kb);
     return 0;
 }
