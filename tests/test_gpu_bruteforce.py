@@ -430,3 +430,17 @@ def test_fp4_screen_survivors_knob(zv, oracle):
     assert recs[0] <= recs[1] + 0.01 and recs[1] <= recs[2] + 0.01 and recs[2] >= 0.9, recs
     with pytest.raises(zv.ZvdbError):
         idx.set_screen_survivors(100)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(70_000, 1, 128, 1), (70_000, 2, 128, 10), (200_000, 3, 64, 10), (300_000, 6, 64, 10)])
+def test_exact_screens_on_dense_low_dimensional_rows(zv, oracle, n, d, nq, k):
+    """Many rows in a handful of dimensions sit inside the rounding band of the screens' |v|^2 - 2 q.v form (70k points on
+    a line are 1e-5 apart): up to 4 dimensions every screen is evaluated in fp32, up to 8 the screens keep 128 survivors.
+    The exact routes stay exact, bit for bit (found by tools/fuzz_bruteforce.py)."""
+    V = oracle.uniform_rows(1000 + n + d, 0, n, d)
+    Q = oracle.uniform_rows(5000 + n + d, 0, nq, d)
+    idx = _index(zv, V)
+    ri, rd, _ = oracle.bruteforce_topk(V, Q, k)
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+        ids, dist, _ = idx.search_bruteforce(Q, k, mode)
+        assert np.array_equal(ids, ri) and np.array_equal(dist, rd), mode

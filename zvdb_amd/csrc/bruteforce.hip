@@ -1024,7 +1024,13 @@ uint32_t debug_flags() {
     return f;
 }
 
+// Up to 4 dimensions a reduced-precision screen cannot tell rows apart (an 8-bit code has 256 values per dimension; 200k
+// points on a line share them by the hundred): such indexes are screened in fp32 whatever screen was asked for -- at 4
+// dimensions the MFMA work is nothing.
+static uint32_t effective_mode(const zvdb_hip_index *h, uint32_t mode) { return h->dim <= 4 ? (uint32_t)ZVDB_BF_F32 : mode; }
+
 BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
+    mode = effective_mode(h, mode);
     BfPlan p{};
     const bool v1 = use_v1() && mode != ZVDB_BF_I8 && mode != ZVDB_BF_FP4;
     p.tile = v1 ? BM : T2;
@@ -1131,13 +1137,14 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                       uint32_t mode, uint64_t id_offset, void *d_ws, uint64_t ws_bytes,
                       uint64_t *d_ids, float *d_dist, uint32_t *d_count, hipStream_t s) {
     if (nq == 0) return ZVDB_OK;
-    // the screen keeps k' = 64 candidates per query; the exact re-rank needs a margin over k to
-    // absorb the screen's rounding (reduced-precision inputs: wider margin).  TODO: 2 keys/lane.
-    const uint32_t kmax = mode == ZVDB_BF_F32 ? KP - 8 : KP - 16;  // (checked below, once the route is known)
     if (mode == ZVDB_BF_BF16 && !(h->flags & ZVDB_FLAG_BF16_MIRROR)) {
         set_error("ZVDB_BF_BF16 needs an index created with ZVDB_FLAG_BF16_MIRROR");
         return ZVDB_ERR_INVALID;
     }
+    mode = effective_mode(h, mode);
+    // the screen keeps k' = 64 candidates per query; the exact re-rank needs a margin over k to
+    // absorb the screen's rounding (reduced-precision inputs: wider margin).
+    const uint32_t kmax = mode == ZVDB_BF_F32 ? KP - 8 : KP - 16;  // (checked below, once the route is known)
     if (h->count > 0xFFFFFFFFull - T2) {
         set_error("shard too large");
         return ZVDB_ERR_UNSUPPORTED;
@@ -1151,7 +1158,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // needs the 128-wide lists.  The approximate fp4 screen switches earlier (k > 32):
     // k of its k' survivors are asked for, and recall@k falls with the slack (k = 48: 0.83 with k' = 64, 0.97 with 128)
     const uint32_t want = mode == ZVDB_BF_FP4 ? h->screen_survivors : 0u;  // zvdb_hip_index_set_screen_survivors
-    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32) || want > (uint32_t)KP;
+    // A handful of dimensions and many rows put more rows inside the screen's rounding band of the k-th neighbour than 64
+    // survivors hold (the screens evaluate |v|^2 - 2 q.v; 70k points on a line are ~1e-5 apart): keep 128 there.
+    const bool dense_low_dim = h->dim <= 8 && h->count > 4096;
+    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32) || want > (uint32_t)KP || dense_low_dim;
     const bool big8 = !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
