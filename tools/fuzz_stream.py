@@ -1,0 +1,44 @@
+# one-off randomized sweep of the LARGE-shard brute-force pipelines (stream kernels, guessed + verified thresholds, wide k)
+# against the oracle on sampled queries.  usage: python tools/fuzz_stream.py [cases] [seed]
+import sys
+sys.path.insert(0, '/root/repo')
+import numpy as np, oracle, zvdb_amd as zv
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for c in range(cases):
+    d = int(rng.choice([64, 96, 100, 128, 192, 200, 384, 768]))
+    n = int(rng.choice([262144, 262145, 300001, 500000, 777777, 1000003]))
+    n = min(n, int(1.0e8 // d))
+    nq = int(rng.choice([1, 255, 256, 257, 700, 1024, 1100]))
+    k = int(rng.choice([1, 10, 16, 17, 32, 48, 64, 100, 112, 200, 240]))
+    metric = int(rng.choice([0, 0, 0, 1]))
+    seed = 7000 + c
+    idx = zv.Index(metric=zv.METRIC_DOT if metric else zv.METRIC_L2SQ)
+    first = int(rng.integers(1, n))
+    idx.add_synthetic(first, d, seed)                       # two adds: the second one ragged
+    idx.add_synthetic(n - first, d, seed, first_row=first)
+    V = oracle.uniform_rows(seed, 0, n, d)
+    Q = oracle.uniform_rows(seed + 100000, 0, nq, d)
+    sel = sorted(set([0, nq // 3, nq - 1]))
+    ri, rd, _ = oracle.bruteforce_topk(V, Q[sel], k, metric=metric)
+    tag = f"case {c}: n={n} d={d} nq={nq} k={k} metric={metric}"
+    ok = True
+    i8, d8, c8 = idx.search_bruteforce(Q, k, zv.BF_I8)
+    if not np.all(c8 == k): ok = False
+    for j, qi in enumerate(sel):
+        if metric == 0:
+            if not (np.array_equal(i8[qi], ri[j]) and np.array_equal(d8[qi], rd[j])): ok = False
+        else:
+            if len(set(i8[qi]) & set(ri[j])) / k < 0.95: ok = False
+    a4, d4, c4 = idx.search_bruteforce(Q, k, zv.BF_FP4)
+    if not (np.all(c4 == k) and np.all(np.diff(d4, axis=1) >= 0)): ok = False
+    rec = np.mean([len(set(a4[qi]) & set(ri[j])) / k for j, qi in enumerate(sel)])
+    if rec < 0.6: ok = False
+    if metric == 0:
+        for j, qi in enumerate(sel):
+            for e in range(0, k, max(1, k // 5)):
+                if oracle.distance(Q[qi], V[int(a4[qi, e])]) != d4[qi, e]: ok = False
+    print(("ok      " if ok else "MISMATCH") + " " + tag + f" fp4 recall {rec:.3f}", flush=True)
+    bad += 0 if ok else 1
+print("done:", cases, "cases,", bad, "mismatches")
