@@ -2,12 +2,13 @@
 import sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, oracle, zvdb_amd as zv
-for metric, mname in ((zv.METRIC_L2SQ, "l2"), (zv.METRIC_DOT, "dot"), (zv.METRIC_COSINE, "cos")):
+for metric, mname in ((zv.METRIC_L2SQ, "l2"), (zv.METRIC_DOT, "dot"), (zv.METRIC_COSINE, "cos"), (zv.METRIC_DOT, "dot+"), (zv.METRIC_COSINE, "cos+")):
     for d in (128, 768, 1536):
         for n in (30_000, 300_000):
             nq = 64
-            V = oracle.uniform_rows(31, 0, n, d) - (0.0 if mname == "l2" else 0.5)
-            Q = oracle.uniform_rows(32, 0, nq, d) - (0.0 if mname == "l2" else 0.5)
+            off = 0.0 if mname in ("l2", "dot+", "cos+") else 0.5   # "+": rows and queries of one sign (U[0,1))
+            V = oracle.uniform_rows(31, 0, n, d) - off
+            Q = oracle.uniform_rows(32, 0, nq, d) - off
             idx = zv.Index(metric=metric)
             idx.add(V)
             out = []

@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
 // its step was placed by the ROWS' spread (fp4: RMS, int8: largest magnitude), and a query of another scale (cosine rows
 // are normalised at insert, queries arrive as they are) would clip or vanish.  One wave per query: out = q * target / stat(q).
 __global__ __launch_bounds__(64) void k_rescale_queries(const float *__restrict__ q, uint32_t nq, uint32_t dim, int use_absmax,
-                                                        float target, float *__restrict__ out) {
+                                                        float target, float *__restrict__ out, float add /* the quantiser's offset */) {
     const uint32_t r = blockIdx.x;
     const int lane = threadIdx.x;
     if (r >= nq) return;
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(64) void k_rescale_queries(const float *__restrict_
     }
     const float stat = use_absmax ? acc : sqrtf(acc / (float)dim);
     const float f = (stat > 0.0f && stat < __builtin_inff()) ? target / stat : 1.0f;
-    for (uint32_t c = lane; c < dim; c += kWave) out[(size_t)r * dim + c] = q[(size_t)r * dim + c] * f;
+    for (uint32_t c = lane; c < dim; c += kWave) out[(size_t)r * dim + c] = q[(size_t)r * dim + c] * f + add;
 }
 
 struct BfPlan {
@@ -1185,7 +1185,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         float *qs = reinterpret_cast<float *>(ws + p.off_qs);
         const bool i8m = mode == ZVDB_BF_I8;
         const float target = i8m ? 127.0f / h->q_inv : (kFp4Amax / 1.7320508f) / h->p_scale;  // rows' |max| / RMS
-        hipLaunchKernelGGL(k_rescale_queries, dim3(nq), dim3(64), 0, s, d_queries, nq, h->dim, i8m ? 1 : 0, target, qs);
+        hipLaunchKernelGGL(k_rescale_queries, dim3(nq), dim3(64), 0, s, d_queries, nq, h->dim, i8m ? 1 : 0, target, qs,
+                           i8m ? 0.0f : h->p_mid);  // (fp4 rows are centred on their mean: the quantiser subtracts it again)
         d_queries = qs;
     }
     if (f7 || s4) {

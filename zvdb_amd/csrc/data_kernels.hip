@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_moments_all(const float *__restrict__ r
 // kFp4Amax / sqrt(3) = 2.6 units.  For uniformly spread data this is exactly "range -> [-4.5, 4.5]" (the measured optimum
 // for the benchmark's generator); for bell-shaped data it keeps the 15 values busy (the extremes clip to +-6 at 2.3 sigma)
 // where a min/max map would leave most elements in the 7 innermost values (recall@10 on N(0,1) data, 1M x 128:
-// 0.93 with the min/max map).  L2 centres on the mean (offsets cancel in q - v); dot / cosine scale around 0 by the RMS.
+// 0.93 with the min/max map).  Every metric centres the rows on the mean (L2: offsets cancel in q - v; dot / cosine: see below).
 int fp4_range(zvdb_hip_index *h, hipStream_t s) {
     double *d_mom = nullptr;
     ZV_HIP(hipMalloc(reinterpret_cast<void **>(&d_mom), 16));
@@ -361,14 +361,12 @@ int fp4_range(zvdb_hip_index *h, hipStream_t s) {
     const double cnt = (double)h->count * (double)h->dim;
     const double mean = got[0] / cnt, ms = got[1] / cnt;
     const double unit = (double)kFp4Amax / 1.7320508075688772;  // fp4 units per standard deviation
-    if (h->metric == ZVDB_METRIC_L2SQ) {
-        const double var = ms - mean * mean;
-        h->p_mid = (float)mean;
-        h->p_scale = var > 0.0 ? (float)(unit / std::sqrt(var)) : 1.0f;
-    } else {
-        h->p_mid = 0.0f;
-        h->p_scale = ms > 0.0 ? (float)(unit / std::sqrt(ms)) : 1.0f;
-    }
+    // dot / cosine: the ROWS are centred too -- q.(v - mu 1) = q.v - mu sum(q) ranks like q.v for every query -- so that rows
+    // of one sign (e.g. embeddings after a ReLU, U[0,1) data) use both halves of the code range; the QUERY is not centred
+    // (that term would depend on the row): k_rescale_queries hands the quantiser q * f + mu, which it maps to q * f * scale.
+    const double var = ms - mean * mean;
+    h->p_mid = (float)mean;
+    h->p_scale = var > 0.0 ? (float)(unit / std::sqrt(var)) : 1.0f;
     return ZVDB_OK;
 }
 
