@@ -404,3 +404,36 @@ def test_hnsw_with_bf16_valued_rows_uses_the_step_binding(zv, oracle):
     ri, rd = ref.search(q, 10)
     gi, gd = got.search_ids(q, 10)
     assert np.array_equal(ri, gi) and np.array_equal(rd, gd)
+
+
+def test_compat_search_from_two_streams(zv, oracle):
+    """Batched compat searches launched on two streams of one index (they share the index's tie-flag scratch: each launch
+    pair waits for the previous one's marker) return what a single stream returns -- on data where many queries take the
+    equal-minima fallback."""
+    import torch
+    from zvdb_amd.index import Index
+    rng = np.random.default_rng(5)
+    V = np.floor(rng.random((4000, 4), dtype=np.float32) * 3).astype(np.float32)
+    h = zv.HNSW(8, 200)
+    h.insert_many(V, np.zeros(len(V), dtype=np.int32))
+    idx = Index._from_handle(h._L.zvdb_host_hnsw_handle(h._p))
+    dev = torch.device("cuda", 0)
+    nq, k, d = 3000, 10, 4
+    qa = torch.from_numpy(V[:nq].copy()).to(dev)
+    qb = torch.from_numpy((V[500:500 + nq] + np.float32(0.25)).copy()).to(dev)
+    def run(q, stream):
+        ids = torch.empty((nq, k), dtype=torch.int64, device=dev); dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+        idx.search_graph_dev(q.data_ptr(), nq, d, k, 0, 0, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream.cuda_stream)
+        return ids, dd, cnt
+    s0 = torch.cuda.current_stream()
+    ra = run(qa, s0); rb = run(qb, s0)
+    torch.cuda.synchronize()
+    want = [t.cpu().numpy().copy() for t in ra + rb]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(s0); s2.wait_stream(s0)
+    for _ in range(10):
+        ga = run(qa, s1); gb = run(qb, s2)
+        torch.cuda.synchronize()
+        got = [t.cpu().numpy() for t in ga + gb]
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))

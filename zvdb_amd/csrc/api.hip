@@ -89,6 +89,19 @@ int ensure_capacity(zvdb_hip_index *h, uint64_t want) {
     return ZVDB_OK;
 }
 
+// tie_buf is shared by every compat search on this index, whatever stream it is launched on: a search waits for the
+// previous one's last kernel before it touches the flags, and leaves its own marker behind
+static int tie_begin(zvdb_hip_index *h, hipStream_t s) {
+    if (!h->tie_event) ZV_HIP(hipEventCreateWithFlags(&h->tie_event, hipEventDisableTiming));
+    if (h->tie_event_set) ZV_HIP(hipStreamWaitEvent(s, h->tie_event, 0));
+    return ZVDB_OK;
+}
+static int tie_end(zvdb_hip_index *h, hipStream_t s) {
+    ZV_HIP(hipEventRecord(h->tie_event, s));
+    h->tie_event_set = true;
+    return ZVDB_OK;
+}
+
 static int ensure_tie(zvdb_hip_index *h, uint64_t nq) {
     if (nq <= h->tie_cap) return ZVDB_OK;
     if (h->tie_buf) { ZV_HIP(hipDeviceSynchronize()); ZV_HIP(hipFree(h->tie_buf)); h->tie_buf = nullptr; h->tie_cap = 0; }
@@ -252,6 +265,7 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->adj_up);
     (void)hipFree(h->deg_up);
     (void)hipFree(h->tie_buf);
+    if (h->tie_event) (void)hipEventDestroy(h->tie_event);
     (void)hipFree(h->scratch);
     (void)hipFree(h->rows_q);
     (void)hipFree(h->norm_q);
@@ -837,7 +851,10 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
         return ZVDB_ERR_NODE_NOT_FOUND;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ef == 0) ZV_CHECK(ensure_tie(h, nq));
+    if (ef == 0) {
+        ZV_CHECK(ensure_tie(h, nq));
+        ZV_CHECK(tie_begin(h, s));
+    }
     timing_begin(h, s);
     int rc;
     if (ef == 0)
@@ -851,6 +868,7 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
                               static_cast<uint32_t *>(d_count),
                               static_cast<unsigned long long *>(d_stats), s);
     timing_end(h, s);
+    if (ef == 0 && rc == ZVDB_OK) ZV_CHECK(tie_end(h, s));
     return rc;
 }
 
@@ -885,6 +903,7 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
             ZV_CHECK(ensure_ins_block(h, total + 64));
             ZV_CHECK(ensure_scratch(h, 64));
             ZV_CHECK(ensure_tie(h, 1));
+            ZV_CHECK(tie_begin(h, h->stream));
             unsigned char *hb = static_cast<unsigned char *>(h->ins_host), *dbs = static_cast<unsigned char *>(h->ins_dev);
             std::memcpy(hb, queries, (size_t)dim * 4);
             const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;
@@ -895,6 +914,7 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
                                           reinterpret_cast<uint64_t *>(dbs + qb), reinterpret_cast<float *>(dbs + qb + ib),
                                           reinterpret_cast<uint32_t *>(dbs + qb + ib + db),
                                           static_cast<unsigned long long *>(h->scratch), h->stream, h->tie_buf));
+            ZV_CHECK(tie_end(h, h->stream));
             ZV_CHECK(launch_publish(reinterpret_cast<unsigned long long *>(dbs + qb + ib + db + cb),
                                     static_cast<const unsigned long long *>(h->scratch), 8,
                                     reinterpret_cast<uint32_t *>(dbs + total), seq, h->stream));
@@ -924,12 +944,16 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
         float *d_dist = reinterpret_cast<float *>(scr + qb + ib);
         uint32_t *d_cnt = reinterpret_cast<uint32_t *>(scr + qb + ib + db);
         unsigned long long *d_st = reinterpret_cast<unsigned long long *>(scr + qb + ib + db + cb);
-        if (ef == 0) ZV_CHECK(ensure_tie(h, nq));
+        if (ef == 0) {
+            ZV_CHECK(ensure_tie(h, nq));
+            ZV_CHECK(tie_begin(h, h->stream));
+        }
         int rc = ef == 0 ? launch_search_compat(h, reinterpret_cast<float *>(scr), nq, k, (uint32_t)entry, 0,
                                                 d_ids, d_dist, d_cnt, d_st, h->stream, h->tie_buf)
                          : launch_search_ef(h, reinterpret_cast<float *>(scr), nq, k, ef, (uint32_t)entry,
                                             0, d_ids, d_dist, d_cnt, d_st, h->stream);
         ZV_CHECK(rc);
+        if (ef == 0) ZV_CHECK(tie_end(h, h->stream));
         unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr);
         ZV_HIP(hipMemcpyAsync(pin + qb, scr + qb, ib + db + cb + 64, hipMemcpyDeviceToHost, h->stream));
         ZV_HIP(hipStreamSynchronize(h->stream));

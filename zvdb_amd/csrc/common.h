@@ -117,6 +117,8 @@ struct zvdb_hip_index {
     uint32_t max_level = 0;  // over the nodes inserted through zvdb_hip_insert_batch
     uint32_t *tie_buf = nullptr;  // [tie_cap] per-query "equal minima" flags of k_search_compat_fast
     uint64_t tie_cap = 0;
+    hipEvent_t tie_event = nullptr;  // end of the last launch pair that used tie_buf: the next one (any stream) waits for it
+    bool tie_event_set = false;
     // int8 scalar-quantised mirror for ZVDB_BF_I8 (lazy; rebuilt when rows were added)
     int8_t *rows_q = nullptr;   // [cap_q][ldq], ldq = round_up(dim, 128)
     int32_t *norm_q = nullptr;  // [cap_q] sum q^2
