@@ -222,6 +222,10 @@ int zvdb_hip_search_bruteforce_dev(zvdb_hip_index *h, const void *d_queries, uin
                                    uint32_t dim, uint32_t k, uint32_t mode, uint64_t id_offset,
                                    void *d_workspace, uint64_t workspace_bytes,
                                    void *d_ids, void *d_dist, void *d_count, void *stream);
+/* The *_dev entry points take device pointers and launch on the CALLER's stream without a host round trip: results are
+ * ready in stream order.  The handle's mutex covers the host side only -- a caller that mutates the index (add / insert)
+ * while searches it launched are still running on other streams orders the two itself (the host-pointer calls always
+ * return with their device work complete). */
 int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t nq, uint32_t dim,
                               uint32_t k, uint32_t ef, uint64_t entry, uint64_t id_offset,
                               void *d_ids, void *d_dist, void *d_count, void *d_stats,
