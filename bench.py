@@ -306,14 +306,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available() or zv.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("ZVDB_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0  # rehearsal of the N > 1 logic on a one-GPU box: every rank on cuda:0 (with ZVDB_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # ZVDB_BENCH_FORCE_DIST=1: rehearse the N > 1 step (RCCL all-gather + packed merge) at world size 1
     dist_on = world > 1 or os.environ.get("ZVDB_BENCH_FORCE_DIST") == "1"
+    cpu_coll = os.environ.get("ZVDB_BENCH_BACKEND", "nccl") != "nccl"
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("ZVDB_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for the rehearsal above
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.rehearse_shard_of > 1 and world == 1:
         args.rows //= args.rehearse_shard_of
@@ -355,7 +362,13 @@ def main():
         idx.search_bruteforce_dev(q.data_ptr(), B, D, K, m, lo, ws.data_ptr(), ws_bytes, l_ids.data_ptr(),
                                   l_dist.data_ptr(), l_cnt.data_ptr(), stream)
         if dist_on:
-            dist.all_gather_into_tensor(g_pack, l_pack)
+            if cpu_coll:  # (gloo rehearsal: host-memory collective)
+                torch.cuda.synchronize()
+                g_host = torch.empty(world * pk_bytes, dtype=torch.uint8)
+                dist.all_gather_into_tensor(g_host, l_pack.cpu())
+                g_pack.copy_(g_host)
+            else:
+                dist.all_gather_into_tensor(g_pack, l_pack)
             zv.merge_topk_packed_dev(g_pack.data_ptr(), pk_bytes, world, B, K, o_ids.data_ptr(), o_dist.data_ptr(),
                                      o_cnt.data_ptr(), stream)
             return o_ids, o_dist
@@ -412,7 +425,7 @@ def main():
         kms, kn = idx.timing_read()
         idx.timing_enable(False)
         if dist_on:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if cpu_coll else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, kms, kn
