@@ -1,5 +1,5 @@
 # one-off randomized parity sweep of the brute-force routes against the oracle (exact screens: ids + distances bit for bit;
-# fp4: counts, order, exact distances of whatever it returns).  usage: python tools/fuzz_bruteforce.py [cases] [seed]
+# fp4: counts, order, exact distances of whatever it returns).  usage: python tests/manual/fuzz_bruteforce.py [cases] [seed]
 import sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, oracle, zvdb_amd as zv

@@ -1,5 +1,5 @@
 # one-off randomized sweep of the LARGE-shard brute-force pipelines (stream kernels, guessed + verified thresholds, wide k)
-# against the oracle on sampled queries.  usage: python tools/fuzz_stream.py [cases] [seed]
+# against the oracle on sampled queries.  usage: python tests/manual/fuzz_stream.py [cases] [seed]
 import sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, oracle, zvdb_amd as zv

@@ -436,7 +436,7 @@ def test_fp4_screen_survivors_knob(zv, oracle):
 def test_exact_screens_on_dense_low_dimensional_rows(zv, oracle, n, d, nq, k):
     """Many rows in a handful of dimensions sit inside the rounding band of the screens' |v|^2 - 2 q.v form (70k points on
     a line are 1e-5 apart): up to 4 dimensions every screen is evaluated in fp32, up to 8 the screens keep 128 survivors.
-    The exact routes stay exact, bit for bit (found by tools/fuzz_bruteforce.py)."""
+    The exact routes stay exact, bit for bit (found by tests/manual/fuzz_bruteforce.py)."""
     V = oracle.uniform_rows(1000 + n + d, 0, n, d)
     Q = oracle.uniform_rows(5000 + n + d, 0, nq, d)
     idx = _index(zv, V)
