@@ -106,7 +106,8 @@ def cpu_baseline(args, gpu_ids, gpu_dist, q_host):
 
 
 def extras(args, zv, torch):
-    """Secondary measurements (not the headline): C2 and the reference-continuity shape."""
+    """Secondary measurements (not the headline): C2 and the reference-continuity shape.  The oracle appears here in the
+    role it has in the cpu_baseline leg: the checker of the GPU results and the timed CPU baseline beside them."""
     import numpy as np
 
     import oracle
