@@ -1,0 +1,46 @@
+# one-off randomized parity sweep of the ef-mode beam search (extension; specification = the oracle's search_ef) on random
+# kNN graphs: ids, distances, counts and evaluation / pop counters bit for bit.  usage: python tests/manual/fuzz_ef.py [cases] [seed]
+import sys
+sys.path.insert(0, '/root/repo')
+import numpy as np, oracle, zvdb_amd as zv
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for c in range(cases):
+    n = int(rng.choice([50, 300, 2000, 6000]))
+    d = int(rng.choice([3, 16, 48, 100, 128, 200]))
+    m = int(rng.choice([2, 4, 8, 12, 16, 32]))
+    m = min(m, n - 1)
+    ties = bool(rng.random() < 0.25)
+    V = rng.random((n, d), dtype=np.float32)
+    if ties: V = np.floor(V * 4).astype(np.float32)
+    nn, _, _ = oracle.bruteforce_topk(V, V, m + 1)
+    ref = oracle.HNSW(m, 200)
+    for r in V: ref.insert(r, 0)
+    adj = np.zeros((n, m), dtype=np.uint32); deg = np.zeros(n, dtype=np.uint32)
+    for i in range(n):
+        nb = [int(x) for x in nn[i] if int(x) != i][:m]
+        ref.set_neighbors(i, 0, nb)
+        adj[i, :len(nb)] = nb; deg[i] = len(nb)
+    idx = zv.Index(m=m)
+    idx.add(V)
+    idx.upload_graph(adj, deg)
+    Q = rng.random((16, d), dtype=np.float32)
+    if ties: Q = np.floor(Q * 4).astype(np.float32)
+    ok = True
+    for _ in range(3):
+        k = int(rng.choice([1, 5, 10, 25, 60]))
+        ef = int(max(k, rng.choice([1, 10, 33, 64, 128, 300])))
+        try:
+            ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
+        except zv.ZvdbError as e:
+            print(f"case {c}: n={n} d={d} m={m} k={k} ef={ef}: {e}"); continue
+        ref.reset_counters()
+        for qi, q in enumerate(Q):
+            ri, rd = ref.search_ef(q, k, ef)
+            if not (cnt[qi] == len(ri) and np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)): ok = False
+        cs = ref.counters()
+        if (ev, pp) != (cs.search_dist_evals, cs.search_pops): ok = False
+        if not ok: print(f"MISMATCH case {c}: n={n} d={d} m={m} ties={ties} k={k} ef={ef}", flush=True); break
+    bad += 0 if ok else 1
+print("done:", cases, "cases,", bad, "mismatches")
