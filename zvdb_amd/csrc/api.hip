@@ -275,6 +275,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     if (h->ins_host) (void)hipHostFree(h->ins_host);
     (void)hipFree(h->rows_pf);
     (void)hipFree(h->rows_qf);
+    (void)hipFree(h->rows_hf);
+    (void)hipFree(h->norm_hf);
     (void)hipFree(h->norm_qf);
     (void)hipFree(h->norm_pf);
     (void)hipFree(h->q_range);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             if (c > (uint32_t)F7_MARK) {
                 if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
                 if (lane == 0) cnt[q] = 0;
-                prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, sel + wave * sel_scratch_bytes<KPV>());
+                prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt + q * NSUB, q, lane, kp, tau_g, sel + wave * sel_scratch_bytes<KPV>());
             }
         }
         __syncthreads();
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
             const uint32_t qg2 = qt * T2 + q2;
             const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)F7_CAP);
             if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-            prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * sel_scratch_bytes<KPV>());
+            prune_query<false, true, KPV>(kept, subs, tau, nkept, subcnt + q2 * NSUB, q2, lane, kp, nullptr, sel + wave * sel_scratch_bytes<KPV>());
 #pragma unroll
             for (int c2i = 0; c2i < KPV / 64; ++c2i)  // (the list as prune_query left it: compacted, ~0 padded)
                 partial[((size_t)qg2 * Stot + list_base + s) * KPV + lane + 64 * c2i] = kept[(size_t)q2 * KPV + lane + 64 * c2i];

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             if (c > (uint32_t)I8_MARK) {
                 if (lane < NSUB) subcnt[q * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
                 if (lane == 0) cnt[q] = 0;
-                prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q, lane, kp, tau_g, sel + wave * sel_scratch_bytes<KPV>());
+                prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt + q * NSUB, q, lane, kp, tau_g, sel + wave * sel_scratch_bytes<KPV>());
             }
         }
         __syncthreads();
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
             const uint32_t qg2 = qt * I8_TQ + q2;
             const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)I8_CAP);
             if (lane < NSUB) subcnt[q2 * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
-            prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt, q2, lane, kp, nullptr, sel + wave * sel_scratch_bytes<KPV>());
+            prune_query<INT, true, KPV>(kept, subs, tau_f, nkept, subcnt + q2 * NSUB, q2, lane, kp, nullptr, sel + wave * sel_scratch_bytes<KPV>());
 #pragma unroll
             for (int c2i = 0; c2i < KPV / 64; ++c2i)
                 partial[((size_t)qg2 * Stot + list_base + s) * KPV + lane + 64 * c2i] = kept[(size_t)q2 * KPV + lane + 64 * c2i];

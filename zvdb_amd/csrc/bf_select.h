@@ -27,14 +27,14 @@ template <int KPV> constexpr int sel_scratch_bytes() { return SEL_HIST_BYTES + (
 // Returns the lane's first kept entry (KPV = 64: the whole list, one per lane).
 template <bool INTKEY, bool INCL = false, int KPV = KP>
 __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, const uint64_t *__restrict__ sub,
-                                                float *tau, uint32_t *nkept, uint32_t *subcnt, int q, int lane,
+                                                float *tau, uint32_t *nkept, uint32_t *subcnt /* the query's NSUB fill counters */, int q, int lane,
                                                 uint32_t kp, uint32_t *tau_g, unsigned char *scratch) {
     constexpr int EPL = KPV / kWave;  // kept entries per lane
     static_assert(KPV == 64 || KPV == 128 || KPV == 256, "kept list width");
     uint32_t *hist = reinterpret_cast<uint32_t *>(scratch);
     uint64_t *stage = reinterpret_cast<uint64_t *>(scratch + SEL_HIST_BYTES);  // [KPV]
-    const uint32_t n0 = min(subcnt[q * NSUB + 0], (uint32_t)SUBCAP), n1 = min(subcnt[q * NSUB + 1], (uint32_t)SUBCAP);
-    const uint32_t n2 = min(subcnt[q * NSUB + 2], (uint32_t)SUBCAP), n3 = min(subcnt[q * NSUB + 3], (uint32_t)SUBCAP);
+    const uint32_t n0 = min(subcnt[0], (uint32_t)SUBCAP), n1 = min(subcnt[1], (uint32_t)SUBCAP);
+    const uint32_t n2 = min(subcnt[2], (uint32_t)SUBCAP), n3 = min(subcnt[3], (uint32_t)SUBCAP);
     const uint32_t p1 = n0, p2 = n0 + n1, p3 = p2 + n2, total = p3 + n3;
     uint32_t ncarry = nkept[q];
     uint64_t carry[EPL];
@@ -83,7 +83,7 @@ __device__ __forceinline__ uint64_t prune_query(uint64_t *__restrict__ kept, con
     const uint64_t last = ncarry == kp ? wave_max64(mx) : ~0ull;
     if (lane == 0) {
         nkept[q] = ncarry;
-        subcnt[q * NSUB + 0] = 0; subcnt[q * NSUB + 1] = 0; subcnt[q * NSUB + 2] = 0; subcnt[q * NSUB + 3] = 0;
+        subcnt[0] = 0; subcnt[1] = 0; subcnt[2] = 0; subcnt[3] = 0;
         if (ncarry == kp) {
             if (INTKEY) {
                 int32_t *ti = reinterpret_cast<int32_t *>(tau);

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
                         const u32x4 c4 = *reinterpret_cast<const u32x4 *>(subcnt + q * NSUB);
                         if (max(max(c4.x, c4.y), max(c4.z, c4.w)) > (uint32_t)SUBHW) {
                             if ((dbg & 16) && lane == 0) atomicAdd(&dbgbuf[2], 1ull);
-                            prune_query<INT, false, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, tau_g, smem + LDS4_SEL + wave * SEL_SCRATCH);
+                            prune_query<INT, false, KPV>(kept, subs, tau, nkept, subcnt + q * NSUB, q, lane, kp, tau_g, smem + LDS4_SEL + wave * SEL_SCRATCH);
                         }
                     }
                     __syncthreads();
@@ -804,7 +804,7 @@ uint32_t ncross = 0;
     for (int q = wave; q < T2; q += NW) {
         const uint32_t qg = qt * T2 + q;
         if (qg >= nq) continue;
-        const uint64_t best = prune_query<INT, false, KPV>(kept, subs, tau, nkept, subcnt, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
+        const uint64_t best = prune_query<INT, false, KPV>(kept, subs, tau, nkept, subcnt + q * NSUB, q, lane, kp, nullptr, smem + LDS4_SEL + wave * SEL_SCRATCH);
         partial[((size_t)qg * Stot + list_base + s) * KPV + lane] = best;
 #pragma unroll
         for (int c = 1; c < KPV / 64; ++c)  // (the rest of the list as prune_query left it: compacted, ~0 padded)
@@ -1056,7 +1056,8 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     p.off_q = off;
     off += round_up64(std::max<uint64_t>((uint64_t)p.nq_pad * p.row_bytes,
                                          mode == ZVDB_BF_FP4 && (fp4s_eligible(h) || fp4s128_eligible(h)) ? fp4s_query_bytes(h, p.nq_pad)
-                                         : mode == ZVDB_BF_I8 && i8s_eligible(h) ? i8s_query_bytes(h, p.nq_pad) : 0), 256);
+                                         : mode == ZVDB_BF_I8 && i8s_eligible(h) ? i8s_query_bytes(h, p.nq_pad)
+                                         : mode == ZVDB_BF_BF16 && bf16s_eligible(h) ? bf16s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
     off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap,
                               (uint64_t)std::max(p.QT * p.S, p.QT8 * p.S8) * BLKV_ENTRIES) * 8;
@@ -1166,6 +1167,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
     const bool s4 = mode == ZVDB_BF_FP4 && !f7 && fp4s128_eligible(h) && (big8 || wide_k);
+    // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
+    // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
+    const bool sb = mode == ZVDB_BF_BF16 && bf16s_eligible(h) && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64);
+    if (sb) ZV_CHECK(ensure_bf16_frag_mirror(h, s));
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
     if (ws_bytes < p.total) {
@@ -1191,6 +1196,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     }
     if (f7 || s4) {
         ZV_CHECK(launch_fp4s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
+    } else if (sb) {
+        ZV_CHECK(launch_bf16s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else if (s8) {
         ZV_CHECK(launch_i8s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else {
@@ -1206,11 +1213,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t nlists = p.S, stot_lists = p.S;
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
-    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4) && big8);
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4) && big8) || sb;
     // k' = 64 survivors per query (one per lane of the selects) carry k <= 48 (56 with the exact fp32 screen); the stream
     // kernels also run with k' = 128 (two entries per lane), which carries k <= 112 -- on large shards inside the guessed-
     // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
-    const bool stream_route = f7 || s8 || s4;
+    const bool stream_route = f7 || s8 || s4 || sb;
     // (the staged kernel has the same two list widths; the v1 kernel kept for A/B has only k' = 64)
     // The stream kernels go on to k' = 256 (four entries per lane): k <= 240, and the fp4 screen uses it from k > 64
     // (recall@100: 0.84 with 128 survivors).
@@ -1310,7 +1317,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             const bool t128 = s8 || s4;               // 128-query tiles (QT8 x S8 workgroups)
             const uint32_t SS = t128 ? p.S8 : p.S;  // streams = lists per query and scan
             float *mom = reinterpret_cast<float *>(cand);  // (cand is free until the scan)
-            if (s8) {
+            if (sb) {
+                ZV_CHECK(launch_bf16s_guess(h, q_op, nq, p.QT, SS, mom, z, tau_g, vflag, s));
+                ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            } else if (s8) {
                 ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             } else if (s4) {
@@ -1326,7 +1336,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
                                kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv);
-            if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
+            if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
+            else if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, kpv, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids,

@@ -131,6 +131,11 @@ struct zvdb_hip_index {
     unsigned char *rows_qf = nullptr;
     int32_t *norm_qf = nullptr;  // [cap_qf], INT_MAX past count
     uint64_t cap_qf = 0, count_qf = 0;
+    // bf16 mirror in MFMA fragment order (Layout16, bf_bf16_stream.hip) for the register-resident-query stream kernel of
+    // ZVDB_BF_BF16: [block of 16 rows][k-step of 32 elements][lane 0..63][16 B]; rows padded to a multiple of 1536
+    unsigned char *rows_hf = nullptr;
+    float *norm_hf = nullptr;  // [cap_hf + 64] sum of the squared bf16 values (0: dot / cosine), +inf past count
+    uint64_t cap_hf = 0, count_hf = 0;
     // fp4 (E2M1) scalar-quantised mirror for ZVDB_BF_FP4 (lazy, like the int8 one)
     unsigned char *rows_p = nullptr;  // [cap_p][ldp] bytes, 2 codes per byte (low nibble = even element), ldp = round_up(dim, 256) / 2
     float *norm_p = nullptr;          // [cap_p] sum of the squared fp4 VALUES (exact in fp32)
@@ -254,6 +259,19 @@ int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint
                         uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s);
 int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                          float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
+
+// ---- bf_bf16_stream.hip ------------------------------------------------------
+bool bf16s_eligible(const zvdb_hip_index *h);
+uint32_t bf16s_ksteps(uint32_t dim);
+uint64_t bf16s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad);
+uint64_t bf16s_moment_bytes(uint32_t QT, uint32_t S);
+int ensure_bf16_frag_mirror(zvdb_hip_index *h, hipStream_t s);
+int launch_bf16s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op, hipStream_t s);
+int launch_bf16s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand,
+                      uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate,
+                      uint32_t kpv, hipStream_t s);
+int launch_bf16s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, float *mom, float z,
+                       uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
 
 // ---- bf_fp4_stream.hip -------------------------------------------------------
 bool fp4s_eligible(const zvdb_hip_index *h);
