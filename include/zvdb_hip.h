@@ -225,7 +225,11 @@ int zvdb_hip_search_bruteforce_dev(zvdb_hip_index *h, const void *d_queries, uin
 /* The *_dev entry points take device pointers and launch on the CALLER's stream without a host round trip: results are
  * ready in stream order.  The handle's mutex covers the host side only -- a caller that mutates the index (add / insert)
  * while searches it launched are still running on other streams orders the two itself (the host-pointer calls always
- * return with their device work complete). */
+ * return with their device work complete).
+ * d_stats: NULL (no counters), or device memory for THREE unsigned 64-bit words that the CALLER zeroes before the launch
+ * and the kernels add to: [0] distance evaluations E, [1] frontier pops P (the figures of SURVEY 8d's roofline,
+ * bytes = E d sizeof(elt) + P M0 4), [2] ef mode only: queries whose visited set overflowed (their result is not to
+ * spec; the host-pointer entry point turns a non-zero count into an error). */
 int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t nq, uint32_t dim,
                               uint32_t k, uint32_t ef, uint64_t entry, uint64_t id_offset,
                               void *d_ids, void *d_dist, void *d_count, void *d_stats,

@@ -386,6 +386,123 @@ __global__ __launch_bounds__(512, 2) void k_regq16(const unsigned char *__restri
     if (stamps && tid == 0) { stamps[2 * b] = __builtin_amdgcn_s_memtime() - t0; stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
+// ---- variant: 16x16x32, STAGGERED halves.  Ring of 6 half-units (24 fragments each), a barrier every 24 fragments placed
+// mid-stream (before fragments 12 and 36 of a unit); waves 4-7 (the SIMD partners of waves 0-3) run 24 fragments behind, so a
+// wave's epilogue / unit turn-over falls into the steady MFMA stream of its partner.  The A-read ring never drains.
+// Barrier i (per wave, counted from 0) validates half-unit i + 1; after it the wave issues its pieces of half-unit i + 4.
+template <int KS, int R, int STAGGER>
+__global__ __launch_bounds__(512, 2) void k_regq16s(const unsigned char *__restrict__ Qf, const unsigned char *__restrict__ Vf,
+                                                     const float *__restrict__ vnorm, uint32_t G, uint32_t S, uint32_t QT,
+                                                     uint32_t *__restrict__ out, unsigned long long *__restrict__ stamps) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    static_assert(KS == 48 && 48 % R == 0, "geometry");
+    constexpr int F = 48, H = 24, K2 = 24;
+    constexpr uint32_t HSLOT = H * 1024 + 256;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = STAGGER && wave >= 4;
+    const uint32_t fq = lane >> 4;
+    const uint32_t b = blockIdx.x, x = b & 7, jb = b >> 3;
+    const uint32_t qt = jb % QT, s = (jb / QT) * 8 + x;
+    const uint32_t per = (G + S - 1) / S;
+    const uint32_t g0 = min(s * per, G), g1 = min(g0 + per, G);
+    const uint32_t n = g1 - g0;
+    if (n == 0) return;
+    const uint32_t hmax = 2 * n - 1;
+    u32x4 B[KS];
+    {
+        const unsigned char *qsrc = Qf + ((size_t)(qt * 8 + wave) * KS) * 1024 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
+    }
+    const uint32_t lane16 = (uint32_t)lane * 16;
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
+    // DMA of half-unit h (clamped source) into half-slot h % 6: 3 pieces per wave (+ the unit's norms by wave 0 for even h)
+    const __attribute__((address_space(1))) unsigned char *nsrc = nullptr;
+    unsigned char *ndst = nullptr;
+    auto dma_setup = [&](uint32_t h) {
+        const uint32_t hc = min(h, hmax);
+        nsrc = uniform_ptr(Vf + ((size_t)(g0 + (hc >> 1)) * F + (size_t)(hc & 1) * H) * 1024);
+        ndst = smem + (h % 6) * HSLOT;
+        if (wave == 0 && !(h & 1))
+            __builtin_amdgcn_global_load_lds((gptr_t)(vnorm + (size_t)(g0 + (hc >> 1)) * 32 + lane), (lptr_t)(ndst + H * 1024), 4, 0, 0);
+    };
+    auto dma_piece = [&](int p) {
+        const uint32_t piece = (uint32_t)wave + 8u * p;
+        __builtin_amdgcn_global_load_lds((gptr_t)(nsrc + piece * 1024 + lane16), (lptr_t)(ndst + piece * 1024), 16, 0, 0);
+    };
+    for (uint32_t h = 0; h < 4; ++h) { dma_setup(h); dma_piece(0); dma_piece(1); dma_piece(2); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t bi = 0;  // barriers executed
+    auto barrier_hook = [&]() {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        dma_setup(bi + 4);
+        bi += 1;
+    };
+    if (late) { barrier_hook(); dma_piece(0); dma_piece(1); }
+
+    float best0 = -__builtin_inff(), best1 = best0;
+    // first unit: norms + the first R fragments
+    uint32_t base = lds0 + lane16, nb = lds0 + H * 1024 + 16 * fq;
+    f32x4v nv[2];
+    asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:64" : "=&v"(nv[0]), "=&v"(nv[1]) : "v"(nb));
+    u32x4 A[R];
+    static_for<R>([&](auto jc) { constexpr int J = decltype(jc)::value; lds_read128<J * 1024>(A[J], base); });
+    for (uint32_t t = 0; t < n; ++t) {
+        const uint32_t sn = (2 * (t + 1)) % 6;
+        const uint32_t base_next = lds0 + sn * HSLOT + lane16, nb_next = lds0 + sn * HSLOT + H * 1024 + 16 * fq;
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(nv[0]), "+v"(nv[1]) : "n"(R));
+        f32x4v acc[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[rb][0][r] = -0.5f * nv[rb][r]; acc[rb][1][r] = acc[rb][0][r]; }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<F>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            constexpr int SL = J % R;
+            constexpr int RB = J / K2, JJ = J % K2;
+            if constexpr (J == 12 || J == 36) {
+                if (!(t == 0 && J == 12 && !STAGGER)) barrier_hook();  // (unstaggered: everything up to half-unit 3 is resident at the start)
+            }
+            lgkm_wait<R - 1>(A[SL]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[RB][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[SL]), __builtin_bit_cast(bf16x8, B[JJ]), acc[RB][0], 0, 0, 0);
+            acc[RB][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[SL]), __builtin_bit_cast(bf16x8, B[K2 + JJ]), acc[RB][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int N2 = J + R;
+            if constexpr (N2 < H) lds_read128<N2 * 1024>(A[SL], base);
+            else if constexpr (N2 < F) lds_read128<(int)HSLOT + (N2 - H) * 1024>(A[SL], base);
+            else lds_read128<(N2 - F) * 1024>(A[SL], base_next);
+            if constexpr (J == 14 || J == 38) { if (bi > 0) dma_piece(0); }
+            if constexpr (J == 22 || J == 46) { if (bi > 0) dma_piece(1); }
+            if constexpr (J == 30 || J == 6) { if (bi > 0) dma_piece(2); }
+            if constexpr (J == 40) {
+                asm volatile("ds_read_b128 %0, %2 offset:0\n\tds_read_b128 %1, %2 offset:64" : "=&v"(nv[0]), "=&v"(nv[1]) : "v"(nb_next));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        float m0 = acc[0][0][0], m1 = acc[0][1][0];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { m0 = fmaxf(m0, acc[rb][0][r]); m1 = fmaxf(m1, acc[rb][1][r]); }
+        best0 = fmaxf(best0, m0);
+        best1 = fmaxf(best1, m1);
+        base = base_next;
+    }
+    if (STAGGER && !late) { if (wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    best0 = fmaxf(best0, __shfl_xor(best0, 16)); best0 = fmaxf(best0, __shfl_xor(best0, 32));
+    best1 = fmaxf(best1, __shfl_xor(best1, 16)); best1 = fmaxf(best1, __shfl_xor(best1, 32));
+    if (lane < 16) { atomicMax(out + qt * 256 + wave * 32 + lane, fkey(best0)); atomicMax(out + qt * 256 + wave * 32 + 16 + lane, fkey(best1)); }
+    if (stamps && tid == 0) { stamps[2 * b] = __builtin_amdgcn_s_memtime() - t0; stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+
 // Layout16 generator (rows and queries alike)
 __global__ void k_gen_frag16(uint64_t seed, uint64_t nrows, uint32_t dim, uint32_t K2, uint64_t units, unsigned char *out) {
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -459,7 +576,7 @@ static double run_k(const char *name, K kern, int threads, const unsigned char *
     static unsigned long long *stamps = nullptr;
     if (!stamps) CK(hipMalloc(&stamps, 256 * 16));
     const uint32_t QT = nq / 256, S = 256 / QT;
-    const size_t lds = 3 * (KS * 1024 + 256);
+    const size_t lds = 6 * (24 * 1024 + 256);
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -552,6 +669,13 @@ int main(int argc, char **argv) {
         run_k("16x16x32, 8 waves x 32 queries, R=4", k_regq16<KS, 4>, 512, Qf16, Vf16, vn, G, nq, out, 6);
         run_k("16x16x32, 8 waves x 32 queries, R=6", k_regq16<KS, 6>, 512, Qf16, Vf16, vn, G, nq, out, 6);
         run_k("16x16x32, R=6, spread DMA", k_regq16<KS, 6, 1>, 512, Qf16, Vf16, vn, G, nq, out, 6);
+        run_k("check16s", k_regq16s<KS, 6, 1>, 512, Qf16, Vf16, vn, (uint32_t)gsmall, nq, out, 2);
+        check("check16s (staggered)", out, ref, nq);
+        run_k("check16s0", k_regq16s<KS, 6, 0>, 512, Qf16, Vf16, vn, (uint32_t)gsmall, nq, out, 2);
+        check("check16s0 (half-unit ring, no stagger)", out, ref, nq);
+        run_k("16x16x32 half-unit ring, STAGGERED, R=6", k_regq16s<KS, 6, 1>, 512, Qf16, Vf16, vn, G, nq, out, 6);
+        run_k("16x16x32 half-unit ring, no stagger, R=6", k_regq16s<KS, 6, 0>, 512, Qf16, Vf16, vn, G, nq, out, 6);
+        run_k("16x16x32 half-unit ring, STAGGERED, R=4", k_regq16s<KS, 4, 1>, 512, Qf16, Vf16, vn, G, nq, out, 6);
         run_k("16x16x32, R=4, spread DMA", k_regq16<KS, 4, 1>, 512, Qf16, Vf16, vn, G, nq, out, 6);
         if (argc > 3) {  // the same on rows and queries centred on 0 (L2 distances do not change)
             const float half = 0.5f;

@@ -35,7 +35,10 @@ int ensure_ins_block(zvdb_hip_index *h, size_t bytes) {
     if (h->ins_bytes >= bytes) return ZVDB_OK;
     if (h->ins_host) { ZV_HIP(hipStreamSynchronize(h->stream)); ZV_HIP(hipHostFree(h->ins_host)); h->ins_host = nullptr; h->ins_bytes = 0; }
     const size_t nb = round_up64(bytes, 4096);
-    ZV_HIP(hipHostMalloc(&h->ins_host, nb, hipHostMallocMapped));
+    // fine-grained (coherent): the host polls a sequence word the kernel stores at system scope; with coarse-grained
+    // memory that store need not be visible before the kernel ends and every call would burn its whole spin budget
+    ZV_HIP(hipHostMalloc(&h->ins_host, nb, hipHostMallocMapped | hipHostMallocCoherent));
+    if (!h->ins_host) { set_error("hipHostMalloc returned no block"); return ZVDB_ERR_OOM; }
     ZV_HIP(hipHostGetDevicePointer(&h->ins_dev, h->ins_host, 0));
     h->ins_bytes = nb;
     return ZVDB_OK;
@@ -725,6 +728,35 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
     if (out_first_id) *out_first_id = h->count;
     const uint32_t m = h->m, rw = 4 + h->gstride, ow = 4 + m;
     uint64_t done = 0, rec_out = 0;
+    {   // Everything that can fail for want of memory is reserved for ALL n points before the first launch, so that a
+        // failure leaves the index as it was (the reference's insert leaves a consistent index on error: errdefer,
+        // hnsw.zig:80): a later chunk must not fail after earlier chunks advanced count and the device lists.
+        uint64_t ups = 0, recs_all = 0, rec_chunk_max = 0, rec_chunk = 0;
+        uint32_t ml = h->max_level;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (i == 0 && h->count == 0) { ml = levels[0]; ups += levels[0]; continue; }
+            const uint64_t pos = i - (h->count == 0 ? 1 : 0);
+            if (pos % 8192 == 0) rec_chunk = 0;
+            const uint64_t r = std::min(levels[i], ml) + 1;
+            recs_all += r;
+            rec_chunk += r;
+            rec_chunk_max = std::max(rec_chunk_max, rec_chunk);
+            ups += levels[i];
+            ml = std::max(ml, levels[i]);
+        }
+        if (recs_all > recs_cap) {
+            set_error("record buffer too small: need %llu records", (unsigned long long)recs_all);
+            return ZVDB_ERR_INVALID;
+        }
+        ZV_CHECK(ensure_capacity(h, h->count + n));
+        ZV_CHECK(ensure_upper(h, h->up_count + ups));
+        const uint64_t ncm = std::min<uint64_t>(8192, n);
+        const size_t need = round_up64(ncm * dim * sizeof(float), 256) + round_up64(ncm * sizeof(InsertParam), 256) +
+                            round_up64(rec_chunk_max * rw * 4, 256) + 64;
+        if (n > 4) { ZV_CHECK(ensure_pin(h, need)); ZV_CHECK(ensure_scratch(h, need)); }
+        else ZV_CHECK(ensure_ins_block(h, need));
+        ZV_CHECK(ensure_pin(h, (size_t)dim * 4 + 64));
+    }
     if (h->count == 0) {  // the first node: nothing to scan or connect to (:110-112)
         ZV_CHECK(ensure_capacity(h, 1));
         ZV_CHECK(ensure_upper(h, levels[0]));

@@ -1302,7 +1302,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             // adaptive part: a batch that needed a repair (keys not Gaussian enough, e.g. low dimensions) loosens the guess of
             // the following batches by half a standard deviation, up to +2 (too loose is self-correcting, only slower)
             if (!h->guess_flag_host) {
-                ZV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->guess_flag_host), 64, hipHostMallocMapped));
+                ZV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->guess_flag_host), 64, hipHostMallocMapped | hipHostMallocCoherent));  // (fine-grained: read while kernels run)
+                if (!h->guess_flag_host) { set_error("hipHostMalloc returned no block"); return ZVDB_ERR_OOM; }
                 h->guess_flag_host[0] = 0;
                 ZV_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->guess_flag_dev), h->guess_flag_host, 0));
             }

@@ -155,14 +155,15 @@ __global__ __launch_bounds__(64) void k_greedy_layer0(const float *__restrict__ 
 // strict '<' is reproduced by ranks -- rank(i) = #{d_j < d_i} + #{j < i : d_j == d_i}; the first m stay).  All on the
 // device mirror of layer 0; `out` receives what the host mirror must adopt.
 
-__global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+// (`rows` is read and written -- the new row is copied in and read back -- hence one plain pointer: see k_insert_full)
+__global__ __launch_bounds__(64) void k_insert_layer0(float *rows, uint32_t ld, uint32_t dim, int metric,
                                                       uint32_t *adj, uint32_t *deg, uint32_t gstride,
                                                       uint32_t m, uint32_t first_owner, uint32_t ep_in, unsigned char *__restrict__ out_base,
                                                       uint32_t seq, const float *__restrict__ point_src /* optional: [n][dim] new points */,
-                                                      float *__restrict__ rows_w, uint32_t n_batch, uint32_t out_stride) {
+                                                      uint32_t n_batch, uint32_t out_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    const uint32_t cap = gstride + 1;                       // a list holds at most gstride entries before the append
+    const uint32_t cap = (gstride + 1 + 3) & ~3u;           // a list holds at most gstride entries before the append (padded: ql is 16-byte aligned)
     uint32_t *lst = reinterpret_cast<uint32_t *>(smem);     // [cap]
     float *dst = reinterpret_cast<float *>(lst + cap);      // [cap]
     uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ 
     if (point_src) {  // Node.init's copy (:24-26) done here: the point goes to its row AND to LDS, which the walks below read
         for (uint32_t i = lane; i < dim; i += kWave) {
             const float v = point_src[(size_t)b * dim + i];
-            rows_w[(size_t)owner * ld + i] = v;
+            rows[(size_t)owner * ld + i] = v;
             ql[i] = v;
         }
         __syncthreads();
@@ -282,19 +283,21 @@ __global__ __launch_bounds__(64) void k_insert_layer0(const float *__restrict__ 
 // layer <= the new node's level, connect (:106-108) with both shrinks.  Per (insert, layer <= min(level, max_level)) one
 // record {ep, owner_n, ep_n, ep_has_layer, ep's list} tells the host mirror what to adopt.  Parameters per insert are
 // computed by the host (level, first upper-layer slot, record offset, max_level before the insert).
-__global__ __launch_bounds__(64) void k_insert_full(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+// `rows` is read AND written (Node.init's copy of the new row is read back by ep's shrink and by later inserts of the batch):
+// one plain pointer, no restrict / const, so the compiler may not treat the loads as invariant.
+__global__ __launch_bounds__(64) void k_insert_full(float *rows, uint32_t ld, uint32_t dim, int metric,
                                                     uint32_t *adj, uint32_t *deg, uint32_t *adj_up, uint32_t *deg_up,
                                                     uint32_t *lvl, uint32_t *slot, uint32_t gstride, uint32_t m,
                                                     uint32_t first_owner, uint32_t n_batch, const float *__restrict__ points,
-                                                    const InsertParam *__restrict__ params, float *__restrict__ rows_w,
+                                                    const InsertParam *__restrict__ params,
                                                     uint32_t *__restrict__ recs, uint32_t *seq_dst, uint32_t seq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
-    const uint32_t cap = gstride + 1;
+    const uint32_t cap = (gstride + 1 + 3) & ~3u;             // (list arrays padded to 16 bytes: q is read by ds_read_b128)
     uint32_t *lst = reinterpret_cast<uint32_t *>(smem);       // [cap]
     float *dst = reinterpret_cast<float *>(lst + cap);        // [cap]
     uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
-    float *q = reinterpret_cast<float *>(srt + cap);          // [dim]
+    float *q = reinterpret_cast<float *>(srt + cap);          // [dim], 16-byte aligned
     const uint32_t rec_words = 4 + gstride;
     auto ld_u32 = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     for (uint32_t b = 0; b < n_batch; ++b) {
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(64) void k_insert_full(const float *__restrict__ ro
         if (lane == 0) { lvl[owner] = level; slot[owner] = my_slot; }
         for (uint32_t i = lane; i < dim; i += kWave) {  // Node.init's copy (:24-26): to the row and to LDS
             const float v = points[(size_t)b * dim + i];
-            rows_w[(size_t)owner * ld + i] = v;
+            rows[(size_t)owner * ld + i] = v;
             q[i] = v;
         }
         __syncthreads();
@@ -423,10 +426,10 @@ __global__ __launch_bounds__(64) void k_insert_full(const float *__restrict__ ro
 int launch_insert_full(const zvdb_hip_index *h, uint32_t first_owner, uint32_t n, const float *points, const InsertParam *params,
                        uint32_t *recs, uint32_t *seq_dst, uint32_t seq, hipStream_t s) {
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    const size_t lds = 3ull * (h->gstride + 1) * sizeof(uint32_t) + (size_t)h->dim * sizeof(float);
+    const size_t lds = 3ull * ((h->gstride + 1 + 3) & ~3u) * sizeof(uint32_t) + (size_t)h->dim * sizeof(float);
     if (lds > 48 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_full), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_insert_full, dim3(1), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj, h->deg, h->adj_up, h->deg_up,
-                       h->lvl, h->slot, h->gstride, h->m, first_owner, n, points, params, h->rows, recs, seq_dst, seq);
+                       h->lvl, h->slot, h->gstride, h->m, first_owner, n, points, params, recs, seq_dst, seq);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }
@@ -460,10 +463,10 @@ size_t insert_l0_out_bytes(const zvdb_hip_index *h) { return round_up64(sizeof(I
 int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
                          hipStream_t s, uint32_t n_batch, uint32_t out_stride) {
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    const size_t lds = 3ull * (h->gstride + 1) * sizeof(uint32_t) + (point_src ? (size_t)h->dim * sizeof(float) : 0);
+    const size_t lds = 3ull * ((h->gstride + 1 + 3) & ~3u) * sizeof(uint32_t) + (point_src ? (size_t)h->dim * sizeof(float) : 0);
     if (lds > 48 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_layer0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_insert_layer0, dim3(1), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj, h->deg, h->gstride,
-                       h->m, owner, ep, static_cast<unsigned char *>(d_out), seq, point_src, h->rows, n_batch,
+                       h->m, owner, ep, static_cast<unsigned char *>(d_out), seq, point_src, n_batch,
                        out_stride ? out_stride : (uint32_t)insert_l0_out_bytes(h));
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
