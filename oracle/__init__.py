@@ -71,6 +71,8 @@ def lib():
     L.orc_hnsw_insert.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_int]
     L.orc_hnsw_search.restype = C.c_size_t
     L.orc_hnsw_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, u64p, f32p]
+    L.orc_hnsw_search_ef_ex.restype = C.c_size_t
+    L.orc_hnsw_search_ef_ex.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, u64p, f32p]
     L.orc_hnsw_search_ef.restype = C.c_size_t
     L.orc_hnsw_search_ef.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p]
     L.orc_hnsw_count.restype = C.c_size_t
@@ -181,12 +183,13 @@ class HNSW:
                                     _p(ids, C.c_uint64), _p(dist, C.c_float))
         return ids[:n].copy(), dist[:n].copy()
 
-    def search_ef(self, query, k: int, ef: int) -> Tuple[np.ndarray, np.ndarray]:
+    def search_ef(self, query, k: int, ef: int, metric: int = 0, entry: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """ef-mode beam search (extension; the spec of k_search_ef): metric 0 = squared L2, 1 = inner product."""
         q = _f32(query)
         ids = np.zeros(max(k, 1), dtype=np.uint64)
         dist = np.zeros(max(k, 1), dtype=np.float32)
-        n = self._L.orc_hnsw_search_ef(self._h, _p(q, C.c_float), q.size, k, ef,
-                                       _p(ids, C.c_uint64), _p(dist, C.c_float))
+        n = self._L.orc_hnsw_search_ef_ex(self._h, _p(q, C.c_float), q.size, k, ef, metric, entry,
+                                          _p(ids, C.c_uint64), _p(dist, C.c_float))
         return ids[:n].copy(), dist[:n].copy()
 
     def count(self) -> int:

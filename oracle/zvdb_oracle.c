@@ -68,6 +68,26 @@ float orc_distance_blocked16_f32(const float *a, const float *b, size_t d) {
     return p[0];
 }
 
+/* the same 16-way blocked order for the inner-product metrics: -(sum a*b) (extension; see orc_hnsw_search_ef_ex) */
+float orc_neg_dot_blocked16_f32(const float *a, const float *b, size_t d) {
+    float p[16];
+    for (int l = 0; l < 16; ++l) p[l] = 0.0f;
+    const size_t nchunks = (d + 3) / 4;
+    for (size_t c = 0; c < nchunks; ++c) {
+        const int l = (int)(c & 15);
+        for (size_t j = 0; j < 4; ++j) {
+            const size_t i = 4 * c + j;
+            if (i < d) p[l] += a[i] * b[i];
+        }
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+        float t[16];
+        for (int l = 0; l < 16; ++l) t[l] = p[l] + p[l ^ off];
+        for (int l = 0; l < 16; ++l) p[l] = t[l];
+    }
+    return -p[0];
+}
+
 float orc_neg_dot_f32(const float *a, const float *b, size_t d) {
     float sum = 0.0f;
     for (size_t i = 0; i < d; ++i) sum += a[i] * b[i];
@@ -388,9 +408,9 @@ static int lex_less(float da, uint64_t ia, float db, uint64_t ib) {
     return da < db || (da == db && ia < ib);
 }
 
-size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
-                          size_t ef, uint64_t *out_ids, float *out_dist) {
-    if (!h->has_entry || k == 0 || ef == 0 || d != h->dim) return 0;
+size_t orc_hnsw_search_ef_ex(orc_hnsw *h, const float *query, size_t d, size_t k, size_t ef, int metric, size_t entry,
+                             uint64_t *out_ids, float *out_dist) {
+    if (!h->has_entry || k == 0 || ef == 0 || d != h->dim || entry >= h->count) return 0;
     if (ef < k) ef = k;
     float *wd = (float *)malloc(ef * sizeof(float));
     uint64_t *wi = (uint64_t *)malloc(ef * sizeof(uint64_t));
@@ -399,8 +419,7 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
     if (!wd || !wi || !wx || !visited) { free(wd); free(wi); free(wx); free(visited); return 0; }
     size_t wn = 0;
 
-    const size_t entry = h->entry_point;
-    wd[0] = orc_distance_blocked16_f32(query, h->nodes[entry].point, d);
+    wd[0] = metric ? orc_neg_dot_blocked16_f32(query, h->nodes[entry].point, d) : orc_distance_blocked16_f32(query, h->nodes[entry].point, d);
     h->ctr.search_dist_evals += 1;
     wi[0] = entry; wx[0] = 0; wn = 1;
     visited[entry] = 1;
@@ -416,7 +435,7 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
             const size_t nb = (size_t)lst->items[i];
             if (visited[nb]) continue;
             visited[nb] = 1;
-            const float dn = orc_distance_blocked16_f32(query, h->nodes[nb].point, d);
+            const float dn = metric ? orc_neg_dot_blocked16_f32(query, h->nodes[nb].point, d) : orc_distance_blocked16_f32(query, h->nodes[nb].point, d);
             h->ctr.search_dist_evals += 1;
             if (wn == ef && !lex_less(dn, nb, wd[wn - 1], wi[wn - 1])) continue;
             size_t pos = wn < ef ? wn : ef - 1; /* slot that gets freed / appended */
@@ -432,7 +451,7 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
     /* first k of W, re-evaluated exactly (a1) and ordered by (exact distance, id) */
     for (size_t i = 0; i < nres; ++i) {
         const uint64_t id = wi[i];
-        const float de = orc_distance_f32(query, h->nodes[id].point, d);
+        const float de = metric ? orc_neg_dot_f32(query, h->nodes[id].point, d) : orc_distance_f32(query, h->nodes[id].point, d);
         size_t pos = i;
         while (pos > 0 && lex_less(de, id, out_dist[pos - 1], out_ids[pos - 1])) {
             out_dist[pos] = out_dist[pos - 1]; out_ids[pos] = out_ids[pos - 1];
@@ -442,6 +461,11 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
     }
     free(wd); free(wi); free(wx); free(visited);
     return nres;
+}
+
+size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
+                          size_t ef, uint64_t *out_ids, float *out_dist) {
+    return orc_hnsw_search_ef_ex(h, query, d, k, ef, 0, h->entry_point, out_ids, out_dist);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -88,6 +88,12 @@ float orc_distance_blocked16_f32(const float *a, const float *b, size_t d);
  *   result = first min(k,|W|) entries of W.                                   */
 size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
                           size_t ef, uint64_t *out_ids, float *out_dist);
+/* the same beam search from a chosen entry node under a chosen metric: 0 = squared L2 (above), 1 = inner product --
+ * traversal distance -(16-way blocked sum of a*b) (orc_neg_dot_blocked16_f32), final order by the sequential
+ * orc_neg_dot_f32 (cosine = inner product over rows and queries normalised by the caller). */
+float orc_neg_dot_blocked16_f32(const float *a, const float *b, size_t d);
+size_t orc_hnsw_search_ef_ex(orc_hnsw *h, const float *query, size_t d, size_t k, size_t ef, int metric, size_t entry,
+                             uint64_t *out_ids, float *out_dist);
 
 size_t orc_hnsw_count(const orc_hnsw *h);
 size_t orc_hnsw_dim(const orc_hnsw *h);

@@ -1,7 +1,7 @@
 # one-off randomized parity sweep of the brute-force routes against the oracle (exact screens: ids + distances bit for bit;
 # fp4: counts, order, exact distances of whatever it returns).  usage: python tests/manual/fuzz_bruteforce.py [cases] [seed]
 import sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle, zvdb_amd as zv
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

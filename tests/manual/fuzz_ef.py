@@ -1,7 +1,7 @@
 # one-off randomized parity sweep of the ef-mode beam search (extension; specification = the oracle's search_ef) on random
 # kNN graphs: ids, distances, counts and evaluation / pop counters bit for bit.  usage: python tests/manual/fuzz_ef.py [cases] [seed]
 import sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle, zvdb_amd as zv
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

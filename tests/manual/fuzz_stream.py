@@ -1,7 +1,7 @@
 # one-off randomized sweep of the LARGE-shard brute-force pipelines (stream kernels, guessed + verified thresholds, wide k)
 # against the oracle on sampled queries.  usage: python tests/manual/fuzz_stream.py [cases] [seed]
 import sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle, zvdb_amd as zv
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -14,7 +14,7 @@ for c in range(cases):
     k = int(rng.choice([1, 10, 16, 17, 32, 48, 64, 100, 112, 200, 240]))
     metric = int(rng.choice([0, 0, 0, 1]))
     seed = 7000 + c
-    idx = zv.Index(metric=zv.METRIC_DOT if metric else zv.METRIC_L2SQ)
+    idx = zv.Index(metric=zv.METRIC_DOT if metric else zv.METRIC_L2SQ, flags=zv.FLAG_BF16_MIRROR)
     first = int(rng.integers(1, n))
     idx.add_synthetic(first, d, seed)                       # two adds: the second one ragged
     idx.add_synthetic(n - first, d, seed, first_row=first)
@@ -31,6 +31,13 @@ for c in range(cases):
             if not (np.array_equal(i8[qi], ri[j]) and np.array_equal(d8[qi], rd[j])): ok = False
         else:
             if len(set(i8[qi]) & set(ri[j])) / k < 0.95: ok = False
+    if d <= 768 and k <= 240:  # the bf16 register-resident-query stream kernel (exact screen under L2)
+        b16, db16, cb16 = idx.search_bruteforce(Q, k, zv.BF_BF16)
+        if not np.all(cb16 == k): ok = False
+        for j, qi in enumerate(sel):
+            if metric == 0:
+                if not (np.array_equal(b16[qi], ri[j]) and np.array_equal(db16[qi], rd[j])): ok = False
+            elif len(set(b16[qi]) & set(ri[j])) / k < 0.95: ok = False
     a4, d4, c4 = idx.search_bruteforce(Q, k, zv.BF_FP4)
     if not (np.all(c4 == k) and np.all(np.diff(d4, axis=1) >= 0)): ok = False
     rec = np.mean([len(set(a4[qi]) & set(ri[j])) / k for j, qi in enumerate(sel)])

@@ -1,0 +1,279 @@
+"""GPU tests shaped like BASELINE.json's configs (C2 .. C5) and of the bf16 stream route that carries the headline.
+
+Every comparison is against the oracle (oracle/: CPU restatement; test infrastructure) on the same seeded inputs at sizes
+it finishes in seconds, plus size-independent properties at BASELINE's full sizes.  Bit-exact ids and distances wherever a
+route is exact (brute force with the fp32 / bf16 / int8 screens, ef-mode against the oracle's ef spec)."""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def zv():
+    import zvdb_amd
+    assert zvdb_amd.device_count() > 0
+    return zvdb_amd
+
+
+def _oracle_topk_mt(oracle, V, Q, k, metric=0, threads=16):
+    """oracle.bruteforce_topk with the queries split over host threads (ctypes releases the GIL)."""
+    nq = len(Q)
+    threads = max(1, min(threads, nq, os.cpu_count() or 1))
+    parts = [(t * nq // threads, (t + 1) * nq // threads) for t in range(threads)]
+    res = [None] * threads
+
+    def work(t):
+        a, b = parts[t]
+        res[t] = oracle.bruteforce_topk(V, np.ascontiguousarray(Q[a:b]), k, metric=metric)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    return tuple(np.concatenate([r[i] for r in res], axis=0) for i in range(3))
+
+
+# ---- the bf16 register-resident-query stream kernel (bf_bf16_stream.hip): every instantiated row width -----------------
+@pytest.mark.parametrize("n,d,nq,k,metric", [
+    (600_000, 96, 300, 10, "l2"),       # KS = 8, six 32-row groups per ring slot
+    (600_000, 200, 261, 48, "l2"),      # KS = 16, three groups per slot; k = the 64-survivor maximum
+    (530_003, 500, 300, 10, "l2"),      # KS = 32; nothing a multiple of anything
+    (300_017, 768, 1024, 10, "l2"),     # KS = 48: the headline's geometry, four query tiles
+    (300_017, 768, 1000, 100, "l2"),    # k' = 128 lists
+    (600_000, 128, 300, 200, "l2"),     # k' = 256 lists
+    (600_000, 96, 300, 10, "dot"),
+    (400_000, 130, 520, 25, "cosine"),
+])
+def test_bf16_stream_route_exact(zv, oracle, n, d, nq, k, metric):
+    m = {"l2": zv.METRIC_L2SQ, "dot": zv.METRIC_DOT, "cosine": zv.METRIC_COSINE}[metric]
+    shift = 0.0 if metric == "l2" else 0.5
+    idx = zv.Index(flags=zv.FLAG_BF16_MIRROR, metric=m)
+    idx.add_synthetic(n, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d) - np.float32(shift)
+    bi, bd, bc = idx.search_bruteforce(Q, k, zv.BF_BF16)
+    assert np.all(bc == k) and np.all(bi < n) and np.all(np.diff(bd, axis=1) >= 0)
+    # the whole batch against an independently tested exact route of the same library (fp32 screen up to k = 56, int8 beyond)
+    other = zv.BF_F32 if k <= 56 else zv.BF_I8
+    ei, ed, ec = idx.search_bruteforce(Q, k, other)
+    if metric == "l2" or other == zv.BF_F32:
+        assert np.array_equal(bi, ei) and np.array_equal(bd, ed) and np.array_equal(bc, ec)
+    # sampled queries against the oracle over the regenerated rows
+    sel = [0, 1, nq // 2, nq - 2, nq - 1]
+    if metric == "cosine":
+        V = np.stack([idx.get_vector(i) for i in range(0, n)]) if n <= 50_000 else None
+    else:
+        V = oracle.uniform_rows(0x5EED, 0, n, d)
+    if V is not None:
+        ri, rd, _ = oracle.bruteforce_topk(V, np.ascontiguousarray(Q[sel]), k, metric=0 if metric == "l2" else 1)
+        assert np.array_equal(bi[sel], ri) and np.array_equal(bd[sel], rd)
+    bi2, bd2, _ = idx.search_bruteforce(Q, k, zv.BF_BF16)  # a second batch on the warm mirror: identical
+    assert np.array_equal(bi, bi2) and np.array_equal(bd, bd2)
+
+
+def test_bf16_stream_guess_verified_repaired_and_staged_agree(zv, oracle, tmp_path):
+    """One scan against GUESSED thresholds, verified by the merge, repaired by a gated re-scan: the default, a guess forced
+    far too tight (every query repaired), far too loose (prune rounds through the out-of-line select) and the staged kernel
+    (ZVDB_BF_BF16_KERNEL=v6, learned thresholds) must all return the oracle's exact top-k."""
+    code = (
+        "import sys, numpy as np, oracle, zvdb_amd as zv\n"
+        "idx = zv.Index(flags=zv.FLAG_BF16_MIRROR); idx.add_synthetic(600_000, 160, 0x5EED)\n"
+        "Q = oracle.uniform_rows(0xC0FFEE, 0, 300, 160)\n"
+        "i, d, c = idx.search_bruteforce(Q, 10, zv.BF_BF16)\n"
+        "idx.add_synthetic(50_001, 160, 0x5EED, first_row=600_000)\n"   # grown: the lazy fragment mirror is rebuilt
+        "i2, d2, c2 = idx.search_bruteforce(Q, 10, zv.BF_BF16)\n"
+        "np.savez(sys.argv[1], i=i, d=d, c=c, i2=i2, d2=d2, c2=c2)\n")
+    res = {}
+    for name, env in {"guess": {}, "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2.5"},
+                      "staged": {"ZVDB_BF_BF16_KERNEL": "v6"}}.items():
+        out = tmp_path / (name + ".npz")
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, name + ": " + r.stdout + r.stderr
+        res[name] = np.load(out)
+    V = oracle.uniform_rows(0x5EED, 0, 650_001, 160)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, 300, 160)
+    sel = [0, 7, 150, 299]
+    ri, rd, _ = oracle.bruteforce_topk(V[:600_000], Q[sel], 10)
+    ri2, rd2, _ = oracle.bruteforce_topk(V, Q[sel], 10)
+    for name, r in res.items():
+        assert np.array_equal(r["i"], res["guess"]["i"]) and np.array_equal(r["d"], res["guess"]["d"]), name
+        assert np.array_equal(r["i2"], res["guess"]["i2"]) and np.array_equal(r["d2"], res["guess"]["d2"]), name
+        assert np.array_equal(r["i"][sel], ri) and np.array_equal(r["d"][sel], rd), name
+        assert np.array_equal(r["i2"][sel], ri2) and np.array_equal(r["d2"][sel], rd2), name
+
+
+# ---- C2: 1M x 128 fp32 brute force, batch 256 (BASELINE configs[1]) at FULL size --------------------------------------
+def test_c2_full_size_every_query_against_the_oracle(zv, oracle):
+    n, d, nq, k = 1_000_000, 128, 256, 10
+    idx = zv.Index(dim=d, capacity=n, flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(n, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    ri, rd, rc = _oracle_topk_mt(oracle, V, Q, k)
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+        ids, dist, cnt = idx.search_bruteforce(Q, k, mode)
+        assert np.array_equal(ids, ri) and np.array_equal(dist, rd) and np.array_equal(cnt, rc), mode
+
+
+# ---- C3: 10M x 768 fp32, batch 1024 (BASELINE configs[2]) -------------------------------------------------------------
+def test_c3_graph_route_m16_ef128_d768_batch1024_vs_oracle_spec(zv, oracle):
+    """ef = 128, M = 16, d = 768, batch 1024 -- the config's graph parameters -- at an N the oracle affords: GPU-built exact
+    16-NN layer-0 lists, ef-mode search bit-exact against the oracle's ef spec (ids, distances, evaluation and pop counts)."""
+    n, d, M, nq, k, ef = 20_000, 768, 16, 1024, 10, 128
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    idx = zv.Index(dim=d, capacity=n, m=M, flags=zv.FLAG_BF16_MIRROR)
+    idx.add(V)
+    idx.build_knn_graph(M, zv.BF_I8)
+    ref = oracle.HNSW(M, 200)
+    for r in V:
+        ref.insert(r, 0)
+    for i in range(n):
+        ref.set_neighbors(i, 0, [int(x) for x in idx.get_neighbors(i)])
+    # the lists themselves: exact kNN by (distance, id) on sampled nodes
+    smp = list(range(0, n, 997))
+    nn, _, _ = oracle.bruteforce_topk(V, V[smp], M + 1)
+    for r, i in enumerate(smp):
+        assert [int(x) for x in idx.get_neighbors(i)] == [int(x) for x in nn[r] if int(x) != i][:M]
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
+    ref.reset_counters()
+    for qi in range(nq):
+        ri, rd = ref.search_ef(Q[qi], k, ef)
+        assert cnt[qi] == len(ri)
+        assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd), qi
+    c = ref.counters()
+    assert (ev, pp) == (c.search_dist_evals, c.search_pops)
+
+
+def test_c3_full_size_10m_x_768_headline_route_properties(zv, oracle):
+    """The headline route (bf16 stream screen + exact re-rank) at BASELINE's full size: k results per query, ascending, every
+    returned distance bit-equal to the oracle's a1 distance on the regenerated row, and no row of a 250k-row sample beats a
+    query's k-th result without being in it (what bench.py's checker does, as a test)."""
+    n, d, nq, k = 10_000_000, 768, 1024, 10
+    idx = zv.Index(dim=d, capacity=n, flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(n, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    ids, dist, cnt = idx.search_bruteforce(Q, k, zv.BF_BF16)
+    assert np.all(cnt == k) and np.all(ids < n)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    for qi in (0, 1, 511, 1022, 1023):
+        for j in range(k):
+            row = oracle.uniform_rows(0x5EED, int(ids[qi, j]), 1, d)[0]
+            assert oracle.distance(Q[qi], row) == dist[qi, j]
+    ns, qs = 250_000, list(range(0, nq, 64))
+    for first in (0, 7_000_000):  # two slices of the corpus
+        V = oracle.uniform_rows(0x5EED, first, ns, d)
+        ri, rd, _ = _oracle_topk_mt(oracle, V, Q[qs], k)
+        for r, qi in enumerate(qs):
+            got = set(int(x) for x in ids[qi])
+            for j in range(k):
+                assert not (rd[r, j] < dist[qi, k - 1] and int(ri[r, j]) + first not in got), (qi, j)
+    # and the int8 route (an independent screen) returns the same neighbours at this size
+    i8, d8, _ = idx.search_bruteforce(Q, k, zv.BF_I8)
+    assert np.array_equal(i8, ids) and np.array_equal(d8, dist)
+
+
+# ---- C4: bf16 rows, 8 id-range shards (BASELINE configs[3]) on one GPU -------------------------------------------------
+def test_c4_bf16_rows_eight_shards_bruteforce_and_graph(zv, oracle):
+    """Rows stored with bf16 semantics (ZVDB_FLAG_BF16_ROWS) in 8 id-range shards: per-shard search with global id offsets,
+    [G][nq][k] gathered layout, HIP k-way merge == the oracle over bf16_round(rows).  Both routes of the config: brute force
+    (bf16 screen, lossless on such rows) and the per-shard graph (M = 16, ef = 128) merged across shards."""
+    import torch
+    from zvdb_amd.sharded import shard_range
+    n, d, nq, k, G, M, ef = 48_000, 768, 64, 10, 8, 16, 128
+    V = oracle.bf16_round(oracle.uniform_rows(0x5EED, 0, n, d))
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.current_stream().cuda_stream
+    q_t = torch.from_numpy(Q).to(dev)
+    g_ids = torch.empty((G * nq, k), dtype=torch.int64, device=dev)
+    g_dist = torch.empty((G * nq, k), dtype=torch.float32, device=dev)
+    g_cnt = torch.empty((G * nq,), dtype=torch.int32, device=dev)
+    shards, refs = [], []
+    for r in range(G):
+        lo, hi = shard_range(n, G, r)
+        idx = zv.Index(dim=d, capacity=hi - lo, m=M, flags=zv.FLAG_BF16_MIRROR | zv.FLAG_BF16_ROWS)
+        idx.add_synthetic(hi - lo, d, 0x5EED, first_row=lo)  # rounded to bf16 as it is added
+        assert np.array_equal(idx.get_vector(5), V[lo + 5])
+        shards.append((idx, lo, hi))
+    o_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    o_dist = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    o_cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+    # brute force
+    keep = []
+    for r, (idx, lo, hi) in enumerate(shards):
+        wsb = idx.bruteforce_workspace(nq, k, zv.BF_BF16)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        keep.append(ws)
+        idx.search_bruteforce_dev(q_t.data_ptr(), nq, d, k, zv.BF_BF16, lo, ws.data_ptr(), wsb, g_ids[r * nq:(r + 1) * nq].data_ptr(),
+                                  g_dist[r * nq:(r + 1) * nq].data_ptr(), g_cnt[r * nq:(r + 1) * nq].data_ptr(), s)
+    zv.merge_topk_dev(g_ids.data_ptr(), g_dist.data_ptr(), g_cnt.data_ptr(), G, nq, k, o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
+    assert np.array_equal(o_ids.cpu().numpy().astype(np.uint64), ri) and np.array_equal(o_dist.cpu().numpy(), rd)
+    # graph route per shard, merged
+    per_i = np.zeros((G, nq, k), dtype=np.uint64)
+    per_d = np.zeros((G, nq, k), dtype=np.float32)
+    per_c = np.zeros((G, nq), dtype=np.uint32)
+    for r, (idx, lo, hi) in enumerate(shards):
+        idx.build_knn_graph(M, zv.BF_BF16)
+        ref = oracle.HNSW(M, 200)
+        for row in V[lo:hi]:
+            ref.insert(row, 0)
+        for i in range(hi - lo):
+            ref.set_neighbors(i, 0, [int(x) for x in idx.get_neighbors(i)])
+        idx.search_graph_dev(q_t.data_ptr(), nq, d, k, ef, 0, lo, g_ids[r * nq:(r + 1) * nq].data_ptr(), g_dist[r * nq:(r + 1) * nq].data_ptr(),
+                             g_cnt[r * nq:(r + 1) * nq].data_ptr(), 0, s)
+        for qi in range(nq):
+            a, b = ref.search_ef(Q[qi], k, ef)
+            per_i[r, qi, :len(a)] = a + np.uint64(lo)
+            per_d[r, qi, :len(a)] = b
+            per_c[r, qi] = len(a)
+    zv.merge_topk_dev(g_ids.data_ptr(), g_dist.data_ptr(), g_cnt.data_ptr(), G, nq, k, o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), s)
+    torch.cuda.synchronize()
+    mi, md, mc = oracle.merge_topk(per_i, per_d, per_c, k)
+    assert np.array_equal(o_ids.cpu().numpy().astype(np.uint64), mi) and np.array_equal(o_dist.cpu().numpy(), md)
+    assert np.array_equal(o_cnt.cpu().numpy().astype(np.uint32), mc)
+
+
+# ---- C5: 1536-d cosine, bf16 rows, k = 100, ef = 256 (BASELINE configs[4]) at reduced N --------------------------------
+def test_c5_cosine_1536d_bf16_rows_k100_ef256(zv, oracle):
+    n, d, nq, k, M, ef = 12_000, 1536, 32, 100, 32, 256
+    Vraw = oracle.uniform_rows(31, 0, n, d) - np.float32(0.5)
+    Q = oracle.uniform_rows(32, 0, nq, d) - np.float32(0.5)
+    idx = zv.Index(metric=zv.METRIC_COSINE, m=M, flags=zv.FLAG_BF16_MIRROR | zv.FLAG_BF16_ROWS)
+    idx.add(Vraw)
+    S = np.stack([idx.get_vector(i) for i in range(n)])  # stored rows: normalised, then rounded to bf16
+    assert not np.any(S.view(np.uint32) & 0xFFFF)
+    assert np.allclose(np.linalg.norm(S.astype(np.float64), axis=1), 1.0, atol=4e-3)
+    # brute force, k = 100: the exact routes rank like the oracle over the stored rows (inner product; queries as given)
+    ri, rd, _ = oracle.bruteforce_topk(S, Q, k, metric=1)
+    for mode in (zv.BF_F32, zv.BF_BF16):
+        ids, dist, cnt = idx.search_bruteforce(Q, k, mode)
+        assert np.all(cnt == k)
+        assert np.array_equal(ids, ri), mode
+    a4, _, _ = idx.search_bruteforce(Q, k, zv.BF_FP4)
+    assert np.mean([len(set(a4[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.95
+    # graph route: exact 32-NN lists under the index's metric, ef = 256 beam search, recall@100 against the brute force
+    idx.build_knn_graph(M, zv.BF_BF16)
+    ref = oracle.HNSW(M, 200)
+    for row in S:
+        ref.insert(row, 0)
+    for i in range(n):
+        ref.set_neighbors(i, 0, [int(x) for x in idx.get_neighbors(i)])
+    gi, gd, gc = idx.search_graph(Q, k, ef=ef)
+    qn = Q / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    hits = 0
+    for qi in range(nq):
+        hits += len(set(int(x) for x in gi[qi, :gc[qi]]) & set(int(x) for x in ri[qi]))
+        assert np.all(np.diff(gd[qi, :gc[qi]]) >= 0)
+    assert hits / (nq * k) >= 0.5  # (a 32-regular exact-kNN graph entered at node 0: measured ~0.8; the bar guards regressions)
+    del qn
