@@ -341,26 +341,6 @@ def test_bruteforce_dot_metric(zv, oracle):
         assert np.array_equal(ids, ri) and np.array_equal(dist, rd)
 
 
-@pytest.mark.parametrize("env", [{"ZVDB_BF_KERNEL": "v1"}, {"ZVDB_BF_KERNEL": "v4"}, {"ZVDB_BF_NI": "4"}])
-def test_bruteforce_ab_kernels_still_correct(zv, oracle, env):
-    """Kernel generations kept for A/B: v1 (128x128 register staged), v4 (64-byte slices, 4-stage ring),
-    and the experimental one-wave-per-SIMD variant (ZVDB_BF_NI=4)."""
-    import subprocess, sys, os
-    code = (
-        "import os, numpy as np, oracle, zvdb_amd as zv\n"
-        "V = oracle.uniform_rows(3, 0, 5000, 96); Q = oracle.uniform_rows(4, 0, 70, 96)\n"
-        "idx = zv.Index(flags=zv.FLAG_BF16_MIRROR); idx.add(V)\n"
-        "ri, rd, _ = oracle.bruteforce_topk(V, Q, 10)\n"
-        "for m in (zv.BF_F32, zv.BF_BF16) + (() if os.environ.get('ZVDB_BF_KERNEL') == 'v1' else (zv.BF_I8,)):\n"
-        "    i, d, _ = idx.search_bruteforce(Q, 10, m)\n"
-        "    assert np.array_equal(i, ri) and np.array_equal(d, rd)\n"
-        "print('v1 ok')\n")
-    env = dict(os.environ, **env)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True)
-    assert out.returncode == 0 and "v1 ok" in out.stdout, out.stdout + out.stderr
-
-
 def test_bruteforce_limits(zv, oracle):
     idx = zv.Index()
     idx.add(oracle.uniform_rows(1, 0, 10, 8))

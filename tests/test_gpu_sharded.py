@@ -176,3 +176,24 @@ def test_two_rank_processes_on_the_hip_backend(oracle):
     ret = mgr.dict()
     mp.spawn(_hip_rank, args=(2, port, 20_001, 64, 33, 10, ret), nprocs=2, join=True)
     assert all(ret.get(r, False) for r in range(2)), dict(ret)
+
+
+def test_bench_under_torchrun_with_the_rccl_backend_world_size_1(oracle):
+    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), at the
+    one world size a one-GPU box allows: the process group is RCCL ("nccl"), the step is search -> ONE packed
+    all_gather_into_tensor -> zvdb_hip_merge_topk_packed_dev, the timing is barrier-bracketed and all-reduced (MAX).
+    ZVDB_BENCH_FORCE_DIST=1 keeps that path on at world size 1."""
+    import json, os, subprocess, sys
+    import zvdb_amd as zv
+    assert zv.device_count() > 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZVDB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--rows", "400000", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-paths"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["dtype"] == "bf16" and out["recall_at_10"] == 1.0
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0

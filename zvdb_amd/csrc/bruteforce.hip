@@ -1,24 +1,17 @@
-// bruteforce.hip -- K4: batched brute-force Q x V^T on MFMA with a fused, never-materialised
-// per-query top-k' selection, followed by a k-way merge of the per-stream lists and (in
-// exact_kernels.hip) the exact fp32 re-rank.  No reference symbol exists for this path (a10):
-// north_star names it; it is the recall-guaranteed route and the ground-truth generator.
+// bruteforce.hip -- K4: batched brute-force Q x V^T on MFMA with a fused, never-materialised per-query top-k'
+// selection, followed by a merge of the per-stream lists and (in exact_kernels.hip) the exact fp32 re-rank.  No
+// reference symbol exists for this path (a10): north_star names it; it is the recall-guaranteed route.
 //
-//   screen distance   d'(q,v) = |v|^2 - 2 q.v   (the |q|^2 term is constant per query)
-//   q.v               fp32 MFMA v_mfma_f32_32x32x2_f32 (exact fma chain) on the fp32 rows, or
-//                     bf16 MFMA v_mfma_f32_32x32x16_bf16 on the bf16 mirror (fp32 accumulate)
-//   selection         per (query tile, corpus stream) workgroup: running threshold tau[q] =
-//                     64th best screen distance seen so far by this workgroup; only d' < tau is
-//                     appended (LDS atomic slot + 8-byte global store); a buffer that crosses
-//                     its high-water mark is pruned to its exact best 64 by one wave (bitonic
-//                     sort / merge on 64-bit (dist,id) keys in registers).  Streams scan rows
-//                     in increasing id order, so '<' implements "ties by lower id" exactly.
+//   screen key        |v'|^2 / 2 - q'.v'  (the |q|^2 term is constant per query; dot / cosine: -q'.v')
+//   q'.v'             fp32 MFMA v_mfma_f32_32x32x2_f32 on the fp32 rows, bf16 / int8 / fp4 MFMA on mirrors
+//   selection         per (query tile, corpus stream) workgroup: exact k' best (key, id) pairs by radix select
+//                     (bf_select.h), shared thresholds across workgroups, "ties by lower id" exact
 //
-// Work decomposition (DESIGN.md "K4"): 128 x 128 output tile per step, 4 waves as 2(M) x 2(N),
-// each wave 64 x 64 = 2 x 2 MFMA 32x32 fragments (64 accumulator VGPRs); K is walked in
-// 128-byte slices of every row (32 fp32 or 64 bf16 elements), register-staged global -> LDS,
-// double buffered, one barrier per slice; 2 workgroups per CU hide the epilogue / prune of one
-// behind the MFMAs of the other.  Block id -> (stream, query tile) keeps all query tiles of a
-// stream on one XCD so each 128-row corpus slab is fetched from HBM once per XCD L2.
+// This file holds the STAGED scan (k_bf_scan5: 256 x 256 output tile, 8 waves of 128 x 64, operands through a 2-stage
+// LDS-DMA ring of 128-byte row slices), used for the fp32 screen, for small shards of every screen and for rows too
+// wide for the stream kernels (bf_bf16_stream.hip, bf_i8_stream.hip, bf_fp4_stream.hip), plus the host-side pipeline
+// of every route (launch_bruteforce).  Earlier generations (v1: 128 x 128 register-staged; v4: 64-byte slices, 4-stage
+// ring; a one-wave-per-SIMD 128 x 128 wave tile) are in the git history and in profiles/r1/ (A/B numbers).
 #include "common.h"
 #include "wave_select.h"
 #include "bf_select.h"
@@ -27,272 +20,12 @@ namespace zvdb {
 
 namespace {
 
-constexpr int BM = 128, BN = 128;   // output tile: queries x corpus rows
 constexpr int KB = 128;             // bytes of every row consumed per K slice
 constexpr int HW = 192;             // prune when a buffer holds more than this
-constexpr int CAP = HW + BN;        // appends of one tile can never overflow
-constexpr int TILE_BYTES = BM * KB; // 16 KiB per operand per stage
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-// ascending bitonic sort of 64 keys, one per lane
-__device__ __forceinline__ uint64_t wave_sort64(uint64_t key, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint64_t o = shfl_xor64(key, j);
-            const bool up = (lane & k) == 0;
-            const bool lower = (lane & j) == 0;
-            key = (lower == up) ? umin64(key, o) : umax64(key, o);
-        }
-    }
-    return key;
-}
-// best, nw: ascending; returns the 64 smallest of the union, ascending
-__device__ __forceinline__ uint64_t wave_merge64(uint64_t best, uint64_t nw, int lane) {
-    uint64_t m = umin64(best, shfl64(nw, 63 - lane));
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        const uint64_t o = shfl_xor64(m, j);
-        m = (lane & j) == 0 ? umin64(m, o) : umax64(m, o);
-    }
-    return m;
-}
-
-__device__ __forceinline__ uint64_t make_key(float d, uint32_t id) {
-    return ((uint64_t)f32_key(d) << 32) | id;
-}
-
-// Reduce row `row`'s candidate buffer to its exact best KP (sorted, at the front).
-// INTKEY: tau holds an int32 screen value (i8 path) instead of an fp32 one.
-template <int CAPV = CAP, bool INTKEY = false>
-__device__ __forceinline__ uint64_t prune_row(uint64_t *__restrict__ buf, uint32_t *cnt, uint32_t *nsorted,
-                                              float *tau, int row, int lane, uint32_t *tau_g = nullptr) {
-    const uint32_t n = min(cnt[row], (uint32_t)CAPV);
-    const uint32_t ns = nsorted[row];
-    uint64_t best = ~0ull;
-    for (uint32_t base = 0; base < n; base += kWave) {
-        const uint32_t i = base + lane;
-        uint64_t key = i < n ? buf[i] : ~0ull;
-        if (!(base == 0 && ns == kWave)) key = wave_sort64(key, lane);
-        best = base == 0 ? key : wave_merge64(best, key, lane);
-    }
-    if (n > 0 && best != ~0ull) buf[lane] = best;
-    const uint32_t kept = min(n, (uint32_t)KP);
-    const uint64_t last = shfl64(best, KP - 1);
-    if (lane == 0) {
-        cnt[row] = kept;
-        nsorted[row] = kept == KP ? KP : 0;  // a short list is re-sorted next time (it is cheap)
-        // never loosen a bound already tightened from the shared threshold
-        if (INTKEY) {
-            int32_t *ti = reinterpret_cast<int32_t *>(tau);
-            const int32_t nt = kept == KP ? (int32_t)((uint32_t)(last >> 32) ^ 0x80000000u) : 0x7FFFFFFF;
-            if (nt < ti[row]) ti[row] = nt;
-        } else {
-            const float nt = kept == KP ? f32_unkey((uint32_t)(last >> 32)) : __builtin_inff();
-            if (nt < tau[row]) tau[row] = nt;
-        }
-        // publish: this stream's 64th best bounds the global 64th best from above
-        if (tau_g && kept == KP) atomicMin(tau_g, (uint32_t)(last >> 32));
-    }
-    return best;
-}
-
-template <bool BF16>
-__global__ __launch_bounds__(256, 2) void k_bf_scan(
-    const unsigned char *__restrict__ A, const unsigned char *__restrict__ B, uint32_t row_bytes,
-    uint32_t KT, const float *__restrict__ vnorm, uint32_t N, uint32_t nq, float alpha,
-    uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
-    uint64_t *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *tiles = smem;                                   // [2 stages][A | B] 64 KiB
-    float *tau = reinterpret_cast<float *>(smem + 4 * TILE_BYTES); // [BM]
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(tau + BM);        // [BM]
-    uint32_t *nsorted = cnt + BM;                                  // [BM]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // block -> (stream s, query tile qt): all QT tiles of a stream share (blockIdx % 8), i.e.
-    // one XCD under round-robin placement (speed only, never correctness).
-    const uint32_t b = blockIdx.x;
-    const uint32_t x = b & 7, j = b >> 3;
-    const uint32_t qt = j % QT;
-    const uint32_t s = (j / QT) * 8 + x;
-    const uint32_t per = (NT + S - 1) / S;
-    const uint32_t t_begin = min(s * per, NT), t_end = min(t_begin + per, NT);
-
-    uint64_t *mybuf = cand + (size_t)b * BM * CAP;
-    if (tid < BM) {
-        tau[tid] = (qt * BM + tid) < nq ? __builtin_inff() : -__builtin_inff();
-        cnt[tid] = 0;
-        nsorted[tid] = 0;
-    }
-
-    // staging map: chunk c = tid + 256*i -> row c>>3, 16-byte chunk c&7 (8 lanes = one 128-B line)
-    const unsigned char *a_base = A + (size_t)qt * BM * row_bytes;  // wave-uniform
-    uint32_t a_off[4], lds_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t c = tid + 256 * i;
-        const uint32_t row = c >> 3, ch = c & 7;
-        a_off[i] = row * row_bytes + ch * 16;
-        lds_off[i] = row * KB + ((ch ^ ((row >> 1) & 7)) << 4);
-    }
-    // fragment read map: lane reads 16 B of row (l & 31), chunk 2*cc + (l >> 5), swizzled
-    const uint32_t fr = lane & 31, fh = lane >> 5;
-
-    for (uint32_t t = t_begin; t < t_end; ++t) {
-        const uint32_t col0 = t * BN;
-        const unsigned char *b_base = B + (size_t)col0 * row_bytes;  // wave-uniform
-        uint32_t b_off[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t c = tid + 256 * i;
-            const uint32_t row = min((uint32_t)(c >> 3), N - 1 - col0);  // clamp: masked in the epilogue
-            b_off[i] = row * row_bytes + (c & 7) * 16;
-        }
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-        u32x4 ra[4], rb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const u32x4 *>(a_base + a_off[i]);
-            rb[i] = *reinterpret_cast<const u32x4 *>(b_base + b_off[i]);
-        }
-        __syncthreads();  // previous tile's readers are done with stage 0 / state arrays settled
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4 *>(tiles + lds_off[i]) = ra[i];
-            *reinterpret_cast<u32x4 *>(tiles + TILE_BYTES + lds_off[i]) = rb[i];
-        }
-        __syncthreads();
-
-        for (uint32_t kt = 0; kt < KT; ++kt) {
-            const unsigned char *st = tiles + (kt & 1) * 2 * TILE_BYTES;
-            const bool more = kt + 1 < KT;
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ra[i] = *reinterpret_cast<const u32x4 *>(a_base + (size_t)(kt + 1) * KB + a_off[i]);
-                    rb[i] = *reinterpret_cast<const u32x4 *>(b_base + (size_t)(kt + 1) * KB + b_off[i]);
-                }
-            }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                u32x4 fa[2], fb[2];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const uint32_t row = wm * 64 + mi * 32 + fr;
-                    fa[mi] = *reinterpret_cast<const u32x4 *>(
-                        st + row * KB + (((2 * cc + fh) ^ ((row >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const uint32_t row = wn * 64 + ni * 32 + fr;
-                    fb[ni] = *reinterpret_cast<const u32x4 *>(
-                        st + TILE_BYTES + row * KB + (((2 * cc + fh) ^ ((row >> 1) & 7)) << 4));
-                }
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        if (BF16) {
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, fa[mi]), __builtin_bit_cast(bf16x8, fb[ni]),
-                                acc[mi][ni], 0, 0, 0);
-                        } else {
-                            const f32x4 x = __builtin_bit_cast(f32x4, fa[mi]);
-                            const f32x4 y = __builtin_bit_cast(f32x4, fb[ni]);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc[mi][ni], 0, 0, 0);
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc[mi][ni], 0, 0, 0);
-                        }
-                    }
-            }
-            if (more) {
-                unsigned char *nx = tiles + ((kt + 1) & 1) * 2 * TILE_BYTES;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    *reinterpret_cast<u32x4 *>(nx + lds_off[i]) = ra[i];
-                    *reinterpret_cast<u32x4 *>(nx + TILE_BYTES + lds_off[i]) = rb[i];
-                }
-            }
-            __syncthreads();
-        }
-
-        // ---- fused selection epilogue -------------------------------------------------
-        // C layout (32x32): column = lane & 31 (corpus row), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-        {
-            const uint32_t qb = wm * 64 + 4 * fh;  // lane's first query row; (mi, r) add constants
-            const float *tau_l = tau + qb;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const uint32_t col = col0 + wn * 64 + ni * 32 + fr;
-                const float vn = col < N ? (vnorm ? vnorm[col] : 0.0f) : __builtin_inff();
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int qc = mi * 32 + (r & 3) + 8 * (r >> 2);  // compile-time constant
-                        const float d = __builtin_fmaf(alpha, acc[mi][ni][r], vn);
-                        if (d < tau_l[qc]) {
-                            // rare path: keep its address arithmetic inside the branch (an opaque
-                            // copy of the row index stops LICM from hoisting 32 address pairs)
-                            uint32_t qrow = qb + qc;
-                            asm volatile("" : "+v"(qrow));
-                            const uint32_t slot = atomicAdd(&cnt[qrow], 1u);
-                            if (slot < (uint32_t)CAP) mybuf[(size_t)qrow * CAP + slot] = make_key(d, col);
-                        }
-                    }
-                }
-            }
-        }
-        const int over = __syncthreads_or(tid < BM && cnt[tid] > (uint32_t)HW);
-        if (over) {
-            for (int row = wave; row < BM; row += 4)
-                if (cnt[row] > (uint32_t)HW) prune_row(mybuf + (size_t)row * CAP, cnt, nsorted, tau, row, lane);
-        }
-    }
-
-    // ---- stream end: exact best KP per query -> partial[q][s][KP] ------------------------
-    __syncthreads();
-    for (int row = wave; row < BM; row += 4) {
-        const uint32_t q = qt * BM + row;
-        if (q >= nq) continue;
-        uint64_t best = ~0ull;
-        if (cnt[row] > 0) best = prune_row(mybuf + (size_t)row * CAP, cnt, nsorted, tau, row, lane);
-        partial[((size_t)q * S + s) * KP + lane] = best;
-    }
-}
-
-
-// =====================================================================================
-// (v2, superseded) 256 x 256 output tile, 8 waves as 2(M) x 4(N), 128 x 64 per wave = 4 x 2 MFMA
-// 32x32 fragments (128 accumulator VGPRs), operands staged by LDS-DMA
-// (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass), two 64 KiB stages, the
-// next 128-byte K slice (or the next tile's first slice) in flight behind every slice's MFMAs
-// and behind the epilogue.  One workgroup per CU.  Bytes per flop are half the 128 x 128
-// tile's: 64 KiB of operands per 8.4 MFLOP (bf16) / 16.8 MOP (i8) slice.
-//
-// LDS-DMA writes wave-uniform base + lane*16, i.e. 8 whole 128-B rows per wave-instruction, so
-// the XOR swizzle of the LDS image is applied to the per-lane SOURCE chunk: the lane that fills
-// (row r, slot c') fetches chunk c' ^ ((r>>1)&7) of row r.
-// MODE: 0 = fp32 (32x32x2 f32), 1 = bf16 (32x32x16), 2 = int8 (32x32x32, i32 accumulate),
-//       3 = fp4 E2M1 (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, fp32 accumulate: products and
-//           sums of fp4 values are small multiples of 1/4, so the fp32 accumulation is exact).
 // =====================================================================================
 constexpr bool kFp4Pipe = false;
 static_assert(T2 == 256, "bf_select.h");  //                    // tile edge (queries and corpus rows)
@@ -813,32 +546,7 @@ uint32_t ncross = 0;
     }
 }
 
-// Merge the S sorted per-stream lists of each query into the global best KP (ids only; the
-// exact distances are recomputed by k_rerank).  One wave per query.
-// tau_out (optional): key of the kp-th best so far -> the exact shared threshold for the next pass.
-__global__ __launch_bounds__(64) void k_bf_merge(const uint64_t *__restrict__ partial, uint32_t S, uint32_t Stot,
-                                                 uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
-                                                 uint32_t kp) {
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.x;
-    const uint64_t *p = partial + (size_t)q * Stot * KP;
-    uint64_t best = p[lane];
-    for (uint32_t s = 1; s < S; ++s) {
-        const uint64_t nw = p[(size_t)s * KP + lane];
-        if (__builtin_amdgcn_readfirstlane((uint32_t)(nw >> 32)) == 0xFFFFFFFFu &&
-            __builtin_amdgcn_readfirstlane((uint32_t)nw) == 0xFFFFFFFFu)
-            continue;  // empty list (its smallest key is the sentinel)
-        best = wave_merge64(best, nw, lane);
-    }
-    if (cand_ids) cand_ids[(size_t)q * KP + lane] = best == ~0ull ? 0xFFFFFFFFu : (uint32_t)best;
-    if (tau_out) {
-        const uint64_t kth = shfl64(best, (int)kp - 1);
-        if (lane == 0) tau_out[q] = (uint32_t)(kth >> 32);  // 0xFFFFFFFF when fewer than kp candidates exist
-    }
-}
-
-
-// v4 lists are UNSORTED (valid entries compacted to the front, ~0 padded).  Select-based merge: the
+// The lists are UNSORTED (valid entries compacted to the front, ~0 padded).  Select-based merge: the
 // valid keys of all lists of a query are gathered into LDS (one lane per list, 64 lists at a time),
 // then one radix select yields the kp best.  Output: candidate ids (unordered) and/or the kp-th key.
 // vmode 0: plain.  vmode 1 (verification of guessed thresholds): a query whose lists hold fewer than kp keys cannot
@@ -1002,20 +710,6 @@ struct BfPlan {
     uint32_t QT8, S8;  // int8 stream kernel: tiles of 128 queries, streams
 };
 
-int kernel_version() {  // ZVDB_BF_KERNEL = v1 | v4 | v6 (default): older generations kept for A/B.
-    // v6 = v4 with full-line (8 rows x 128 B) LDS-DMA pieces, 128-byte slices and a 2-stage ring; it shares
-    // every host-side path with v4, so kernel_version() reports 4 for both and is_v6() tells them apart.
-    static const int v = [] {
-        const char *e = getenv("ZVDB_BF_KERNEL");
-        return (e && e[0] == 'v' && e[1] == '1') ? 1 : 4;
-    }();
-    return v;
-}
-bool use_v1() { return kernel_version() == 1; }
-bool is_v6() {
-    static const bool v = [] { const char *e = getenv("ZVDB_BF_KERNEL"); return !e || (e[0] == 'v' && e[1] == '6'); }();
-    return v;
-}
 uint32_t debug_flags() {
     static const uint32_t f = [] {
         const char *e = getenv("ZVDB_BF_DEBUG");
@@ -1032,9 +726,8 @@ static uint32_t effective_mode(const zvdb_hip_index *h, uint32_t mode) { return 
 BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     mode = effective_mode(h, mode);
     BfPlan p{};
-    const bool v1 = use_v1() && mode != ZVDB_BF_I8 && mode != ZVDB_BF_FP4;
-    p.tile = v1 ? BM : T2;
-    p.cap = v1 ? CAP : CAP2;
+    p.tile = T2;
+    p.cap = CAP2;
     p.nq_pad = round_up(std::max(nq, 1u), p.tile);
     p.QT = p.nq_pad / p.tile;
     p.NT = (uint32_t)((h->count + p.tile - 1) / p.tile);
@@ -1043,8 +736,8 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     else if (mode == ZVDB_BF_FP4) { p.row_bytes = round_up(h->dim, 256) / 2; p.row_elems = p.row_bytes; /* prep kernel: per byte */ }
     else { p.row_elems = h->ld; p.row_bytes = h->ld * 4; }
     p.KT = p.row_bytes / KB;
-    // resident workgroups: v1 2 per CU, v2 1 per CU; streams in multiples of 8 (XCD groups)
-    const uint32_t resident = v1 ? 512 : 256;
+    // resident workgroups: 1 per CU; streams in multiples of 8 (XCD groups)
+    const uint32_t resident = 256;
     uint32_t S = std::max(8u, (resident / p.QT) / 8 * 8);
     while (S > 8 && S > p.NT) S -= 8;  // do not create streams with no tiles
     p.S = S;
@@ -1077,22 +770,12 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     return p;
 }
 
-int wave_tile_ni() {
-    static const int v = [] { const char *e = getenv("ZVDB_BF_NI"); return (e && e[0] == '4') ? 4 : 2; }();
-    return v;
-}
-
 // k-slice rotation per query tile (nibble qt&7), each < KT.  ZVDB_BF_ROT=<hex> overrides (A/B).
 uint32_t rot_table(uint32_t KT) {
     static const uint32_t env = [] { const char *e = getenv("ZVDB_BF_ROT"); return e ? (uint32_t)strtoul(e, nullptr, 16) : 0x53145420u; }();
     uint32_t t = 0;
     for (int i = 0; i < 8; ++i) t |= (((env >> (4 * i)) & 15u) % KT) << (4 * i);
     return t;
-}
-
-int slice_bytes() {
-    static const int v = [] { const char *e = getenv("ZVDB_BF_KBV"); return (e && e[0] == '6') ? 64 : 128; }();
-    return v;
 }
 
 template <int MODE, int NI, int KBV, int KPV = KP>
@@ -1222,7 +905,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // The stream kernels go on to k' = 256 (four entries per lane): k <= 240, and the fp4 screen uses it from k > 64
     // (recall@100: 0.84 with 128 survivors).
     const bool widest = stream_route && (k > (uint32_t)KPW - 16 || (mode == ZVDB_BF_FP4 && k > 64) || want > (uint32_t)KPW);
-    const uint32_t kpv = !(wide_k && (stream_route || p.tile != BM)) ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
+    const uint32_t kpv = !wide_k ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
     if (k > (kpv != (uint32_t)KP ? kpv - 16 : kmax)) {
         set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d on the stream routes: "
                   "ZVDB_BF_I8 with dim <= 768, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
@@ -1231,24 +914,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
-    if (p.tile == BM) {  // v1 (kept for A/B: ZVDB_BF_KERNEL=v1)
-        const bool bf16 = mode == ZVDB_BF_BF16;
-        const float *vn = l2 ? (bf16 ? h->norm_h : h->norm) : nullptr;
-        const size_t lds = 4 * TILE_BYTES + 3 * BM * 4;
-        if (bf16) {
-            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_bf_scan<true>, dim3(p.QT * p.S), dim3(256), lds, s, q_op,
-                               reinterpret_cast<const unsigned char *>(h->rows_h), p.row_bytes, p.KT, vn, N, nq,
-                               (float)alpha_i, p.QT, p.S, p.NT, cand, partial);
-        } else {
-            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_bf_scan<false>, dim3(p.QT * p.S), dim3(256), lds, s, q_op,
-                               reinterpret_cast<const unsigned char *>(h->rows), p.row_bytes, p.KT, vn, N, nq,
-                               (float)alpha_i, p.QT, p.S, p.NT, cand, partial);
-        }
-    } else {
+    {
         // The passes share one exact threshold: each pass but the last is followed by a merge of all lists;
         // a merge of its per-stream lists yields, per query, the exact k'-th best screen key so far
         // (tau_G); pass B scans the rest against it (folded in at every tile start, together with
@@ -1389,24 +1055,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128, KPW>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
                 return launch_scan5<0, 2, 128, KPW>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
             }
-            if (mode == ZVDB_BF_FP4 && !is_v6())  // A/B: 64-byte slices, 4-stage ring (3 slices in flight)
-                return launch_scan5<3, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-            if (mode == ZVDB_BF_FP4)  // default: full-line pieces, 128-byte (256-element) slices
-                return launch_scan5<3, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-            if (kernel_version() == 4 && wave_tile_ni() == 4) {  // experimental: one wave per SIMD
-                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-                if (mode == ZVDB_BF_I8) return launch_scan5<2, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-                return launch_scan5<0, 4, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-            }
-            if (kernel_version() == 4 && is_v6()) {  // default: full-line DMA pieces, 2-stage ring
-                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-                if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-                return launch_scan5<0, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-            }
-            // v4 = the same kernel with 64-byte slices / 16 x 64 B DMA pieces / 4-stage ring
-            if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-            if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
-            return launch_scan5<0, 2, 64>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            if (mode == ZVDB_BF_FP4) return launch_scan5<3, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            if (mode == ZVDB_BF_I8) return launch_scan5<2, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
+            return launch_scan5<0, 2, 128>(q, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau_g, kp, ps.t0, ps.nt, list_base, Stot, pcnt, s);
         };
         uint32_t lists = 0;
         for (int i = 0; i < np; ++i) {
@@ -1448,7 +1100,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 c[0], c[1], c[2], c[3], (double)c[4] / (p.QT * p.S), (double)c[5] / (p.QT * p.S),
                 (double)c[8] / (p.QT * p.S), (double)c[6] / (p.QT * p.S), (double)c[7] / (p.QT * p.S));
     }
-    if (p.tile != BM && kernel_version() == 4) {
+    {
         const uint32_t kpf = kpv != (uint32_t)KP ? kpv
                              : mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
         const uint32_t cap = kpf + 64 * kpv;
@@ -1458,8 +1110,6 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial,
                            reinterpret_cast<const uint32_t *>(ws + p.off_pcnt), nlists, stot_lists, cand_ids,
                            (uint32_t *)nullptr, kpf, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
-    } else {
-        hipLaunchKernelGGL(k_bf_merge, dim3(nq), dim3(64), 0, s, partial, nlists, stot_lists, cand_ids, (uint32_t *)nullptr, (uint32_t)KP);
     }
     ZV_HIP(hipGetLastError());
     return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
