@@ -288,13 +288,15 @@ def extras(args, zv, torch):
     }
     del h, ref, gidx
 
-    # ---- graph route at scale (BASELINE configs[2] shape, reduced N): GPU-built exact 16-NN layer-0 graph,
-    # ef-mode beam search from node 0 (extension; spec = oracle), recall vs the brute-force route ------------
+    # ---- graph route at scale (BASELINE configs[2] shape, reduced N): the bulk HNSW graph (M = 16: heuristic forward links
+    # over the 64 exact nearest + reverse links, cut to 32; upper layers), ef-mode beam search entered by hierarchical
+    # descent (extension; spec = oracle), recall vs the brute-force route.  On i.i.d. uniform 768-d rows no graph reaches the
+    # bar (profiles/r2/graph_recall_*.txt hold the curves, incl. data with neighbourhood structure where it does) ------------
     NG, DG, BG = args.extras_graph_rows, 768, 1024
-    g = zv.Index(dim=DG, capacity=NG, m=16, flags=zv.FLAG_BF16_MIRROR)
+    g = zv.Index(dim=DG, capacity=NG, m=32, graph_stride=32, flags=zv.FLAG_BF16_MIRROR)
     g.add_synthetic(NG, DG, CORPUS_SEED)
     t0 = time.perf_counter()
-    g.build_knn_graph(16, zv.BF_I8)
+    g.build_graph(16, 64, zv.BF_I8, 7)
     t_build = time.perf_counter() - t0
     qg = torch.empty((BG, DG), dtype=torch.float32, device=dev)
     zv.fill_synthetic_dev(qg.data_ptr(), BG, DG, QUERY_SEED, 0, stream)
@@ -308,11 +310,11 @@ def extras(args, zv, torch):
                             cnt.data_ptr(), stream)
     torch.cuda.synchronize()
     gt = ids.cpu().numpy().copy()
-    graph = {"rows": NG, "dim": DG, "M": 16, "batch": BG, "knn_graph_build_s": t_build,
-             "knn_graph_build_rows_per_s": NG / t_build, "ef": {}}
+    graph = {"rows": NG, "dim": DG, "M": 16, "ef_construction": 64, "layer0_cap": 32, "batch": BG, "graph_build_s": t_build,
+             "graph_build_rows_per_s": NG / t_build, "entry": "hierarchical descent (ZVDB_ENTRY_DESCEND)", "ef": {}}
     for ef in (64, 128, 256):
         st.zero_()
-        g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, 0, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
+        g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
                            st.data_ptr(), stream)
         torch.cuda.synchronize()
         got = ids.cpu().numpy()
@@ -320,7 +322,7 @@ def extras(args, zv, torch):
         ev = int(st[0].item())
         t0 = time.perf_counter()
         for _ in range(3):
-            g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, 0, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
+            g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / 3
         bytes_q = ev / BG * DG * 4

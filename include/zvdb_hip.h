@@ -141,6 +141,24 @@ int zvdb_hip_get_neighbors(zvdb_hip_index *h, uint64_t node, uint64_t *out_ids, 
  * with the brute-force MFMA path in batches of rows; lists are stored nearest first.  degree <=
  * graph_stride.  `mode` = enum zvdb_bf_mode of the screen (final order is exact either way). */
 int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode);
+/* Bulk construction of a recall-competent HNSW graph on the device (SURVEY 8f rank 1 + 3; NOT reference parity: the
+ * reference insert links one edge per layer and never reads ef_construction, hnsw.zig:59,:106-108 -- this call gives the
+ * reference's parameters the meaning they have in HNSW proper).  Specification: the oracle (orc_bulk_level,
+ * orc_graph_select, orc_graph_build_layer0), matched bit for bit:
+ *   levels   level(i) = trailing one-bits of mix64(level_seed, i), cap 31 (hnsw.zig:172-180's distribution);
+ *   layer 0  candidates = each node's min(ef_construction, 96) exact nearest neighbours; forward links by the HNSW
+ *            neighbour-selection heuristic with keep-pruned fill (cap M); reverse links added; the union is cut to
+ *            2 M links with the same heuristic (graph_stride >= 2 M; M <= 32);
+ *   layer L  the M exact nearest among the nodes whose level reaches L;
+ *   entry    the first node of the highest level (zvdb_hip_graph_info).
+ * Replaces every layer of the index's graph.  Search it with zvdb_hip_search_graph(ef > 0, entry = ZVDB_ENTRY_DESCEND):
+ * a greedy descent through the upper layers picks each query's layer-0 entry, then the ef-mode beam search runs. */
+int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, uint32_t mode, uint64_t level_seed);
+int zvdb_hip_graph_info(zvdb_hip_index *h, uint64_t *out_entry, uint32_t *out_max_level);
+/* connections[layer] of a node on the device (layer 0: zvdb_hip_get_neighbors); NODE_NOT_FOUND if the node lacks the layer */
+int zvdb_hip_get_neighbors_layer(zvdb_hip_index *h, uint64_t node, uint32_t layer, uint64_t *out_ids, uint32_t cap, uint32_t *out_n);
+/* `entry` value of the graph searches: per-query entry = hierarchical descent from the bulk graph's top node */
+#define ZVDB_ENTRY_DESCEND 0xFFFFFFFFFFFFFFFFull
 
 /* ---- a1/a2/a3 seam: distance(query, rows[ids]) (hnsw.zig:86,:96,:160-161) -- */
 /* out[i] = distance(query, row ids[i]) in EXACT reference arithmetic (strict

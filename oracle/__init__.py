@@ -96,6 +96,13 @@ def lib():
     L.orc_bruteforce_topk.restype = None
     L.orc_bruteforce_topk.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
                                       C.c_size_t, C.c_int, u64p, f32p, u32p]
+    L.orc_bulk_level.restype = C.c_uint32
+    L.orc_bulk_level.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_graph_build_layer0.restype = None
+    L.orc_graph_build_layer0.argtypes = [f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, u64p, f32p, C.c_size_t, C.c_size_t,
+                                         C.c_size_t, C.c_size_t, u32p, u32p]
+    L.orc_hnsw_descend.restype = C.c_size_t
+    L.orc_hnsw_descend.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_int, C.c_size_t]
     L.orc_merge_topk.restype = None
     L.orc_merge_topk.argtypes = [u64p, f32p, u32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p, u32p]
     _lib = L
@@ -192,6 +199,11 @@ class HNSW:
                                           _p(ids, C.c_uint64), _p(dist, C.c_float))
         return ids[:n].copy(), dist[:n].copy()
 
+    def descend(self, query, metric: int = 0, top: int = 0) -> int:
+        """Hierarchical entry descent of the bulk graph (extension; the spec of k_descend): layer-0 entry of the beam."""
+        q = _f32(query)
+        return int(self._L.orc_hnsw_descend(self._h, _p(q, C.c_float), q.size, metric, top))
+
     def count(self) -> int:
         return int(self._L.orc_hnsw_count(self._h))
 
@@ -268,3 +280,77 @@ def merge_topk(ids, dist, count, k: int):
     lib().orc_merge_topk(_p(ids, C.c_uint64), _p(dist, C.c_float), _p(count, C.c_uint32), G, nq, k,
                          _p(oi, C.c_uint64), _p(od, C.c_float), _p(oc, C.c_uint32))
     return oi, od, oc
+
+
+# ---- bulk graph construction (extension; the specification of zvdb_hip_build_graph: oracle/zvdb_oracle.c) ------------------
+def bulk_levels(seed: int, n: int) -> np.ndarray:
+    L = lib()
+    return np.array([L.orc_bulk_level(seed, i) for i in range(n)], dtype=np.uint32)
+
+
+def _knn_excluding_self(V, rows, k: int, metric: int, threads: int = 8):
+    """For every row of V[rows] its k nearest among V[rows] by (distance, id), itself excluded: the row's own entry is
+    removed from the top-(k+1); if it is not among them (more than k exact duplicates ahead of it) the last entry goes."""
+    import threading
+    sub = np.ascontiguousarray(V[rows])
+    n = len(rows)
+    kk = min(k + 1, n)
+    ids = np.zeros((n, kk), dtype=np.uint64)
+    dist = np.zeros((n, kk), dtype=np.float32)
+    parts = [(t * n // threads, (t + 1) * n // threads) for t in range(threads)]
+
+    def work(a, b):
+        if b > a:
+            i, d, _ = bruteforce_topk(sub, sub[a:b], kk, metric)
+            ids[a:b], dist[a:b] = i, d
+
+    th = [threading.Thread(target=work, args=p) for p in parts]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    kout = min(k, n - 1)
+    oi = np.zeros((n, max(kout, 1)), dtype=np.uint64)
+    od = np.zeros((n, max(kout, 1)), dtype=np.float32)
+    for r in range(n):
+        keep = [j for j in range(kk) if ids[r, j] != r][:kout]
+        oi[r, :kout] = ids[r, keep]
+        od[r, :kout] = dist[r, keep]
+    return oi[:, :kout], od[:, :kout]
+
+
+def graph_build_layer0(V, cand_ids, cand_dist, M: int, M0: int, cmax: int, metric: int = 0):
+    V = _f32(V)
+    N, d = V.shape
+    cand_ids = np.ascontiguousarray(cand_ids, dtype=np.uint64)
+    cand_dist = _f32(cand_dist)
+    adj = np.zeros((N, M0), dtype=np.uint32)
+    deg = np.zeros(N, dtype=np.uint32)
+    lib().orc_graph_build_layer0(_p(V, C.c_float), N, d, d, metric, _p(cand_ids, C.c_uint64), _p(cand_dist, C.c_float),
+                                 cand_ids.shape[1], M, M0, cmax, _p(adj, C.c_uint32), _p(deg, C.c_uint32))
+    return adj, deg
+
+
+def build_bulk_graph(V, M: int, ef_construction: int, level_seed: int, metric: int = 0, cmax: int = 128):
+    """The whole bulk graph as the specification defines it: levels from the counter hash, layer 0 = heuristic selection over
+    the ef_construction exact nearest + reverse links, capped at M0 = 2 M; every upper layer L = the M exact nearest among
+    the nodes whose level reaches L.  Returns (HNSW holding points, levels and every list; top entry node)."""
+    V = _f32(V)
+    N = V.shape[0]
+    levels = bulk_levels(level_seed, N)
+    h = HNSW(2 * M, ef_construction)
+    for i in range(N):
+        h.insert(V[i], int(levels[i]))
+    ci, cd = _knn_excluding_self(V, np.arange(N), min(ef_construction, N - 1), metric)
+    adj, deg = graph_build_layer0(V, ci, cd, M, 2 * M, cmax, metric)
+    for i in range(N):
+        h.set_neighbors(i, 0, adj[i, :deg[i]])
+    for L in range(1, int(levels.max()) + 1):
+        rows = np.nonzero(levels >= L)[0]
+        if len(rows) > 1:
+            ui, _ = _knn_excluding_self(V, rows, M, metric)
+            for r, node in enumerate(rows):
+                h.set_neighbors(int(node), L, rows[ui[r].astype(np.int64)])
+        else:
+            for node in rows:
+                h.set_neighbors(int(node), L, [])
+    top = int(np.argmax(levels))  # the first node of the highest level
+    return h, levels, top

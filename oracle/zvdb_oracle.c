@@ -468,6 +468,136 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
     return orc_hnsw_search_ef_ex(h, query, d, k, ef, 0, h->entry_point, out_ids, out_dist);
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* bulk graph construction + hierarchical entry descent                      */
+/* EXTENSION: no reference symbol -- the reference   */
+/* insert links one edge per layer (hnsw.zig:106-108) and never reads         */
+/* ef_construction (hnsw.zig:59).  These functions ARE the specification the  */
+/* HIP builder (graph_build.hip) and k_descend must match bit for bit.        */
+/* ------------------------------------------------------------------------ */
+uint32_t orc_bulk_level(uint64_t seed, uint64_t id) {
+    /* hnsw.zig:172-180's distribution (each further level with probability 1/2, cap 31) from a counter hash:
+     * level = number of leading coin flips that came up "continue" = trailing one-bits of the hash */
+    const uint64_t x = orc_mix64(seed, id);
+    uint32_t level = 0;
+    while (level < 31 && ((x >> level) & 1ull)) ++level;
+    return level;
+}
+
+static float pair_dist(const float *a, const float *b, size_t d, int metric) {
+    return metric ? orc_neg_dot_f32(a, b, d) : orc_distance_f32(a, b, d);
+}
+
+/* The HNSW neighbour-selection heuristic with keep-pruned fill.  Candidates of `base` arrive sorted ascending by
+ * (distance to base, id).  Walk them in that order while fewer than cap are kept: a candidate c is kept iff
+ * d(base, c) < d(c, s) for EVERY s kept so far (strict), else it is set aside; afterwards the set-aside ones fill the
+ * list up to cap in their order.  Output order = kept order, then fills. */
+size_t orc_graph_select(const float *V, size_t d, size_t ld, int metric, const uint64_t *cand_ids, const float *cand_dist,
+                        size_t ncand, size_t cap, uint64_t *out_ids, float *out_dist) {
+    size_t nk = 0, np = 0;
+    uint64_t *pr_i = (uint64_t *)malloc((ncand + 1) * sizeof(uint64_t));
+    float *pr_d = (float *)malloc((ncand + 1) * sizeof(float));
+    for (size_t i = 0; i < ncand && nk < cap; ++i) {
+        const float *c = V + cand_ids[i] * ld;
+        int good = 1;
+        for (size_t j = 0; j < nk; ++j) {
+            const float dcs = pair_dist(c, V + out_ids[j] * ld, d, metric);
+            if (!(cand_dist[i] < dcs)) { good = 0; break; }
+        }
+        if (good) { out_ids[nk] = cand_ids[i]; out_dist[nk] = cand_dist[i]; ++nk; }
+        else { pr_i[np] = cand_ids[i]; pr_d[np] = cand_dist[i]; ++np; }
+    }
+    for (size_t i = 0; i < np && nk < cap; ++i) { out_ids[nk] = pr_i[i]; out_dist[nk] = pr_d[i]; ++nk; }
+    free(pr_i); free(pr_d);
+    return nk;
+}
+
+/* Layer-0 lists of the bulk graph.  cand_ids / cand_dist [N][ncand]: every node's ncand exact nearest neighbours
+ * (self excluded) ascending by (distance, id).
+ *   S[u]  = select(u, cand[u], cap M)                                  -- forward links
+ *   C[v]  = S[v] u { (u, d(u,v)) : v in S[u] }, duplicates removed,     -- plus reverse links
+ *           sorted by (distance, id), truncated to the first cmax
+ *   L0[v] = select(v, C[v], cap M0)                                     -- degree cap with the same heuristic
+ * adj [N][M0] (u32), deg [N]. */
+void orc_graph_build_layer0(const float *V, size_t N, size_t d, size_t ld, int metric, const uint64_t *cand_ids,
+                            const float *cand_dist, size_t ncand, size_t M, size_t M0, size_t cmax, uint32_t *adj, uint32_t *deg) {
+    uint64_t *s_ids = (uint64_t *)malloc(N * M * sizeof(uint64_t));
+    float *s_dist = (float *)malloc(N * M * sizeof(float));
+    size_t *s_n = (size_t *)malloc(N * sizeof(size_t));
+    size_t *r_n = (size_t *)calloc(N + 1, sizeof(size_t));
+    for (size_t u = 0; u < N; ++u) {
+        s_n[u] = orc_graph_select(V, d, ld, metric, cand_ids + u * ncand, cand_dist + u * ncand, ncand, M, s_ids + u * M, s_dist + u * M);
+        for (size_t j = 0; j < s_n[u]; ++j) r_n[s_ids[u * M + j] + 1] += 1;
+    }
+    for (size_t v = 0; v < N; ++v) r_n[v + 1] += r_n[v];  /* CSR offsets */
+    const size_t total = r_n[N];
+    uint64_t *r_ids = (uint64_t *)malloc((total + 1) * sizeof(uint64_t));
+    float *r_dist = (float *)malloc((total + 1) * sizeof(float));
+    size_t *cur = (size_t *)malloc(N * sizeof(size_t));
+    for (size_t v = 0; v < N; ++v) cur[v] = r_n[v];
+    for (size_t u = 0; u < N; ++u)
+        for (size_t j = 0; j < s_n[u]; ++j) {
+            const size_t v = (size_t)s_ids[u * M + j];
+            r_ids[cur[v]] = u; r_dist[cur[v]] = s_dist[u * M + j]; cur[v] += 1;
+        }
+    for (size_t v = 0; v < N; ++v) {
+        const size_t nr = r_n[v + 1] - r_n[v], nc = s_n[v] + nr;
+        uint64_t *ci = (uint64_t *)malloc((nc + 1) * sizeof(uint64_t));
+        float *cd = (float *)malloc((nc + 1) * sizeof(float));
+        size_t n = 0;
+        for (size_t j = 0; j < s_n[v]; ++j) { ci[n] = s_ids[v * M + j]; cd[n] = s_dist[v * M + j]; ++n; }
+        for (size_t j = 0; j < nr; ++j) {
+            const uint64_t u = r_ids[r_n[v] + j];
+            int dup = 0;
+            for (size_t t = 0; t < s_n[v]; ++t) if (s_ids[v * M + t] == u) { dup = 1; break; }
+            if (!dup) { ci[n] = u; cd[n] = r_dist[r_n[v] + j]; ++n; }
+        }
+        for (size_t i = 1; i < n; ++i) {  /* insertion sort by (distance, id) */
+            const uint64_t ti = ci[i]; const float td = cd[i];
+            size_t pos = i;
+            while (pos > 0 && lex_less(td, ti, cd[pos - 1], ci[pos - 1])) { ci[pos] = ci[pos - 1]; cd[pos] = cd[pos - 1]; --pos; }
+            ci[pos] = ti; cd[pos] = td;
+        }
+        if (n > cmax) n = cmax;
+        uint64_t *oi = (uint64_t *)malloc((M0 + 1) * sizeof(uint64_t));
+        float *od = (float *)malloc((M0 + 1) * sizeof(float));
+        const size_t k = orc_graph_select(V, d, ld, metric, ci, cd, n, M0, oi, od);
+        for (size_t j = 0; j < k; ++j) adj[v * M0 + j] = (uint32_t)oi[j];
+        deg[v] = (uint32_t)k;
+        free(ci); free(cd); free(oi); free(od);
+    }
+    free(s_ids); free(s_dist); free(s_n); free(r_n); free(r_ids); free(r_dist); free(cur);
+}
+
+/* Hierarchical entry descent: from `top` (the bulk graph's entry: a node of the highest level) go down the layers
+ * max_level .. 1; on each layer repeat { scan the WHOLE list of the current node in list order with the traversal
+ * distance (16-way blocked, as the beam search), keep the strict arg-min ('<': the earliest entry wins ties), move there }
+ * until no neighbour is closer (hnsw.zig:90-104's greedy step, run top-down).  Returns the layer-0 entry of the beam. */
+size_t orc_hnsw_descend(orc_hnsw *h, const float *query, size_t d, int metric, size_t top) {
+    if (!h->has_entry || d != h->dim || top >= h->count) return 0;
+    size_t cur = top;
+    float dcur = metric ? orc_neg_dot_blocked16_f32(query, h->nodes[cur].point, d) : orc_distance_blocked16_f32(query, h->nodes[cur].point, d);
+    h->ctr.search_dist_evals += 1;
+    for (size_t layer = h->nodes[top].nconn - 1; layer >= 1; --layer) {
+        for (;;) {
+            if (layer >= h->nodes[cur].nconn) break;
+            const idlist *lst = &h->nodes[cur].conn[layer];
+            size_t best = cur;
+            float dbest = dcur;
+            for (size_t i = 0; i < lst->len; ++i) {
+                const size_t nb = (size_t)lst->items[i];
+                const float dn = metric ? orc_neg_dot_blocked16_f32(query, h->nodes[nb].point, d) : orc_distance_blocked16_f32(query, h->nodes[nb].point, d);
+                h->ctr.search_dist_evals += 1;
+                if (dn < dbest) { dbest = dn; best = nb; }
+            }
+            if (best == cur) break;
+            cur = best; dcur = dbest;
+        }
+    }
+    return cur;
+}
+
 /* ------------------------------------------------------------------------ */
 /* accessors                                                                 */
 /* ------------------------------------------------------------------------ */

@@ -118,6 +118,16 @@ typedef struct {
 void orc_hnsw_counters(const orc_hnsw *h, orc_counters *out);
 void orc_hnsw_reset_counters(orc_hnsw *h);
 
+/* ---- bulk graph construction + hierarchical entry descent (EXTENSION; SURVEY 8f rank 1 + 3; parity unpinned by the
+ * reference, whose insert links one edge per layer and never reads ef_construction: hnsw.zig:59,:106-108).  These
+ * functions are the specification of graph_build.hip and k_descend; semantics are spelled out at their definitions. */
+uint32_t orc_bulk_level(uint64_t seed, uint64_t id);
+size_t orc_graph_select(const float *V, size_t d, size_t ld, int metric, const uint64_t *cand_ids, const float *cand_dist,
+                        size_t ncand, size_t cap, uint64_t *out_ids, float *out_dist);
+void orc_graph_build_layer0(const float *V, size_t N, size_t d, size_t ld, int metric, const uint64_t *cand_ids,
+                            const float *cand_dist, size_t ncand, size_t M, size_t M0, size_t cmax, uint32_t *adj, uint32_t *deg);
+size_t orc_hnsw_descend(orc_hnsw *h, const float *query, size_t d, int metric, size_t top);
+
 /* ---- a10: exact brute-force top-k (EXTENSION, parity unpinned) ------------ */
 /* For each query the k smallest a1 distances over rows [0,N), ascending,
  * ties by lower id.  metric: 0 = L2^2 (a1), 1 = -dot, 2 = cosine (rows and

@@ -14,6 +14,7 @@ METRIC_L2SQ, METRIC_DOT, METRIC_COSINE = 0, 1, 2
 BF_F32, BF_BF16, BF_I8, BF_FP4 = 0, 1, 2, 3
 FLAG_BF16_MIRROR = 1
 FLAG_BF16_ROWS = 2
+ENTRY_DESCEND = 0xFFFFFFFFFFFFFFFF  # search_graph entry: hierarchical descent from the bulk graph's top node
 ABI_VERSION = 1
 
 
@@ -61,6 +62,9 @@ HIP_SYMBOLS = [
                                               _vp, _vp]),
     ("zvdb_hip_search_graph_dev", _i32, [_vp, _vp, _u32, _u32, _u32, _u32, _u64, _u64, _vp, _vp, _vp, _vp,
                                          _vp]),
+    ("zvdb_hip_build_graph", _i32, [_vp, _u32, _u32, _u32, _u64]),
+    ("zvdb_hip_graph_info", _i32, [_vp, _u64p, _u32p]),
+    ("zvdb_hip_get_neighbors_layer", _i32, [_vp, _u64, _u32, _u64p, _u32, _u32p]),
     ("zvdb_hip_merge_topk_dev", _i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_merge_topk_packed_dev", _i32, [_vp, _u64, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_index_set_shard_count", _i32, [_vp, _u32]),

@@ -880,12 +880,20 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
     ZV_CHECK(settle_own_stream(h));
     ZV_CHECK(check_query_args(h, dim, k));
     ZV_ARG(h->count > 0 && k > 0, "search_graph_dev needs a non-empty index and k > 0");
+    const bool descend = entry == ZVDB_ENTRY_DESCEND;
+    if (descend) {
+        if (ef == 0 || !h->bulk_graph) {
+            set_error("ZVDB_ENTRY_DESCEND needs ef > 0 and a graph built by zvdb_hip_build_graph");
+            return ZVDB_ERR_INVALID;
+        }
+        entry = h->bulk_top;
+    }
     if (entry >= h->count) {
         set_error("NodeNotFound: entry %llu", (unsigned long long)entry);
         return ZVDB_ERR_NODE_NOT_FOUND;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ef == 0) {
+    if (ef == 0 || descend) {  // (tie_buf doubles as the per-query entry buffer of the descent)
         ZV_CHECK(ensure_tie(h, nq));
         ZV_CHECK(tie_begin(h, s));
     }
@@ -896,13 +904,17 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
                                   id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
                                   static_cast<uint32_t *>(d_count),
                                   static_cast<unsigned long long *>(d_stats), s, h->tie_buf);
-    else
-        rc = launch_search_ef(h, static_cast<const float *>(d_queries), nq, k, ef, (uint32_t)entry,
-                              id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
-                              static_cast<uint32_t *>(d_count),
-                              static_cast<unsigned long long *>(d_stats), s);
+    else {
+        rc = descend ? launch_descend(h, static_cast<const float *>(d_queries), nq, (uint32_t)entry, h->tie_buf,
+                                      static_cast<unsigned long long *>(d_stats), s) : ZVDB_OK;
+        if (rc == ZVDB_OK)
+            rc = launch_search_ef(h, static_cast<const float *>(d_queries), nq, k, ef, (uint32_t)entry,
+                                  id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
+                                  static_cast<uint32_t *>(d_count),
+                                  static_cast<unsigned long long *>(d_stats), s, descend ? h->tie_buf : nullptr);
+    }
     timing_end(h, s);
-    if (ef == 0 && rc == ZVDB_OK) ZV_CHECK(tie_end(h, s));
+    if ((ef == 0 || descend) && rc == ZVDB_OK) ZV_CHECK(tie_end(h, s));
     return rc;
 }
 
@@ -970,6 +982,14 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
         ZV_CHECK(stage_queries(h, queries, nq, reinterpret_cast<float *>(scr)));
         ZV_HIP(hipMemsetAsync(scr + qb + ib + db + cb, 0, 64, h->stream));
         // unlock-free inner call: we already hold the mutex, so call the launchers directly
+        const bool descend = entry == ZVDB_ENTRY_DESCEND;
+        if (descend) {
+            if (ef == 0 || !h->bulk_graph) {
+                set_error("ZVDB_ENTRY_DESCEND needs ef > 0 and a graph built by zvdb_hip_build_graph");
+                return ZVDB_ERR_INVALID;
+            }
+            entry = h->bulk_top;
+        }
         if (entry >= h->count) {
             set_error("NodeNotFound: entry %llu", (unsigned long long)entry);
             return ZVDB_ERR_NODE_NOT_FOUND;
@@ -978,16 +998,17 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
         float *d_dist = reinterpret_cast<float *>(scr + qb + ib);
         uint32_t *d_cnt = reinterpret_cast<uint32_t *>(scr + qb + ib + db);
         unsigned long long *d_st = reinterpret_cast<unsigned long long *>(scr + qb + ib + db + cb);
-        if (ef == 0) {
+        if (ef == 0 || descend) {
             ZV_CHECK(ensure_tie(h, nq));
             ZV_CHECK(tie_begin(h, h->stream));
         }
+        if (descend) ZV_CHECK(launch_descend(h, reinterpret_cast<float *>(scr), nq, (uint32_t)entry, h->tie_buf, d_st, h->stream));
         int rc = ef == 0 ? launch_search_compat(h, reinterpret_cast<float *>(scr), nq, k, (uint32_t)entry, 0,
                                                 d_ids, d_dist, d_cnt, d_st, h->stream, h->tie_buf)
                          : launch_search_ef(h, reinterpret_cast<float *>(scr), nq, k, ef, (uint32_t)entry,
-                                            0, d_ids, d_dist, d_cnt, d_st, h->stream);
+                                            0, d_ids, d_dist, d_cnt, d_st, h->stream, descend ? h->tie_buf : nullptr);
         ZV_CHECK(rc);
-        if (ef == 0) ZV_CHECK(tie_end(h, h->stream));
+        if (ef == 0 || descend) ZV_CHECK(tie_end(h, h->stream));
         unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr);
         ZV_HIP(hipMemcpyAsync(pin + qb, scr + qb, ib + db + cb + 64, hipMemcpyDeviceToHost, h->stream));
         ZV_HIP(hipStreamSynchronize(h->stream));
@@ -1096,6 +1117,53 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode) 
         ZV_CHECK(launch_results_to_adj(h, d_ids, d_cnt, k, r0, n, degree, h->stream));
     }
     ZV_HIP(hipStreamSynchronize(h->stream));
+    return ZVDB_OK;
+}
+
+int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, uint32_t mode, uint64_t level_seed) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(settle_own_stream(h));
+    ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
+    ZV_ARG(M >= 1 && M <= 32 && 2 * M <= h->gstride, "M must be in [1, 32] and 2 M <= graph_stride (layer 0 keeps up to 2 M links)");
+    ZV_ARG(ef_construction >= 1, "ef_construction must be >= 1");
+    if (h->count > 0xFFFFFFF0ull) { set_error("shard too large"); return ZVDB_ERR_UNSUPPORTED; }
+    if (h->count == 0) return ZVDB_OK;
+    if (h->count == 1) {
+        ZV_HIP(hipMemsetAsync(h->deg, 0, 4, h->stream));
+        ZV_HIP(hipStreamSynchronize(h->stream));
+    }
+    return build_bulk_graph(h, M, ef_construction, mode, level_seed, ensure_upper);
+}
+
+int zvdb_hip_graph_info(zvdb_hip_index *h, uint64_t *out_entry, uint32_t *out_max_level) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (out_entry) *out_entry = h->bulk_graph ? h->bulk_top : 0;
+    if (out_max_level) *out_max_level = h->max_level;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_get_neighbors_layer(zvdb_hip_index *h, uint64_t node, uint32_t layer, uint64_t *out_ids, uint32_t cap, uint32_t *out_n) {
+    ZV_ARG(h && out_n, "null argument");
+    if (layer == 0) return zvdb_hip_get_neighbors(h, node, out_ids, cap, out_n);
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    if (node >= h->count || !h->lvl) { set_error("NodeNotFound: %llu", (unsigned long long)node); return ZVDB_ERR_NODE_NOT_FOUND; }
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    uint32_t lv = 0, sl = 0;
+    ZV_HIP(hipMemcpy(&lv, h->lvl + node, 4, hipMemcpyDeviceToHost));
+    if (layer > lv) { set_error("node %llu has no layer %u", (unsigned long long)node, layer); return ZVDB_ERR_NODE_NOT_FOUND; }
+    ZV_HIP(hipMemcpy(&sl, h->slot + node, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> tmp(h->gstride);
+    uint32_t n = 0;
+    const size_t row = (size_t)sl + layer - 1;
+    ZV_HIP(hipMemcpy(&n, h->deg_up + row, 4, hipMemcpyDeviceToHost));
+    n = std::min(n, h->gstride);
+    ZV_HIP(hipMemcpy(tmp.data(), h->adj_up + row * h->gstride, (size_t)n * 4, hipMemcpyDeviceToHost));
+    *out_n = n;
+    for (uint32_t i = 0; i < n && i < cap; ++i) out_ids[i] = tmp[i];
     return ZVDB_OK;
 }
 

@@ -114,7 +114,9 @@ struct zvdb_hip_index {
     uint32_t *lvl = nullptr, *slot = nullptr;       // [cap]
     uint32_t *adj_up = nullptr, *deg_up = nullptr;  // [up_cap][gstride], [up_cap]
     uint64_t up_cap = 0, up_count = 0;
-    uint32_t max_level = 0;  // over the nodes inserted through zvdb_hip_insert_batch
+    uint32_t max_level = 0;  // over the nodes inserted through zvdb_hip_insert_batch / of the bulk graph
+    bool bulk_graph = false;  // zvdb_hip_build_graph ran: every layer is the bulk graph's, bulk_top its entry node
+    uint32_t bulk_top = 0;
     uint32_t *tie_buf = nullptr;  // [tie_cap] per-query "equal minima" flags of k_search_compat_fast
     uint64_t tie_cap = 0;
     hipEvent_t tie_event = nullptr;  // end of the last launch pair that used tie_buf: the next one (any stream) waits for it
@@ -211,7 +213,10 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
                          uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, uint32_t *d_tie = nullptr /* [nq] scratch: enables the unordered-frontier kernel */);
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
-                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s);
+                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s,
+                     const uint32_t *d_entries = nullptr /* per-query entry nodes (launch_descend) */);
+int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
+                   unsigned long long *d_stats, hipStream_t s);
 // exact re-rank of candidate lists: cand[nq][kc] u32 (0xFFFFFFFF = empty) -> top-k by (dist,id)
 int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, const uint32_t *d_cand,
                   uint32_t kc, uint32_t k, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
@@ -259,6 +264,11 @@ int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint
                         uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s);
 int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                          float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
+
+// ---- graph_build.hip ---------------------------------------------------------
+uint32_t bulk_level(uint64_t seed, uint64_t id);
+int build_bulk_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, uint32_t mode, uint64_t level_seed,
+                     int (*ensure_upper_fn)(zvdb_hip_index *, uint64_t));
 
 // ---- bf_bf16_stream.hip ------------------------------------------------------
 bool bf16s_eligible(const zvdb_hip_index *h);

@@ -13,63 +13,11 @@
 //   k_rerank            K5     exact re-rank + (dist,id) top-k of brute-force candidates
 #include "common.h"
 #include "wave_select.h"
+#include "exact_dist.h"
 
 #pragma clang fp contract(off)
 
 namespace zvdb {
-
-// ---- a1 ---------------------------------------------------------------------
-// One lane walks one whole row sequentially (the ONLY order that is bit-exact);
-// parallelism comes from different lanes taking different rows.  q may live in
-// LDS (broadcast reads) or global memory (uniform address).
-template <int METRIC>
-__device__ __forceinline__ float exact_dist(const float *__restrict__ q,
-                                            const float *__restrict__ row, uint32_t dim) {
-    float sum = 0.0f;
-    const uint32_t d4 = dim & ~3u;
-    uint32_t i = 0;
-    // 16 x 16-byte loads in flight per lane: the walk is bound by memory latency (rows are random 3-KB gathers),
-    // not by the dependent add chain
-#pragma unroll 16
-    for (; i < d4; i += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(row + i);
-        const float4 a = *reinterpret_cast<const float4 *>(q + i);
-        if (METRIC == ZVDB_METRIC_L2SQ) {
-            float t;
-            t = a.x - v.x; t = t * t; sum = sum + t;
-            t = a.y - v.y; t = t * t; sum = sum + t;
-            t = a.z - v.z; t = t * t; sum = sum + t;
-            t = a.w - v.w; t = t * t; sum = sum + t;
-        } else {
-            float t;
-            t = a.x * v.x; sum = sum + t;
-            t = a.y * v.y; sum = sum + t;
-            t = a.z * v.z; sum = sum + t;
-            t = a.w * v.w; sum = sum + t;
-        }
-    }
-    for (; i < dim; ++i) {
-        if (METRIC == ZVDB_METRIC_L2SQ) {
-            float t = q[i] - row[i];
-            t = t * t;
-            sum = sum + t;
-        } else {
-            const float t = q[i] * row[i];
-            sum = sum + t;
-        }
-    }
-    return METRIC == ZVDB_METRIC_L2SQ ? sum : -sum;
-}
-
-__device__ __forceinline__ float exact_dist_rt(int metric, const float *q, const float *row,
-                                               uint32_t dim) {
-    return metric == ZVDB_METRIC_L2SQ ? exact_dist<ZVDB_METRIC_L2SQ>(q, row, dim)
-                                      : exact_dist<ZVDB_METRIC_DOT>(q, row, dim);
-}
-
-__device__ __forceinline__ bool lex_less(float da, uint32_t ia, float db, uint32_t ib) {
-    return da < db || (da == db && ia < ib);
-}
 
 // ---- K1: out[i] = distance(query, rows[ids[i]]) ------------------------------
 __global__ __launch_bounds__(256) void k_exact_distances(const float *__restrict__ rows, uint32_t ld,
@@ -847,31 +795,6 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
 // partials are combined by the xor butterfly 8,4,2,1.  Four neighbour rows are in flight per wave
 // step instead of one row per lane walking 3 KB alone: same bytes, coalesced, 4x fewer dependent
 // loads per lane.  The k results are re-evaluated with the exact reference arithmetic (a1).
-template <int METRIC>
-__device__ __forceinline__ float blocked16_dist(const float *__restrict__ q /*LDS, zero padded to x4*/,
-                                                const float *__restrict__ row, uint32_t nchunks, int t) {
-    float s = 0.0f;
-    for (uint32_t c = t; c < nchunks; c += 16) {
-        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * c);  // rows are zero padded to ld
-        const float4 a = *reinterpret_cast<const float4 *>(q + 4 * c);
-        float u;
-        if (METRIC == ZVDB_METRIC_L2SQ) {
-            u = a.x - v.x; u = u * u; s = s + u;
-            u = a.y - v.y; u = u * u; s = s + u;
-            u = a.z - v.z; u = u * u; s = s + u;
-            u = a.w - v.w; u = u * u; s = s + u;
-        } else {
-            u = a.x * v.x; s = s + u;
-            u = a.y * v.y; s = s + u;
-            u = a.z * v.z; s = s + u;
-            u = a.w * v.w; s = s + u;
-        }
-    }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) s = s + __shfl_xor(s, off);
-    return METRIC == ZVDB_METRIC_L2SQ ? s : -s;
-}
-
 // Beam W: UNSORTED set of <= ef 64-bit keys ((monotone fp32 key << 32) | id) + an "expanded" flag per slot,
 // double buffered in LDS.  The oracle's sorted-list formulation is equivalent to set semantics:
 //   next node to expand = minimum key among unexpanded entries          (one wave min-reduction)
@@ -884,8 +807,9 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
-    uint32_t hash_bits, uint32_t efp) {
+    uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (entries) entry = entries[blockIdx.x];
     float *q = reinterpret_cast<float *>(smem);
     uint64_t *wk = reinterpret_cast<uint64_t *>(q + dim_pad);          // [2][efp]
     uint32_t *wx = reinterpret_cast<uint32_t *>(wk + 2 * efp);         // [2][efp] expanded flags
@@ -1108,9 +1032,79 @@ __global__ __launch_bounds__(64) void k_search_ef(
     }
 }
 
+// ---- hierarchical entry descent of the bulk graph (extension; specification: orc_hnsw_descend) -----------------------------
+// One wave per query: from the graph's top node down the layers max_level .. 1; on each layer repeat { scan the WHOLE
+// list of the current node in list order with the blocked traversal distance, keep the strict arg-min (the earliest entry
+// wins ties), move there } until nothing is closer (hnsw.zig:90-104's greedy step, run top-down, on the device's upper-layer
+// lists: node's layer L list = row slot[node] + L - 1 of adj_up).  Four neighbours per wave step (16 lanes per row).
+__global__ __launch_bounds__(64) void k_descend(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+                                                const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ slot,
+                                                const uint32_t *__restrict__ adj_up, const uint32_t *__restrict__ deg_up, uint32_t gstride,
+                                                const float *__restrict__ queries, uint32_t top, uint32_t *__restrict__ out_entry,
+                                                unsigned long long *__restrict__ stats, uint32_t dim_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, t = lane & 15;
+    const uint32_t qi = blockIdx.x;
+    const float *qg = queries + (size_t)qi * dim;
+    for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
+    __syncthreads();
+    const uint32_t nchunks = (dim + 3) / 4;
+    auto bdist = [&](uint32_t node) {
+        const float *r = rows + (size_t)node * ld;
+        return metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, r, nchunks, t) : blocked16_dist<ZVDB_METRIC_DOT>(q, r, nchunks, t);
+    };
+    uint32_t cur = top;
+    float dcur = bdist(cur);
+    dcur = __shfl(dcur, 0);
+    unsigned long long evals = 1;
+    for (uint32_t layer = lvl[top]; layer >= 1; --layer) {
+        for (;;) {
+            if (lvl[cur] < layer) break;
+            const size_t row = (size_t)slot[cur] + layer - 1;
+            const uint32_t dg = min(deg_up[row], gstride);
+            uint32_t best = cur;
+            float dbest = dcur;
+            for (uint32_t base = 0; base < dg; base += 4) {
+                const uint32_t j = base + (uint32_t)g;
+                const uint32_t nb = j < dg ? adj_up[row * gstride + j] : cur;
+                const float dn = bdist(nb);
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {  // list order: strict '<' keeps the earliest of equal minima
+                    const float d = __shfl(dn, 16 * gg);
+                    const uint32_t id = (uint32_t)__shfl((int)nb, 16 * gg);
+                    if (base + (uint32_t)gg < dg && d < dbest) { dbest = d; best = id; }
+                }
+            }
+            evals += dg;
+            if (best == cur) break;
+            cur = best;
+            dcur = dbest;
+        }
+    }
+    if (lane == 0) {
+        out_entry[qi] = cur;
+        if (stats) atomicAdd(&stats[0], evals);
+    }
+}
+
+int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
+                   unsigned long long *d_stats, hipStream_t s) {
+    if (nq == 0) return ZVDB_OK;
+    const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
+    const size_t lds = 4ull * dim_pad;
+    ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_descend), lds));
+    const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
+    hipLaunchKernelGGL(k_descend, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->lvl, h->slot, h->adj_up, h->deg_up, h->gstride,
+                       d_queries, top, d_entries, d_stats, dim_pad);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
-                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s) {
+                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, const uint32_t *d_entries) {
     if (nq == 0) return ZVDB_OK;
     if (ef < k) ef = k;
     const uint64_t N = h->count;
@@ -1131,7 +1125,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     hipLaunchKernelGGL(k_search_ef, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj,
                        h->deg, h->gstride, (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids,
-                       d_dist, d_count, d_stats, dim_pad, hash_bits, efp);
+                       d_dist, d_count, d_stats, dim_pad, hash_bits, efp, d_entries);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

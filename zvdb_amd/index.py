@@ -97,6 +97,23 @@ class Index:
         """Batched GPU construction of the layer-0 graph: exact `degree`-NN lists."""
         check(self._L.zvdb_hip_build_knn_graph(self._h, degree, mode))
 
+    def build_graph(self, M: int, ef_construction: int = 64, mode: int = _lib.BF_I8, level_seed: int = 1) -> None:
+        """Bulk construction of a recall-competent HNSW graph (SURVEY 8f rank 1 + 3): heuristic forward links over the
+        ef_construction exact nearest + reverse links, cut to 2 M; upper layers; entry = first node of the highest level.
+        Search it with search_graph(ef > 0, entry = ENTRY_DESCEND)."""
+        check(self._L.zvdb_hip_build_graph(self._h, M, ef_construction, mode, level_seed))
+
+    def graph_info(self) -> Tuple[int, int]:
+        e, ml = C.c_uint64(0), C.c_uint32(0)
+        check(self._L.zvdb_hip_graph_info(self._h, C.byref(e), C.byref(ml)))
+        return e.value, ml.value
+
+    def get_neighbors_layer(self, node: int, layer: int) -> np.ndarray:
+        out = np.zeros(4096, dtype=np.uint64)
+        n = C.c_uint32(0)
+        check(self._L.zvdb_hip_get_neighbors_layer(self._h, node, layer, out.ctypes.data_as(_u64p), out.size, C.byref(n)))
+        return out[:n.value].copy()
+
     def get_neighbors(self, node: int) -> np.ndarray:
         out = np.zeros(4096, dtype=np.uint64)
         n = C.c_uint32(0)
