@@ -82,11 +82,13 @@ typedef struct zvdb_hip_config {
 } zvdb_hip_config;
 
 #define ZVDB_FLAG_BF16_MIRROR 1u /* keep a bf16 copy of the rows for ZVDB_BF_BF16 */
-/* bf16 STORAGE semantics ("bf16 = storage type with fp32 accumulate"): every element is
- * rounded to bf16 (round-to-nearest-even) when it is added -- after the cosine normalisation -- so get_vector, every
- * exact distance and every re-rank is the reference's fp32 arithmetic (hnsw.zig:182-192) over bf16-representable values,
- * and the bf16 mirror is lossless.  Round 1 holds the rounded values in fp32 containers (the footprint is not halved
- * yet).  Queries are never rounded. */
+/* bf16 row STORAGE ("bf16 = storage type with fp32 accumulate"): every element is rounded
+ * to bf16 (round-to-nearest-even) when it is added -- after the cosine normalisation -- and the index keeps ONLY the bf16
+ * rows (2 bytes per element: half the HBM footprint and half the bytes every gather-bound kernel moves; there is no fp32
+ * container).  get_vector widens exactly; every exact distance and every re-rank is the reference's fp32 arithmetic
+ * (hnsw.zig:182-192), in its order, over the widened values -- bit-identical to an fp32 index fed bf16-representable rows.
+ * The bf16 brute-force screen is lossless on such an index and also serves ZVDB_BF_F32.  Queries are never rounded.
+ * zvdb_hip_insert_batch (the fused reference insert) serves fp32 rows only; the step-by-step insert calls work. */
 #define ZVDB_FLAG_BF16_ROWS 2u
 
 typedef struct zvdb_hip_search_stats {
@@ -155,6 +157,9 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode);
  * a greedy descent through the upper layers picks each query's layer-0 entry, then the ef-mode beam search runs. */
 int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, uint32_t mode, uint64_t level_seed);
 int zvdb_hip_graph_info(zvdb_hip_index *h, uint64_t *out_entry, uint32_t *out_max_level);
+/* HBM accounting: bytes of one stored row (fp32: 4 ld; ZVDB_FLAG_BF16_ROWS: 2 ldh) and the bytes this index holds on the device
+ * right now (row storage, norms, adjacency of every layer, and whichever lazily built mirrors exist). */
+int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *out_resident_bytes);
 /* connections[layer] of a node on the device (layer 0: zvdb_hip_get_neighbors); NODE_NOT_FOUND if the node lacks the layer */
 int zvdb_hip_get_neighbors_layer(zvdb_hip_index *h, uint64_t node, uint32_t layer, uint64_t *out_ids, uint32_t cap, uint32_t *out_n);
 /* `entry` value of the graph searches: per-query entry = hierarchical descent from the bulk graph's top node */

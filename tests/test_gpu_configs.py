@@ -277,3 +277,34 @@ def test_c5_cosine_1536d_bf16_rows_k100_ef256(zv, oracle):
         assert np.all(np.diff(gd[qi, :gc[qi]]) >= 0)
     assert hits / (nq * k) >= 0.5  # (a 32-regular exact-kNN graph entered at node 0: measured ~0.8; the bar guards regressions)
     del qn
+
+
+def test_bf16_row_storage_halves_the_footprint_and_keeps_every_route_exact(zv, oracle):
+    """ZVDB_FLAG_BF16_ROWS keeps ONLY bf16 rows on the device (no fp32 container): half the bytes per row, and every exact
+    route -- distances seam, reference-compat search, ef-mode search, brute force on every screen -- equals the same route on an
+    fp32 index fed the bf16-rounded rows (and therefore the oracle on them), bit for bit."""
+    n, d, M = 20_000, 768, 16
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    Vr = oracle.bf16_round(V)
+    a = zv.Index(dim=d, capacity=n, m=M, flags=zv.FLAG_BF16_ROWS)
+    a.add(V)
+    b = zv.Index(dim=d, capacity=n, m=M)
+    b.add(Vr)
+    ra, ta = a.storage_info()
+    rb, tb = b.storage_info()
+    assert ra == 768 * 2 and rb == 768 * 4 and ta < 0.56 * tb, (ra, rb, ta, tb)
+    assert np.array_equal(a.get_vector(123), Vr[123])
+    Q = oracle.uniform_rows(0xC0FFEE, 0, 64, d)
+    ids = np.arange(0, n, 37, dtype=np.uint64)
+    assert np.array_equal(a.distances(Q[0], ids), b.distances(Q[0], ids))
+    assert np.array_equal(a.distances_from(5, ids), b.distances_from(5, ids))
+    for idx in (a, b):
+        idx.build_knn_graph(M, zv.BF_I8)
+    for ef in (0, 64):
+        ia, da, ca, sa = a.search_graph(Q, 10, ef=ef, with_stats=True)
+        ib, db, cb, sb = b.search_graph(Q, 10, ef=ef, with_stats=True)
+        assert np.array_equal(ia, ib) and np.array_equal(da, db) and np.array_equal(ca, cb) and sa == sb, ef
+    ri, rd, _ = oracle.bruteforce_topk(Vr, Q, 10)
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+        i1, d1, _ = a.search_bruteforce(Q, 10, mode)
+        assert np.array_equal(i1, ri) and np.array_equal(d1, rd), mode

@@ -78,9 +78,10 @@ int ensure_capacity(zvdb_hip_index *h, uint64_t want) {
         return ZVDB_ERR_UNSUPPORTED;
     }
     const uint64_t ncap = std::max<uint64_t>({want, h->cap * 2, 1024});
-    ZV_CHECK(regrow(&h->rows, h->count * h->ld, ncap * h->ld, h->stream));
+    const bool bf16_rows = (h->flags & ZVDB_FLAG_BF16_ROWS) != 0;  // bf16 is THE row storage: no fp32 container
+    if (!bf16_rows) ZV_CHECK(regrow(&h->rows, h->count * h->ld, ncap * h->ld, h->stream));
     ZV_CHECK(regrow(&h->norm, h->count, ncap, h->stream));
-    if (h->flags & ZVDB_FLAG_BF16_MIRROR) {
+    if ((h->flags & ZVDB_FLAG_BF16_MIRROR) || bf16_rows) {
         ZV_CHECK(regrow(&h->rows_h, h->count * h->ldh, ncap * h->ldh, h->stream));
         ZV_CHECK(regrow(&h->norm_h, h->count, ncap, h->stream));
     }
@@ -172,12 +173,48 @@ static int settle_own_stream(zvdb_hip_index *h) {
     return ZVDB_OK;
 }
 
-// rows [first, first+n) are in place in h->rows: normalise (cosine), norms, bf16 mirror
+// rows [first, first+n) are in place in h->rows: normalise (cosine), norms, bf16 mirror (fp32-row indexes)
 static int finish_rows(zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s) {
     if (h->metric == ZVDB_METRIC_COSINE)
         ZV_CHECK(launch_normalize_rows(h->rows + first * h->ld, h->dim, h->ld, n, s));
-    if (h->flags & ZVDB_FLAG_BF16_ROWS) ZV_CHECK(launch_round_rows_bf16(h->rows + first * h->ld, h->dim, h->ld, n, s));
     ZV_CHECK(launch_finalize_rows(h, first, n, s));
+    return ZVDB_OK;
+}
+
+// device pointer to row `owner` as an fp32 query [dim] (distances_from, shrinkConnections' owner): the row itself for fp32
+// rows, a widened copy in a small per-index buffer for bf16 rows (valid until the next call; stream order)
+static int owner_query(zvdb_hip_index *h, uint64_t owner, const float **out) {
+    if (!(h->flags & ZVDB_FLAG_BF16_ROWS)) { *out = h->rows + owner * h->ld; return ZVDB_OK; }
+    if (!h->qrow_f32) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->qrow_f32), (size_t)std::max(h->ldh, 64u) * sizeof(float)));
+    ZV_CHECK(launch_rows_to_f32(h, owner, 1, h->qrow_f32, h->stream));
+    *out = h->qrow_f32;
+    return ZVDB_OK;
+}
+
+// Appends n rows at ids [count, count + n).  `fill(dst, r0, cnt)` writes rows [r0, r0 + cnt) of the incoming batch as fp32 with
+// row stride h->ld (zero padded) into dst on stream s.  fp32-row indexes: dst = the rows' final place, one call.
+// ZVDB_FLAG_BF16_ROWS: the rows pass through a bounded fp32 staging chunk (<= 256 MiB) -- normalised there under cosine --
+// and are stored as bf16 (RNE) only; the staging chunk is the only fp32 copy that ever exists.
+template <class Fill>
+static int add_rows(zvdb_hip_index *h, uint64_t n, hipStream_t s, Fill fill) {
+    const uint64_t first = h->count;
+    if (!(h->flags & ZVDB_FLAG_BF16_ROWS)) {
+        ZV_CHECK(fill(h->rows + first * h->ld, (uint64_t)0, n));
+        return finish_rows(h, first, n, s);
+    }
+    const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(n, (256ull << 20) / ((uint64_t)h->ld * sizeof(float))));
+    if (h->stage_rows < chunk) {
+        if (h->stage_f32) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->stage_f32)); h->stage_f32 = nullptr; h->stage_rows = 0; }
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->stage_f32), chunk * h->ld * sizeof(float)));
+        h->stage_rows = chunk;
+    }
+    for (uint64_t r0 = 0; r0 < n; r0 += chunk) {
+        const uint64_t cnt = std::min(chunk, n - r0);
+        ZV_HIP(hipMemsetAsync(h->stage_f32, 0, cnt * h->ld * sizeof(float), s));
+        ZV_CHECK(fill(h->stage_f32, r0, cnt));
+        if (h->metric == ZVDB_METRIC_COSINE) ZV_CHECK(launch_normalize_rows(h->stage_f32, h->dim, h->ld, cnt, s));
+        ZV_CHECK(launch_store_rows_bf16(h, h->stage_f32, first + r0, cnt, s));
+    }
     return ZVDB_OK;
 }
 
@@ -279,6 +316,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->rows_pf);
     (void)hipFree(h->rows_qf);
     (void)hipFree(h->rows_hf);
+    (void)hipFree(h->stage_f32);
+    (void)hipFree(h->qrow_f32);
     (void)hipFree(h->norm_hf);
     (void)hipFree(h->norm_qf);
     (void)hipFree(h->norm_pf);
@@ -314,19 +353,20 @@ int zvdb_hip_add(zvdb_hip_index *h, const float *rows, uint64_t n, uint32_t dim,
     if (first_id) *first_id = h->count;
     if (n == 0) return ZVDB_OK;
     ZV_CHECK(ensure_capacity(h, h->count + n));
-    float *dst = h->rows + h->count * h->ld;
-    // chunked through the pinned buffer so the copy is a real async DMA
-    const uint64_t chunk_rows = std::max<uint64_t>(1, (8u << 20) / (dim * sizeof(float)));
-    for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
-        const uint64_t nr = std::min(chunk_rows, n - r0);
-        const size_t bytes = nr * dim * sizeof(float);
-        ZV_CHECK(ensure_pin(h, bytes));
-        std::memcpy(h->pin.ptr, rows + r0 * dim, bytes);
-        ZV_HIP(hipMemcpy2DAsync(dst + r0 * h->ld, h->ld * sizeof(float), h->pin.ptr, dim * sizeof(float),
-                                dim * sizeof(float), nr, hipMemcpyHostToDevice, h->stream));
-        ZV_HIP(hipStreamSynchronize(h->stream));
-    }
-    ZV_CHECK(finish_rows(h, h->count, n, h->stream));
+    ZV_CHECK(add_rows(h, n, h->stream, [&](float *dst, uint64_t b0, uint64_t cnt) -> int {
+        // chunked through the pinned buffer so the copy is a real async DMA
+        const uint64_t chunk_rows = std::max<uint64_t>(1, (8u << 20) / (dim * sizeof(float)));
+        for (uint64_t r0 = 0; r0 < cnt; r0 += chunk_rows) {
+            const uint64_t nr = std::min(chunk_rows, cnt - r0);
+            const size_t bytes = nr * dim * sizeof(float);
+            ZV_CHECK(ensure_pin(h, bytes));
+            std::memcpy(h->pin.ptr, rows + (b0 + r0) * dim, bytes);
+            ZV_HIP(hipMemcpy2DAsync(dst + r0 * h->ld, h->ld * sizeof(float), h->pin.ptr, dim * sizeof(float),
+                                    dim * sizeof(float), nr, hipMemcpyHostToDevice, h->stream));
+            ZV_HIP(hipStreamSynchronize(h->stream));
+        }
+        return ZVDB_OK;
+    }));
     ZV_HIP(hipStreamSynchronize(h->stream));
     h->count += n;
     return ZVDB_OK;
@@ -343,9 +383,9 @@ int zvdb_hip_add_dev(zvdb_hip_index *h, const void *d_rows, uint64_t n, uint32_t
     if (n == 0) return ZVDB_OK;
     ZV_CHECK(ensure_capacity(h, h->count + n));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    ZV_CHECK(launch_pack_rows(static_cast<const float *>(d_rows), dim, h->rows + h->count * h->ld, h->ld,
-                              n, s));
-    ZV_CHECK(finish_rows(h, h->count, n, s));
+    ZV_CHECK(add_rows(h, n, s, [&](float *dst, uint64_t b0, uint64_t cnt) -> int {
+        return launch_pack_rows(static_cast<const float *>(d_rows) + b0 * dim, dim, dst, h->ld, cnt, s);
+    }));
     ZV_HIP(hipStreamSynchronize(s));
     h->count += n;
     return ZVDB_OK;
@@ -360,8 +400,9 @@ int zvdb_hip_add_synthetic(zvdb_hip_index *h, uint64_t n, uint32_t dim, uint64_t
     if (first_id) *first_id = h->count;
     if (n == 0) return ZVDB_OK;
     ZV_CHECK(ensure_capacity(h, h->count + n));
-    ZV_CHECK(launch_fill_synthetic(h->rows + h->count * h->ld, n, dim, h->ld, seed, first_row, h->stream));
-    ZV_CHECK(finish_rows(h, h->count, n, h->stream));
+    ZV_CHECK(add_rows(h, n, h->stream, [&](float *dst, uint64_t b0, uint64_t cnt) -> int {
+        return launch_fill_synthetic(dst, cnt, dim, h->ld, seed, first_row + b0, h->stream);
+    }));
     ZV_HIP(hipStreamSynchronize(h->stream));
     h->count += n;
     return ZVDB_OK;
@@ -387,6 +428,16 @@ int zvdb_hip_get_vector(zvdb_hip_index *h, uint64_t id, float *out, uint32_t dim
     if (dim != h->dim) {
         set_error("Mismatched dimensions (index %u, got %u)", h->dim, dim);
         return ZVDB_ERR_DIM_MISMATCH;
+    }
+    if (h->flags & ZVDB_FLAG_BF16_ROWS) {  // bf16 storage: widen on the host (exact)
+        std::vector<uint16_t> tmp(dim);
+        ZV_HIP(hipMemcpyAsync(tmp.data(), h->rows_h + id * h->ldh, dim * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+        ZV_HIP(hipStreamSynchronize(h->stream));
+        for (uint32_t i = 0; i < dim; ++i) {
+            const uint32_t u = (uint32_t)tmp[i] << 16;
+            std::memcpy(out + i, &u, 4);
+        }
+        return ZVDB_OK;
     }
     ZV_HIP(hipMemcpyAsync(out, h->rows + id * h->ld, dim * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     ZV_HIP(hipStreamSynchronize(h->stream));
@@ -485,7 +536,9 @@ static int distances_impl(zvdb_hip_index *h, const float *host_query, uint64_t o
         const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;
         volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(hb + 2 * ib);
         *flag = 0;
-        ZV_CHECK(launch_exact_distances(h, h->rows + owner * h->ld, reinterpret_cast<const uint32_t *>(db), n,
+        const float *d_owner = nullptr;
+        ZV_CHECK(owner_query(h, owner, &d_owner));
+        ZV_CHECK(launch_exact_distances(h, d_owner, reinterpret_cast<const uint32_t *>(db), n,
                                         reinterpret_cast<float *>(db + ib), h->stream));
         ZV_CHECK(launch_publish(nullptr, nullptr, 0, reinterpret_cast<uint32_t *>(db + 2 * ib), seq, h->stream));
         for (int spin = 0; spin < 40000 && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) __builtin_ia32_pause();
@@ -516,7 +569,7 @@ static int distances_impl(zvdb_hip_index *h, const float *host_query, uint64_t o
         h2d_off = 0;
         h2d_bytes += qb;
     } else {
-        d_query = h->rows + owner * h->ld;
+        ZV_CHECK(owner_query(h, owner, &d_query));
     }
     ZV_HIP(hipMemcpyAsync(scr + h2d_off, pin + h2d_off, h2d_bytes, hipMemcpyHostToDevice, h->stream));
     uint32_t *d_ids = reinterpret_cast<uint32_t *>(scr + qb);
@@ -605,8 +658,9 @@ int zvdb_hip_insert_layer0(zvdb_hip_index *h, const float *point, uint32_t dim, 
     // entries are computed BEHIND it in the stream (nothing on the insert path reads them): one launch on the critical path
     const bool fast = !first && h->metric == ZVDB_METRIC_L2SQ && !(h->flags & ZVDB_FLAG_BF16_ROWS) && (size_t)dim * 4 <= 96 * 1024;
     if (!fast) {
-        ZV_CHECK(launch_copy_row(static_cast<const float *>(h->ins_dev), h->rows + id * h->ld, dim, h->stream));
-        ZV_CHECK(finish_rows(h, id, 1, h->stream));
+        ZV_CHECK(add_rows(h, 1, h->stream, [&](float *dst, uint64_t, uint64_t) -> int {
+            return launch_copy_row(static_cast<const float *>(h->ins_dev), dst, dim, h->stream);
+        }));
     }
     unsigned char *res = static_cast<unsigned char *>(h->ins_host) + row_bytes;
     if (!first) {
@@ -1111,8 +1165,7 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode) 
     for (uint64_t r0 = 0; r0 < h->count; r0 += B) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(B, h->count - r0);
         // queries = rows [r0, r0+n) as dense [n][dim]
-        ZV_HIP(hipMemcpy2DAsync(d_q, h->dim * sizeof(float), h->rows + r0 * h->ld, h->ld * sizeof(float),
-                                h->dim * sizeof(float), n, hipMemcpyDeviceToDevice, h->stream));
+        ZV_CHECK(launch_rows_to_f32(h, r0, n, d_q, h->stream));
         ZV_CHECK(launch_bruteforce(h, d_q, n, k, mode, 0, scr + qb + ib + db + cb, wsb, d_ids, d_dist, d_cnt, h->stream));
         ZV_CHECK(launch_results_to_adj(h, d_ids, d_cnt, k, r0, n, degree, h->stream));
     }
@@ -1135,6 +1188,30 @@ int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction
         ZV_HIP(hipStreamSynchronize(h->stream));
     }
     return build_bulk_graph(h, M, ef_construction, mode, level_seed, ensure_upper);
+}
+
+int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *out_resident_bytes) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    const bool hb = (h->flags & ZVDB_FLAG_BF16_ROWS) != 0;
+    if (out_row_bytes) *out_row_bytes = hb ? (uint64_t)h->ldh * 2 : (uint64_t)h->ld * 4;
+    if (out_resident_bytes) {
+        uint64_t b = 0;
+        if (h->rows) b += h->cap * h->ld * 4;
+        if (h->rows_h) b += h->cap * h->ldh * 2;
+        if (h->norm) b += h->cap * 4;
+        if (h->norm_h) b += h->cap * 4;
+        if (h->adj) b += h->cap * h->gstride * 4 + h->cap * 4;
+        if (h->lvl) b += h->cap * 8;
+        if (h->adj_up) b += h->up_cap * h->gstride * 4 + h->up_cap * 4;
+        if (h->rows_q) b += h->cap_q * h->ldq + h->cap_q * 4;
+        if (h->rows_qf) b += h->cap_qf * i8s_ksteps(h->dim) * 32 + h->cap_qf * 4;
+        if (h->rows_p) b += h->cap_p * h->ldp + h->cap_p * 4;
+        if (h->rows_pf) b += h->cap_pf * fp4s_ksteps(h->dim) * 32 + h->cap_pf * 4;
+        if (h->rows_hf) b += h->cap_hf * bf16s_ksteps(h->dim) * 32 + (h->cap_hf + 64) * 4;
+        *out_resident_bytes = b;
+    }
+    return ZVDB_OK;
 }
 
 int zvdb_hip_graph_info(zvdb_hip_index *h, uint64_t *out_entry, uint32_t *out_max_level) {

@@ -27,6 +27,7 @@
 #include "wave_select.h"
 #include "bf_select.h"
 #include "stream_common.h"
+#include "row_types.h"
 
 namespace zvdb {
 
@@ -389,7 +390,8 @@ __device__ __forceinline__ uint32_t bh_bf16_bits(float v) {  // RNE, finite inpu
 }
 
 // rows (fp32, row-major) -> Layout16 (header).  Rows >= n and elements >= dim are 0.
-__global__ __launch_bounds__(256) void k_bf16_pack_frag(const float *__restrict__ src, uint32_t dim, uint32_t ld, uint64_t n, uint64_t units,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_bf16_pack_frag(const RT *__restrict__ src, uint32_t dim, uint32_t ld, uint64_t n, uint64_t units,
                                                         uint32_t K2, unsigned char *__restrict__ out) {
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= units) return;
@@ -400,18 +402,19 @@ __global__ __launch_bounds__(256) void k_bf16_pack_frag(const float *__restrict_
     const uint32_t k0 = 32 * j + 8 * (l >> 4);
     u32x4 w = {0, 0, 0, 0};
     if (row < n) {
-        const float *v = src + row * ld;
+        const RT *v = src + row * ld;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const uint32_t k = k0 + e;
-            if (k < dim) w[e >> 1] |= bh_bf16_bits(v[k]) << (16 * (e & 1));
+            if (k < dim) w[e >> 1] |= bh_bf16_bits(row_elem(v, k)) << (16 * (e & 1));
         }
     }
     *reinterpret_cast<u32x4 *>(out + u * 16) = w;
 }
 
 // norm[r] = sum over the bf16-rounded row of v'^2 (L2; 0 for dot / cosine), +inf for r >= n: one wave per row
-__global__ __launch_bounds__(256) void k_bf16_frag_norms(const float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n, uint64_t n_pad,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_bf16_frag_norms(const RT *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n, uint64_t n_pad,
                                                          int l2, float *__restrict__ norm) {
     const int lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -422,9 +425,9 @@ __global__ __launch_bounds__(256) void k_bf16_frag_norms(const float *__restrict
     }
     float sacc = 0.0f;
     if (l2) {
-        const float *v = rows + r * ld;
+        const RT *v = rows + r * ld;
         for (uint32_t c = lane; c < dim; c += 64) {
-            const float f = __uint_as_float(bh_bf16_bits(v[c]) << 16);
+            const float f = __uint_as_float(bh_bf16_bits(row_elem(v, c)) << 16);
             sacc += f * f;
         }
 #pragma unroll
@@ -495,11 +498,15 @@ int ensure_bf16_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
         h->cap_hf = ncap;
     }
     const uint64_t units = rows_pad / 16 * (KS / 2) * 64;
-    hipLaunchKernelGGL(k_bf16_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, units, KS / 2,
-                       h->rows_hf);
-    hipLaunchKernelGGL(k_bf16_frag_norms, dim3((uint32_t)((rows_pad + 64 + 3) / 4)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count,
-                       rows_pad + 64, h->metric == ZVDB_METRIC_L2SQ ? 1 : 0, h->norm_hf);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {  // (bf16 rows: the mirror is a lossless re-ordering)
+        using RT = row_elem_t<decltype(rows)>;
+        hipLaunchKernelGGL(k_bf16_pack_frag<RT>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, rows, h->dim, ld, h->count, units, KS / 2,
+                           h->rows_hf);
+        hipLaunchKernelGGL(k_bf16_frag_norms<RT>, dim3((uint32_t)((rows_pad + 64 + 3) / 4)), dim3(256), 0, s, rows, h->dim, ld, h->count,
+                           rows_pad + 64, h->metric == ZVDB_METRIC_L2SQ ? 1 : 0, h->norm_hf);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     h->count_hf = h->count;
     (void)bf16s_groups_per_unit;
     return ZVDB_OK;
@@ -508,7 +515,7 @@ int ensure_bf16_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
 int launch_bf16s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op, hipStream_t s) {
     const uint32_t KS = bf16s_ksteps(h->dim);
     const uint64_t units = (uint64_t)nq_pad / 16 * (KS / 2) * 64;
-    hipLaunchKernelGGL(k_bf16_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim, (uint64_t)nq, units,
+    hipLaunchKernelGGL(k_bf16_pack_frag<float>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim, (uint64_t)nq, units,
                        KS / 2, q_op);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;

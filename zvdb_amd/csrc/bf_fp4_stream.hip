@@ -25,6 +25,7 @@
 #include "wave_select.h"
 #include "bf_select.h"
 #include "stream_common.h"
+#include "row_types.h"
 
 namespace zvdb {
 
@@ -567,7 +568,8 @@ __global__ __launch_bounds__(64) void k_fp4_guess(const float *__restrict__ mom,
 // layout 1 / 2 (16x16x128 shape): a 1-KiB block = 16 rows x 128 elements, lane l = row (l & 15), elements 32 (l >> 4) +
 // [0, 32); a 32-row group holds its KS blocks as [k-step][row half] (1: corpus, the order the stream consumes them) or
 // [row half][k-step] (2: queries, so that a 16-query fragment's k-steps are contiguous in the resident tile).
-__global__ __launch_bounds__(256) void k_fp4_pack_frag(const float *__restrict__ src, uint32_t dim, uint32_t ld,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_fp4_pack_frag(const RT *__restrict__ src, uint32_t dim, uint32_t ld,
                                                        uint64_t n, uint64_t units, uint32_t KS, float mid, float scale,
                                                        unsigned char *__restrict__ out, int layout) {
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -585,11 +587,11 @@ __global__ __launch_bounds__(256) void k_fp4_pack_frag(const float *__restrict__
     }
     u32x4 w = {0, 0, 0, 0};
     if (row < n) {
-        const float *v = src + row * ld;
+        const RT *v = src + row * ld;
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
             const uint32_t k = k0 + e;
-            const uint32_t code = k < dim ? fp4_e2m1_code((v[k] - mid) * scale) : 0u;
+            const uint32_t code = k < dim ? fp4_e2m1_code((row_elem(v, k) - mid) * scale) : 0u;
             w[e >> 3] |= code << (4 * (e & 7));
         }
     }
@@ -597,7 +599,8 @@ __global__ __launch_bounds__(256) void k_fp4_pack_frag(const float *__restrict__
 }
 
 // |v'|^2 of the quantised row (exact in fp32); rows in [n, n_pad) get +inf so that padded rows never pass
-__global__ __launch_bounds__(256) void k_fp4_norms(const float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_fp4_norms(const RT *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
                                                    uint64_t n_pad, float mid, float scale, float *__restrict__ norm) {
     const int lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -606,9 +609,9 @@ __global__ __launch_bounds__(256) void k_fp4_norms(const float *__restrict__ row
         if (lane == 0) norm[r] = __builtin_inff();
         return;
     }
-    const float *v = rows + r * ld;
+    const RT *v = rows + r * ld;
     float s = 0.0f;
-    for (uint32_t c = lane; c < dim; c += 64) s += fp4_e2m1_sq(fp4_e2m1_code((v[c] - mid) * scale));
+    for (uint32_t c = lane; c < dim; c += 64) s += fp4_e2m1_sq(fp4_e2m1_code((row_elem(v, c) - mid) * scale));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) norm[r] = s;
@@ -656,11 +659,15 @@ int ensure_fp4_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     }
     ZV_CHECK(fp4_range(h, s));
     const uint64_t units = rows_pad / 32 * KS * 64;
-    hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, h->rows, h->dim, h->ld,
-                       h->count, units, KS, h->p_mid, h->p_scale, h->rows_pf, (fp4s_shape() == 16 && KS <= 12) ? 1 : 0);
-    hipLaunchKernelGGL(k_fp4_norms, dim3((uint32_t)((rows_pad + 3) / 4)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count,
-                       rows_pad, h->p_mid, h->p_scale, h->norm_pf);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = row_elem_t<decltype(rows)>;
+        hipLaunchKernelGGL(k_fp4_pack_frag<RT>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, rows, h->dim, ld, h->count, units, KS,
+                           h->p_mid, h->p_scale, h->rows_pf, (fp4s_shape() == 16 && KS <= 12) ? 1 : 0);
+        hipLaunchKernelGGL(k_fp4_norms<RT>, dim3((uint32_t)((rows_pad + 3) / 4)), dim3(256), 0, s, rows, h->dim, ld, h->count, rows_pad, h->p_mid,
+                           h->p_scale, h->norm_pf);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     h->count_pf = h->count;
     return ZVDB_OK;
 }
@@ -669,7 +676,7 @@ int launch_fp4s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
                              unsigned char *q_op, hipStream_t s) {
     const uint32_t KS = fp4s_ksteps(h->dim);
     const uint64_t units = (uint64_t)nq_pad / 32 * KS * 64;
-    hipLaunchKernelGGL(k_fp4_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim,
+    hipLaunchKernelGGL(k_fp4_pack_frag<float>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim,
                        (uint64_t)nq, units, KS, h->p_mid, h->p_scale, q_op, (fp4s_shape() == 16 && KS <= 12) ? 2 : 0);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;

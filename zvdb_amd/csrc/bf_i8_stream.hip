@@ -16,6 +16,7 @@
 #include "wave_select.h"
 #include "bf_select.h"
 #include "stream_common.h"
+#include "row_types.h"
 
 namespace zvdb {
 
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(64) void k_i8_guess(const float *__restrict__ mom, 
 
 // rows (fp32, row-major) -> int8 fragment order: unit (group g, k-step j, lane l) = the 16 codes of row 32 g + (l & 31),
 // elements 32 j + 16 (l >> 5) + [0, 16); the quantiser is the int8 mirror's (data_kernels.hip:k_quantize_rows)
-__global__ __launch_bounds__(256) void k_i8_pack_frag(const float *__restrict__ src, uint32_t dim, uint32_t ld, uint64_t n,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_i8_pack_frag(const RT *__restrict__ src, uint32_t dim, uint32_t ld, uint64_t n,
                                                       uint64_t units, uint32_t KS, float q_lo, float q_inv, int affine,
                                                       unsigned char *__restrict__ out) {
     const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -382,13 +384,14 @@ __global__ __launch_bounds__(256) void k_i8_pack_frag(const float *__restrict__ 
     const uint32_t k0 = 32 * j + 16 * (l >> 5);
     u32x4 w = {0, 0, 0, 0};
     if (row < n) {
-        const float *v = src + row * ld;
+        const RT *v = src + row * ld;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const uint32_t k = k0 + e;
             int qv = 0;
             if (k < dim) {
-                const float f = affine ? __builtin_rintf((v[k] - q_lo) * q_inv) - 128.0f : __builtin_rintf(v[k] * q_inv);
+                const float x = row_elem(v, k);
+                const float f = affine ? __builtin_rintf((x - q_lo) * q_inv) - 128.0f : __builtin_rintf(x * q_inv);
                 qv = (int)fminf(fmaxf(f, -128.0f), 127.0f);
             }
             w[e >> 2] |= (uint32_t)(qv & 255) << (8 * (e & 3));
@@ -397,7 +400,8 @@ __global__ __launch_bounds__(256) void k_i8_pack_frag(const float *__restrict__ 
     *reinterpret_cast<u32x4 *>(out + u * 16) = w;
 }
 
-__global__ __launch_bounds__(256) void k_i8_norms(const float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_i8_norms(const RT *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
                                                   uint64_t n_pad, float q_lo, float q_inv, int affine, int32_t *__restrict__ norm) {
     const int lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -406,10 +410,11 @@ __global__ __launch_bounds__(256) void k_i8_norms(const float *__restrict__ rows
         if (lane == 0) norm[r] = 0x7FFFFFFF;
         return;
     }
-    const float *v = rows + r * ld;
+    const RT *v = rows + r * ld;
     int s = 0;
     for (uint32_t c = lane; c < dim; c += 64) {
-        const float f = affine ? __builtin_rintf((v[c] - q_lo) * q_inv) - 128.0f : __builtin_rintf(v[c] * q_inv);
+        const float x = row_elem(v, c);
+        const float f = affine ? __builtin_rintf((x - q_lo) * q_inv) - 128.0f : __builtin_rintf(x * q_inv);
         const int qv = (int)fminf(fmaxf(f, -128.0f), 127.0f);
         s += qv * qv;
     }
@@ -485,11 +490,15 @@ int ensure_i8_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     ZV_CHECK(i8_range(h, s));
     const int affine = h->metric == ZVDB_METRIC_L2SQ ? 1 : 0;
     const uint64_t units = rows_pad / 32 * KS * 64;
-    hipLaunchKernelGGL(k_i8_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count,
-                       units, KS, h->q_lo, h->q_inv, affine, h->rows_qf);
-    hipLaunchKernelGGL(k_i8_norms, dim3((uint32_t)((rows_pad + 3) / 4)), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, rows_pad,
-                       h->q_lo, h->q_inv, affine, h->norm_qf);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = row_elem_t<decltype(rows)>;
+        hipLaunchKernelGGL(k_i8_pack_frag<RT>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, rows, h->dim, ld, h->count, units, KS,
+                           h->q_lo, h->q_inv, affine, h->rows_qf);
+        hipLaunchKernelGGL(k_i8_norms<RT>, dim3((uint32_t)((rows_pad + 3) / 4)), dim3(256), 0, s, rows, h->dim, ld, h->count, rows_pad, h->q_lo,
+                           h->q_inv, affine, h->norm_qf);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     h->count_qf = h->count;
     return ZVDB_OK;
 }
@@ -498,7 +507,7 @@ int launch_i8s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uin
                             hipStream_t s) {
     const uint32_t KS = i8s_ksteps(h->dim);
     const uint64_t units = (uint64_t)nq_pad / 32 * KS * 64;
-    hipLaunchKernelGGL(k_i8_pack_frag, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim, (uint64_t)nq,
+    hipLaunchKernelGGL(k_i8_pack_frag<float>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim, (uint64_t)nq,
                        units, KS, h->q_lo, h->q_inv, h->metric == ZVDB_METRIC_L2SQ ? 1 : 0, q_op);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;

@@ -721,7 +721,12 @@ uint32_t debug_flags() {
 // Up to 4 dimensions a reduced-precision screen cannot tell rows apart (an 8-bit code has 256 values per dimension; 200k
 // points on a line share them by the hundred): such indexes are screened in fp32 whatever screen was asked for -- at 4
 // dimensions the MFMA work is nothing.
-static uint32_t effective_mode(const zvdb_hip_index *h, uint32_t mode) { return h->dim <= 4 ? (uint32_t)ZVDB_BF_F32 : mode; }
+// An index that STORES bf16 rows (ZVDB_FLAG_BF16_ROWS) has no fp32 operand for the fp32-MFMA screen: its bf16 screen is lossless
+// (the operands ARE the rows), so ZVDB_BF_F32 -- and the tiny-dimension rule above -- are served by it.
+static uint32_t effective_mode(const zvdb_hip_index *h, uint32_t mode) {
+    if (h->flags & ZVDB_FLAG_BF16_ROWS) return (mode == ZVDB_BF_F32 || h->dim <= 4) ? (uint32_t)ZVDB_BF_BF16 : mode;
+    return h->dim <= 4 ? (uint32_t)ZVDB_BF_F32 : mode;
+}
 
 BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     mode = effective_mode(h, mode);
@@ -821,8 +826,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                       uint32_t mode, uint64_t id_offset, void *d_ws, uint64_t ws_bytes,
                       uint64_t *d_ids, float *d_dist, uint32_t *d_count, hipStream_t s) {
     if (nq == 0) return ZVDB_OK;
-    if (mode == ZVDB_BF_BF16 && !(h->flags & ZVDB_FLAG_BF16_MIRROR)) {
-        set_error("ZVDB_BF_BF16 needs an index created with ZVDB_FLAG_BF16_MIRROR");
+    if (mode == ZVDB_BF_BF16 && !(h->flags & (ZVDB_FLAG_BF16_MIRROR | ZVDB_FLAG_BF16_ROWS))) {
+        set_error("ZVDB_BF_BF16 needs an index created with ZVDB_FLAG_BF16_MIRROR (or bf16 row storage, ZVDB_FLAG_BF16_ROWS)");
         return ZVDB_ERR_INVALID;
     }
     mode = effective_mode(h, mode);

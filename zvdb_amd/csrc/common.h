@@ -92,8 +92,9 @@ struct PinnedBuf {
 }  // namespace zvdb
 
 // Device-resident index.  Layout (DESIGN.md "Data layout in HBM"):
-//   rows   : fp32 [cap][ld]   row-major, ld = round_up(dim, 32), zero padded
-//   rows_h : bf16 [cap][ldh]  row-major mirror, ldh = round_up(dim, 64) (optional)
+//   rows   : fp32 [cap][ld]   row-major, ld = round_up(dim, 32), zero padded (absent with ZVDB_FLAG_BF16_ROWS)
+//   rows_h : bf16 [cap][ldh]  row-major, ldh = round_up(dim, 64): optional mirror (ZVDB_FLAG_BF16_MIRROR), or THE row storage
+//            (ZVDB_FLAG_BF16_ROWS: every exact kernel reads it, widening to fp32; row_types.h)
 //   norm   : fp32 [cap]       sum v^2 over the fp32 row   (MFMA screen only)
 //   norm_h : fp32 [cap]       sum v^2 over the bf16 row
 //   adj    : u32  [cap][gstride]  layer-0 lists, deg : u32 [cap]
@@ -162,6 +163,9 @@ struct zvdb_hip_index {
     bool own_stream_busy = false;  // a fused insert left its finalize kernel running on h->stream (see settle_own_stream)
     uint32_t screen_survivors = 0;  // zvdb_hip_index_set_screen_survivors: minimum k' of the fp4 screen (0 = from k)
     uint32_t shard_count = 1;  // zvdb_hip_index_set_shard_count: the approximate screen keeps its share of the survivors
+    float *stage_f32 = nullptr;  // ZVDB_FLAG_BF16_ROWS: bounded fp32 staging chunk of the add paths (rows are stored as bf16 only)
+    uint64_t stage_rows = 0;
+    float *qrow_f32 = nullptr;   // ZVDB_FLAG_BF16_ROWS: one row widened to fp32 (a row of the index used as a query)
     hipStream_t stream = nullptr;
     // pinned host staging + device scratch for the host-pointer entry points
     zvdb::PinnedBuf pin;
@@ -230,6 +234,7 @@ int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld
 int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
 int launch_round_rows_bf16(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);  // ZVDB_FLAG_BF16_ROWS
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
+int launch_store_rows_bf16(const zvdb_hip_index *h, const float *d_stage, uint64_t first, uint64_t n, hipStream_t s);  // ZVDB_FLAG_BF16_ROWS
 int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
 int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s);
 int fp4_range(zvdb_hip_index *h, hipStream_t s);  // sets p_mid / p_scale from the rows' value range
@@ -267,6 +272,7 @@ int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uin
 
 // ---- graph_build.hip ---------------------------------------------------------
 uint32_t bulk_level(uint64_t seed, uint64_t id);
+int launch_rows_to_f32(const zvdb_hip_index *h, uint64_t first, uint64_t n, float *d_out, hipStream_t s);
 int build_bulk_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, uint32_t mode, uint64_t level_seed,
                      int (*ensure_upper_fn)(zvdb_hip_index *, uint64_t));
 

@@ -1,6 +1,7 @@
 // data_kernels.hip -- row ingestion (pack / synthetic / normalise / norms + bf16 mirror)
 // and the k-way merge that consumes the RCCL all-gather of per-shard top-k lists.
 #include "common.h"
+#include "row_types.h"
 
 #include <cmath>
 
@@ -152,6 +153,46 @@ __global__ __launch_bounds__(256) void k_finalize_rows(const float *__restrict__
     }
 }
 
+// ZVDB_FLAG_BF16_ROWS: rows staged as fp32 [n][ld] (already normalised under cosine) -> the index's bf16 row storage
+// rows_h[first + r] (RNE, zero padded to ldh) and the rows' squared norms over the stored values.  One wave per row.
+__global__ __launch_bounds__(256) void k_store_rows_bf16(const float *__restrict__ stage, uint32_t dim, uint32_t ld, uint16_t *__restrict__ rows_h,
+                                                         uint32_t ldh, float *__restrict__ norm, float *__restrict__ norm_h, uint64_t first,
+                                                         uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float *v = stage + r * ld;
+    uint16_t *o = rows_h + (first + r) * ldh;
+    float sh = 0.0f;
+    for (uint32_t c = lane * 4; c < ldh; c += 256) {
+        uint16_t b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j] = (c + j < dim) ? f32_to_bf16_rne(v[c + j]) : (uint16_t)0;
+            const float f = __uint_as_float((uint32_t)b[j] << 16);
+            sh += f * f;
+        }
+        uint2 pk;
+        pk.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+        pk.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
+        *reinterpret_cast<uint2 *>(o + c) = pk;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sh += __shfl_xor(sh, off);
+    if (lane == 0) {
+        norm[first + r] = sh;
+        norm_h[first + r] = sh;
+    }
+}
+
+int launch_store_rows_bf16(const zvdb_hip_index *h, const float *d_stage, uint64_t first, uint64_t n, hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    hipLaunchKernelGGL(k_store_rows_bf16, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, s, d_stage, h->dim, h->ld, h->rows_h, h->ldh, h->norm,
+                       h->norm_h, first, n);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s) {
     if (n == 0) return ZVDB_OK;
     hipLaunchKernelGGL(k_finalize_rows, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
@@ -164,14 +205,15 @@ int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hi
 // ---- int8 scalar-quantised mirror (ZVDB_BF_I8) -------------------------------------------------
 // One global range for the whole shard: L2 uses the affine map q = rint((x - lo) * 255/(hi-lo)) - 128
 // (offsets cancel in q_a - q_b); dot/cosine use the symmetric map q = rint(x * 127/max|x|).
-__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ rows, uint32_t dim, uint32_t ld,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_minmax(const RT *__restrict__ rows, uint32_t dim, uint32_t ld,
                                                 uint64_t n, uint32_t *__restrict__ range) {
     float lo = __builtin_inff(), hi = -__builtin_inff();
     const uint64_t total = n * ld;
     for (uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total;
          t += (uint64_t)gridDim.x * blockDim.x * 4) {
         const uint32_t c = (uint32_t)(t % ld);
-        const float4 v = *reinterpret_cast<const float4 *>(rows + t);
+        const float4 v = row_load4(rows + t);
         if (c + 0 < dim) { lo = fminf(lo, v.x); hi = fmaxf(hi, v.x); }
         if (c + 1 < dim) { lo = fminf(lo, v.y); hi = fmaxf(hi, v.y); }
         if (c + 2 < dim) { lo = fminf(lo, v.z); hi = fmaxf(hi, v.z); }
@@ -188,14 +230,15 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ rows, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_quantize_rows(const float *__restrict__ rows, uint32_t dim,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_quantize_rows(const RT *__restrict__ rows, uint32_t dim,
                                                        uint32_t ld, int8_t *__restrict__ rows_q,
                                                        uint32_t ldq, int32_t *__restrict__ norm_q,
                                                        uint64_t n, float q_lo, float q_inv, int affine) {
     const int lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
-    const float *v = rows + r * ld;
+    const RT *v = rows + r * ld;
     int s = 0;
     for (uint32_t c = lane * 4; c < ldq; c += 256) {
         int q[4];
@@ -203,7 +246,7 @@ __global__ __launch_bounds__(256) void k_quantize_rows(const float *__restrict__
         for (int j = 0; j < 4; ++j) {
             int qv = 0;
             if (c + j < dim) {
-                const float x = v[c + j];
+                const float x = row_elem(v, c + j);
                 const float f = affine ? __builtin_rintf((x - q_lo) * q_inv) - 128.0f : __builtin_rintf(x * q_inv);
                 qv = (int)fminf(fmaxf(f, -128.0f), 127.0f);
             }
@@ -223,10 +266,13 @@ int i8_range(zvdb_hip_index *h, hipStream_t s) {
     if (!h->q_range) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->q_range), 8));
     const uint32_t init[2] = {0xFFFFFFFFu, 0u};
     ZV_HIP(hipMemcpyAsync(h->q_range, init, 8, hipMemcpyHostToDevice, s));
-    const uint64_t total4 = h->count * h->ld / 4;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((total4 + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_minmax, dim3(grid), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, h->q_range);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        const uint64_t total4 = h->count * ld / 4;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((total4 + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(k_minmax<row_elem_t<decltype(rows)>>, dim3(grid), dim3(256), 0, s, rows, h->dim, ld, h->count, h->q_range);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     uint32_t got[2];
     ZV_HIP(hipMemcpyAsync(got, h->q_range, 8, hipMemcpyDeviceToHost, s));
     ZV_HIP(hipStreamSynchronize(s));  // (lazy one-off build; not on the steady-state search path)
@@ -258,9 +304,12 @@ int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
     }
     ZV_CHECK(i8_range(h, s));
     const bool affine = h->metric == ZVDB_METRIC_L2SQ;
-    hipLaunchKernelGGL(k_quantize_rows, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
-                       h->ld, h->rows_q, h->ldq, h->norm_q, h->count, h->q_lo, h->q_inv, affine ? 1 : 0);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        hipLaunchKernelGGL(k_quantize_rows<row_elem_t<decltype(rows)>>, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, rows, h->dim, ld,
+                           h->rows_q, h->ldq, h->norm_q, h->count, h->q_lo, h->q_inv, affine ? 1 : 0);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     h->count_q = h->count;
     return ZVDB_OK;
 }
@@ -269,14 +318,15 @@ int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
 // Same global range as the int8 mirror, mapped onto [-kFp4Amax, kFp4Amax] and rounded to the nearest fp4
 // value: L2 centres the range (offsets cancel in q_a - q_b), dot/cosine scale symmetrically around 0.
 // One wave per row; a lane packs 8 consecutive elements into one dword (low nibble = even element).
-__global__ __launch_bounds__(256) void k_quantize_rows_fp4(const float *__restrict__ rows, uint32_t dim, uint32_t ld,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_quantize_rows_fp4(const RT *__restrict__ rows, uint32_t dim, uint32_t ld,
                                                            unsigned char *__restrict__ rows_p, uint32_t ldp,
                                                            float *__restrict__ norm_p, uint64_t n, float mid,
                                                            float scale) {
     const int lane = threadIdx.x & 63;
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
-    const float *v = rows + r * ld;
+    const RT *v = rows + r * ld;
     float s = 0.0f;  // multiples of 1/4 below 2^24: exact in any summation order
     for (uint32_t c = lane * 8; c < ldp * 2; c += 512) {
         uint32_t w = 0;
@@ -284,7 +334,7 @@ __global__ __launch_bounds__(256) void k_quantize_rows_fp4(const float *__restri
         for (int j = 0; j < 8; ++j) {
             uint32_t code = 0;
             if (c + j < dim) {
-                code = fp4_e2m1_code((v[c + j] - mid) * scale);
+                code = fp4_e2m1_code((row_elem(v, c + j) - mid) * scale);
                 s += fp4_e2m1_sq(code);
             }
             w |= code << (4 * j);
@@ -310,21 +360,25 @@ int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s) {
         h->cap_p = ncap;
     }
     ZV_CHECK(fp4_range(h, s));
-    hipLaunchKernelGGL(k_quantize_rows_fp4, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
-                       h->ld, h->rows_p, h->ldp, h->norm_p, h->count, h->p_mid, h->p_scale);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        hipLaunchKernelGGL(k_quantize_rows_fp4<row_elem_t<decltype(rows)>>, dim3((uint32_t)((h->count + 3) / 4)), dim3(256), 0, s, rows, h->dim, ld,
+                           h->rows_p, h->ldp, h->norm_p, h->count, h->p_mid, h->p_scale);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     h->count_p = h->count;
     return ZVDB_OK;
 }
 
 // sum and sum of squares of all (unpadded) elements: one fp64 pair of atomics per wave
-__global__ __launch_bounds__(256) void k_moments_all(const float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_moments_all(const RT *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n,
                                                      double *__restrict__ out /* [2] */) {
     double s1 = 0.0, s2 = 0.0;
     const uint64_t total = n * ld;
     for (uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total; t += (uint64_t)gridDim.x * blockDim.x * 4) {
         const uint32_t c = (uint32_t)(t % ld);
-        const float4 v = *reinterpret_cast<const float4 *>(rows + t);
+        const float4 v = row_load4(rows + t);
         const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -350,10 +404,13 @@ int fp4_range(zvdb_hip_index *h, hipStream_t s) {
     double *d_mom = nullptr;
     ZV_HIP(hipMalloc(reinterpret_cast<void **>(&d_mom), 16));
     ZV_HIP(hipMemsetAsync(d_mom, 0, 16, s));
-    const uint64_t total4 = h->count * h->ld / 4;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((total4 + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_moments_all, dim3(grid), dim3(256), 0, s, h->rows, h->dim, h->ld, h->count, d_mom);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        const uint64_t total4 = h->count * ld / 4;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((total4 + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(k_moments_all<row_elem_t<decltype(rows)>>, dim3(grid), dim3(256), 0, s, rows, h->dim, ld, h->count, d_mom);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     double got[2];
     ZV_HIP(hipMemcpyAsync(got, d_mom, 16, hipMemcpyDeviceToHost, s));
     ZV_HIP(hipStreamSynchronize(s));  // (lazy one-off build; not on the steady-state search path)

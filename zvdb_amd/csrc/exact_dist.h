@@ -3,6 +3,7 @@
 // pragma below additionally pins it, so hipcc's default -ffp-contract=fast-honor-pragmas cannot fuse mul + add into v_fma.
 #pragma once
 #include "common.h"
+#include "row_types.h"
 
 #pragma clang fp contract(off)
 
@@ -12,6 +13,10 @@ namespace zvdb {
 // One lane walks one whole row sequentially (the ONLY order that is bit-exact);
 // parallelism comes from different lanes taking different rows.  q may live in
 // LDS (broadcast reads) or global memory (uniform address).
+#define ZV_A1_STEP(av, vv)                                                            \
+    if (METRIC == ZVDB_METRIC_L2SQ) { float t_ = (av) - (vv); t_ = t_ * t_; sum = sum + t_; } \
+    else { const float t_ = (av) * (vv); sum = sum + t_; }
+
 template <int METRIC>
 __device__ __forceinline__ float exact_dist(const float *__restrict__ q,
                                             const float *__restrict__ row, uint32_t dim) {
@@ -24,35 +29,33 @@ __device__ __forceinline__ float exact_dist(const float *__restrict__ q,
     for (; i < d4; i += 4) {
         const float4 v = *reinterpret_cast<const float4 *>(row + i);
         const float4 a = *reinterpret_cast<const float4 *>(q + i);
-        if (METRIC == ZVDB_METRIC_L2SQ) {
-            float t;
-            t = a.x - v.x; t = t * t; sum = sum + t;
-            t = a.y - v.y; t = t * t; sum = sum + t;
-            t = a.z - v.z; t = t * t; sum = sum + t;
-            t = a.w - v.w; t = t * t; sum = sum + t;
-        } else {
-            float t;
-            t = a.x * v.x; sum = sum + t;
-            t = a.y * v.y; sum = sum + t;
-            t = a.z * v.z; sum = sum + t;
-            t = a.w * v.w; sum = sum + t;
-        }
+        ZV_A1_STEP(a.x, v.x) ZV_A1_STEP(a.y, v.y) ZV_A1_STEP(a.z, v.z) ZV_A1_STEP(a.w, v.w)
     }
-    for (; i < dim; ++i) {
-        if (METRIC == ZVDB_METRIC_L2SQ) {
-            float t = q[i] - row[i];
-            t = t * t;
-            sum = sum + t;
-        } else {
-            const float t = q[i] * row[i];
-            sum = sum + t;
-        }
-    }
+    for (; i < dim; ++i) { ZV_A1_STEP(q[i], row[i]) }
     return METRIC == ZVDB_METRIC_L2SQ ? sum : -sum;
 }
 
-__device__ __forceinline__ float exact_dist_rt(int metric, const float *q, const float *row,
-                                               uint32_t dim) {
+// bf16 rows: 16-byte loads carry 8 elements
+template <int METRIC>
+__device__ __forceinline__ float exact_dist(const float *__restrict__ q,
+                                            const bf16_t *__restrict__ row, uint32_t dim) {
+    float sum = 0.0f;
+    const uint32_t d8 = dim & ~7u;
+    uint32_t i = 0;
+#pragma unroll 16
+    for (; i < d8; i += 8) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(row + i);
+        const float4 a = *reinterpret_cast<const float4 *>(q + i);
+        const float4 b = *reinterpret_cast<const float4 *>(q + i + 4);
+        ZV_A1_STEP(a.x, bf16_lo(w.x)) ZV_A1_STEP(a.y, bf16_hi(w.x)) ZV_A1_STEP(a.z, bf16_lo(w.y)) ZV_A1_STEP(a.w, bf16_hi(w.y))
+        ZV_A1_STEP(b.x, bf16_lo(w.z)) ZV_A1_STEP(b.y, bf16_hi(w.z)) ZV_A1_STEP(b.z, bf16_lo(w.w)) ZV_A1_STEP(b.w, bf16_hi(w.w))
+    }
+    for (; i < dim; ++i) { ZV_A1_STEP(q[i], row_elem(row, i)) }
+    return METRIC == ZVDB_METRIC_L2SQ ? sum : -sum;
+}
+
+template <typename RT>
+__device__ __forceinline__ float exact_dist_rt(int metric, const float *q, const RT *row, uint32_t dim) {
     return metric == ZVDB_METRIC_L2SQ ? exact_dist<ZVDB_METRIC_L2SQ>(q, row, dim)
                                       : exact_dist<ZVDB_METRIC_DOT>(q, row, dim);
 }
@@ -62,31 +65,20 @@ __device__ __forceinline__ bool lex_less(float da, uint32_t ia, float db, uint32
 }
 
 // 16-way BLOCKED traversal distance of the ef-mode beam search and the entry descent (specification:
-// orc_distance_blocked16_f32 / orc_neg_dot_blocked16_f32): lane t of a 16-lane group takes the 4-float chunks t, t + 16, ...
+// orc_distance_blocked16_f32 / orc_neg_dot_blocked16_f32): lane t of a 16-lane group takes the 4-element chunks t, t + 16, ...
 // of the row, accumulates them sequentially, un-contracted; the 16 partials are combined by the xor butterfly 8, 4, 2, 1.
-template <int METRIC>
+template <int METRIC, typename RT>
 __device__ __forceinline__ float blocked16_dist(const float *__restrict__ q /*LDS, zero padded to x4*/,
-                                                const float *__restrict__ row, uint32_t nchunks, int t) {
-    float s = 0.0f;
+                                                const RT *__restrict__ row, uint32_t nchunks, int t) {
+    float sum = 0.0f;
     for (uint32_t c = t; c < nchunks; c += 16) {
-        const float4 v = *reinterpret_cast<const float4 *>(row + 4 * c);  // rows are zero padded to ld
+        const float4 v = row_load4(row + 4 * c);  // rows are zero padded to ld
         const float4 a = *reinterpret_cast<const float4 *>(q + 4 * c);
-        float u;
-        if (METRIC == ZVDB_METRIC_L2SQ) {
-            u = a.x - v.x; u = u * u; s = s + u;
-            u = a.y - v.y; u = u * u; s = s + u;
-            u = a.z - v.z; u = u * u; s = s + u;
-            u = a.w - v.w; u = u * u; s = s + u;
-        } else {
-            u = a.x * v.x; s = s + u;
-            u = a.y * v.y; s = s + u;
-            u = a.z * v.z; s = s + u;
-            u = a.w * v.w; s = s + u;
-        }
+        ZV_A1_STEP(a.x, v.x) ZV_A1_STEP(a.y, v.y) ZV_A1_STEP(a.z, v.z) ZV_A1_STEP(a.w, v.w)
     }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) s = s + __shfl_xor(s, off);
-    return METRIC == ZVDB_METRIC_L2SQ ? s : -s;
+    for (int off = 8; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off);
+    return METRIC == ZVDB_METRIC_L2SQ ? sum : -sum;
 }
 
 }  // namespace zvdb

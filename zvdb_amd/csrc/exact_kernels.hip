@@ -19,15 +19,27 @@
 
 namespace zvdb {
 
+static int set_dyn_lds(const void *fn, size_t bytes) {
+    if (bytes > 160 * 1024) {
+        set_error("per-query search state needs %zu B of LDS (> 160 KiB): k*m too large", bytes);
+        return ZVDB_ERR_UNSUPPORTED;
+    }
+    if (bytes > 48 * 1024) {
+        ZV_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
+    return ZVDB_OK;
+}
+
 // ---- K1: out[i] = distance(query, rows[ids[i]]) ------------------------------
-__global__ __launch_bounds__(256) void k_exact_distances(const float *__restrict__ rows, uint32_t ld,
+template <typename RT>
+__global__ __launch_bounds__(256) void k_exact_distances(const RT *__restrict__ rows, uint32_t ld,
                                                          uint32_t dim, int metric,
                                                          const float *__restrict__ query,
                                                          const uint32_t *__restrict__ ids, uint32_t n,
                                                          float *__restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float *row = rows + (size_t)ids[i] * ld;
+    const RT *row = rows + (size_t)ids[i] * ld;
     out[i] = exact_dist_rt(metric, query, row, dim);
 }
 
@@ -35,25 +47,31 @@ int launch_exact_distances(const zvdb_hip_index *h, const float *d_query, const 
                            uint32_t n, float *d_out, hipStream_t s) {
     if (n == 0) return ZVDB_OK;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    hipLaunchKernelGGL(k_exact_distances, dim3((n + 255) / 256), dim3(256), 0, s, h->rows, h->ld,
-                       h->dim, metric, d_query, d_ids, n, d_out);
-    ZV_HIP(hipGetLastError());
-    return ZVDB_OK;
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        hipLaunchKernelGGL(k_exact_distances<RT>, dim3((n + 255) / 256), dim3(256), 0, s, rows, ld, h->dim, metric, d_query, d_ids, n, d_out);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    });
 }
 
 // ---- a2: layer-0 greedy descent of insert (hnsw.zig:88-104) --------------------
 // One wave.  Each while-iteration scans the WHOLE list of the node that is current at
 // the top of the iteration (hnsw.zig:92-94); the running best uses strict '<' so the
 // list's arg-min wins and the earliest entry wins ties (hnsw.zig:97).
-__global__ __launch_bounds__(64) void k_greedy_layer0(const float *__restrict__ rows, uint32_t ld,
+template <typename RT>
+__global__ __launch_bounds__(64) void k_greedy_layer0(const RT *__restrict__ rows, uint32_t ld,
                                                       uint32_t dim, int metric,
                                                       const uint32_t *__restrict__ adj,
                                                       const uint32_t *__restrict__ deg,
                                                       uint32_t gstride, uint32_t owner,
                                                       uint32_t *ep_io, float *dist_io,
                                                       unsigned long long *evals_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g0[];
     const int lane = threadIdx.x;
-    const float *q = rows + (size_t)owner * ld;
+    float *q = reinterpret_cast<float *>(smem_g0);  // the owner's row, widened to fp32 ([dim], 16-byte aligned)
+    for (uint32_t i = lane; i < dim; i += kWave) q[i] = row_elem(rows + (size_t)owner * ld, i);
+    __syncthreads();
     uint32_t ep = *ep_io;
     float cur = *dist_io;
     unsigned long long evals = 0;
@@ -104,7 +122,10 @@ __global__ __launch_bounds__(64) void k_greedy_layer0(const float *__restrict__ 
 // device mirror of layer 0; `out` receives what the host mirror must adopt.
 
 // (`rows` is read and written -- the new row is copied in and read back -- hence one plain pointer: see k_insert_full)
-__global__ __launch_bounds__(64) void k_insert_layer0(float *rows, uint32_t ld, uint32_t dim, int metric,
+// RT = stored row element.  bf16 rows (ZVDB_FLAG_BF16_ROWS): the point is already in its row (point_src == nullptr); a row used
+// as the QUERY of a distance (the new point; ep as the owner of its shrink) is widened into LDS first.
+template <typename RT>
+__global__ __launch_bounds__(64) void k_insert_layer0(RT *rows, uint32_t ld, uint32_t dim, int metric,
                                                       uint32_t *adj, uint32_t *deg, uint32_t gstride,
                                                       uint32_t m, uint32_t first_owner, uint32_t ep_in, unsigned char *__restrict__ out_base,
                                                       uint32_t seq, const float *__restrict__ point_src /* optional: [n][dim] new points */,
@@ -115,7 +136,8 @@ __global__ __launch_bounds__(64) void k_insert_layer0(float *rows, uint32_t ld, 
     uint32_t *lst = reinterpret_cast<uint32_t *>(smem);     // [cap]
     float *dst = reinterpret_cast<float *>(lst + cap);      // [cap]
     uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
-    float *ql = reinterpret_cast<float *>(srt + cap);       // [dim] (only with point_src)
+    float *ql = reinterpret_cast<float *>(srt + cap);       // [dim] (with point_src, or bf16 rows)
+    float *qo = ql + ((dim + 3) & ~3u);                     // [dim] (bf16 rows: the other node's row as a query)
     // A BATCH is n_batch inserts executed one after the other by this one wave (insert i + 1 sees the lists insert i left:
     // the same result as n_batch separate calls, without their launches).  The lists are re-read through L2 (agent-scope
     // loads) because this CU's vector L1 may still hold what an earlier iteration read.
@@ -125,15 +147,21 @@ __global__ __launch_bounds__(64) void k_insert_layer0(float *rows, uint32_t ld, 
     InsertL0Out *out = reinterpret_cast<InsertL0Out *>(out_base + (size_t)b * out_stride);
     uint32_t *out_ep_list = reinterpret_cast<uint32_t *>(out + 1);
     uint32_t *out_owner_list = out_ep_list + gstride;
-    const float *q = rows + (size_t)owner * ld;
-    if (point_src) {  // Node.init's copy (:24-26) done here: the point goes to its row AND to LDS, which the walks below read
-        for (uint32_t i = lane; i < dim; i += kWave) {
-            const float v = point_src[(size_t)b * dim + i];
-            rows[(size_t)owner * ld + i] = v;
-            ql[i] = v;
+    const float *q = ql;
+    if constexpr (std::is_same_v<RT, float>) {
+        q = rows + (size_t)owner * ld;
+        if (point_src) {  // Node.init's copy (:24-26) done here: the point goes to its row AND to LDS, which the walks below read
+            for (uint32_t i = lane; i < dim; i += kWave) {
+                const float v = point_src[(size_t)b * dim + i];
+                rows[(size_t)owner * ld + i] = v;
+                ql[i] = v;
+            }
+            __syncthreads();
+            q = ql;
         }
+    } else {
+        for (uint32_t i = lane; i < dim; i += kWave) ql[i] = row_elem(rows + (size_t)owner * ld, i);
         __syncthreads();
-        q = ql;
     }
     // :86 -- one lane walks the row (the only bit-exact order), the wave adopts its value
     float cur = 0.0f;
@@ -178,7 +206,15 @@ __global__ __launch_bounds__(64) void k_insert_layer0(float *rows, uint32_t ld, 
         uint32_t n = n0 + 1;
         __syncthreads();
         if (n > m) {                                          // :146 shrink
-            const float *o = (node == owner) ? q : rows + (size_t)node * ld;
+            const float *o = q;
+            if (node != owner) {
+                if constexpr (std::is_same_v<RT, float>) o = rows + (size_t)node * ld;
+                else {
+                    for (uint32_t i = lane; i < dim; i += kWave) qo[i] = row_elem(rows + (size_t)node * ld, i);
+                    __syncthreads();
+                    o = qo;
+                }
+            }
             for (uint32_t i = lane; i < n; i += kWave) dst[i] = exact_dist_rt(metric, o, rows + (size_t)lst[i] * ld, dim);  // :160-161
             __syncthreads();
             for (uint32_t i = lane; i < n; i += kWave) {
@@ -411,11 +447,21 @@ size_t insert_l0_out_bytes(const zvdb_hip_index *h) { return round_up64(sizeof(I
 int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, void *d_out, uint32_t seq, const float *point_src,
                          hipStream_t s, uint32_t n_batch, uint32_t out_stride) {
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    const size_t lds = 3ull * ((h->gstride + 1 + 3) & ~3u) * sizeof(uint32_t) + (point_src ? (size_t)h->dim * sizeof(float) : 0);
-    if (lds > 48 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_insert_layer0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_insert_layer0, dim3(1), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj, h->deg, h->gstride,
-                       h->m, owner, ep, static_cast<unsigned char *>(d_out), seq, point_src, n_batch,
-                       out_stride ? out_stride : (uint32_t)insert_l0_out_bytes(h));
+    const size_t lists = 3ull * ((h->gstride + 1 + 3) & ~3u) * sizeof(uint32_t), dimb = (size_t)((h->dim + 3) & ~3u) * sizeof(float);
+    if (h->flags & ZVDB_FLAG_BF16_ROWS) {
+        if (point_src) { set_error("fused point copy needs fp32 rows"); return ZVDB_ERR_INVALID; }
+        const size_t lds = lists + 2 * dimb;
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_insert_layer0<bf16_t>), lds));
+        hipLaunchKernelGGL(k_insert_layer0<bf16_t>, dim3(1), dim3(64), lds, s, reinterpret_cast<bf16_t *>(h->rows_h), h->ldh, h->dim, metric, h->adj,
+                           h->deg, h->gstride, h->m, owner, ep, static_cast<unsigned char *>(d_out), seq, point_src, n_batch,
+                           out_stride ? out_stride : (uint32_t)insert_l0_out_bytes(h));
+    } else {
+        const size_t lds = lists + (point_src ? dimb : 0);
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_insert_layer0<float>), lds));
+        hipLaunchKernelGGL(k_insert_layer0<float>, dim3(1), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj, h->deg, h->gstride,
+                           h->m, owner, ep, static_cast<unsigned char *>(d_out), seq, point_src, n_batch,
+                           out_stride ? out_stride : (uint32_t)insert_l0_out_bytes(h));
+    }
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }
@@ -423,10 +469,15 @@ int launch_insert_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t ep, v
 int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep_io,
                          float *d_dist_io, unsigned long long *d_evals, hipStream_t s) {
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    hipLaunchKernelGGL(k_greedy_layer0, dim3(1), dim3(64), 0, s, h->rows, h->ld, h->dim, metric,
-                       h->adj, h->deg, h->gstride, owner, d_ep_io, d_dist_io, d_evals);
-    ZV_HIP(hipGetLastError());
-    return ZVDB_OK;
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        const size_t lds = (size_t)round_up(std::max(h->dim, 1u), 4) * sizeof(float);
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_greedy_layer0<RT>), lds));
+        hipLaunchKernelGGL(k_greedy_layer0<RT>, dim3(1), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, owner, d_ep_io,
+                           d_dist_io, d_evals);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    });
 }
 
 // ---- LDS-resident per-query state helpers (one wave owns them) ------------------
@@ -516,8 +567,9 @@ __device__ __forceinline__ void heap_remove(LdsHeap &hp, uint32_t &id, float &di
 }
 
 // ---- a5/a6: reference-compat search (hnsw.zig:194-236) -------------------------
+template <typename RT>
 __global__ __launch_bounds__(64) void k_search_compat(
-    const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
     uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
@@ -615,8 +667,9 @@ __global__ __launch_bounds__(64) void k_search_compat(
 // among EQUAL minima.  When the minimum is not unique at a pop, this kernel gives the query up (tie[qi] = 1) and the exact
 // emulation runs it instead (gated launch right behind this one): identical results either way, ~10x fewer dependent LDS
 // round trips in the common case.
+template <typename RT>
 __global__ __launch_bounds__(64) void k_search_compat_fast(
-    const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
     uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
@@ -740,16 +793,6 @@ __global__ __launch_bounds__(64) void k_search_compat_fast(
     }
 }
 
-static int set_dyn_lds(const void *fn, size_t bytes) {
-    if (bytes > 160 * 1024) {
-        set_error("per-query search state needs %zu B of LDS (> 160 KiB): k*m too large", bytes);
-        return ZVDB_ERR_UNSUPPORTED;
-    }
-    if (bytes > 48 * 1024) {
-        ZV_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    }
-    return ZVDB_OK;
-}
 
 static uint32_t bits_for(uint64_t entries) {  // table with >= 2x entries, at least 64 slots
     uint32_t b = 6;
@@ -768,22 +811,26 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
     const uint32_t hash_bits = bits_for(bound);
     const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
     const size_t lds = 4ull * (dim_pad + 2ull * heap_cap + (1ull << hash_bits) + 2ull * rcap + 2 * kWave);
-    ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat), lds));
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool fast_off = [] { const char *e = getenv("ZVDB_COMPAT_SEARCH"); return e && e[0] == 'h'; }();  // "heap": emulation only
-    if (d_tie && !fast_off) {  // unordered-frontier kernel first; the exact emulation serves the queries it gave up on
-        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat_fast), lds));
-        hipLaunchKernelGGL(k_search_compat_fast, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric,
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat<RT>), lds));
+        uint32_t *tie = d_tie;
+        if (tie && !fast_off) {  // unordered-frontier kernel first; the exact emulation serves the queries it gave up on
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat_fast<RT>), lds));
+            hipLaunchKernelGGL(k_search_compat_fast<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric,
+                               h->adj, h->deg, h->gstride, (uint32_t)N, d_queries, k, entry, id_offset, d_ids,
+                               d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, tie);
+        } else {
+            tie = nullptr;
+        }
+        hipLaunchKernelGGL(k_search_compat<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric,
                            h->adj, h->deg, h->gstride, (uint32_t)N, d_queries, k, entry, id_offset, d_ids,
-                           d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, d_tie);
-    } else {
-        d_tie = nullptr;
-    }
-    hipLaunchKernelGGL(k_search_compat, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric,
-                       h->adj, h->deg, h->gstride, (uint32_t)N, d_queries, k, entry, id_offset, d_ids,
-                       d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, d_tie);
-    ZV_HIP(hipGetLastError());
-    return ZVDB_OK;
+                           d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, tie);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    });
 }
 
 // ---- ef-mode beam search (extension; specification: oracle/zvdb_oracle.h) --------
@@ -801,8 +848,9 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
 //   after an expansion   W = best ef of (W u fresh candidates)           (one radix select per expansion,
 //                                                                         only when a candidate beats the worst)
 // so the per-candidate sorted insertions (two barriers per 64 slots shifted) of the first version are gone.
+template <typename RT>
 __global__ __launch_bounds__(64) void k_search_ef(
-    const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
@@ -834,7 +882,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t hash_used = 0;
     bool overflow = false;
     if (N > 0 && k > 0) {
-        const float *erow = rows + (size_t)entry * ld;
+        const RT *erow = rows + (size_t)entry * ld;
         const float d0 = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, erow, nchunks, t)
                                                     : blocked16_dist<ZVDB_METRIC_DOT>(q, erow, nchunks, t);
         if (lane == 0) { wk[0] = ((uint64_t)f32_key(d0) << 32) | entry; wx[0] = 0; }
@@ -875,7 +923,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 // four independent accumulators, so 16 rows x 3 KB are in flight per wave step
                 for (uint32_t r16 = 0; r16 < cnt; r16 += 16) {
                     if (((fb >> r16) & 0xFFFFull) == 0) continue;
-                    const float *rp[4];
+                    const RT *rp[4];
                     bool fr[4];
                     float sacc[4];
 #pragma unroll
@@ -900,7 +948,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                             const uint32_t ce = min(c, lastc);
                             aa[i] = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) vv[i][u] = *reinterpret_cast<const float4 *>(rp[u] + 4 * ce);
+                            for (int u = 0; u < 4; ++u) vv[i][u] = row_load4(rp[u] + 4 * ce);
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -1037,7 +1085,8 @@ __global__ __launch_bounds__(64) void k_search_ef(
 // list of the current node in list order with the blocked traversal distance, keep the strict arg-min (the earliest entry
 // wins ties), move there } until nothing is closer (hnsw.zig:90-104's greedy step, run top-down, on the device's upper-layer
 // lists: node's layer L list = row slot[node] + L - 1 of adj_up).  Four neighbours per wave step (16 lanes per row).
-__global__ __launch_bounds__(64) void k_descend(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+template <typename RT>
+__global__ __launch_bounds__(64) void k_descend(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
                                                 const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ slot,
                                                 const uint32_t *__restrict__ adj_up, const uint32_t *__restrict__ deg_up, uint32_t gstride,
                                                 const float *__restrict__ queries, uint32_t top, uint32_t *__restrict__ out_entry,
@@ -1052,7 +1101,7 @@ __global__ __launch_bounds__(64) void k_descend(const float *__restrict__ rows, 
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
     auto bdist = [&](uint32_t node) {
-        const float *r = rows + (size_t)node * ld;
+        const RT *r = rows + (size_t)node * ld;
         return metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, r, nchunks, t) : blocked16_dist<ZVDB_METRIC_DOT>(q, r, nchunks, t);
     };
     uint32_t cur = top;
@@ -1094,12 +1143,15 @@ int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq,
     if (nq == 0) return ZVDB_OK;
     const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
     const size_t lds = 4ull * dim_pad;
-    ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_descend), lds));
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    hipLaunchKernelGGL(k_descend, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->lvl, h->slot, h->adj_up, h->deg_up, h->gstride,
-                       d_queries, top, d_entries, d_stats, dim_pad);
-    ZV_HIP(hipGetLastError());
-    return ZVDB_OK;
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_descend<RT>), lds));
+        hipLaunchKernelGGL(k_descend<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->lvl, h->slot, h->adj_up, h->deg_up, h->gstride,
+                           d_queries, top, d_entries, d_stats, dim_pad);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    });
 }
 
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
@@ -1121,20 +1173,24 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     };
     while (lds_bytes(hash_bits) > 160 * 1024 && hash_bits > 8) --hash_bits;
     const size_t lds = lds_bytes(hash_bits);
-    ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef), lds));
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    hipLaunchKernelGGL(k_search_ef, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, h->adj,
-                       h->deg, h->gstride, (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids,
-                       d_dist, d_count, d_stats, dim_pad, hash_bits, efp, d_entries);
-    ZV_HIP(hipGetLastError());
-    return ZVDB_OK;
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT>), lds));
+        hipLaunchKernelGGL(k_search_ef<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj,
+                           h->deg, h->gstride, (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids,
+                           d_dist, d_count, d_stats, dim_pad, hash_bits, efp, d_entries);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    });
 }
 
 // ---- K5: exact re-rank of brute-force candidates ---------------------------------
 // cand[q][kc] (u32 local ids, 0xFFFFFFFF = empty).  One wave per query: every lane takes
 // candidates lane, lane+64, ... and computes the reference-exact distance; the final order
 // is (exact dist, id) ascending, duplicates dropped.
-__global__ __launch_bounds__(64) void k_rerank(const float *__restrict__ rows, uint32_t ld,
+template <typename RT>
+__global__ __launch_bounds__(64) void k_rerank(const RT *__restrict__ rows, uint32_t ld,
                                                uint32_t dim, int metric,
                                                const float *__restrict__ queries,
                                                const uint32_t *__restrict__ cand, uint32_t kc,
@@ -1210,17 +1266,18 @@ __global__ __launch_bounds__(64) void k_rerank(const float *__restrict__ rows, u
 // reference's (hnsw.zig:182-192): one lane, strictly ascending k, sub / mul / add, no contraction.
 typedef const __attribute__((address_space(1))) void *rr_gptr_t;
 typedef __attribute__((address_space(3))) void *rr_lptr_t;
-constexpr int RR_CH = 64;  // floats per chunk (256 B)
-
-// KC = 64 or 128 candidates per query (KC / 64 batches of 64 rows through the same two stage buffers)
-template <int KC>
-__global__ __launch_bounds__(64) void k_rerank_staged(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+// KC = 64 or 128 candidates per query (KC / 64 batches of 64 rows through the same two stage buffers).  RT = stored row
+// element: a 256-byte chunk holds 64 fp32 / 128 bf16 elements, a 16-byte piece 4 / 8.
+template <int KC, typename RT>
+__global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
                                                       const float *__restrict__ queries, const uint32_t *__restrict__ cand,
                                                       uint32_t k, uint64_t id_offset, uint64_t *__restrict__ out_ids,
                                                       float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
                                                       uint32_t dim_pad /* multiple of 64 */) {
     constexpr uint32_t kc = KC;
     constexpr int NB = KC / 64;
+    constexpr int RR_CH = 256 / (int)sizeof(RT);  // elements per chunk
+    constexpr int EPP = 16 / (int)sizeof(RT);     // elements per 16-byte piece
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *stage = smem;                                              // [2][64 rows][256 B]
     float *q = reinterpret_cast<float *>(smem + 2 * 64 * 256);               // [dim_pad], zero padded
@@ -1251,12 +1308,12 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const float *__restrict__ 
         __syncthreads();
     }
     const uint32_t nch = (ld + RR_CH - 1) / RR_CH;
-    const uint32_t row_bytes = ld * 4;
+    const uint32_t row_bytes = ld * (uint32_t)sizeof(RT);
 #pragma unroll 1
     for (int bt = 0; bt < NB; ++bt) {
         // DMA side: instruction t fills rows 4t .. 4t+3 of this batch; this lane serves row 4t + (lane >> 4), position lane & 15
         uint32_t src_off[16];  // byte offset of my piece inside a chunk of row (4t + lane/16), before the chunk offset
-        const float *src_row[16];
+        const RT *src_row[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const uint32_t r = 4 * t + (lane >> 4);
@@ -1273,7 +1330,7 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const float *__restrict__ 
             for (int t = 0; t < 16; ++t) {
                 if (t >= nt_used) break;
                 // the row's last chunk may be short (ld is a multiple of 32 floats): stay inside the row
-                const uint32_t off = min(c * (RR_CH * 4) + src_off[t], row_bytes - 16);
+                const uint32_t off = min(c * 256u + src_off[t], row_bytes - 16);
                 __builtin_amdgcn_global_load_lds((rr_gptr_t)(reinterpret_cast<const unsigned char *>(src_row[t]) + off),
                                                  (rr_lptr_t)(stage + buf * (64 * 256) + t * 1024), 16, 0, 0);
             }
@@ -1289,13 +1346,24 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const float *__restrict__ 
             const uint32_t kend = min(dim, k0 + RR_CH);
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                const uint32_t kk = k0 + 4 * p;
+                const uint32_t kk = k0 + EPP * p;
                 if (kk >= kend) break;
-                const float4 v = *reinterpret_cast<const float4 *>(mine + ((p ^ (lane & 15)) << 4));
-                const float4 a = *reinterpret_cast<const float4 *>(q + kk);
-                const float vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a.x, a.y, a.z, a.w};
+                float vv[EPP], aa[EPP];
+                if constexpr (sizeof(RT) == 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(mine + ((p ^ (lane & 15)) << 4));
+                    vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
+                } else {
+                    const uint4 w = *reinterpret_cast<const uint4 *>(mine + ((p ^ (lane & 15)) << 4));
+                    vv[0] = bf16_lo(w.x); vv[1] = bf16_hi(w.x); vv[2] = bf16_lo(w.y); vv[3] = bf16_hi(w.y);
+                    vv[4] = bf16_lo(w.z); vv[5] = bf16_hi(w.z); vv[6] = bf16_lo(w.w); vv[7] = bf16_hi(w.w);
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e4 = 0; e4 < EPP; e4 += 4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(q + kk + e4);
+                    aa[e4] = a.x; aa[e4 + 1] = a.y; aa[e4 + 2] = a.z; aa[e4 + 3] = a.w;
+                }
+#pragma unroll
+                for (int e = 0; e < EPP; ++e) {
                     if (kk + e < kend) {
                         if (metric == ZVDB_METRIC_L2SQ) {
                             float t = aa[e] - vv[e];
@@ -1346,32 +1414,30 @@ int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, 
     if (nq == 0) return ZVDB_OK;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool staged_off = [] { const char *e = getenv("ZVDB_RERANK"); return e && e[0] == 'v' && e[1] == '1'; }();
-    if ((kc == 64 || kc == 128 || kc == 256) && h->ld >= 64 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
-        const uint32_t dp = round_up(h->dim, 64);
-        const size_t lds2 = 2 * 64 * 256 + 4ull * (dp + 2ull * kc);
-        if (kc == 64) {
-            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<64>), lds2));
-            hipLaunchKernelGGL(k_rerank_staged<64>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
-                               id_offset, d_ids, d_dist, d_count, dp);
-        } else if (kc == 128) {
-            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<128>), lds2));
-            hipLaunchKernelGGL(k_rerank_staged<128>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
-                               id_offset, d_ids, d_dist, d_count, dp);
-        } else {
-            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank_staged<256>), lds2));
-            hipLaunchKernelGGL(k_rerank_staged<256>, dim3(nq), dim3(64), lds2, s, h->rows, h->ld, h->dim, metric, d_queries, d_cand, k,
-                               id_offset, d_ids, d_dist, d_count, dp);
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        if ((kc == 64 || kc == 128 || kc == 256) && ld * sizeof(RT) >= 256 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
+            const uint32_t dp = round_up(h->dim, 256 / (uint32_t)sizeof(RT));  // q is read a whole chunk at a time
+            const size_t lds2 = 2 * 64 * 256 + 4ull * (dp + 2ull * kc);
+            auto go = [&](auto kern) -> int {
+                ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds2));
+                hipLaunchKernelGGL(kern, dim3(nq), dim3(64), lds2, s, rows, ld, h->dim, metric, d_queries, d_cand, k, id_offset, d_ids, d_dist,
+                                   d_count, dp);
+                ZV_HIP(hipGetLastError());
+                return ZVDB_OK;
+            };
+            if (kc == 64) return go(k_rerank_staged<64, RT>);
+            if (kc == 128) return go(k_rerank_staged<128, RT>);
+            return go(k_rerank_staged<256, RT>);
         }
+        const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
+        const size_t lds = 4ull * (dim_pad + 2ull * kc);
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank<RT>), lds));
+        hipLaunchKernelGGL(k_rerank<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, d_queries, d_cand, kc, k, id_offset, d_ids, d_dist,
+                           d_count, dim_pad);
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
-    }
-    const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
-    const size_t lds = 4ull * (dim_pad + 2ull * kc);
-    ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank), lds));
-    hipLaunchKernelGGL(k_rerank, dim3(nq), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, d_queries,
-                       d_cand, kc, k, id_offset, d_ids, d_dist, d_count, dim_pad);
-    ZV_HIP(hipGetLastError());
-    return ZVDB_OK;
+    });
 }
 
 }  // namespace zvdb

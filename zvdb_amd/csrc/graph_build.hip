@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_gb_cands(const uint64_t *__restrict__ i
 
 // select() of the header on candidates held in LDS (cid / cdist [n], ascending by (distance, id)); the result (ids, distances)
 // goes to kid / kdist [cap] in LDS; returns its length (wave-uniform).  q = LDS staging of one row (dim floats).
-__device__ __forceinline__ uint32_t gb_select(const float *rows, uint32_t ld, uint32_t dim, int metric, const uint32_t *cid, const float *cdist,
+template <typename RT>
+__device__ __forceinline__ uint32_t gb_select(const RT *rows, uint32_t ld, uint32_t dim, int metric, const uint32_t *cid, const float *cdist,
                                               uint32_t n, uint32_t cap, uint32_t *kid, float *kdist, uint32_t *aside, float *q, int lane) {
     uint32_t nk = 0, na = 0;
     for (uint32_t i = 0; i < n && nk < cap; ++i) {
@@ -62,8 +63,8 @@ __device__ __forceinline__ uint32_t gb_select(const float *rows, uint32_t ld, ui
         bool bad = false;
         if (nk > 0) {
             __syncthreads();  // (one wave per block: orders the LDS staging against the previous step's reads)
-            const float *crow = rows + (size_t)c * ld;
-            for (uint32_t e = lane; e < dim; e += kWave) q[e] = crow[e];
+            const RT *crow = rows + (size_t)c * ld;
+            for (uint32_t e = lane; e < dim; e += kWave) q[e] = row_elem(crow, e);
             __syncthreads();
             if ((uint32_t)lane < nk) {
                 const float dcs = exact_dist_rt(metric, q, rows + (size_t)kid[lane] * ld, dim);
@@ -88,7 +89,8 @@ __device__ __forceinline__ uint32_t gb_select(const float *rows, uint32_t ld, ui
 }
 
 // forward links S[u] = select(u, F[u], M); counts the reverse links every target will receive
-__global__ __launch_bounds__(64) void k_gb_select_fwd(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric, uint32_t N,
+template <typename RT>
+__global__ __launch_bounds__(64) void k_gb_select_fwd(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric, uint32_t N,
                                                       const uint32_t *__restrict__ c_ids, const float *__restrict__ c_dist,
                                                       const uint32_t *__restrict__ c_n, uint32_t pool, uint32_t M,
                                                       uint32_t *__restrict__ s_ids, float *__restrict__ s_dist, uint32_t *__restrict__ s_n,
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(256) void k_gb_fill_rev(uint32_t N, uint32_t M, con
 }
 
 // L0[v] = select(v, first cmax of (S[v] u reverse links) by (distance, id), M0)
-__global__ __launch_bounds__(64) void k_gb_select_final(const float *__restrict__ rows, uint32_t ld, uint32_t dim, int metric, uint32_t N, uint32_t M,
+template <typename RT>
+__global__ __launch_bounds__(64) void k_gb_select_final(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric, uint32_t N, uint32_t M,
                                                         uint32_t M0, const uint32_t *__restrict__ s_ids, const float *__restrict__ s_dist,
                                                         const uint32_t *__restrict__ s_n, const uint64_t *__restrict__ r_off,
                                                         const uint32_t *__restrict__ r_src, const float *__restrict__ r_dist,
@@ -199,13 +202,15 @@ __global__ __launch_bounds__(64) void k_gb_select_final(const float *__restrict_
 }
 
 // rows of a layer's nodes -> dense [n][dim] (the layer is searched as an index of its own)
-__global__ __launch_bounds__(256) void k_gb_gather_rows(const float *__restrict__ rows, uint32_t ld, uint32_t dim, const uint32_t *__restrict__ nodes,
-                                                        uint64_t n, float *__restrict__ out) {
+// (nodes == nullptr: rows [first, first + n) in place -- the queries of a self-kNN batch, widened to fp32)
+template <typename RT>
+__global__ __launch_bounds__(256) void k_gb_gather_rows(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, const uint32_t *__restrict__ nodes,
+                                                        uint64_t first, uint64_t n, float *__restrict__ out) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t r = t / dim;
     if (r >= n) return;
     const uint32_t c = (uint32_t)(t % dim);
-    out[r * dim + c] = rows[(size_t)nodes[r] * ld + c];
+    out[r * dim + c] = row_elem(rows + (size_t)(nodes ? nodes[r] : first + r) * ld, c);
 }
 
 // upper layer L: search results of the layer's rows [r0, r0 + n) (LOCAL ids) -> the nodes' lists at layer L
@@ -257,8 +262,7 @@ int gb_self_knn(zvdb_hip_index *src, uint32_t k, uint32_t mode, F consume) {
     uint32_t *d_cnt = reinterpret_cast<uint32_t *>(scr + qb + ib + db);
     for (uint64_t r0 = 0; r0 < src->count; r0 += B) {
         const uint32_t n = (uint32_t)std::min<uint64_t>(B, src->count - r0);
-        ZV_HIP(hipMemcpy2DAsync(d_q, src->dim * sizeof(float), src->rows + r0 * src->ld, src->ld * sizeof(float), src->dim * sizeof(float), n,
-                                hipMemcpyDeviceToDevice, src->stream));
+        ZV_CHECK(launch_rows_to_f32(src, r0, n, d_q, src->stream));
         ZV_CHECK(launch_bruteforce(src, d_q, n, k, mode, 0, scr + qb + ib + db + cb, wsb, d_ids, d_dist, d_cnt, src->stream));
         ZV_CHECK(consume(d_ids, d_dist, d_cnt, k, r0, n));
     }
@@ -266,6 +270,18 @@ int gb_self_knn(zvdb_hip_index *src, uint32_t k, uint32_t mode, F consume) {
 }
 
 }  // namespace
+
+// rows [first, first + n) of the index as dense fp32 [n][dim] (queries of the self-kNN passes: graph builders)
+int launch_rows_to_f32(const zvdb_hip_index *h, uint64_t first, uint64_t n, float *d_out, hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        const uint64_t threads = n * h->dim;
+        hipLaunchKernelGGL(k_gb_gather_rows<row_elem_t<decltype(rows)>>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, rows, ld, h->dim,
+                           (const uint32_t *)nullptr, first, n, d_out);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    });
+}
 
 uint32_t bulk_level(uint64_t seed, uint64_t id) {  // oracle: orc_bulk_level
     const uint64_t x = mix64(seed, id);
@@ -321,14 +337,18 @@ int build_bulk_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, ui
         ZV_HIP(hipMemsetAsync(c_n.p, 0, N * 4, s));
     }
     const size_t lds = gb_lds_bytes(h->dim);
-    if (lds > 48 * 1024) {
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_select_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_select_final), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipLaunchKernelGGL(k_gb_select_fwd, dim3((uint32_t)N), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, (uint32_t)N, c_ids.as<uint32_t>(),
-                       c_dist.as<float>(), c_n.as<uint32_t>(), std::max(pool, 1u), M, s_ids.as<uint32_t>(), s_dist.as<float>(), s_n.as<uint32_t>(),
-                       r_cnt.as<uint32_t>());
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = row_elem_t<decltype(rows)>;
+        if (lds > 48 * 1024) {
+            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_select_fwd<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gb_select_final<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        hipLaunchKernelGGL(k_gb_select_fwd<RT>, dim3((uint32_t)N), dim3(64), lds, s, rows, ld, h->dim, metric, (uint32_t)N, c_ids.as<uint32_t>(),
+                           c_dist.as<float>(), c_n.as<uint32_t>(), std::max(pool, 1u), M, s_ids.as<uint32_t>(), s_dist.as<float>(), s_n.as<uint32_t>(),
+                           r_cnt.as<uint32_t>());
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     // CSR offsets of the reverse links (host scan: N words each way)
     std::vector<uint32_t> rc(N);
     ZV_HIP(hipMemcpyAsync(rc.data(), r_cnt.p, N * 4, hipMemcpyDeviceToHost, s));
@@ -347,10 +367,13 @@ int build_bulk_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, ui
                            s_dist.as<float>(), s_n.as<uint32_t>(), r_off.as<uint64_t>(), r_cnt.as<uint32_t>(), r_src.as<uint32_t>(), r_dist.as<float>());
         ZV_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_gb_select_final, dim3((uint32_t)N), dim3(64), lds, s, h->rows, h->ld, h->dim, metric, (uint32_t)N, M, M0,
-                       s_ids.as<uint32_t>(), s_dist.as<float>(), s_n.as<uint32_t>(), r_off.as<uint64_t>(), r_src.as<uint32_t>(), r_dist.as<float>(),
-                       h->adj, h->deg, h->gstride);
-    ZV_HIP(hipGetLastError());
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        hipLaunchKernelGGL(k_gb_select_final<row_elem_t<decltype(rows)>>, dim3((uint32_t)N), dim3(64), lds, s, rows, ld, h->dim, metric, (uint32_t)N, M,
+                           M0, s_ids.as<uint32_t>(), s_dist.as<float>(), s_n.as<uint32_t>(), r_off.as<uint64_t>(), r_src.as<uint32_t>(),
+                           r_dist.as<float>(), h->adj, h->deg, h->gstride);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
     ZV_HIP(hipStreamSynchronize(s));
 
     // ---- upper layers: each one an index of its own over the gathered rows of its nodes ---------------------------------
@@ -366,9 +389,12 @@ int build_bulk_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, ui
         ZV_HIP(hipMemcpyAsync(d_nodes.p, nodes.data(), n * 4, hipMemcpyHostToDevice, s));
         {
             const uint64_t threads = n * h->dim;
-            hipLaunchKernelGGL(k_gb_gather_rows, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, h->rows, h->ld, h->dim, d_nodes.as<uint32_t>(), n,
-                               d_rows.as<float>());
-            ZV_HIP(hipGetLastError());
+            ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+                hipLaunchKernelGGL(k_gb_gather_rows<row_elem_t<decltype(rows)>>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, rows, ld, h->dim,
+                                   d_nodes.as<uint32_t>(), 0ull, n, d_rows.as<float>());
+                ZV_HIP(hipGetLastError());
+                return ZVDB_OK;
+            }));
         }
         ZV_HIP(hipStreamSynchronize(s));
         zvdb_hip_config cfg{};

@@ -108,6 +108,12 @@ class Index:
         check(self._L.zvdb_hip_graph_info(self._h, C.byref(e), C.byref(ml)))
         return e.value, ml.value
 
+    def storage_info(self) -> Tuple[int, int]:
+        """(bytes of one stored row, bytes resident on the device for this index)."""
+        rb, tb = C.c_uint64(0), C.c_uint64(0)
+        check(self._L.zvdb_hip_storage_info(self._h, C.byref(rb), C.byref(tb)))
+        return rb.value, tb.value
+
     def get_neighbors_layer(self, node: int, layer: int) -> np.ndarray:
         out = np.zeros(4096, dtype=np.uint64)
         n = C.c_uint32(0)
