@@ -848,7 +848,9 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
 //   after an expansion   W = best ef of (W u fresh candidates)           (one radix select per expansion,
 //                                                                         only when a candidate beats the worst)
 // so the per-candidate sorted insertions (two barriers per 64 slots shifted) of the first version are gone.
-template <typename RT>
+// PROF = 1 (ZVDB_EF_PROF=1, diagnostic): per-phase shader-cycle sums of wave 0's lane 0 go to g_ef_prof (results unchanged)
+__device__ unsigned long long g_ef_prof[8];
+template <typename RT, int PROF = 0>
 __global__ __launch_bounds__(64) void k_search_ef(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
@@ -878,6 +880,9 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t wn = 0, cur = 0;
     uint64_t worst = ~0ull;  // max key of W, valid when wn == ef
     unsigned long long evals = 0, pops = 0;
+    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
+    auto stamp = [&](int ph) { if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); pf[ph] += n - pt; pt = n; } };
+    if constexpr (PROF) pt = __builtin_amdgcn_s_memtime();
     const uint32_t hash_limit = (1u << hash_bits) - (1u << (hash_bits - 2));  // 75 % load cap
     uint32_t hash_used = 0;
     bool overflow = false;
@@ -904,6 +909,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 if (W[i] == kbest) X[i] = 1;
             const uint32_t cid = (uint32_t)kbest;
             pops += 1;
+            stamp(0);  // next-to-expand scan
             const uint32_t dg_all = deg[cid];  // lists longer than 64 are walked 64 entries at a time
             for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
@@ -919,6 +925,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 nb_i[lane] = nbl;
                 const unsigned long long fb = __ballot(fresh1);
                 __syncthreads();
+                stamp(1);  // degree + list load + visited test-and-set
                 // (2) blocked distances, 16 rows per step: group g walks rows r16 + 4u + g (u = 0..3) with
                 // four independent accumulators, so 16 rows x 3 KB are in flight per wave step
                 for (uint32_t r16 = 0; r16 < cnt; r16 += 16) {
@@ -933,28 +940,28 @@ __global__ __launch_bounds__(64) void k_search_ef(
                         rp[u] = rows + (size_t)(fr[u] ? nb_i[j] : 0u) * ld;
                         sacc[u] = 0.0f;
                     }
-                    // super-steps of 64 chunks: each lane loads its 4 chunks of all 4 rows first (16 independent
-                    // 16-byte loads in flight, branch-free: a stale group re-reads row 0, ~95 % are fresh),
-                    // then accumulates them in increasing chunk order (the blocked16 spec)
+                    // super-steps of 64 * SS chunks: each lane loads ITS chunks of all 4 rows first -- SS * 16 independent loads in
+                    // flight (a 768-d row is ONE super-step at SS = 3: the phase is bound by load latency, ~2 us per dependent
+                    // batch under load, not by bytes -- bf16 rows halve the bytes at the same latency), branch-free (a stale
+                    // group re-reads row 0, ~95 % are fresh) -- then accumulates them in increasing chunk order (the blocked16 spec)
+                    constexpr int SS = 3;  // (measured 1M x 768, ef = 128, batch 1,024 / 4,096 / 16,384: fp32 rows 637k / 741k / 807k QPS, bf16 rows 701k / 810k / 891k; SS = 1: 654k / 660k / 729k either way)
                     const uint32_t lastc = ld / 4 - 1;
-                    for (uint32_t c0 = 0; c0 < nchunks; c0 += 64) {
-                        float4 vv[4][4];
-                        float4 aa[4];
-                        bool okc[4];
+                    for (uint32_t c0 = 0; c0 < nchunks; c0 += 64 * SS) {
+                        float4 vv[4 * SS][4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const uint32_t c = c0 + t + 16 * i;
-                            okc[i] = c < nchunks;
-                            const uint32_t ce = min(c, lastc);
-                            aa[i] = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
+                        for (int i = 0; i < 4 * SS; ++i) {
+                            const uint32_t ce = min(c0 + t + 16 * i, lastc);
 #pragma unroll
                             for (int u = 0; u < 4; ++u) vv[i][u] = row_load4(rp[u] + 4 * ce);
                         }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = 0; i < 4 * SS; ++i) {
+                            const uint32_t c = c0 + t + 16 * i;
+                            const bool okc = c < nchunks;
+                            const float4 a = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
-                                const float4 a = aa[i], v = vv[i][u];
+                                const float4 v = vv[i][u];
                                 float w0, w1, w2, w3;
                                 if (metric == ZVDB_METRIC_L2SQ) {
                                     w0 = a.x - v.x; w0 = w0 * w0; w1 = a.y - v.y; w1 = w1 * w1;
@@ -962,7 +969,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                                 } else {
                                     w0 = a.x * v.x; w1 = a.y * v.y; w2 = a.z * v.z; w3 = a.w * v.w;
                                 }
-                                if (!okc[i]) { w0 = 0.0f; w1 = 0.0f; w2 = 0.0f; w3 = 0.0f; }  // +0 leaves the sum unchanged
+                                if (!okc) { w0 = 0.0f; w1 = 0.0f; w2 = 0.0f; w3 = 0.0f; }  // +0 leaves the sum unchanged
                                 sacc[u] = sacc[u] + w0; sacc[u] = sacc[u] + w1;
                                 sacc[u] = sacc[u] + w2; sacc[u] = sacc[u] + w3;
                             }
@@ -979,13 +986,14 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 hash_used += (uint32_t)__popcll(fb);
                 evals += (unsigned long long)__popcll(fb);
                 __syncthreads();
+                stamp(2);  // blocked distances of the fresh neighbours
                 // (3) W = best ef of (W u fresh candidates): lane j holds candidate j
                 uint64_t ck = ~0ull;
                 if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
                 const bool pass = ck != ~0ull && (wn < ef || ck < worst);
                 const unsigned long long pm = __ballot(pass);
                 const uint32_t na = (uint32_t)__popcll(pm);
-                if (na == 0) continue;
+                if (na == 0) { stamp(3); continue; }
                 W = wk + cur * efp;
                 X = wx + cur * efp;
                 if (wn + na <= ef) {  // room: append
@@ -998,6 +1006,35 @@ __global__ __launch_bounds__(64) void k_search_ef(
                         for (uint32_t i = lane; i < wn; i += kWave) mx = umax64(mx, W[i]);
                         worst = wave_max64(mx);
                     }
+                } else if (na <= 8) {
+                    // few candidates (the steady state of a search: W is full and most neighbours lose against its worst):
+                    // the oracle's own sequential rule, candidate by candidate in list order -- while there is room append,
+                    // else replace the worst entry if the candidate beats it and find the new worst.  Same set as the select
+                    // below at ~400 cycles per accepted candidate instead of one 5,000-cycle radix select per pop.
+                    unsigned long long todo = pm;
+                    while (todo) {
+                        const int l = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const uint64_t ckl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ck >> 32), l) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ck, l);
+                        bool wrote = false;
+                        if (wn < ef) {
+                            if (lane == 0) { W[wn] = ckl; X[wn] = 0; }
+                            wn += 1;
+                            wrote = true;
+                        } else if (ckl < worst) {
+                            for (uint32_t i = lane; i < wn; i += kWave)
+                                if (W[i] == worst) { W[i] = ckl; X[i] = 0; }  // (keys are distinct: exactly one slot)
+                            wrote = true;
+                        }
+                        if (wrote && wn == ef) {
+                            __syncthreads();
+                            uint64_t mx = 0;
+                            for (uint32_t i = lane; i < wn; i += kWave) mx = umax64(mx, W[i]);
+                            worst = wave_max64(mx);
+                        }
+                    }
+                    __syncthreads();
                 } else {  // select the ef best of the union, compact into the other buffer
                     const uint32_t Ew = (wn + kWave - 1) / kWave;
                     const uint64_t ckp = pass ? ck : ~0ull;
@@ -1026,10 +1063,12 @@ __global__ __launch_bounds__(64) void k_search_ef(
                     worst = T;
                     __syncthreads();
                 }
+                stamp(3);  // beam update (append / radix select)
             }
         }
         __syncthreads();
     }
+    stamp(4);
     // the k smallest keys of W, re-evaluated with the exact reference arithmetic, ordered by (exact distance, id)
     const uint32_t nres = wn < k ? wn : k;
     uint64_t *W = wk + cur * efp;
@@ -1076,6 +1115,12 @@ __global__ __launch_bounds__(64) void k_search_ef(
             atomicAdd(&stats[0], evals);
             atomicAdd(&stats[1], pops);
             if (overflow) atomicAdd(&stats[2], 1ull);  // visited set exhausted: result not to spec
+        }
+        if constexpr (PROF) {
+            stamp(5);  // final k: exact re-evaluation + order
+            for (int i = 0; i < 6; ++i) atomicAdd(&g_ef_prof[i], pf[i]);
+            atomicAdd(&g_ef_prof[6], pops);
+            atomicAdd(&g_ef_prof[7], 1ull);
         }
     }
 }
@@ -1176,6 +1221,21 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
+        if (prof) {  // diagnostic build of the same kernel: per-phase cycles, printed after a synchronise
+            unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}, got[8];
+            ZV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ef_prof), zero, sizeof(zero)));
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 1>), lds));
+            hipLaunchKernelGGL((k_search_ef<RT, 1>), dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
+                               d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hash_bits, efp, d_entries);
+            ZV_HIP(hipStreamSynchronize(s));
+            ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
+            const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
+            fprintf(stderr, "[zvdb ef prof] %llu queries, %.1f pops each; shader cycles per POP: next-scan %.0f, list+visited %.0f, distances %.0f, beam update %.0f; "
+                    "per QUERY: tail %.0f, final-k %.0f, total %.0f\n", got[7], np / nw, got[0] / np, got[1] / np, got[2] / np, got[3] / np, got[4] / nw,
+                    got[5] / nw, (got[0] + got[1] + got[2] + got[3] + got[4] + got[5]) / nw);
+            return ZVDB_OK;
+        }
         ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT>), lds));
         hipLaunchKernelGGL(k_search_ef<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj,
                            h->deg, h->gstride, (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids,
