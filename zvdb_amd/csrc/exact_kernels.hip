@@ -901,15 +901,18 @@ __global__ __launch_bounds__(64) void k_search_ef(
             uint32_t *X = wx + cur * efp;
             // next to expand: the smallest unexpanded key
             uint64_t lm = ~0ull;
+            uint32_t li = 0;  // slot of this lane's smallest unexpanded key
             for (uint32_t i = lane; i < wn; i += kWave)
-                if (X[i] == 0) lm = umin64(lm, W[i]);
+                if (X[i] == 0 && W[i] < lm) { lm = W[i]; li = i; }
             const uint64_t kbest = wave_min64(lm);
             if (kbest == ~0ull) break;
-            for (uint32_t i = lane; i < wn; i += kWave)
-                if (W[i] == kbest) X[i] = 1;
+            if (lm == kbest) X[li] = 1;  // (keys are distinct: one lane)
             const uint32_t cid = (uint32_t)kbest;
             pops += 1;
             stamp(0);  // next-to-expand scan
+            // the degree and the first 64 list slots are requested TOGETHER (both depend on cid only): one memory round trip per
+            // pop instead of two (slots past the degree hold stale or zero ids and are masked below)
+            const uint32_t nb_first = (uint32_t)lane < gstride ? adj[(size_t)cid * gstride + lane] : 0u;
             const uint32_t dg_all = deg[cid];  // lists longer than 64 are walked 64 entries at a time
             for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 uint32_t nbl = 0;
                 bool fresh1 = false;
                 if ((uint32_t)lane < cnt && !overflow) {
-                    nbl = adj[(size_t)cid * gstride + lbase + lane];
+                    nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
                     fresh1 = hash_insert_atomic(hash, hash_bits, nbl);
                 }
                 nb_i[lane] = nbl;
