@@ -157,6 +157,13 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode);
  * a greedy descent through the upper layers picks each query's layer-0 entry, then the ef-mode beam search runs. */
 int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, uint32_t mode, uint64_t level_seed);
 int zvdb_hip_graph_info(zvdb_hip_index *h, uint64_t *out_entry, uint32_t *out_max_level);
+/* On-disk index format (the reference is memory-only): one flat little-endian file -- a 256-byte header, then
+ * the device arrays as they sit in HBM (rows as stored: fp32 or bf16; norms; every layer's adjacency; levels), each section
+ * 256-byte aligned, so a loader may mmap the file and upload the sections as they are.  Lazily built mirrors are not stored.
+ * zvdb_hip_load creates a new index (device = HIP ordinal, -1 = current) holding exactly what was saved: the same rows, graph
+ * (reference-compat or bulk, incl. its entry) and therefore the same search results. */
+int zvdb_hip_save(zvdb_hip_index *h, const char *path);
+int zvdb_hip_load(const char *path, int32_t device, zvdb_hip_index **out);
 /* HBM accounting: bytes of one stored row (fp32: 4 ld; ZVDB_FLAG_BF16_ROWS: 2 ldh) and the bytes this index holds on the device
  * right now (row storage, norms, adjacency of every layer, and whichever lazily built mirrors exist). */
 int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *out_resident_bytes);

@@ -75,3 +75,49 @@ def test_bulk_graph_recall_beats_the_knn_graph(zv, oracle):
     r_bulk = recall(idx.search_graph(Q, k, ef=128, entry=zv.ENTRY_DESCEND)[0])
     r_bulk_512 = recall(idx.search_graph(Q, k, ef=512, entry=zv.ENTRY_DESCEND)[0])
     assert r_bulk >= 0.75 and r_bulk > r_knn + 0.1 and r_bulk_512 >= 0.97, (r_knn, r_bulk, r_bulk_512)
+
+
+@pytest.mark.parametrize("kind", ["compat_fp32", "bulk_bf16_rows"])
+def test_on_disk_format_round_trip(zv, oracle, tmp_path, kind):
+    """zvdb_hip_save / zvdb_hip_load: the loaded index holds the same rows, the same graph on every layer
+    (reference-compat or bulk, with its entry) and returns the same results on every route, bit for bit; the file is the flat
+    layout the header documents (magic, 256-byte aligned sections, size = header + sections)."""
+    n, d = 5000, 96
+    V = oracle.uniform_rows(77, 0, n, d)
+    Q = oracle.uniform_rows(78, 0, 32, d)
+    path = str(tmp_path / "index.zvdb")
+    if kind == "compat_fp32":
+        h = zv.HNSW(8, 200)
+        ref = oracle.HNSW(8, 200, level_seed=3)
+        for r in V[:1500]:
+            ref.insert(r)
+        lv = np.array([ref.node_level(i) for i in range(1500)], dtype=np.int32)
+        h.insert_many(V[:1500], lv)
+        idx = h.index
+        n = 1500
+        searches = [dict(k=10, ef=0, entry=0), dict(k=10, ef=32, entry=0)]
+    else:
+        idx = zv.Index(m=16, graph_stride=16, flags=zv.FLAG_BF16_ROWS)
+        idx.add(V)
+        idx.build_graph(8, 40, zv.BF_BF16, 11)
+        searches = [dict(k=10, ef=64, entry=zv.ENTRY_DESCEND), dict(k=5, ef=16, entry=0)]
+    idx.save(path)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"ZVDBHIP1" and len(raw) % 256 == 0
+    got = zv.Index.load(path)
+    assert got.count() == n and got.dim == d and got.graph_info() == idx.graph_info() and got.storage_info()[0] == idx.storage_info()[0]
+    for i in range(0, n, 37):
+        assert np.array_equal(got.get_vector(i), idx.get_vector(i))
+        assert np.array_equal(got.get_neighbors(i), idx.get_neighbors(i))
+    for s in searches:
+        a = idx.search_graph(Q, s["k"], ef=s["ef"], entry=s["entry"], with_stats=True)
+        b = got.search_graph(Q, s["k"], ef=s["ef"], entry=s["entry"], with_stats=True)
+        assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3], s
+    mode = zv.BF_BF16 if kind != "compat_fp32" else zv.BF_I8
+    ai, ad, ac = idx.search_bruteforce(Q, 10, mode)
+    bi, bd, bc = got.search_bruteforce(Q, 10, mode)
+    assert np.array_equal(ai, bi) and np.array_equal(ad, bd)
+    with open(path, "r+b") as f:  # a truncated file is refused, not half-loaded
+        f.truncate(len(raw) // 2)
+    with pytest.raises(zv.ZvdbError):
+        zv.Index.load(path)

@@ -65,6 +65,8 @@ HIP_SYMBOLS = [
     ("zvdb_hip_build_graph", _i32, [_vp, _u32, _u32, _u32, _u64]),
     ("zvdb_hip_graph_info", _i32, [_vp, _u64p, _u32p]),
     ("zvdb_hip_storage_info", _i32, [_vp, _u64p, _u64p]),
+    ("zvdb_hip_save", _i32, [_vp, C.c_char_p]),
+    ("zvdb_hip_load", _i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
     ("zvdb_hip_get_neighbors_layer", _i32, [_vp, _u64, _u32, _u64p, _u32, _u32p]),
     ("zvdb_hip_merge_topk_dev", _i32, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_merge_topk_packed_dev", _i32, [_vp, _u64, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),

@@ -6,6 +6,9 @@
 
 #include "common.h"
 
+#include <sys/types.h>
+#include <unistd.h>
+
 namespace zvdb {
 
 static thread_local char g_err[512] = "";
@@ -1188,6 +1191,137 @@ int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction
         ZV_HIP(hipStreamSynchronize(h->stream));
     }
     return build_bulk_graph(h, M, ef_construction, mode, level_seed, ensure_upper);
+}
+
+
+// ---- on-disk index format (absent in the reference, which is memory-only) -------------------------------
+// One flat little-endian file: a 256-byte header, then the device arrays exactly as they sit in HBM, each 256-byte aligned and
+// in this order -- rows (fp32 [count][ld], or bf16 [count][ldh] with ZVDB_FLAG_BF16_ROWS), norm [count], adj [count][gstride],
+// deg [count], lvl [count], slot [count], adj_up [up_count][gstride], deg_up [up_count].  Lazily built mirrors are NOT stored
+// (they are functions of the rows and rebuild on first use); the optional row-major bf16 mirror is recomputed on load.
+// The layout is the upload layout: a loader may mmap the file and hipMemcpy each section as is.
+namespace {
+struct ZvdbFileHeader {
+    char magic[8];  // "ZVDBHIP1"
+    uint32_t version, dim, ld, ldh, metric, m, ef_construction, gstride, flags, max_level, bulk_graph, bulk_top;
+    uint64_t count, up_count;
+    uint64_t off_rows, off_norm, off_adj, off_deg, off_lvl, off_slot, off_adj_up, off_deg_up, file_bytes;
+    unsigned char pad[256 - 8 - 12 * 4 - 11 * 8];
+};
+static_assert(sizeof(ZvdbFileHeader) == 256, "header size");
+
+int copy_section_out(zvdb_hip_index *h, FILE *f, const void *dev, uint64_t bytes, uint64_t off) {
+    if (fseeko(f, (off_t)off, SEEK_SET) != 0) { set_error("seek failed"); return ZVDB_ERR_INVALID; }
+    const uint64_t chunk = 64ull << 20;
+    ZV_CHECK(ensure_pin(h, (size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(bytes, 1))));
+    for (uint64_t o = 0; o < bytes; o += chunk) {
+        const uint64_t nb = std::min(chunk, bytes - o);
+        ZV_HIP(hipMemcpyAsync(h->pin.ptr, static_cast<const unsigned char *>(dev) + o, nb, hipMemcpyDeviceToHost, h->stream));
+        ZV_HIP(hipStreamSynchronize(h->stream));
+        if (fwrite(h->pin.ptr, 1, nb, f) != nb) { set_error("short write"); return ZVDB_ERR_INVALID; }
+    }
+    return ZVDB_OK;
+}
+int copy_section_in(zvdb_hip_index *h, FILE *f, void *dev, uint64_t bytes, uint64_t off) {
+    if (fseeko(f, (off_t)off, SEEK_SET) != 0) { set_error("seek failed"); return ZVDB_ERR_INVALID; }
+    const uint64_t chunk = 64ull << 20;
+    ZV_CHECK(ensure_pin(h, (size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(bytes, 1))));
+    for (uint64_t o = 0; o < bytes; o += chunk) {
+        const uint64_t nb = std::min(chunk, bytes - o);
+        if (fread(h->pin.ptr, 1, nb, f) != nb) { set_error("short read: truncated index file"); return ZVDB_ERR_INVALID; }
+        ZV_HIP(hipMemcpyAsync(static_cast<unsigned char *>(dev) + o, h->pin.ptr, nb, hipMemcpyHostToDevice, h->stream));
+        ZV_HIP(hipStreamSynchronize(h->stream));
+    }
+    return ZVDB_OK;
+}
+}  // namespace
+
+int zvdb_hip_save(zvdb_hip_index *h, const char *path) {
+    ZV_ARG(h && path, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_CHECK(settle_own_stream(h));
+    ZV_HIP(hipStreamSynchronize(h->stream));
+    const bool hb = (h->flags & ZVDB_FLAG_BF16_ROWS) != 0;
+    ZvdbFileHeader hd{};
+    std::memcpy(hd.magic, "ZVDBHIP1", 8);
+    hd.version = 1; hd.dim = h->dim; hd.ld = h->ld; hd.ldh = h->ldh; hd.metric = h->metric; hd.m = h->m;
+    hd.ef_construction = h->ef_construction; hd.gstride = h->gstride; hd.flags = h->flags; hd.max_level = h->max_level;
+    hd.bulk_graph = h->bulk_graph ? 1u : 0u; hd.bulk_top = h->bulk_top; hd.count = h->count; hd.up_count = h->up_count;
+    const uint64_t n = h->count, rowb = hb ? (uint64_t)h->ldh * 2 : (uint64_t)h->ld * 4;
+    uint64_t off = 256;
+    auto place = [&](uint64_t bytes) { const uint64_t o = off; off = round_up64(off + bytes, 256); return o; };
+    hd.off_rows = place(n * rowb); hd.off_norm = place(n * 4); hd.off_adj = place(n * h->gstride * 4); hd.off_deg = place(n * 4);
+    hd.off_lvl = place(n * 4); hd.off_slot = place(n * 4); hd.off_adj_up = place(h->up_count * h->gstride * 4); hd.off_deg_up = place(h->up_count * 4);
+    hd.file_bytes = off;
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("cannot open %s for writing", path); return ZVDB_ERR_INVALID; }
+    int rc = ZVDB_OK;
+    if (fwrite(&hd, 1, sizeof(hd), f) != sizeof(hd)) { set_error("short write"); rc = ZVDB_ERR_INVALID; }
+    if (rc == ZVDB_OK && n) {
+        rc = copy_section_out(h, f, hb ? (const void *)h->rows_h : (const void *)h->rows, n * rowb, hd.off_rows);
+        if (rc == ZVDB_OK) rc = copy_section_out(h, f, h->norm, n * 4, hd.off_norm);
+        if (rc == ZVDB_OK) rc = copy_section_out(h, f, h->adj, n * h->gstride * 4, hd.off_adj);
+        if (rc == ZVDB_OK) rc = copy_section_out(h, f, h->deg, n * 4, hd.off_deg);
+        if (rc == ZVDB_OK) rc = copy_section_out(h, f, h->lvl, n * 4, hd.off_lvl);
+        if (rc == ZVDB_OK) rc = copy_section_out(h, f, h->slot, n * 4, hd.off_slot);
+        if (rc == ZVDB_OK && h->up_count) rc = copy_section_out(h, f, h->adj_up, h->up_count * h->gstride * 4, hd.off_adj_up);
+        if (rc == ZVDB_OK && h->up_count) rc = copy_section_out(h, f, h->deg_up, h->up_count * 4, hd.off_deg_up);
+    }
+    if (rc == ZVDB_OK && ftruncate(fileno(f), (off_t)hd.file_bytes) != 0) { set_error("cannot size %s", path); rc = ZVDB_ERR_INVALID; }
+    if (fclose(f) != 0 && rc == ZVDB_OK) { set_error("close failed"); rc = ZVDB_ERR_INVALID; }
+    return rc;
+}
+
+int zvdb_hip_load(const char *path, int32_t device, zvdb_hip_index **out) {
+    ZV_ARG(path && out, "null argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_error("cannot open %s", path); return ZVDB_ERR_INVALID; }
+    ZvdbFileHeader hd{};
+    if (fread(&hd, 1, sizeof(hd), f) != sizeof(hd) || std::memcmp(hd.magic, "ZVDBHIP1", 8) != 0 || hd.version != 1) {
+        fclose(f);
+        set_error("%s is not a zvdb-hip index file (version 1)", path);
+        return ZVDB_ERR_INVALID;
+    }
+    zvdb_hip_config cfg{};
+    cfg.abi_version = ZVDB_HIP_ABI_VERSION; cfg.dim = hd.dim; cfg.metric = hd.metric; cfg.m = hd.m; cfg.ef_construction = hd.ef_construction;
+    cfg.device = device; cfg.flags = hd.flags; cfg.graph_stride = hd.gstride; cfg.capacity = hd.count;
+    zvdb_hip_index *h = nullptr;
+    int rc = zvdb_hip_create(&cfg, &h);
+    if (rc != ZVDB_OK) { fclose(f); return rc; }
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        const bool hb = (h->flags & ZVDB_FLAG_BF16_ROWS) != 0;
+        const uint64_t n = hd.count, rowb = hb ? (uint64_t)h->ldh * 2 : (uint64_t)h->ld * 4;
+        if ((hd.dim && (hd.ld != h->ld || hd.ldh != h->ldh)) || hd.gstride != h->gstride) { set_error("index file geometry mismatch"); rc = ZVDB_ERR_INVALID; }
+        if (rc == ZVDB_OK && n) {
+            rc = ensure_capacity(h, n);
+            if (rc == ZVDB_OK && hd.up_count) rc = ensure_upper(h, hd.up_count);
+            if (rc == ZVDB_OK) rc = copy_section_in(h, f, hb ? (void *)h->rows_h : (void *)h->rows, n * rowb, hd.off_rows);
+            if (rc == ZVDB_OK) rc = copy_section_in(h, f, h->norm, n * 4, hd.off_norm);
+            if (rc == ZVDB_OK) rc = copy_section_in(h, f, h->adj, n * h->gstride * 4, hd.off_adj);
+            if (rc == ZVDB_OK) rc = copy_section_in(h, f, h->deg, n * 4, hd.off_deg);
+            if (rc == ZVDB_OK) rc = copy_section_in(h, f, h->lvl, n * 4, hd.off_lvl);
+            if (rc == ZVDB_OK) rc = copy_section_in(h, f, h->slot, n * 4, hd.off_slot);
+            if (rc == ZVDB_OK && hd.up_count) rc = copy_section_in(h, f, h->adj_up, hd.up_count * h->gstride * 4, hd.off_adj_up);
+            if (rc == ZVDB_OK && hd.up_count) rc = copy_section_in(h, f, h->deg_up, hd.up_count * 4, hd.off_deg_up);
+            if (rc == ZVDB_OK) {
+                if (hb) {  // the stored norms are those of the bf16 rows
+                    if (hipMemcpyAsync(h->norm_h, h->norm, n * 4, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) rc = ZVDB_ERR_HIP;
+                } else {
+                    rc = launch_finalize_rows(h, 0, n, h->stream);  // norms + the optional row-major bf16 mirror, from the rows
+                }
+            }
+            if (rc == ZVDB_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = ZVDB_ERR_HIP;
+        }
+        if (rc == ZVDB_OK) {
+            h->count = n; h->up_count = hd.up_count; h->max_level = hd.max_level; h->bulk_graph = hd.bulk_graph != 0; h->bulk_top = hd.bulk_top;
+        }
+    }
+    fclose(f);
+    if (rc != ZVDB_OK) { zvdb_hip_destroy(h); return rc; }
+    *out = h;
+    return ZVDB_OK;
 }
 
 int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *out_resident_bytes) {

@@ -404,7 +404,7 @@ int build_bulk_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, ui
         cfg.m = h->m;
         cfg.ef_construction = h->ef_construction;
         cfg.device = h->device;
-        cfg.flags = h->flags & ZVDB_FLAG_BF16_MIRROR;
+        cfg.flags = h->flags & (ZVDB_FLAG_BF16_MIRROR | ZVDB_FLAG_BF16_ROWS);  // (bf16 rows: the gathered values are bf16-representable, re-rounding is the identity)
         cfg.graph_stride = 1;
         cfg.capacity = n;
         zvdb_hip_index *sub = nullptr;

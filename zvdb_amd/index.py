@@ -4,6 +4,7 @@ pointers (e.g. ``torch.Tensor.data_ptr()``) plus a stream handle and only enqueu
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -107,6 +108,19 @@ class Index:
         e, ml = C.c_uint64(0), C.c_uint32(0)
         check(self._L.zvdb_hip_graph_info(self._h, C.byref(e), C.byref(ml)))
         return e.value, ml.value
+
+    def save(self, path: str) -> None:
+        """Write the index (rows as stored, every layer of the graph) to one flat file (include/zvdb_hip.h: on-disk format)."""
+        check(self._L.zvdb_hip_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path: str, device: int = -1) -> "Index":
+        L = _lib.hip()
+        h = C.c_void_p()
+        check(L.zvdb_hip_load(os.fsencode(path), device, C.byref(h)))
+        self = cls._from_handle(h.value)
+        self._own = True
+        return self
 
     def storage_info(self) -> Tuple[int, int]:
         """(bytes of one stored row, bytes resident on the device for this index)."""
