@@ -857,7 +857,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool s4 = mode == ZVDB_BF_FP4 && !f7 && fp4s128_eligible(h) && (big8 || wide_k);
     // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
     // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
-    const bool sb = mode == ZVDB_BF_BF16 && bf16s_eligible(h) && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64);
+    // (from 8 tiles = 64 row groups per stream: BASELINE configs[1], 1M x 128 at batch 256 = 256 streams of 15 tiles, rides it)
+    const bool sb = mode == ZVDB_BF_BF16 && bf16s_eligible(h) && !guess_off && p.NT >= 8 * p.S && !(debug_flags() & 64);
     if (sb) ZV_CHECK(ensure_bf16_frag_mirror(h, s));
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
