@@ -66,6 +66,12 @@ template <int O0, int O1> __device__ __forceinline__ void bh_lds_read_norms(f32x
     asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(a), "=&v"(b) : "v"(addr), "n"(O0), "n"(O1));
 }
 template <int N> __device__ __forceinline__ void bh_lgkm_wait2(f32x4 &a, f32x4 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
+// every outstanding LDS read has landed: ties ALL ring registers, so that code behind it (the cold append / prune path, which may
+// spill or copy registers around its call) only ever sees landed values
+__device__ __forceinline__ void bh_lgkm_drain(u32x4 (&a)[BH_R]) {
+    static_assert(BH_R == 6, "operand list below");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+}
 template <int N> __device__ __forceinline__ void bh_lgkm_wait(u32x4 &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
 
 // Exact prune of the calling wave's 32 queries whose append buffer passed MARK.  Out of line and cold on purpose: the scan
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
                     const float m1 = fmaxf(fmaxf(fmaxf(acc[0][1][0], acc[0][1][1]), fmaxf(acc[0][1][2], acc[0][1][3])),
                                            fmaxf(fmaxf(acc[1][1][0], acc[1][1][1]), fmaxf(acc[1][1][2], acc[1][1][3])));
                     if (__ballot(m0 > thr0 || m1 > thr1)) {
+                        if constexpr (NG > 1) bh_lgkm_drain(A);  // (mid-unit epilogue: the ring may hold reads still in flight)
                         bool need = false;
 #pragma unroll
                         for (int qb = 0; qb < 2; ++qb)
