@@ -30,8 +30,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr bool kFp4Pipe = false;
 static_assert(T2 == 256, "bf_select.h");  //                    // tile edge (queries and corpus rows)
 constexpr int CAP2 = HW + T2;                // per-row candidate buffer of the v2 scan
-constexpr int STAGE2 = 2 * T2 * KB;          // A + B = 64 KiB per stage
-constexpr int LDS2 = 2 * STAGE2 + 3 * T2 * 4;
 
 using i32x16 = __attribute__((ext_vector_type(16))) int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;

@@ -232,7 +232,6 @@ int launch_fill_synthetic(float *d_out, uint64_t nrows, uint32_t dim, uint32_t l
 int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld, uint64_t n,
                      hipStream_t s);
 int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
-int launch_round_rows_bf16(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);  // ZVDB_FLAG_BF16_ROWS
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
 int launch_store_rows_bf16(const zvdb_hip_index *h, const float *d_stage, uint64_t first, uint64_t n, hipStream_t s);  // ZVDB_FLAG_BF16_ROWS
 int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
