@@ -98,6 +98,46 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// per row: norm = sum v^2 (fp32), bf16 mirror row + its own norm.  One wave per row.
+__global__ __launch_bounds__(256) void k_finalize_rows(const float *__restrict__ rows, uint32_t dim,
+                                                       uint32_t ld, uint16_t *__restrict__ rows_h,
+                                                       uint32_t ldh, float *__restrict__ norm,
+                                                       float *__restrict__ norm_h, uint64_t first,
+                                                       uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = first + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= first + n) return;
+    const float *v = rows + r * ld;
+    float s = 0.0f, sh = 0.0f;
+    for (uint32_t c = lane * 4; c < ld; c += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(v + c);
+        s += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        if (rows_h) {
+            const uint16_t b0 = f32_to_bf16_rne(x.x), b1 = f32_to_bf16_rne(x.y);
+            const uint16_t b2 = f32_to_bf16_rne(x.z), b3 = f32_to_bf16_rne(x.w);
+            const float f0 = __uint_as_float((uint32_t)b0 << 16), f1 = __uint_as_float((uint32_t)b1 << 16);
+            const float f2 = __uint_as_float((uint32_t)b2 << 16), f3 = __uint_as_float((uint32_t)b3 << 16);
+            sh += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;
+            uint2 pk;
+            pk.x = (uint32_t)b0 | ((uint32_t)b1 << 16);
+            pk.y = (uint32_t)b2 | ((uint32_t)b3 << 16);
+            *reinterpret_cast<uint2 *>(rows_h + r * ldh + c) = pk;
+        }
+    }
+    if (rows_h)
+        for (uint32_t c = ld + lane * 4; c < ldh; c += 256)
+            *reinterpret_cast<uint2 *>(rows_h + r * ldh + c) = make_uint2(0, 0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        sh += __shfl_xor(sh, off);
+    }
+    if (lane == 0) {
+        norm[r] = s;
+        if (norm_h) norm_h[r] = sh;
+    }
+}
+
 // ZVDB_FLAG_BF16_ROWS: rows staged as fp32 [n][ld] (already normalised under cosine) -> the index's bf16 row storage
 // rows_h[first + r] (RNE, zero padded to ldh) and the rows' squared norms over the stored values.  One wave per row.
 __global__ __launch_bounds__(256) void k_store_rows_bf16(const float *__restrict__ stage, uint32_t dim, uint32_t ld, uint16_t *__restrict__ rows_h,
