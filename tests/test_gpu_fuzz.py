@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("script,cases,seed", [
     ("fuzz_bruteforce.py", 24, 11),   # small / ragged shards: every screen, both metrics, k up to 112
     ("fuzz_compat.py", 16, 12),       # reference-compat insert on every layer + search, incl. tie-heavy grids
-    ("fuzz_ef.py", 10, 13),           # ef-mode beam search on random kNN graphs vs the oracle's ef spec
+    ("fuzz_ef.py", 24, 7),            # ef-mode beam search on random kNN graphs vs the oracle's ef spec: fp32 / bf16 rows, register and LDS beam kernels
     ("fuzz_stream.py", 6, 14),        # large shards: stream kernels (bf16 / int8 / fp4), guessed + verified thresholds, wide k
 ])
 def test_seeded_fuzz_sweep(script, cases, seed):

@@ -833,6 +833,153 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
     });
 }
 
+// ---- traversal distances of one list window (shared by both ef kernels) ---------------------------------------------------
+// nb_d[j] <- blocked16 distance (oracle: orc_distance_blocked16_f32) between q (LDS, zero padded) and row nb_i[j], for the
+// positions j < cnt whose bit is set in fb.  fp32 rows: 16 lanes per row, 16-byte loads.  bf16 rows: 8 lanes per row (below).
+template <typename RT>
+__device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows, uint32_t ld, const float *q, uint32_t nchunks, int metric,
+                                                    uint32_t cnt, unsigned long long fb, const uint32_t *nb_i, float *nb_d, int lane) {
+    const int g = lane >> 4, t = lane & 15;  // 4 row groups of 16 lanes
+    // (2) blocked distances, 16 rows per step: group g walks rows r16 + 4u + g (u = 0..3) with
+    // four independent accumulators, so 16 rows x 3 KB are in flight per wave step
+    for (uint32_t r16 = 0; r16 < cnt; r16 += 16) {
+        if (((fb >> r16) & 0xFFFFull) == 0) continue;
+        if constexpr (sizeof(RT) == 2) {
+            // bf16 rows: EIGHT lanes per row with 16-byte loads.  Lane a of a group takes bytes 128 m + 16 a of the row
+            // (m = 0, 1, ...): the 8-byte chunks 2a + 16m and 2a + 1 + 16m, i.e. exactly the chunks of the blocked16
+            // partial sums 2a and 2a + 1 in increasing order -- so the lane carries BOTH partials as two sequential
+            // chains, and the spec's butterfly (8, 4, 2, 1 over partial indices) becomes lane xor 4, 2, 1 on each
+            // chain followed by low + high.  Same values as the 16-lane walk, half the load requests per row
+            // (rows are zero padded to a multiple of 128 bytes, so every load is in bounds).
+            const int g8 = lane >> 3, a8 = lane & 7;
+            const uint32_t nm = ld / 64;  // 128-byte lines per row
+            const bf16_t *rp2[2];
+            bool fr2[2];
+            float slo[2], shi[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t j = r16 + 8 * u + g8;
+                fr2[u] = j < cnt && ((fb >> j) & 1ull);
+                rp2[u] = rows + (size_t)(fr2[u] ? nb_i[j] : 0u) * ld + 8 * a8;
+                slo[u] = 0.0f;
+                shi[u] = 0.0f;
+            }
+            // super-steps of MM lines per row, all MM x 2 loads of a lane issued before the first use (branch free: the
+            // counted waits then let the sums of line i start while lines i+1.. are still in flight).  MM follows the row
+            // length -- 768-d rows are ONE super-step of 12.  When MM divides the line count (every power-of-two length
+            // and 768 / 1536) the walk needs no masks at all: the caller pads q with zeros to the rows' padded length, the
+            // rows' own padding is zero, so the tail adds +0.  Other lengths take the MASKED walk: a line past the row's
+            // end re-reads the last one and its terms are forced to +0.
+            auto walk = [&](auto mm_tag, auto masked_tag) {
+                constexpr int MM = decltype(mm_tag)::value;
+                constexpr bool MASKED = decltype(masked_tag)::value;
+                for (uint32_t m0 = 0; m0 < nm; m0 += MM) {
+                    uint4 vv[MM][2];
+#pragma unroll
+                    for (int i = 0; i < MM; ++i) {
+                        const uint32_t me = MASKED ? min(m0 + i, nm - 1) : m0 + i;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) vv[i][u] = *reinterpret_cast<const uint4 *>(rp2[u] + 64 * me);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MM; ++i) {
+                        const uint32_t cl = 2 * a8 + 16 * (m0 + i);
+                        const bool okm = !MASKED || m0 + i < nm;  // (q is padded to whole lines: only a re-read line needs the mask)
+                        const float4 al = *reinterpret_cast<const float4 *>(q + 4 * (MASKED ? min(cl, 16 * nm - 2) : cl));
+                        const float4 ah = *reinterpret_cast<const float4 *>(q + 4 * (MASKED ? min(cl, 16 * nm - 2) : cl) + 4);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint4 w = vv[i][u];
+                            float l0 = bf16_lo(w.x), l1 = bf16_hi(w.x), l2 = bf16_lo(w.y), l3 = bf16_hi(w.y);
+                            float h0 = bf16_lo(w.z), h1 = bf16_hi(w.z), h2 = bf16_lo(w.w), h3 = bf16_hi(w.w);
+                            if (metric == ZVDB_METRIC_L2SQ) {
+                                l0 = al.x - l0; l0 = l0 * l0; l1 = al.y - l1; l1 = l1 * l1;
+                                l2 = al.z - l2; l2 = l2 * l2; l3 = al.w - l3; l3 = l3 * l3;
+                                h0 = ah.x - h0; h0 = h0 * h0; h1 = ah.y - h1; h1 = h1 * h1;
+                                h2 = ah.z - h2; h2 = h2 * h2; h3 = ah.w - h3; h3 = h3 * h3;
+                            } else {
+                                l0 = al.x * l0; l1 = al.y * l1; l2 = al.z * l2; l3 = al.w * l3;
+                                h0 = ah.x * h0; h1 = ah.y * h1; h2 = ah.z * h2; h3 = ah.w * h3;
+                            }
+                            if (!okm) { l0 = 0.0f; l1 = 0.0f; l2 = 0.0f; l3 = 0.0f; h0 = 0.0f; h1 = 0.0f; h2 = 0.0f; h3 = 0.0f; }
+                            slo[u] = slo[u] + l0; slo[u] = slo[u] + l1; slo[u] = slo[u] + l2; slo[u] = slo[u] + l3;
+                            shi[u] = shi[u] + h0; shi[u] = shi[u] + h1; shi[u] = shi[u] + h2; shi[u] = shi[u] + h3;
+                        }
+                    }
+                }
+            };
+            using std::integral_constant;
+            if (nm % 12 == 0) walk(integral_constant<int, 12>{}, std::false_type{});
+            else if (nm % 8 == 0) walk(integral_constant<int, 8>{}, std::false_type{});
+            else if (nm == 4) walk(integral_constant<int, 4>{}, std::false_type{});
+            else if (nm == 2) walk(integral_constant<int, 2>{}, std::false_type{});
+            else if (nm == 1) walk(integral_constant<int, 1>{}, std::false_type{});
+            else walk(integral_constant<int, 6>{}, std::true_type{});
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float sl = slo[u], sh = shi[u];
+#pragma unroll
+                for (int off = 4; off > 0; off >>= 1) { sl = sl + __shfl_xor(sl, off); sh = sh + __shfl_xor(sh, off); }
+                const float sv = sl + sh;
+                if (fr2[u] && a8 == 0) nb_d[r16 + 8 * u + g8] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
+            }
+            continue;
+        }
+        const RT *rp[4];
+        bool fr[4];
+        float sacc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t j = r16 + 4 * u + g;
+            fr[u] = j < cnt && ((fb >> j) & 1ull);
+            rp[u] = rows + (size_t)(fr[u] ? nb_i[j] : 0u) * ld;
+            sacc[u] = 0.0f;
+        }
+        // super-steps of 64 * SS chunks: each lane loads ITS chunks of all 4 rows first -- SS * 16 independent loads in
+        // flight (a 768-d row is ONE super-step at SS = 3: the phase is bound by load latency, ~2 us per dependent
+        // batch under load, not by bytes -- bf16 rows halve the bytes at the same latency), branch-free (a stale
+        // group re-reads row 0, ~95 % are fresh) -- then accumulates them in increasing chunk order (the blocked16 spec)
+        constexpr int SS = 3;  // (measured 1M x 768, ef = 128, batch 1,024 / 4,096 / 16,384: fp32 rows 637k / 741k / 807k QPS, bf16 rows 701k / 810k / 891k; SS = 1: 654k / 660k / 729k either way)
+        const uint32_t lastc = ld / 4 - 1;
+        for (uint32_t c0 = 0; c0 < nchunks; c0 += 64 * SS) {
+            float4 vv[4 * SS][4];
+#pragma unroll
+            for (int i = 0; i < 4 * SS; ++i) {
+                const uint32_t ce = min(c0 + t + 16 * i, lastc);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vv[i][u] = row_load4(rp[u] + 4 * ce);
+            }
+#pragma unroll
+            for (int i = 0; i < 4 * SS; ++i) {
+                const uint32_t c = c0 + t + 16 * i;
+                const bool okc = c < nchunks;
+                const float4 a = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = vv[i][u];
+                    float w0, w1, w2, w3;
+                    if (metric == ZVDB_METRIC_L2SQ) {
+                        w0 = a.x - v.x; w0 = w0 * w0; w1 = a.y - v.y; w1 = w1 * w1;
+                        w2 = a.z - v.z; w2 = w2 * w2; w3 = a.w - v.w; w3 = w3 * w3;
+                    } else {
+                        w0 = a.x * v.x; w1 = a.y * v.y; w2 = a.z * v.z; w3 = a.w * v.w;
+                    }
+                    if (!okc) { w0 = 0.0f; w1 = 0.0f; w2 = 0.0f; w3 = 0.0f; }  // +0 leaves the sum unchanged
+                    sacc[u] = sacc[u] + w0; sacc[u] = sacc[u] + w1;
+                    sacc[u] = sacc[u] + w2; sacc[u] = sacc[u] + w3;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float sv = sacc[u];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) sv = sv + __shfl_xor(sv, off);
+            if (fr[u] && t == 0) nb_d[r16 + 4 * u + g] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
+        }
+    }
+}
+
 // ---- ef-mode beam search (extension; specification: oracle/zvdb_oracle.h) --------
 // W = sorted (dist,id) list of <= ef entries with an "expanded" flag, LDS resident.
 //
@@ -892,6 +1039,8 @@ __global__ __launch_bounds__(64) void k_search_ef(
                                                     : blocked16_dist<ZVDB_METRIC_DOT>(q, erow, nchunks, t);
         if (lane == 0) { wk[0] = ((uint64_t)f32_key(d0) << 32) | entry; wx[0] = 0; }
         wn = 1;
+        if (ef == 1) worst = ((uint64_t)f32_key(d0) << 32) | entry;  // the entry alone fills the beam (found by the two-kernel fuzz: the first
+                                                                      // candidate of an ef = 1 search was compared against an unset worst and lost)
         evals = 1;
         hash_insert_uniform(hash, hash_bits, entry);
         hash_used = 1;
@@ -929,63 +1078,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 const unsigned long long fb = __ballot(fresh1);
                 __syncthreads();
                 stamp(1);  // degree + list load + visited test-and-set
-                // (2) blocked distances, 16 rows per step: group g walks rows r16 + 4u + g (u = 0..3) with
-                // four independent accumulators, so 16 rows x 3 KB are in flight per wave step
-                for (uint32_t r16 = 0; r16 < cnt; r16 += 16) {
-                    if (((fb >> r16) & 0xFFFFull) == 0) continue;
-                    const RT *rp[4];
-                    bool fr[4];
-                    float sacc[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t j = r16 + 4 * u + g;
-                        fr[u] = j < cnt && ((fb >> j) & 1ull);
-                        rp[u] = rows + (size_t)(fr[u] ? nb_i[j] : 0u) * ld;
-                        sacc[u] = 0.0f;
-                    }
-                    // super-steps of 64 * SS chunks: each lane loads ITS chunks of all 4 rows first -- SS * 16 independent loads in
-                    // flight (a 768-d row is ONE super-step at SS = 3: the phase is bound by load latency, ~2 us per dependent
-                    // batch under load, not by bytes -- bf16 rows halve the bytes at the same latency), branch-free (a stale
-                    // group re-reads row 0, ~95 % are fresh) -- then accumulates them in increasing chunk order (the blocked16 spec)
-                    constexpr int SS = 3;  // (measured 1M x 768, ef = 128, batch 1,024 / 4,096 / 16,384: fp32 rows 637k / 741k / 807k QPS, bf16 rows 701k / 810k / 891k; SS = 1: 654k / 660k / 729k either way)
-                    const uint32_t lastc = ld / 4 - 1;
-                    for (uint32_t c0 = 0; c0 < nchunks; c0 += 64 * SS) {
-                        float4 vv[4 * SS][4];
-#pragma unroll
-                        for (int i = 0; i < 4 * SS; ++i) {
-                            const uint32_t ce = min(c0 + t + 16 * i, lastc);
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) vv[i][u] = row_load4(rp[u] + 4 * ce);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4 * SS; ++i) {
-                            const uint32_t c = c0 + t + 16 * i;
-                            const bool okc = c < nchunks;
-                            const float4 a = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const float4 v = vv[i][u];
-                                float w0, w1, w2, w3;
-                                if (metric == ZVDB_METRIC_L2SQ) {
-                                    w0 = a.x - v.x; w0 = w0 * w0; w1 = a.y - v.y; w1 = w1 * w1;
-                                    w2 = a.z - v.z; w2 = w2 * w2; w3 = a.w - v.w; w3 = w3 * w3;
-                                } else {
-                                    w0 = a.x * v.x; w1 = a.y * v.y; w2 = a.z * v.z; w3 = a.w * v.w;
-                                }
-                                if (!okc) { w0 = 0.0f; w1 = 0.0f; w2 = 0.0f; w3 = 0.0f; }  // +0 leaves the sum unchanged
-                                sacc[u] = sacc[u] + w0; sacc[u] = sacc[u] + w1;
-                                sacc[u] = sacc[u] + w2; sacc[u] = sacc[u] + w3;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float sv = sacc[u];
-#pragma unroll
-                        for (int off = 8; off > 0; off >>= 1) sv = sv + __shfl_xor(sv, off);
-                        if (fr[u] && t == 0) nb_d[r16 + 4 * u + g] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
-                    }
-                }
+                ef_window_distances(rows, ld, q, nchunks, metric, cnt, fb, nb_i, nb_d, lane);
                 hash_used += (uint32_t)__popcll(fb);
                 evals += (unsigned long long)__popcll(fb);
                 __syncthreads();
@@ -1128,6 +1221,198 @@ __global__ __launch_bounds__(64) void k_search_ef(
     }
 }
 
+// ---- ef-mode beam search, beam in REGISTERS (ef <= 64 EPL) ---------------------------------------------------------------------
+// Same search, same results as k_search_ef above (keys are distinct, so "the ef best of the union" is one set however it is
+// held); what changes is where W lives.  The profile of the LDS-set kernel (ZVDB_EF_PROF=1, 1M x 768, ef = 128) put a third
+// of every pop into W bookkeeping: ~1,400 cycles to find the next node (LDS scan + a 64-bit wave reduction) and ~3,400 to
+// merge the candidates (one reduction per accepted candidate to find the new worst, or a radix select).  Here W is the
+// oracle's own formulation again -- a list SORTED by key -- spread over the wave's registers: slot s sits in lane s % 64 of
+// wkr[s / 64], the "expanded" flags are one 64-bit scalar mask per block.  Then
+//   next node to expand  = first zero bit of the flag masks                       (scalar ff0 + two readlanes)
+//   worst entry          = slot ef - 1                                            (two readlanes)
+//   insert a candidate   = position by ballot/popcount of (key < candidate), then every block from there on moves up one
+//                          lane with a wave_shr:1 DPP move (the block's last entry carries into lane 0 of the next), the
+//                          flag masks shift alongside on the scalar unit; the entry pushed past slot ef - 1 is the old worst
+// -- no LDS traffic, no barrier, no reduction: ~50 instructions per accepted candidate.  The first k slots are the result.
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+__device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v) {  // lane i <- lane i - 1 (lane 0: unspecified, overwritten by the caller)
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <typename RT, int EPL, int PROF = 0>
+__global__ __launch_bounds__(64) void k_search_ef_reg(
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
+    uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
+    uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
+    uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
+    uint32_t hash_bits, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (entries) entry = entries[blockIdx.x];
+    float *q = reinterpret_cast<float *>(smem);
+    uint32_t *hash = reinterpret_cast<uint32_t *>(q + dim_pad);
+    float *nb_d = reinterpret_cast<float *>(hash + (1u << hash_bits));
+    uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
+    uint32_t *R = nb_i + kWave;                          // [kpad] result ids
+    float *RD = reinterpret_cast<float *>(R + kpad);     // [kpad] their exact distances
+
+    const int lane = threadIdx.x;
+    const int t = lane & 15;
+    const uint32_t qi = blockIdx.x;
+    const float *qg = queries + (size_t)qi * dim;
+    for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
+    for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
+    __syncthreads();
+    const uint32_t nchunks = (dim + 3) / 4;
+
+    uint64_t wkr[EPL];          // sorted beam: slot s = lane s % 64 of wkr[s / 64]; slots >= wn are meaningless
+    uint64_t xm[EPL];           // expanded flags (wave-uniform)
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { wkr[e] = ~0ull; xm[e] = 0; }
+    uint32_t wn = 0;
+    uint64_t worst = ~0ull;     // key of slot ef - 1, valid when wn == ef
+    unsigned long long evals = 0, pops = 0;
+    unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
+    auto stamp = [&](int ph) { if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); pf[ph] += n - pt; pt = n; } };
+    if constexpr (PROF) pt = __builtin_amdgcn_s_memtime();
+    const uint32_t hash_limit = (1u << hash_bits) - (1u << (hash_bits - 2));  // 75 % load cap
+    uint32_t hash_used = 0;
+    bool overflow = false;
+
+    auto insert_sorted = [&](uint64_t ckl) {  // ckl wave-uniform, distinct from every key held; if the beam is full: ckl < worst
+        uint32_t p = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) p += (uint32_t)__popcll(__ballot((uint32_t)(e * kWave + lane) < wn && wkr[e] < ckl));
+        const uint32_t ep = p >> 6, lp = p & 63;
+        uint64_t carry = 0, carrybit = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            if ((uint32_t)e >= ep) {  // (wave-uniform)
+                const bool first = (uint32_t)e == ep;
+                const uint64_t last = readlane64(wkr[e], kWave - 1);
+                const uint64_t sh = wave_shr1_64(wkr[e]);
+                const uint32_t thr = first ? lp : 0u;
+                const uint64_t in0 = first ? ckl : carry;
+                wkr[e] = (uint32_t)lane < thr ? wkr[e] : ((uint32_t)lane == thr ? in0 : sh);
+                const uint64_t lowmask = first ? ((1ull << lp) - 1ull) : 0ull;
+                const uint64_t top = xm[e] >> 63;
+                xm[e] = (xm[e] & lowmask) | ((xm[e] & ~lowmask) << 1) | (first ? 0ull : carrybit);
+                carry = last;
+                carrybit = top;
+            }
+        }
+        if (wn < ef) wn += 1;
+        if (wn == ef) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
+        }
+    };
+
+    if (N > 0 && k > 0) {
+        const RT *erow = rows + (size_t)entry * ld;
+        const float d0 = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, erow, nchunks, t)
+                                                    : blocked16_dist<ZVDB_METRIC_DOT>(q, erow, nchunks, t);
+        insert_sorted(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)f32_key(d0)) << 32) | entry);
+        evals = 1;
+        hash_insert_uniform(hash, hash_bits, entry);
+        hash_used = 1;
+        __syncthreads();
+        for (;;) {
+            // next to expand: the first unexpanded slot
+            uint32_t slot = kWave * EPL;
+#pragma unroll
+            for (int e = EPL - 1; e >= 0; --e)
+                if (~xm[e] != 0ull) slot = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
+            if (slot >= wn) break;
+            uint64_t kbest = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (slot >> 6 == (uint32_t)e) { kbest = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
+            const uint32_t cid = (uint32_t)kbest;
+            pops += 1;
+            stamp(0);  // next-to-expand
+            const uint32_t nb_first = (uint32_t)lane < gstride ? adj[(size_t)cid * gstride + lane] : 0u;
+            const uint32_t dg_all = deg[cid];  // lists longer than 64 are walked 64 entries at a time
+            for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
+                const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
+                __syncthreads();
+                if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
+                uint32_t nbl = 0;
+                bool fresh1 = false;
+                if ((uint32_t)lane < cnt && !overflow) {
+                    nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
+                    fresh1 = hash_insert_atomic(hash, hash_bits, nbl);
+                }
+                nb_i[lane] = nbl;
+                const unsigned long long fb = __ballot(fresh1);
+                __syncthreads();
+                stamp(1);  // degree + list load + visited test-and-set
+                ef_window_distances(rows, ld, q, nchunks, metric, cnt, fb, nb_i, nb_d, lane);
+                hash_used += (uint32_t)__popcll(fb);
+                evals += (unsigned long long)__popcll(fb);
+                __syncthreads();
+                stamp(2);  // blocked distances of the fresh neighbours
+                uint64_t ck = ~0ull;
+                if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
+                unsigned long long todo = __ballot(ck != ~0ull && (wn < ef || ck < worst));
+                while (todo) {  // candidate by candidate in list order (the oracle's rule); the running worst filters again
+                    const int l = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const uint64_t ckl = readlane64(ck, l);
+                    if (wn < ef || ckl < worst) insert_sorted(ckl);
+                }
+                stamp(3);  // beam update
+            }
+        }
+        __syncthreads();
+    }
+    stamp(4);
+    // the first k slots of W, re-evaluated with the exact reference arithmetic, ordered by (exact distance, id)
+    const uint32_t nres = wn < k ? wn : k;
+    if (nres > 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+            if ((uint32_t)(e * kWave + lane) < nres) R[e * kWave + lane] = (uint32_t)wkr[e];
+        __syncthreads();
+        for (uint32_t i = lane; i < nres; i += kWave)
+            RD[i] = exact_dist_rt(metric, q, rows + (size_t)R[i] * ld, dim);
+        __syncthreads();
+        for (uint32_t i = lane; i < nres; i += kWave) {
+            const float di = RD[i];
+            const uint32_t ii = R[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < nres; ++j)
+                if (lex_less(RD[j], R[j], di, ii)) ++rank;
+            out_ids[(size_t)qi * k + rank] = (uint64_t)ii + id_offset;
+            out_dist[(size_t)qi * k + rank] = di;
+        }
+    }
+    for (uint32_t i = nres + lane; i < k; i += kWave) {
+        out_ids[(size_t)qi * k + i] = ~0ull;
+        out_dist[(size_t)qi * k + i] = __builtin_inff();
+    }
+    if (lane == 0) {
+        out_count[qi] = nres;
+        if (stats) {
+            atomicAdd(&stats[0], evals);
+            atomicAdd(&stats[1], pops);
+            if (overflow) atomicAdd(&stats[2], 1ull);  // visited set exhausted: result not to spec
+        }
+        if constexpr (PROF) {
+            stamp(5);  // final k: exact re-evaluation + order
+            for (int i = 0; i < 6; ++i) atomicAdd(&g_ef_prof[i], pf[i]);
+            atomicAdd(&g_ef_prof[6], pops);
+            atomicAdd(&g_ef_prof[7], 1ull);
+        }
+    }
+}
+
 // ---- hierarchical entry descent of the bulk graph (extension; specification: orc_hnsw_descend) -----------------------------
 // One wave per query: from the graph's top node down the layers max_level .. 1; on each layer repeat { scan the WHOLE
 // list of the current node in list order with the blocked traversal distance, keep the strict arg-min (the earliest entry
@@ -1208,29 +1493,41 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     if (nq == 0) return ZVDB_OK;
     if (ef < k) ef = k;
     const uint64_t N = h->count;
-    const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
+    // q in LDS: zero padded to the rows' padded length for bf16 rows (the unmasked 8-lane walk reads whole 128-byte lines)
+    const uint32_t dim_pad = (h->flags & ZVDB_FLAG_BF16_ROWS) ? std::max(h->ldh, 64u) : round_up(std::max(h->dim, 1u), 4);
     // visited set: every node is visited at most once.  Measured evaluations per query are ~1.1 x
     // ef * stride; the table takes >= 3 x ef * stride slots (75 % load cap => room for 2.2 x), because its
     // LDS footprint sets the waves per CU (the first version reserved 8 x and ran ONE wave per CU).
     // A query that still exhausts it is flagged in stats[2] (the host entry point reports it).
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 3 / 2 + 64);
     uint32_t hash_bits = bits_for(want);
-    const uint32_t efp = round_up(ef, kWave);
+    const uint32_t efp = round_up(ef, kWave), kpad = round_up(std::max(k, 1u), kWave);
+    // beam in registers up to ef = 512 (k_search_ef_reg), in LDS beyond (k_search_ef); ZVDB_EF_BEAM=lds forces the LDS kernel
+    const char *beam_env = getenv("ZVDB_EF_BEAM");  // (read per call: the parity test switches it)
+    const bool beam_lds = beam_env && beam_env[0] == 'l';
+    const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : 0;
     auto lds_bytes = [&](uint32_t hb) -> size_t {
+        if (epl) return 4ull * dim_pad + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad;
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
     };
     while (lds_bytes(hash_bits) > 160 * 1024 && hash_bits > 8) --hash_bits;
     const size_t lds = lds_bytes(hash_bits);
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
+    static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
-        static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
+        auto go = [&](auto kern, uint32_t wparam) -> int {
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
+            hipLaunchKernelGGL(kern, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
+                               d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hash_bits, wparam, d_entries);
+            ZV_HIP(hipGetLastError());
+            return ZVDB_OK;
+        };
         if (prof) {  // diagnostic build of the same kernel: per-phase cycles, printed after a synchronise
             unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}, got[8];
             ZV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ef_prof), zero, sizeof(zero)));
-            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 1>), lds));
-            hipLaunchKernelGGL((k_search_ef<RT, 1>), dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
-                               d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hash_bits, efp, d_entries);
+            ZV_CHECK(epl == 2 ? go(k_search_ef_reg<RT, 2, 1>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 1>, kpad)
+                     : epl == 8 ? go(k_search_ef_reg<RT, 8, 1>, kpad) : go(k_search_ef<RT, 1>, efp));
             ZV_HIP(hipStreamSynchronize(s));
             ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
             const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
@@ -1239,12 +1536,8 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                     got[5] / nw, (got[0] + got[1] + got[2] + got[3] + got[4] + got[5]) / nw);
             return ZVDB_OK;
         }
-        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT>), lds));
-        hipLaunchKernelGGL(k_search_ef<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj,
-                           h->deg, h->gstride, (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids,
-                           d_dist, d_count, d_stats, dim_pad, hash_bits, efp, d_entries);
-        ZV_HIP(hipGetLastError());
-        return ZVDB_OK;
+        return epl == 2 ? go(k_search_ef_reg<RT, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4>, kpad)
+               : epl == 8 ? go(k_search_ef_reg<RT, 8>, kpad) : go(k_search_ef<RT>, efp);
     });
 }
 
