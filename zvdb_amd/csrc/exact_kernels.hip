@@ -1074,11 +1074,16 @@ __global__ __launch_bounds__(64) void k_search_ef(
                     nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
                     fresh1 = hash_insert_atomic(hash, hash_bits, nbl);
                 }
-                nb_i[lane] = nbl;
-                const unsigned long long fb = __ballot(fresh1);
+                // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
+                // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
+                const unsigned long long fb0 = __ballot(fresh1);
+                if (fresh1) nb_i[__popcll(fb0 & ((1ull << lane) - 1ull))] = nbl;
+                const uint32_t nf = (uint32_t)__popcll(fb0);
+                const unsigned long long fb = nf == kWave ? ~0ull : (1ull << nf) - 1ull;
                 __syncthreads();
                 stamp(1);  // degree + list load + visited test-and-set
-                ef_window_distances(rows, ld, q, nchunks, metric, cnt, fb, nb_i, nb_d, lane);
+                if (nf == 0) continue;
+                ef_window_distances(rows, ld, q, nchunks, metric, nf, fb, nb_i, nb_d, lane);
                 hash_used += (uint32_t)__popcll(fb);
                 evals += (unsigned long long)__popcll(fb);
                 __syncthreads();
@@ -1349,11 +1354,16 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
                     nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
                     fresh1 = hash_insert_atomic(hash, hash_bits, nbl);
                 }
-                nb_i[lane] = nbl;
-                const unsigned long long fb = __ballot(fresh1);
+                // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
+                // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
+                const unsigned long long fb0 = __ballot(fresh1);
+                if (fresh1) nb_i[__popcll(fb0 & ((1ull << lane) - 1ull))] = nbl;
+                const uint32_t nf = (uint32_t)__popcll(fb0);
+                const unsigned long long fb = nf == kWave ? ~0ull : (1ull << nf) - 1ull;
                 __syncthreads();
                 stamp(1);  // degree + list load + visited test-and-set
-                ef_window_distances(rows, ld, q, nchunks, metric, cnt, fb, nb_i, nb_d, lane);
+                if (nf == 0) continue;
+                ef_window_distances(rows, ld, q, nchunks, metric, nf, fb, nb_i, nb_d, lane);
                 hash_used += (uint32_t)__popcll(fb);
                 evals += (unsigned long long)__popcll(fb);
                 __syncthreads();
@@ -1501,6 +1511,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // A query that still exhausts it is flagged in stats[2] (the host entry point reports it).
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 3 / 2 + 64);
     uint32_t hash_bits = bits_for(want);
+    if (const char *hb_env = getenv("ZVDB_EF_HASH_BITS")) hash_bits = (uint32_t)std::max(8, std::min(15, atoi(hb_env)));  // (experiment)
     const uint32_t efp = round_up(ef, kWave), kpad = round_up(std::max(k, 1u), kWave);
     // beam in registers up to ef = 512 (k_search_ef_reg), in LDS beyond (k_search_ef); ZVDB_EF_BEAM=lds forces the LDS kernel
     const char *beam_env = getenv("ZVDB_EF_BEAM");  // (read per call: the parity test switches it)
