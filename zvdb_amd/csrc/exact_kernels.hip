@@ -1260,7 +1260,9 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (entries) entry = entries[blockIdx.x];
     float *q = reinterpret_cast<float *>(smem);
-    uint32_t *hash = reinterpret_cast<uint32_t *>(q + dim_pad);
+    uint64_t *Wt = reinterpret_cast<uint64_t *>(q + dim_pad);    // [64 EPL] merge scatter buffer: keys ...
+    uint32_t *Ft = reinterpret_cast<uint32_t *>(Wt + kWave * EPL);  // [64 EPL] ... and expanded flags
+    uint32_t *hash = Ft + kWave * EPL;
     float *nb_d = reinterpret_cast<float *>(hash + (1u << hash_bits));
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
     uint32_t *R = nb_i + kWave;                          // [kpad] result ids
@@ -1289,6 +1291,7 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
     uint32_t hash_used = 0;
     bool overflow = false;
 
+    uint32_t pre_id = 0xFFFFFFFFu, pre_adj = 0, pre_deg = 0;  // speculative list prefetch (ids are < N <= 2^32 - 1)
     auto insert_sorted = [&](uint64_t ckl) {  // ckl wave-uniform, distinct from every key held; if the beam is full: ckl < worst
         uint32_t p = 0;
 #pragma unroll
@@ -1342,8 +1345,31 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
             const uint32_t cid = (uint32_t)kbest;
             pops += 1;
             stamp(0);  // next-to-expand
-            const uint32_t nb_first = (uint32_t)lane < gstride ? adj[(size_t)cid * gstride + lane] : 0u;
-            const uint32_t dg_all = deg[cid];  // lists longer than 64 are walked 64 entries at a time
+            // the degree and the first 64 list slots are requested together -- or were already: the list of the NEXT unexpanded
+            // slot is requested speculatively below, a whole distance phase ahead; it is this pop's node unless a candidate of
+            // the previous pop went in before it (then the prefetch is dropped and the list is loaded here)
+            uint32_t nb_first, dg_all;  // lists longer than 64 are walked 64 entries at a time
+            if (cid == pre_id) {
+                nb_first = pre_adj;
+                dg_all = pre_deg;
+            } else {
+                nb_first = (uint32_t)lane < gstride ? adj[(size_t)cid * gstride + lane] : 0u;
+                dg_all = deg[cid];
+            }
+            {
+                uint32_t slot2 = kWave * EPL;
+#pragma unroll
+                for (int e = EPL - 1; e >= 0; --e)
+                    if (~xm[e] != 0ull) slot2 = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
+                pre_id = 0xFFFFFFFFu;
+                if (slot2 < wn) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e)
+                        if (slot2 >> 6 == (uint32_t)e) pre_id = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wkr[e], (int)(slot2 & 63));
+                    pre_adj = (uint32_t)lane < gstride ? adj[(size_t)pre_id * gstride + lane] : 0u;
+                    pre_deg = deg[pre_id];
+                }
+            }
             for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
                 __syncthreads();
@@ -1370,12 +1396,53 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
                 stamp(2);  // blocked distances of the fresh neighbours
                 uint64_t ck = ~0ull;
                 if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
-                unsigned long long todo = __ballot(ck != ~0ull && (wn < ef || ck < worst));
-                while (todo) {  // candidate by candidate in list order (the oracle's rule); the running worst filters again
-                    const int l = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const uint64_t ckl = readlane64(ck, l);
-                    if (wn < ef || ckl < worst) insert_sorted(ckl);
+                const bool pass = ck != ~0ull && (wn < ef || ck < worst);
+                unsigned long long todo = __ballot(pass);
+                const uint32_t na = (uint32_t)__popcll(todo);
+                if (na == 1) {
+                    insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
+                } else if (na > 1) {
+                    // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
+                    // below it); new slot of a candidate = #(W entries below it) + #(candidates below it) -- per candidate two readlanes,
+                    // a compare + add per block and per candidate lane, and a ballot/popcount per block, ~16 instructions against ~70
+                    // for an insertion; then one scatter through LDS (slots >= ef fall off: the best ef of the union stay).
+                    uint32_t shift[EPL], crank = 0, wless = 0;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) shift[e] = 0;
+                    while (todo) {
+                        const int l = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const uint64_t ckl = readlane64(ck, l);
+                        uint32_t below = 0;
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const bool valid = (uint32_t)(e * kWave + lane) < wn;
+                            shift[e] += (valid && ckl < wkr[e]) ? 1u : 0u;
+                            below += (uint32_t)__popcll(__ballot(valid && wkr[e] < ckl));
+                        }
+                        crank += ckl < ck ? 1u : 0u;
+                        if (lane == l) wless = below;
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const uint32_t slot = (uint32_t)(e * kWave + lane), np = slot + shift[e];
+                        if (slot < wn && np < ef) { Wt[np] = wkr[e]; Ft[np] = (uint32_t)(xm[e] >> lane) & 1u; }
+                    }
+                    if (pass && wless + crank < ef) { Wt[wless + crank] = ck; Ft[wless + crank] = 0; }
+                    wn = min(wn + na, ef);
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const uint32_t slot = (uint32_t)(e * kWave + lane);
+                        const bool live = slot < wn;
+                        if (live) wkr[e] = Wt[slot];
+                        xm[e] = __ballot(live && Ft[slot] != 0);
+                    }
+                    if (wn == ef) {
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e)
+                            if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
+                    }
                 }
                 stamp(3);  // beam update
             }
@@ -1518,7 +1585,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     const bool beam_lds = beam_env && beam_env[0] == 'l';
     const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : 0;
     auto lds_bytes = [&](uint32_t hb) -> size_t {
-        if (epl) return 4ull * dim_pad + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad;
+        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad;
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
     };
     while (lds_bytes(hash_bits) > 160 * 1024 && hash_bits > 8) --hash_bits;
