@@ -315,6 +315,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->rows_p);
     (void)hipFree(h->norm_p);
     if (h->guess_flag_host) (void)hipHostFree(h->guess_flag_host);
+    if (h->ef_hint_host) (void)hipHostFree(h->ef_hint_host);
+    (void)hipFree(h->ef_hint_dev);
     if (h->ins_host) (void)hipHostFree(h->ins_host);
     (void)hipFree(h->rows_pf);
     (void)hipFree(h->rows_qf);
@@ -484,6 +486,7 @@ int zvdb_hip_upload_graph(zvdb_hip_index *h, const uint32_t *adj, const uint32_t
     ZV_CHECK(use_device(h));
     ZV_ARG(n <= h->count, "graph has more nodes than the index has rows");
     ZV_ARG(stride <= h->gstride, "graph stride exceeds the device stride");
+    ef_hint_reset(h, h->stream);
     for (uint64_t i = 0; i < n; ++i) {
         ZV_ARG(deg[i] <= stride, "degree exceeds stride");
         for (uint32_t j = 0; j < deg[i]; ++j)
@@ -1154,6 +1157,7 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode) 
     ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
     ZV_ARG(degree >= 1 && degree <= h->gstride, "degree must be in [1, graph_stride]");
     if (h->count == 0) return ZVDB_OK;
+    ef_hint_reset(h, h->stream);
     const uint32_t k = degree + 1;  // the row itself is (one of) its own nearest
     const uint32_t B = 1024;        // rows per search batch
     const size_t ib = round_up64((size_t)B * k * 8, 256), db = round_up64((size_t)B * k * 4, 256);
@@ -1186,6 +1190,7 @@ int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction
     ZV_ARG(ef_construction >= 1, "ef_construction must be >= 1");
     if (h->count > 0xFFFFFFF0ull) { set_error("shard too large"); return ZVDB_ERR_UNSUPPORTED; }
     if (h->count == 0) return ZVDB_OK;
+    ef_hint_reset(h, h->stream);
     if (h->count == 1) {
         ZV_HIP(hipMemsetAsync(h->deg, 0, 4, h->stream));
         ZV_HIP(hipStreamSynchronize(h->stream));

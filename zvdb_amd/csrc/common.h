@@ -154,6 +154,8 @@ struct zvdb_hip_index {
     // calls loosen the guess by guess_adapt standard deviations (no synchronisation: the flag is read whenever it has arrived)
     uint32_t *guess_flag_host = nullptr;  // hipHostMalloc'ed, mapped
     uint32_t *guess_flag_dev = nullptr;   // its device alias
+    mutable uint32_t *ef_hint_dev = nullptr;   // [16] largest visited-set fill seen per ef bucket (exact_kernels.hip: kEfTight)
+    mutable uint32_t *ef_hint_host = nullptr;  // pinned copy, refreshed asynchronously after every ef launch
     float guess_adapt = 0.0f;
     // zvdb_hip_insert_layer0: host-mapped [row | result] block -- the kernels read the point and write the result through
     // it, so an insert submits no copy-engine transfers (each costs ~10 us for a few hundred bytes)
@@ -215,6 +217,7 @@ int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep
 int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                          uint32_t entry, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
                          uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, uint32_t *d_tie = nullptr /* [nq] scratch: enables the unordered-frontier kernel */);
+void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s);
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
                      float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s,

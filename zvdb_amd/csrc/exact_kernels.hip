@@ -11,6 +11,7 @@
 //   k_search_compat     a5/a6  search (hnsw.zig:194-236): one wave per query
 //   k_search_ef         ext.   ef-mode beam search (spec: oracle/zvdb_oracle.h)
 //   k_rerank            K5     exact re-rank + (dist,id) top-k of brute-force candidates
+#include <cstring>
 #include "common.h"
 #include "wave_select.h"
 #include "exact_dist.h"
@@ -996,6 +997,13 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
 //                                                                         only when a candidate beats the worst)
 // so the per-candidate sorted insertions (two barriers per 64 slots shifted) of the first version are gone.
 // PROF = 1 (ZVDB_EF_PROF=1, diagnostic): per-phase shader-cycle sums of wave 0's lane 0 go to g_ef_prof (results unchanged)
+// Visited-set sizing in two passes.  The LDS hash of a query sets the waves per CU, and a size that is SAFE (1.5 ef stride
+// entries) is 3 - 5 x what searches really touch (0.3 - 1.1 ef degree, data dependent): at ef 256 / stride 32 the safe table
+// is 128 KB -- one wave per CU.  So the index remembers the largest fill it has seen per ef bucket (fill_hint, copied to
+// the host asynchronously after every launch); once known, the batch first runs with a table of 2.5 x that (kEfTight: a
+// query that fills it stops, marks its count kEfAgain and writes nothing else) and a second launch with the safe table
+// serves exactly the marked queries (kEfRetry).  Results and counters are those of a single safe pass.
+constexpr uint32_t kEfSingle = 0, kEfTight = 1, kEfRetry = 2, kEfAgain = 0xFFFFFFFFu;
 __device__ unsigned long long g_ef_prof[10];
 template <typename RT, int PROF = 0>
 __global__ __launch_bounds__(64) void k_search_ef(
@@ -1004,8 +1012,10 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
-    uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */) {
+    uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
+    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (pass == kEfRetry && out_count[blockIdx.x] != kEfAgain) return;  // served by the tight pass
     if (entries) entry = entries[blockIdx.x];
     float *q = reinterpret_cast<float *>(smem);
     uint64_t *wk = reinterpret_cast<uint64_t *>(q + dim_pad);          // [2][efp]
@@ -1067,6 +1077,10 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
                 __syncthreads();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
+                if (overflow && pass == kEfTight) {  // the safe-table launch behind this one serves the query
+                    if (lane == 0) out_count[qi] = kEfAgain;
+                    return;
+                }
                 // (1) one lane per neighbour: visited test-and-set; fb = fresh list positions
                 uint32_t nbl = 0;
                 bool fresh1 = false;
@@ -1212,6 +1226,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
     }
     if (lane == 0) {
         out_count[qi] = nres;
+        if (fill_hint) atomicMax(fill_hint, hash_used);
         if (stats) {
             atomicAdd(&stats[0], evals);
             atomicAdd(&stats[1], pops);
@@ -1256,8 +1271,10 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
-    uint32_t hash_bits, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */) {
+    uint32_t hash_bits, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
+    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (pass == kEfRetry && out_count[blockIdx.x] != kEfAgain) return;  // served by the tight pass
     if (entries) entry = entries[blockIdx.x];
     float *q = reinterpret_cast<float *>(smem);
     uint64_t *Wt = reinterpret_cast<uint64_t *>(q + dim_pad);    // [64 EPL] merge scatter buffer: keys ...
@@ -1363,6 +1380,10 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
                 __syncthreads();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
+                if (overflow && pass == kEfTight) {  // the safe-table launch behind this one serves the query
+                    if (lane == 0) out_count[qi] = kEfAgain;
+                    return;
+                }
                 uint32_t nbl = 0;
                 bool fresh1 = false;
                 if ((uint32_t)lane < cnt && !overflow) {
@@ -1478,6 +1499,7 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
     }
     if (lane == 0) {
         out_count[qi] = nres;
+        if (fill_hint) atomicMax(fill_hint, hash_used);
         if (stats) {
             atomicAdd(&stats[0], evals);
             atomicAdd(&stats[1], pops);
@@ -1593,16 +1615,46 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
     };
     while (lds_bytes(hash_bits) > 160 * 1024 && hash_bits > 8) --hash_bits;
-    const size_t lds = lds_bytes(hash_bits);
+    // two-pass sizing (see kEfTight): the largest visited-set fill this index has seen for searches of this ef bucket
+    if (!h->ef_hint_dev) {
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_hint_dev), 64));
+        ZV_HIP(hipMemsetAsync(h->ef_hint_dev, 0, 64, s));
+        ZV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->ef_hint_host), 64, hipHostMallocDefault));
+        std::memset(h->ef_hint_host, 0, 64);
+    }
+    uint32_t bucket = 0;
+    while ((1u << bucket) < ef && bucket < 15) ++bucket;
+    const uint32_t seen = __atomic_load_n(&h->ef_hint_host[bucket], __ATOMIC_RELAXED);
+    const char *tp_env = getenv("ZVDB_EF_TWO_PASS");  // "0": always the safe table; "t<bits>": force the tight table (tests; read per call)
+    uint32_t tight_bits = hash_bits;
+    if (tp_env && tp_env[0] == 't') {
+        tight_bits = std::min(hash_bits, (uint32_t)std::max(8, atoi(tp_env + 1)));
+    } else if (seen && !(tp_env && tp_env[0] == '0')) {
+        tight_bits = 8;
+        while ((1ull << tight_bits) < (uint64_t)seen * 5 / 2 + 128) ++tight_bits;  // <= 40 % load at the largest fill seen
+        tight_bits = std::min(tight_bits, hash_bits);
+    }
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
-        auto go = [&](auto kern, uint32_t wparam) -> int {
+        auto go1 = [&](auto kern, uint32_t wparam, uint32_t hb, uint32_t pass) -> int {
+            const size_t lds = lds_bytes(hb);
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
-                               d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hash_bits, wparam, d_entries);
+                               d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
+                               pass, h->ef_hint_dev + bucket);
             ZV_HIP(hipGetLastError());
+            return ZVDB_OK;
+        };
+        auto go = [&](auto kern, uint32_t wparam) -> int {
+            if (tight_bits < hash_bits) {
+                ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight));
+                ZV_CHECK(go1(kern, wparam, hash_bits, kEfRetry));
+            } else {
+                ZV_CHECK(go1(kern, wparam, hash_bits, kEfSingle));
+            }
+            ZV_HIP(hipMemcpyAsync(h->ef_hint_host, h->ef_hint_dev, 64, hipMemcpyDeviceToHost, s));  // read by a LATER call, never waited for
             return ZVDB_OK;
         };
         if (prof) {  // diagnostic build of the same kernel: per-phase cycles, printed after a synchronise
@@ -1614,13 +1666,22 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
             const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
             fprintf(stderr, "[zvdb ef prof] %llu queries, %.1f pops each; shader cycles per POP: next-scan %.0f, list+visited %.0f, distances %.0f, beam update %.0f; "
-                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop\n", got[7], np / nw, got[0] / np, got[1] / np, got[2] / np, got[3] / np, got[4] / nw,
-                    got[5] / nw, (got[0] + got[1] + got[2] + got[3] + got[4] + got[5]) / nw, got[8] / np, got[9] / np);
+                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop; visited table 2^%u (safe 2^%u)\n", got[7], np / nw,
+                    got[0] / np, got[1] / np, got[2] / np, got[3] / np, got[4] / nw, got[5] / nw, (got[0] + got[1] + got[2] + got[3] + got[4] + got[5]) / nw,
+                    got[8] / np, got[9] / np, tight_bits, hash_bits);
             return ZVDB_OK;
         }
         return epl == 2 ? go(k_search_ef_reg<RT, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4>, kpad)
                : epl == 8 ? go(k_search_ef_reg<RT, 8>, kpad) : go(k_search_ef<RT>, efp);
     });
+}
+
+// the graph changed wholesale (upload / bulk build / load): forget the visited-set fills seen on the old one
+void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s) {
+    if (!h->ef_hint_dev) return;
+    (void)hipMemsetAsync(h->ef_hint_dev, 0, 64, s);
+    (void)hipStreamSynchronize(s);  // (an in-flight copy of the old values must not land after the reset)
+    std::memset(h->ef_hint_host, 0, 64);
 }
 
 // ---- K5: exact re-rank of brute-force candidates ---------------------------------
