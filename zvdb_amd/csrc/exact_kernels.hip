@@ -835,52 +835,52 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
 }
 
 // ---- traversal distances of one list window (shared by both ef kernels) ---------------------------------------------------
-// nb_d[j] <- blocked16 distance (oracle: orc_distance_blocked16_f32) between q (LDS, zero padded) and row nb_i[j], for the
-// positions j < cnt whose bit is set in fb.  fp32 rows: 16 lanes per row, 16-byte loads.  bf16 rows: 8 lanes per row (below).
-template <typename RT>
+// nb_d[j] <- blocked16 distance (oracle: orc_distance_blocked16_f32) between q (LDS, zero padded) and row nb_i[j] for every
+// j < cnt (the fresh neighbours, compacted).  WPQ waves of a workgroup share the window: a step covers G * U * WPQ rows (G
+// lane groups per wave, U rows per group), wave w takes rows r0 + (u WPQ + w) G + g.
+//   fp32 rows: G = 4 groups of 16 lanes; lane t takes the 16-byte chunks t, t + 16, ... of its row, accumulates them in
+//              increasing order (un-contracted), the 16 partials meet in the xor butterfly 8, 4, 2, 1.
+//   bf16 rows: G = 8 groups of EIGHT lanes with 16-byte loads.  Lane a takes bytes 128 m + 16 a of the row (m = 0, 1, ...):
+//              the 8-byte chunks 2a + 16m and 2a + 1 + 16m, i.e. exactly the chunks of the blocked16 partial sums 2a and
+//              2a + 1 in increasing order -- the lane carries BOTH partials as two sequential chains, and the butterfly
+//              over partial indices becomes lane xor 4, 2, 1 on each chain followed by low + high.  Same values as the
+//              16-lane walk, half the load requests per row (rows are zero padded to a multiple of 128 bytes).
+// All loads of a super-step (the whole row at d = 768) are issued before the first use, branch free, so the counted waits
+// let the sums of piece i start while pieces i+1.. are still in flight.
+template <typename RT, int WPQ, int U>
 __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows, uint32_t ld, const float *q, uint32_t nchunks, int metric,
-                                                    uint32_t cnt, unsigned long long fb, const uint32_t *nb_i, float *nb_d, int lane) {
-    const int g = lane >> 4, t = lane & 15;  // 4 row groups of 16 lanes
-    // (2) blocked distances, 16 rows per step: group g walks rows r16 + 4u + g (u = 0..3) with
-    // four independent accumulators, so 16 rows x 3 KB are in flight per wave step
-    for (uint32_t r16 = 0; r16 < cnt; r16 += 16) {
-        if (((fb >> r16) & 0xFFFFull) == 0) continue;
-        if constexpr (sizeof(RT) == 2) {
-            // bf16 rows: EIGHT lanes per row with 16-byte loads.  Lane a of a group takes bytes 128 m + 16 a of the row
-            // (m = 0, 1, ...): the 8-byte chunks 2a + 16m and 2a + 1 + 16m, i.e. exactly the chunks of the blocked16
-            // partial sums 2a and 2a + 1 in increasing order -- so the lane carries BOTH partials as two sequential
-            // chains, and the spec's butterfly (8, 4, 2, 1 over partial indices) becomes lane xor 4, 2, 1 on each
-            // chain followed by low + high.  Same values as the 16-lane walk, half the load requests per row
-            // (rows are zero padded to a multiple of 128 bytes, so every load is in bounds).
-            const int g8 = lane >> 3, a8 = lane & 7;
-            const uint32_t nm = ld / 64;  // 128-byte lines per row
-            const bf16_t *rp2[2];
-            bool fr2[2];
-            float slo[2], shi[2];
+                                                    uint32_t cnt, const uint32_t *nb_i, float *nb_d, int lane, int wave) {
+    if constexpr (sizeof(RT) == 2) {
+        constexpr int G = 8;
+        const int g8 = lane >> 3, a8 = lane & 7;
+        const uint32_t nm = ld / 64;  // 128-byte lines per row
+        for (uint32_t r0 = 0; r0 < cnt; r0 += G * U * WPQ) {
+            if (r0 + (uint32_t)wave * G >= cnt) break;  // (wave-uniform: nothing for this wave in the step)
+            const bf16_t *rp[U];
+            bool fr[U];
+            float slo[U], shi[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const uint32_t j = r16 + 8 * u + g8;
-                fr2[u] = j < cnt && ((fb >> j) & 1ull);
-                rp2[u] = rows + (size_t)(fr2[u] ? nb_i[j] : 0u) * ld + 8 * a8;
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = r0 + (uint32_t)(u * WPQ + wave) * G + g8;
+                fr[u] = j < cnt;
+                rp[u] = rows + (size_t)(fr[u] ? nb_i[j] : 0u) * ld + 8 * a8;
                 slo[u] = 0.0f;
                 shi[u] = 0.0f;
             }
-            // super-steps of MM lines per row, all MM x 2 loads of a lane issued before the first use (branch free: the
-            // counted waits then let the sums of line i start while lines i+1.. are still in flight).  MM follows the row
-            // length -- 768-d rows are ONE super-step of 12.  When MM divides the line count (every power-of-two length
-            // and 768 / 1536) the walk needs no masks at all: the caller pads q with zeros to the rows' padded length, the
-            // rows' own padding is zero, so the tail adds +0.  Other lengths take the MASKED walk: a line past the row's
-            // end re-reads the last one and its terms are forced to +0.
+            // MM lines per row and super-step; MM follows the row length -- 768-d rows are ONE super-step of 12.  When MM divides
+            // the line count (every power-of-two length and 768 / 1536) the walk needs no masks at all: the caller pads q with
+            // zeros to the rows' padded length, the rows' own padding is zero, so the tail adds +0.  Other lengths take the
+            // MASKED walk: a line past the row's end re-reads the last one and its terms are forced to +0.
             auto walk = [&](auto mm_tag, auto masked_tag) {
                 constexpr int MM = decltype(mm_tag)::value;
                 constexpr bool MASKED = decltype(masked_tag)::value;
                 for (uint32_t m0 = 0; m0 < nm; m0 += MM) {
-                    uint4 vv[MM][2];
+                    uint4 vv[MM][U];
 #pragma unroll
                     for (int i = 0; i < MM; ++i) {
                         const uint32_t me = MASKED ? min(m0 + i, nm - 1) : m0 + i;
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) vv[i][u] = *reinterpret_cast<const uint4 *>(rp2[u] + 64 * me);
+                        for (int u = 0; u < U; ++u) vv[i][u] = *reinterpret_cast<const uint4 *>(rp[u] + 64 * me);
                     }
 #pragma unroll
                     for (int i = 0; i < MM; ++i) {
@@ -889,7 +889,7 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
                         const float4 al = *reinterpret_cast<const float4 *>(q + 4 * (MASKED ? min(cl, 16 * nm - 2) : cl));
                         const float4 ah = *reinterpret_cast<const float4 *>(q + 4 * (MASKED ? min(cl, 16 * nm - 2) : cl) + 4);
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < U; ++u) {
                             const uint4 w = vv[i][u];
                             float l0 = bf16_lo(w.x), l1 = bf16_hi(w.x), l2 = bf16_lo(w.y), l3 = bf16_hi(w.y);
                             float h0 = bf16_lo(w.z), h1 = bf16_hi(w.z), h2 = bf16_lo(w.w), h3 = bf16_hi(w.w);
@@ -917,66 +917,69 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
             else if (nm == 1) walk(integral_constant<int, 1>{}, std::false_type{});
             else walk(integral_constant<int, 6>{}, std::true_type{});
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 float sl = slo[u], sh = shi[u];
 #pragma unroll
                 for (int off = 4; off > 0; off >>= 1) { sl = sl + __shfl_xor(sl, off); sh = sh + __shfl_xor(sh, off); }
                 const float sv = sl + sh;
-                if (fr2[u] && a8 == 0) nb_d[r16 + 8 * u + g8] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
+                if (fr[u] && a8 == 0) nb_d[r0 + (uint32_t)(u * WPQ + wave) * G + g8] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
             }
-            continue;
         }
-        const RT *rp[4];
-        bool fr[4];
-        float sacc[4];
+    } else {
+        constexpr int G = 4;
+        const int g = lane >> 4, t = lane & 15;
+        for (uint32_t r0 = 0; r0 < cnt; r0 += G * U * WPQ) {
+            if (r0 + (uint32_t)wave * G >= cnt) break;
+            const RT *rp[U];
+            bool fr[U];
+            float sacc[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t j = r16 + 4 * u + g;
-            fr[u] = j < cnt && ((fb >> j) & 1ull);
-            rp[u] = rows + (size_t)(fr[u] ? nb_i[j] : 0u) * ld;
-            sacc[u] = 0.0f;
-        }
-        // super-steps of 64 * SS chunks: each lane loads ITS chunks of all 4 rows first -- SS * 16 independent loads in
-        // flight (a 768-d row is ONE super-step at SS = 3: the phase is bound by load latency, ~2 us per dependent
-        // batch under load, not by bytes -- bf16 rows halve the bytes at the same latency), branch-free (a stale
-        // group re-reads row 0, ~95 % are fresh) -- then accumulates them in increasing chunk order (the blocked16 spec)
-        constexpr int SS = 3;  // (measured 1M x 768, ef = 128, batch 1,024 / 4,096 / 16,384: fp32 rows 637k / 741k / 807k QPS, bf16 rows 701k / 810k / 891k; SS = 1: 654k / 660k / 729k either way)
-        const uint32_t lastc = ld / 4 - 1;
-        for (uint32_t c0 = 0; c0 < nchunks; c0 += 64 * SS) {
-            float4 vv[4 * SS][4];
-#pragma unroll
-            for (int i = 0; i < 4 * SS; ++i) {
-                const uint32_t ce = min(c0 + t + 16 * i, lastc);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) vv[i][u] = row_load4(rp[u] + 4 * ce);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = r0 + (uint32_t)(u * WPQ + wave) * G + g;
+                fr[u] = j < cnt;
+                rp[u] = rows + (size_t)(fr[u] ? nb_i[j] : 0u) * ld;
+                sacc[u] = 0.0f;
             }
+            // super-steps of 64 * SS chunks (a 768-d row is ONE super-step at SS = 3; measured with U = 4, one wave per query, 1M x 768,
+            // ef = 128, batch 1,024 / 4,096 / 16,384: SS = 3 637k / 741k / 807k QPS, SS = 1 654k / 660k / 729k); a group without a row re-reads row 0
+            constexpr int SS = 3;
+            const uint32_t lastc = ld / 4 - 1;
+            for (uint32_t c0 = 0; c0 < nchunks; c0 += 64 * SS) {
+                float4 vv[4 * SS][U];
 #pragma unroll
-            for (int i = 0; i < 4 * SS; ++i) {
-                const uint32_t c = c0 + t + 16 * i;
-                const bool okc = c < nchunks;
-                const float4 a = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
+                for (int i = 0; i < 4 * SS; ++i) {
+                    const uint32_t ce = min(c0 + t + 16 * i, lastc);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 v = vv[i][u];
-                    float w0, w1, w2, w3;
-                    if (metric == ZVDB_METRIC_L2SQ) {
-                        w0 = a.x - v.x; w0 = w0 * w0; w1 = a.y - v.y; w1 = w1 * w1;
-                        w2 = a.z - v.z; w2 = w2 * w2; w3 = a.w - v.w; w3 = w3 * w3;
-                    } else {
-                        w0 = a.x * v.x; w1 = a.y * v.y; w2 = a.z * v.z; w3 = a.w * v.w;
+                    for (int u = 0; u < U; ++u) vv[i][u] = row_load4(rp[u] + 4 * ce);
+                }
+#pragma unroll
+                for (int i = 0; i < 4 * SS; ++i) {
+                    const uint32_t c = c0 + t + 16 * i;
+                    const bool okc = c < nchunks;
+                    const float4 a = *reinterpret_cast<const float4 *>(q + 4 * min(c, nchunks - 1));
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const float4 v = vv[i][u];
+                        float w0, w1, w2, w3;
+                        if (metric == ZVDB_METRIC_L2SQ) {
+                            w0 = a.x - v.x; w0 = w0 * w0; w1 = a.y - v.y; w1 = w1 * w1;
+                            w2 = a.z - v.z; w2 = w2 * w2; w3 = a.w - v.w; w3 = w3 * w3;
+                        } else {
+                            w0 = a.x * v.x; w1 = a.y * v.y; w2 = a.z * v.z; w3 = a.w * v.w;
+                        }
+                        if (!okc) { w0 = 0.0f; w1 = 0.0f; w2 = 0.0f; w3 = 0.0f; }  // +0 leaves the sum unchanged
+                        sacc[u] = sacc[u] + w0; sacc[u] = sacc[u] + w1;
+                        sacc[u] = sacc[u] + w2; sacc[u] = sacc[u] + w3;
                     }
-                    if (!okc) { w0 = 0.0f; w1 = 0.0f; w2 = 0.0f; w3 = 0.0f; }  // +0 leaves the sum unchanged
-                    sacc[u] = sacc[u] + w0; sacc[u] = sacc[u] + w1;
-                    sacc[u] = sacc[u] + w2; sacc[u] = sacc[u] + w3;
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float sv = sacc[u];
+            for (int u = 0; u < U; ++u) {
+                float sv = sacc[u];
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) sv = sv + __shfl_xor(sv, off);
-            if (fr[u] && t == 0) nb_d[r16 + 4 * u + g] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
+                for (int off = 8; off > 0; off >>= 1) sv = sv + __shfl_xor(sv, off);
+                if (fr[u] && t == 0) nb_d[r0 + (uint32_t)(u * WPQ + wave) * G + g] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
+            }
         }
     }
 }
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
 
     const int lane = threadIdx.x;
-    const int g = lane >> 4, t = lane & 15;  // 4 row groups of 16 lanes
+    const int t = lane & 15;
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
@@ -1097,7 +1100,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 __syncthreads();
                 stamp(1);  // degree + list load + visited test-and-set
                 if (nf == 0) continue;
-                ef_window_distances(rows, ld, q, nchunks, metric, nf, fb, nb_i, nb_d, lane);
+                ef_window_distances<RT, 1, sizeof(RT) == 2 ? 2 : 4>(rows, ld, q, nchunks, metric, nf, nb_i, nb_d, lane, 0);
                 hash_used += (uint32_t)__popcll(fb);
                 evals += (unsigned long long)__popcll(fb);
                 __syncthreads();
@@ -1264,8 +1267,13 @@ __device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v) {  // lane i <- lan
     return ((uint64_t)hi << 32) | lo;
 }
 
-template <typename RT, int EPL, int PROF = 0>
-__global__ __launch_bounds__(64) void k_search_ef_reg(
+// WPQ waves per query (a workgroup of 64 WPQ threads): wave 0 runs the search exactly as described; the distance phase of a
+// window -- 60 - 70 % of a pop -- is shared by all WPQ waves (each takes its rows of the step: ef_window_distances), two
+// workgroup barriers per window (window published in ctl[0] / distances done).  Same results, same counters; what it buys is
+// latency: a 1,024-query batch is one round of resident workgroups either way, its time is the slowest query's chain of pops.
+constexpr uint32_t kEfDone = 0xFFFFFFFFu;  // ctl[0]: no further window (a window has 1 .. 64 rows)
+template <typename RT, int EPL, int WPQ = 1, int PROF = 0>
+__global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_search_ef_reg(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
@@ -1284,15 +1292,39 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
     uint32_t *R = nb_i + kWave;                          // [kpad] result ids
     float *RD = reinterpret_cast<float *>(R + kpad);     // [kpad] their exact distances
+    uint32_t *ctl = reinterpret_cast<uint32_t *>(RD + kpad);  // [4] window hand-over to the helper waves (WPQ > 1)
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int t = lane & 15;
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
-    for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
-    for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
+    for (uint32_t i = threadIdx.x; i < dim_pad; i += kWave * WPQ) q[i] = i < dim ? qg[i] : 0.0f;
+    for (uint32_t i = threadIdx.x; i < (1u << hash_bits); i += kWave * WPQ) hash[i] = 0;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
+    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : 4 / WPQ;  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32)
+    if constexpr (WPQ > 1) {
+        if (wave != 0) {  // helper waves: their share of every published window's distances
+            for (;;) {
+                __syncthreads();  // (A) window published
+                const uint32_t nfh = ctl[0];
+                if (nfh == kEfDone) return;
+                ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, nfh, nb_i, nb_d, lane, wave);
+                __syncthreads();  // (B) distances done
+            }
+        }
+    }
+    // wave 0 from here on; sync_w orders its own LDS traffic (a workgroup barrier when it is the only wave)
+    auto sync_w = [&]() {
+        if constexpr (WPQ == 1) __syncthreads();
+        else __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto release_helpers = [&]() {
+        if constexpr (WPQ > 1) {
+            if (lane == 0) ctl[0] = kEfDone;
+            __syncthreads();  // (A)
+        }
+    };
 
     uint64_t wkr[EPL];          // sorted beam: slot s = lane s % 64 of wkr[s / 64]; slots >= wn are meaningless
     uint64_t xm[EPL];           // expanded flags (wave-uniform)
@@ -1348,7 +1380,7 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
         evals = 1;
         hash_insert_uniform(hash, hash_bits, entry);
         hash_used = 1;
-        __syncthreads();
+        sync_w();
         for (;;) {
             // next to expand: the first unexpanded slot
             uint32_t slot = kWave * EPL;
@@ -1378,10 +1410,11 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
             if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); list_wait += n - pt + (dg_all & 0u); }
             for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
-                __syncthreads();
+                sync_w();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
                 if (overflow && pass == kEfTight) {  // the safe-table launch behind this one serves the query
                     if (lane == 0) out_count[qi] = kEfAgain;
+                    release_helpers();
                     return;
                 }
                 uint32_t nbl = 0;
@@ -1396,7 +1429,12 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
                 if (fresh1) nb_i[__popcll(fb0 & ((1ull << lane) - 1ull))] = nbl;
                 const uint32_t nf = (uint32_t)__popcll(fb0);
                 const unsigned long long fb = nf == kWave ? ~0ull : (1ull << nf) - 1ull;
-                __syncthreads();
+                if (WPQ > 1 && nf != 0) {
+                    if (lane == 0) ctl[0] = nf;
+                    __syncthreads();  // (A) window published to the helper waves
+                } else {
+                    sync_w();
+                }
                 if (lbase == 0 && gstride < kWave) {  // speculative list request for the next pop, in flight during the distance phase (47 % of
                                                       // pops use it at 1M x 768, ef = 128: +1.7 % QPS on bf16 rows, +0.7 % on fp32, A/B on one box)
                     uint32_t slot2 = kWave * EPL;
@@ -1412,10 +1450,10 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
                 }
                 stamp(1);  // degree + list load + visited test-and-set
                 if (nf == 0) continue;
-                ef_window_distances(rows, ld, q, nchunks, metric, nf, fb, nb_i, nb_d, lane);
-                hash_used += (uint32_t)__popcll(fb);
-                evals += (unsigned long long)__popcll(fb);
-                __syncthreads();
+                ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, nf, nb_i, nb_d, lane, 0);
+                hash_used += nf;
+                evals += nf;
+                __syncthreads();  // (B) distances done
                 stamp(2);  // blocked distances of the fresh neighbours
                 uint64_t ck = ~0ull;
                 if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
@@ -1453,7 +1491,7 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
                     }
                     if (pass && wless + crank < ef) { Wt[wless + crank] = ck; Ft[wless + crank] = 0; }
                     wn = min(wn + na, ef);
-                    __syncthreads();
+                    sync_w();
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) {
                         const uint32_t slot = (uint32_t)(e * kWave + lane);
@@ -1470,8 +1508,9 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
                 stamp(3);  // beam update
             }
         }
-        __syncthreads();
+        sync_w();
     }
+    release_helpers();
     stamp(4);
     // the first k slots of W, re-evaluated with the exact reference arithmetic, ordered by (exact distance, id)
     const uint32_t nres = wn < k ? wn : k;
@@ -1479,10 +1518,10 @@ __global__ __launch_bounds__(64) void k_search_ef_reg(
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
             if ((uint32_t)(e * kWave + lane) < nres) R[e * kWave + lane] = (uint32_t)wkr[e];
-        __syncthreads();
+        sync_w();
         for (uint32_t i = lane; i < nres; i += kWave)
             RD[i] = exact_dist_rt(metric, q, rows + (size_t)R[i] * ld, dim);
-        __syncthreads();
+        sync_w();
         for (uint32_t i = lane; i < nres; i += kWave) {
             const float di = RD[i];
             const uint32_t ii = R[i];
@@ -1611,7 +1650,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     const bool beam_lds = beam_env && beam_env[0] == 'l';
     const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : 0;
     auto lds_bytes = [&](uint32_t hb) -> size_t {
-        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad;
+        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad + 16;
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
     };
     while (lds_bytes(hash_bits) > 160 * 1024 && hash_bits > 8) --hash_bits;
@@ -1638,10 +1677,11 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        uint32_t wpq_launch = 1;
         auto go1 = [&](auto kern, uint32_t wparam, uint32_t hb, uint32_t pass) -> int {
             const size_t lds = lds_bytes(hb);
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
-            hipLaunchKernelGGL(kern, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
+            hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
                                pass, h->ef_hint_dev + bucket);
             ZV_HIP(hipGetLastError());
@@ -1660,8 +1700,8 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         if (prof) {  // diagnostic build of the same kernel: per-phase cycles, printed after a synchronise
             unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, got[10];
             ZV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ef_prof), zero, sizeof(zero)));
-            ZV_CHECK(epl == 2 ? go(k_search_ef_reg<RT, 2, 1>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 1>, kpad)
-                     : epl == 8 ? go(k_search_ef_reg<RT, 8, 1>, kpad) : go(k_search_ef<RT, 1>, efp));
+            ZV_CHECK(epl == 2 ? go(k_search_ef_reg<RT, 2, 1, 1>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 1, 1>, kpad)
+                     : epl == 8 ? go(k_search_ef_reg<RT, 8, 1, 1>, kpad) : go(k_search_ef<RT, 1>, efp));
             ZV_HIP(hipStreamSynchronize(s));
             ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
             const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
@@ -1671,6 +1711,16 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                     got[8] / np, got[9] / np, tight_bits, hash_bits);
             return ZVDB_OK;
         }
+        // waves per query.  Measured at 1M x 768, M = 16, ef = 128, batch 1,024 / 4,096 / 16,384 (QPS): fp32 rows 1 wave 775k / 901k /
+        // 993k, 2 waves 863k / 982k / 1.09M, 4 waves 894k / 1.03M / 1.11M; bf16 rows 1.00M / 1.19M / 1.30M, 2 waves 1.23M / 1.54M /
+        // 1.67M, 4 waves 0.69M (8 rows per wave step: half the waves idle on 16-entry lists; with the 16-lane walk 0.94M / 1.20M / 1.29M)
+        uint32_t wpq = sizeof(RT) == 2 ? 2 : 4;
+        if (const char *we = getenv("ZVDB_EF_WPQ")) wpq = (uint32_t)atoi(we);  // (1, 2, 4: experiment / tests; read per call)
+        if (epl == 8 && wpq == 4) wpq = 2;
+        if (epl == 0 || (wpq != 2 && wpq != 4)) wpq = 1;
+        wpq_launch = wpq;
+        if (wpq == 4) return epl == 2 ? go(k_search_ef_reg<RT, 2, 4>, kpad) : go(k_search_ef_reg<RT, 4, 4>, kpad);
+        if (wpq == 2) return epl == 2 ? go(k_search_ef_reg<RT, 2, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 2>, kpad) : go(k_search_ef_reg<RT, 8, 2>, kpad);
         return epl == 2 ? go(k_search_ef_reg<RT, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4>, kpad)
                : epl == 8 ? go(k_search_ef_reg<RT, 8>, kpad) : go(k_search_ef<RT>, efp);
     });
