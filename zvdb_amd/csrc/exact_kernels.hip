@@ -1556,31 +1556,35 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
 }
 
 // ---- hierarchical entry descent of the bulk graph (extension; specification: orc_hnsw_descend) -----------------------------
-// One wave per query: from the graph's top node down the layers max_level .. 1; on each layer repeat { scan the WHOLE
-// list of the current node in list order with the blocked traversal distance, keep the strict arg-min (the earliest entry
-// wins ties), move there } until nothing is closer (hnsw.zig:90-104's greedy step, run top-down, on the device's upper-layer
-// lists: node's layer L list = row slot[node] + L - 1 of adj_up).  Four neighbours per wave step (16 lanes per row).
-template <typename RT>
-__global__ __launch_bounds__(64) void k_descend(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
-                                                const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ slot,
-                                                const uint32_t *__restrict__ adj_up, const uint32_t *__restrict__ deg_up, uint32_t gstride,
-                                                const float *__restrict__ queries, uint32_t top, uint32_t *__restrict__ out_entry,
-                                                unsigned long long *__restrict__ stats, uint32_t dim_pad) {
+// One workgroup of WPQ waves per query: from the graph's top node down the layers max_level .. 1; on each layer repeat { scan
+// the WHOLE list of the current node in list order with the blocked traversal distance, keep the strict arg-min (the earliest
+// entry wins ties), move there } until nothing is closer (hnsw.zig:90-104's greedy step, run top-down, on the device's
+// upper-layer lists: node's layer L list = row slot[node] + L - 1 of adj_up).  The reference's level distribution (each further
+// level with probability 1/2, hnsw.zig:172-180) makes this ~20 layers at 1M nodes, i.e. a chain of ~40 dependent hops: a hop
+// evaluates its whole list (16 rows) in ONE step shared by the waves (ef_window_distances), then every wave takes the same
+// (distance, position) minimum from LDS -- the first version walked 4 rows per step on one wave and cost more than an ef = 32 search.
+template <typename RT, int WPQ>
+__global__ __launch_bounds__(64 * WPQ) void k_descend(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+                                                      const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ slot,
+                                                      const uint32_t *__restrict__ adj_up, const uint32_t *__restrict__ deg_up, uint32_t gstride,
+                                                      const float *__restrict__ queries, uint32_t top, uint32_t *__restrict__ out_entry,
+                                                      unsigned long long *__restrict__ stats, uint32_t dim_pad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *q = reinterpret_cast<float *>(smem);
-    const int lane = threadIdx.x;
-    const int g = lane >> 4, t = lane & 15;
+    float *nb_d = q + dim_pad;                                  // [64]
+    uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);  // [64]
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int t = lane & 15;
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
-    for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
+    for (uint32_t i = threadIdx.x; i < dim_pad; i += kWave * WPQ) q[i] = i < dim ? qg[i] : 0.0f;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
-    auto bdist = [&](uint32_t node) {
-        const RT *r = rows + (size_t)node * ld;
-        return metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, r, nchunks, t) : blocked16_dist<ZVDB_METRIC_DOT>(q, r, nchunks, t);
-    };
+    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : 4 / WPQ;  // 16 rows per step
+    // every wave keeps the same (cur, dcur): all decisions below derive from LDS / global values the waves share
     uint32_t cur = top;
-    float dcur = bdist(cur);
+    float dcur = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, rows + (size_t)cur * ld, nchunks, t)
+                                            : blocked16_dist<ZVDB_METRIC_DOT>(q, rows + (size_t)cur * ld, nchunks, t);
     dcur = __shfl(dcur, 0);
     unsigned long long evals = 1;
     for (uint32_t layer = lvl[top]; layer >= 1; --layer) {
@@ -1590,16 +1594,18 @@ __global__ __launch_bounds__(64) void k_descend(const RT *__restrict__ rows, uin
             const uint32_t dg = min(deg_up[row], gstride);
             uint32_t best = cur;
             float dbest = dcur;
-            for (uint32_t base = 0; base < dg; base += 4) {
-                const uint32_t j = base + (uint32_t)g;
-                const uint32_t nb = j < dg ? adj_up[row * gstride + j] : cur;
-                const float dn = bdist(nb);
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {  // list order: strict '<' keeps the earliest of equal minima
-                    const float d = __shfl(dn, 16 * gg);
-                    const uint32_t id = (uint32_t)__shfl((int)nb, 16 * gg);
-                    if (base + (uint32_t)gg < dg && d < dbest) { dbest = d; best = id; }
-                }
+            for (uint32_t base = 0; base < dg; base += kWave) {
+                const uint32_t cnt = min(dg - base, (uint32_t)kWave);
+                __syncthreads();  // (the previous window's readers are done)
+                if (wave == 0 && (uint32_t)lane < cnt) nb_i[lane] = adj_up[row * gstride + base + lane];
+                __syncthreads();
+                ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, cnt, nb_i, nb_d, lane, wave);
+                __syncthreads();
+                // list order: the smallest (distance, position); strict '<' against the running best keeps the earliest of equal minima
+                const uint64_t key = (uint32_t)lane < cnt ? ((uint64_t)f32_key(nb_d[lane]) << 32) | (uint32_t)lane : ~0ull;
+                const uint32_t jm = (uint32_t)wave_min64(key);
+                const float dm = nb_d[jm];
+                if (dm < dbest) { dbest = dm; best = nb_i[jm]; }
             }
             evals += dg;
             if (best == cur) break;
@@ -1607,7 +1613,7 @@ __global__ __launch_bounds__(64) void k_descend(const RT *__restrict__ rows, uin
             dcur = dbest;
         }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         out_entry[qi] = cur;
         if (stats) atomicAdd(&stats[0], evals);
     }
@@ -1616,14 +1622,16 @@ __global__ __launch_bounds__(64) void k_descend(const RT *__restrict__ rows, uin
 int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
                    unsigned long long *d_stats, hipStream_t s) {
     if (nq == 0) return ZVDB_OK;
-    const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
-    const size_t lds = 4ull * dim_pad;
+    // q in LDS: zero padded to the rows' padded length for bf16 rows (the unmasked 8-lane walk reads whole 128-byte lines)
+    const uint32_t dim_pad = (h->flags & ZVDB_FLAG_BF16_ROWS) ? std::max(h->ldh, 64u) : round_up(std::max(h->dim, 1u), 4);
+    const size_t lds = 4ull * dim_pad + 8ull * kWave;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
-        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_descend<RT>), lds));
-        hipLaunchKernelGGL(k_descend<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->lvl, h->slot, h->adj_up, h->deg_up, h->gstride,
-                           d_queries, top, d_entries, d_stats, dim_pad);
+        constexpr int WPQ = sizeof(RT) == 2 ? 2 : 4;
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_descend<RT, WPQ>), lds));
+        hipLaunchKernelGGL((k_descend<RT, WPQ>), dim3(nq), dim3(64 * WPQ), lds, s, rows, ld, h->dim, metric, h->lvl, h->slot, h->adj_up, h->deg_up,
+                           h->gstride, d_queries, top, d_entries, d_stats, dim_pad);
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
     });
