@@ -1,7 +1,7 @@
 """Recall-vs-ef of the graph routes on the benchmark's data (i.i.d. U[0,1)): SURVEY 7's control (N = 20k, d = 768, M = 32) and a
 larger shard; directed exact-kNN lists entered at node 0 against the bulk graph (heuristic + reverse links, cap 2 M) entered by
 descent.  Prints recall@10, distance evaluations per query and the fraction of N they touch, QPS (batched, resident queries).
-usage: python tests/manual/graph_recall_probe.py [N] [d] [M] [efc] [intrinsic_rank]
+usage: python tests/manual/graph_recall_probe.py [N] [d] [M] [efc] [intrinsic_rank] [bf16rows]
 intrinsic_rank > 0: rows = Z A + 0.01 noise with Z ~ U[0,1)^(N x rank), A a fixed rank x d matrix -- data that HAS neighbourhood
 structure (what embeddings look like), unlike the benchmark's i.i.d. uniform coordinates where distances concentrate."""
 import os, sys, time
@@ -13,10 +13,11 @@ d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 efc = int(sys.argv[4]) if len(sys.argv) > 4 else 96
 rank = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+hrows = len(sys.argv) > 6 and sys.argv[6] == "bf16rows"  # ZVDB_FLAG_BF16_ROWS: the index keeps bf16 rows only (BASELINE configs 4-5)
 nq, k = 1024, 10
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-idx = zv.Index(dim=d, capacity=N, m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_MIRROR)
+idx = zv.Index(dim=d, capacity=N, m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_ROWS if hrows else zv.FLAG_BF16_MIRROR)
 q = torch.empty((nq, d), dtype=torch.float32, device=dev)
 if rank > 0:
     g = torch.Generator(device=dev); g.manual_seed(5)
@@ -61,10 +62,10 @@ def sweep(tag, entry):
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / 3
         print(f"  {tag} ef={ef:5d}: recall@10 {rec:.4f}  evals/query {ev:9.1f} ({ev / N * 100:6.2f} % of N)  {nq / el:10.0f} QPS  "
-              f"{ev * d * 4 * nq / el / 1e12:.2f} TB/s gathered", flush=True)
+              f"{ev * d * (2 if hrows else 4) * nq / el / 1e12:.2f} TB/s gathered", flush=True)
 
 
-print(f"N={N} d={d} M={M} ef_construction={efc} intrinsic_rank={rank or 'none (i.i.d. uniform coordinates)'}")
+print(f"N={N} d={d} M={M} ef_construction={efc} intrinsic_rank={rank or 'none (i.i.d. uniform coordinates)'}{' bf16 rows' if hrows else ''}")
 t0 = time.perf_counter(); idx.build_knn_graph(M, zv.BF_I8); t1 = time.perf_counter()
 print(f" directed exact {M}-NN lists, entry node 0 (build {t1 - t0:.2f} s)")
 sweep("knn(M)   ", 0)
