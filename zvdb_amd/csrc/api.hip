@@ -317,6 +317,7 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     if (h->guess_flag_host) (void)hipHostFree(h->guess_flag_host);
     if (h->ef_hint_host) (void)hipHostFree(h->ef_hint_host);
     (void)hipFree(h->ef_hint_dev);
+    (void)hipFree(h->ef_visit_buf);
     if (h->ins_host) (void)hipHostFree(h->ins_host);
     (void)hipFree(h->rows_pf);
     (void)hipFree(h->rows_qf);
@@ -1081,7 +1082,7 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
             stats->pops = st[1];
         }
         if (st[2] != 0) {
-            set_error("ef-mode visited set exhausted for %llu queries (ef*stride too large for LDS)", st[2]);
+            set_error("ef-mode visited set exhausted for %llu queries (more than 3 ef stride nodes visited)", st[2]);
             return ZVDB_ERR_UNSUPPORTED;
         }
     }

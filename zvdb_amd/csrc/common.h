@@ -156,6 +156,8 @@ struct zvdb_hip_index {
     uint32_t *guess_flag_dev = nullptr;   // its device alias
     mutable uint32_t *ef_hint_dev = nullptr;   // [16] largest visited-set fill seen per ef bucket (exact_kernels.hip: kEfTight)
     mutable uint32_t *ef_hint_host = nullptr;  // pinned copy, refreshed asynchronously after every ef launch
+    mutable uint32_t *ef_visit_buf = nullptr;  // visited sets in global memory for searches whose safe table does not fit the LDS
+    mutable size_t ef_visit_bytes = 0;
     float guess_adapt = 0.0f;
     // zvdb_hip_insert_layer0: host-mapped [row | result] block -- the kernels read the point and write the result through
     // it, so an insert submits no copy-engine transfers (each costs ~10 us for a few hundred bytes)

@@ -1008,7 +1008,9 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
 // serves exactly the marked queries (kEfRetry).  Results and counters are those of a single safe pass.
 constexpr uint32_t kEfSingle = 0, kEfTight = 1, kEfRetry = 2, kEfAgain = 0xFFFFFFFFu;
 __device__ unsigned long long g_ef_prof[10];
-template <typename RT, int PROF = 0>
+// GH: the visited set lives in GLOBAL memory (ghash: one pre-zeroed table of 2^hash_bits slots per query of the launch, query
+// index = block + qoff) -- the safe pass of searches whose safe table does not fit the LDS (ef * stride beyond ~12k)
+template <typename RT, int PROF = 0, bool GH = false>
 __global__ __launch_bounds__(64) void k_search_ef(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
@@ -1016,24 +1018,28 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
-    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint) {
+    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint, uint32_t *ghash, uint32_t qoff) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (pass == kEfRetry && out_count[blockIdx.x] != kEfAgain) return;  // served by the tight pass
-    if (entries) entry = entries[blockIdx.x];
+    const uint32_t qi = blockIdx.x + qoff;
+    if (pass == kEfRetry && out_count[qi] != kEfAgain) return;  // served by the tight pass
+    if (entries) entry = entries[qi];
     float *q = reinterpret_cast<float *>(smem);
     uint64_t *wk = reinterpret_cast<uint64_t *>(q + dim_pad);          // [2][efp]
     uint32_t *wx = reinterpret_cast<uint32_t *>(wk + 2 * efp);         // [2][efp] expanded flags
     uint32_t *hist = wx + 2 * efp;                                     // [256] select scratch
-    uint32_t *hash = hist + 256;
-    float *nb_d = reinterpret_cast<float *>(hash + (1u << hash_bits));
+    uint32_t *lds_hash = hist + 256;
+    float *nb_d = reinterpret_cast<float *>(lds_hash + (GH ? 0u : (1u << hash_bits)));
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
+    uint32_t *hash;  // (one address space per instantiation: LDS atomics or global atomics)
+    if constexpr (GH) hash = ghash + ((size_t)blockIdx.x << hash_bits);
+    else hash = lds_hash;
 
     const int lane = threadIdx.x;
     const int t = lane & 15;
-    const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
-    for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
+    if constexpr (!GH)
+        for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
 
@@ -1280,7 +1286,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
-    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint) {
+    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (pass == kEfRetry && out_count[blockIdx.x] != kEfAgain) return;  // served by the tight pass
     if (entries) entry = entries[blockIdx.x];
@@ -1650,7 +1656,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // LDS footprint sets the waves per CU (the first version reserved 8 x and ran ONE wave per CU).
     // A query that still exhausts it is flagged in stats[2] (the host entry point reports it).
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 3 / 2 + 64);
-    uint32_t hash_bits = bits_for(want);
+    uint32_t hash_bits = bits_for(want);  // the SAFE table
     if (const char *hb_env = getenv("ZVDB_EF_HASH_BITS")) hash_bits = (uint32_t)std::max(8, std::min(15, atoi(hb_env)));  // (experiment)
     const uint32_t efp = round_up(ef, kWave), kpad = round_up(std::max(k, 1u), kWave);
     // beam in registers up to ef = 512 (k_search_ef_reg), in LDS beyond (k_search_ef); ZVDB_EF_BEAM=lds forces the LDS kernel
@@ -1661,7 +1667,17 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad + 16;
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
     };
-    while (lds_bytes(hash_bits) > 160 * 1024 && hash_bits > 8) --hash_bits;
+    // A safe table that leaves fewer than two workgroups per CU (ef * stride beyond ~12k) does not go to the LDS at all: the safe
+    // pass then keeps the visited sets in GLOBAL memory (k_search_ef<GH>: a pre-zeroed table of >= 8 ef stride slots per query in
+    // an index-owned buffer, the batch in chunks of <= 2 GiB) -- slower per pop, but it serves only what the tight LDS pass
+    // handed back (or the first batch of an ef bucket, which establishes the fill), and nothing overflows: before, such searches
+    // ran one wave per CU on a table clamped to the LDS and failed with "visited set exhausted" beyond it.
+    const char *gv_env = getenv("ZVDB_EF_GLOBAL_VISITED");  // "1" / "0": force / forbid the global safe pass (tests; read per call)
+    uint32_t lds_cap_bits = 15;
+    while (lds_bytes(lds_cap_bits) > 160 * 1024 && lds_cap_bits > 8) --lds_cap_bits;
+    const bool safe_global = gv_env ? gv_env[0] == '1' : lds_bytes(hash_bits) > 80 * 1024;
+    if (!safe_global) hash_bits = std::min(hash_bits, lds_cap_bits);
+    uint32_t gbits = bits_for(std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 4 + 64));
     // two-pass sizing (see kEfTight): the largest visited-set fill this index has seen for searches of this ef bucket
     if (!h->ef_hint_dev) {
         ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_hint_dev), 64));
@@ -1673,14 +1689,17 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     while ((1u << bucket) < ef && bucket < 15) ++bucket;
     const uint32_t seen = __atomic_load_n(&h->ef_hint_host[bucket], __ATOMIC_RELAXED);
     const char *tp_env = getenv("ZVDB_EF_TWO_PASS");  // "0": always the safe table; "t<bits>": force the tight table (tests; read per call)
-    uint32_t tight_bits = hash_bits;
+    const uint32_t safe_rank = safe_global ? 32u : hash_bits;  // (a global safe table is "larger" than any LDS one)
+    uint32_t tight_bits = safe_rank;
     if (tp_env && tp_env[0] == 't') {
-        tight_bits = std::min(hash_bits, (uint32_t)std::max(8, atoi(tp_env + 1)));
+        tight_bits = std::min(std::min(safe_rank, lds_cap_bits), (uint32_t)std::max(8, atoi(tp_env + 1)));
     } else if (seen && !(tp_env && tp_env[0] == '0')) {
         tight_bits = 8;
         while ((1ull << tight_bits) < (uint64_t)seen * 5 / 2 + 128) ++tight_bits;  // <= 40 % load at the largest fill seen
-        tight_bits = std::min(tight_bits, hash_bits);
+        if (tight_bits > lds_cap_bits) tight_bits = safe_rank;                      // (does not fit the LDS: no tight pass)
+        tight_bits = std::min(tight_bits, safe_rank);
     }
+    const bool two_pass = tight_bits < safe_rank;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
@@ -1691,17 +1710,35 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
-                               pass, h->ef_hint_dev + bucket);
+                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
-        auto go = [&](auto kern, uint32_t wparam) -> int {
-            if (tight_bits < hash_bits) {
-                ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight));
-                ZV_CHECK(go1(kern, wparam, hash_bits, kEfRetry));
-            } else {
-                ZV_CHECK(go1(kern, wparam, hash_bits, kEfSingle));
+        auto go_global = [&](uint32_t pass) -> int {  // the safe pass with the visited sets in global memory
+            const size_t tb = 4ull << gbits;
+            const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(nq, (2ull << 30) / tb));
+            if (h->ef_visit_bytes < chunk * tb) {
+                if (h->ef_visit_buf) { ZV_HIP(hipStreamSynchronize(s)); (void)hipFree(h->ef_visit_buf); h->ef_visit_buf = nullptr; h->ef_visit_bytes = 0; }
+                ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_visit_buf), chunk * tb));
+                h->ef_visit_bytes = chunk * tb;
             }
+            const size_t lds = 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 8ull * kWave;
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 0, true>), lds));
+            for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
+                const uint32_t nc = (uint32_t)std::min<uint64_t>(chunk, nq - q0);
+                ZV_HIP(hipMemsetAsync(h->ef_visit_buf, 0, (size_t)nc * tb, s));
+                hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(nc), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
+                                   d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, gbits, efp, d_entries,
+                                   pass, h->ef_hint_dev + bucket, h->ef_visit_buf, (uint32_t)q0);
+                ZV_HIP(hipGetLastError());
+            }
+            return ZVDB_OK;
+        };
+        auto go = [&](auto kern, uint32_t wparam) -> int {
+            if (two_pass) ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight));
+            const uint32_t pass = two_pass ? kEfRetry : kEfSingle;
+            if (safe_global) { ZV_CHECK(go_global(pass)); }
+            else { ZV_CHECK(go1(kern, wparam, hash_bits, pass)); }
             ZV_HIP(hipMemcpyAsync(h->ef_hint_host, h->ef_hint_dev, 64, hipMemcpyDeviceToHost, s));  // read by a LATER call, never waited for
             return ZVDB_OK;
         };
@@ -1714,9 +1751,9 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
             const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
             fprintf(stderr, "[zvdb ef prof] %llu queries, %.1f pops each; shader cycles per POP: next-scan %.0f, list+visited %.0f, distances %.0f, beam update %.0f; "
-                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop; visited table 2^%u (safe 2^%u)\n", got[7], np / nw,
+                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop; visited table 2^%u (safe 2^%u%s)\n", got[7], np / nw,
                     got[0] / np, got[1] / np, got[2] / np, got[3] / np, got[4] / nw, got[5] / nw, (got[0] + got[1] + got[2] + got[3] + got[4] + got[5]) / nw,
-                    got[8] / np, got[9] / np, tight_bits, hash_bits);
+                    got[8] / np, got[9] / np, two_pass ? tight_bits : (safe_global ? gbits : hash_bits), safe_global ? gbits : hash_bits, safe_global ? " global" : "");
             return ZVDB_OK;
         }
         // waves per query.  Measured at 1M x 768, M = 16, ef = 128, batch 1,024 / 4,096 / 16,384 (QPS): fp32 rows 1 wave 775k / 901k /
