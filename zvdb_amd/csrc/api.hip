@@ -1082,7 +1082,7 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
             stats->pops = st[1];
         }
         if (st[2] != 0) {
-            set_error("ef-mode visited set exhausted for %llu queries (more than 3 ef stride nodes visited)", st[2]);
+            set_error("ef-mode visited set exhausted for %llu queries (more nodes visited than the table sized from ef * stride holds)", st[2]);
             return ZVDB_ERR_UNSUPPORTED;
         }
     }
