@@ -66,12 +66,14 @@ def sweep(tag, entry):
 
 
 print(f"N={N} d={d} M={M} ef_construction={efc} intrinsic_rank={rank or 'none (i.i.d. uniform coordinates)'}{' bf16 rows' if hrows else ''}")
-t0 = time.perf_counter(); idx.build_knn_graph(M, zv.BF_I8); t1 = time.perf_counter()
-print(f" directed exact {M}-NN lists, entry node 0 (build {t1 - t0:.2f} s)")
-sweep("knn(M)   ", 0)
-t0 = time.perf_counter(); idx.build_knn_graph(2 * M, zv.BF_I8); t1 = time.perf_counter()
-print(f" directed exact {2 * M}-NN lists, entry node 0 (build {t1 - t0:.2f} s)")
-sweep("knn(2M)  ", 0)
+only = os.environ.get("ZVDB_PROBE_ONLY", "")  # "bulk": skip the plain kNN-list graphs (the 10M-row run)
+if only != "bulk":
+    t0 = time.perf_counter(); idx.build_knn_graph(M, zv.BF_I8); t1 = time.perf_counter()
+    print(f" directed exact {M}-NN lists, entry node 0 (build {t1 - t0:.2f} s)")
+    sweep("knn(M)   ", 0)
+    t0 = time.perf_counter(); idx.build_knn_graph(2 * M, zv.BF_I8); t1 = time.perf_counter()
+    print(f" directed exact {2 * M}-NN lists, entry node 0 (build {t1 - t0:.2f} s)")
+    sweep("knn(2M)  ", 0)
 t0 = time.perf_counter(); idx.build_graph(M, efc, zv.BF_I8, 7); t1 = time.perf_counter()
 deg = np.array([len(idx.get_neighbors(i)) for i in range(0, N, max(1, N // 2000))])
 e, ml = idx.graph_info()
