@@ -1,7 +1,7 @@
 # soak: many different query batches through the guessed-threshold pipelines; every batch checked (fp4 recall vs the int8 route,
-# int8 vs the fp32 route on sampled batches, counts, ascending distances)
+# the bf16 stream route == the int8 route, int8 vs the fp32 route on sampled batches, counts, ascending distances)
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, zvdb_amd as zv
 N, D, B, K = 2_000_000, 768, 1024, 10
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 300
@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 idx = zv.Index(dim=D, capacity=N, flags=zv.FLAG_BF16_MIRROR)
 idx.add_synthetic(N, D, 0x5EED)
 s = torch.cuda.current_stream().cuda_stream
-wsb = max(idx.bruteforce_workspace(B, K, m) for m in (zv.BF_F32, zv.BF_I8, zv.BF_FP4))
+wsb = max(idx.bruteforce_workspace(B, K, m) for m in (zv.BF_F32, zv.BF_BF16, zv.BF_I8, zv.BF_FP4))
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 q = torch.empty((B, D), dtype=torch.float32, device=dev)
 def run(mode):
@@ -24,7 +24,8 @@ for b in range(NB):
     zv.fill_synthetic_dev(q.data_ptr(), B, D, 0xC0FFEE + 7919 * b, 0, s)
     i4, d4, c4 = run(zv.BF_FP4)
     i8, d8, c8 = run(zv.BF_I8)
-    ok = bool(np.all(c4 == K) and np.all(c8 == K) and np.all(np.diff(d4, axis=1) >= 0) and np.all(np.diff(d8, axis=1) >= 0))
+    ib, db, cb = run(zv.BF_BF16)
+    ok = bool(np.array_equal(ib, i8) and np.array_equal(db, d8) and np.array_equal(cb, c8) and np.all(c4 == K) and np.all(c8 == K) and np.all(np.diff(d4, axis=1) >= 0) and np.all(np.diff(d8, axis=1) >= 0))
     rec = float(np.mean([len(set(i4[i]) & set(i8[i])) / K for i in range(B)]))
     worst = min(worst, rec)
     if b % 25 == 0:
