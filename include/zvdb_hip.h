@@ -220,7 +220,11 @@ int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, floa
  * `entry` (the reference never moves it off node 0: hnsw.zig:84,:110-112).
  *   ef == 0 : reference-compat mode -- first k pops of a best-first frontier,
  *             then stable sort (bit-exact ids/distances vs the oracle);
- *   ef  > 0 : ef-mode beam search (extension; spec in oracle/zvdb_oracle.h).
+ *   ef  > 0 : ef-mode beam search (extension; spec in oracle/zvdb_oracle.h).  The per-query visited
+ *             set lives in LDS, sized from the fills the index has seen for this ef (a query that
+ *             outgrows it is re-run by a second launch with the safe size); when the safe size
+ *             does not fit (ef * stride beyond ~12k) that launch keeps the visited sets in an
+ *             index-owned device buffer of up to 2 GiB, allocated on first need.
  * Outputs: out_ids[nq*k], out_dist[nq*k], out_count[nq] (count may be < k:
  * test_hnsw.zig:122-125; unused slots are id = UINT64_MAX, dist = +inf).
  * stats may be NULL. */
