@@ -14,10 +14,11 @@ M = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 efc = int(sys.argv[4]) if len(sys.argv) > 4 else 96
 rank = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 hrows = len(sys.argv) > 6 and sys.argv[6] == "bf16rows"  # ZVDB_FLAG_BF16_ROWS: the index keeps bf16 rows only (BASELINE configs 4-5)
-nq, k = 1024, 10
+nq, k = 1024, int(os.environ.get("ZVDB_PROBE_K", "10"))  # (k = 100 + ZVDB_PROBE_METRIC=cosine: BASELINE configs[4]'s shape)
+metric = {"l2": zv.METRIC_L2SQ, "dot": zv.METRIC_DOT, "cosine": zv.METRIC_COSINE}[os.environ.get("ZVDB_PROBE_METRIC", "l2")]
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-idx = zv.Index(dim=d, capacity=N, m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_ROWS if hrows else zv.FLAG_BF16_MIRROR)
+idx = zv.Index(dim=d, capacity=N, m=2 * M, graph_stride=2 * M, metric=metric, flags=zv.FLAG_BF16_ROWS if hrows else zv.FLAG_BF16_MIRROR)
 q = torch.empty((nq, d), dtype=torch.float32, device=dev)
 if rank > 0:
     g = torch.Generator(device=dev); g.manual_seed(5)
@@ -43,6 +44,7 @@ st = torch.zeros(4, dtype=torch.int64, device=dev)
 
 def sweep(tag, entry):
     for ef in (32, 64, 128, 256, 512, 1024):
+        if ef < k: continue
         st.zero_()
         try:
             idx.search_graph_dev(q.data_ptr(), nq, d, k, ef, entry, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), stream)
@@ -61,11 +63,11 @@ def sweep(tag, entry):
             idx.search_graph_dev(q.data_ptr(), nq, d, k, ef, entry, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / 3
-        print(f"  {tag} ef={ef:5d}: recall@10 {rec:.4f}  evals/query {ev:9.1f} ({ev / N * 100:6.2f} % of N)  {nq / el:10.0f} QPS  "
+        print(f"  {tag} ef={ef:5d}: recall@{k} {rec:.4f}  evals/query {ev:9.1f} ({ev / N * 100:6.2f} % of N)  {nq / el:10.0f} QPS  "
               f"{ev * d * (2 if hrows else 4) * nq / el / 1e12:.2f} TB/s gathered", flush=True)
 
 
-print(f"N={N} d={d} M={M} ef_construction={efc} intrinsic_rank={rank or 'none (i.i.d. uniform coordinates)'}{' bf16 rows' if hrows else ''}")
+print(f"N={N} d={d} M={M} k={k} metric={os.environ.get('ZVDB_PROBE_METRIC', 'l2')} ef_construction={efc} intrinsic_rank={rank or 'none (i.i.d. uniform coordinates)'}{' bf16 rows' if hrows else ''}")
 only = os.environ.get("ZVDB_PROBE_ONLY", "")  # "bulk": skip the plain kNN-list graphs (the 10M-row run)
 if only != "bulk":
     t0 = time.perf_counter(); idx.build_knn_graph(M, zv.BF_I8); t1 = time.perf_counter()
