@@ -1,4 +1,5 @@
-# one-off randomized parity sweep of the reference-compat path (insert on every layer + search) against the oracle
+# one-off randomized parity sweep of the reference-compat path (insert on every layer + search) against the oracle; the bulk insert
+# alternates between its three forms (speculative rounds in one cooperative launch / round by round / one wave in order)
 import sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle, zvdb_amd as zv
@@ -19,7 +20,11 @@ for c in range(cases):
     split = int(rng.integers(0, n + 1))
     for i in range(min(split, 50)): got.insert(V[i], _level=int(lv[i]))
     s0 = min(split, 50)
+    form = ("", "rounds", "0")[c % 3]  # ZVDB_INSERT_SPEC: default = cooperative round loop
+    if form: os.environ["ZVDB_INSERT_SPEC"] = form
+    else: os.environ.pop("ZVDB_INSERT_SPEC", None)
     if s0 < n: got.insert_many(V[s0:], lv[s0:])
+    os.environ.pop("ZVDB_INSERT_SPEC", None)
     ok = got.count() == n and got.max_level == ref.max_level
     for i in range(n):
         for layer in range(ref.node_level(i) + 1):

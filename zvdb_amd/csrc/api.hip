@@ -318,6 +318,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     if (h->ef_hint_host) (void)hipHostFree(h->ef_hint_host);
     (void)hipFree(h->ef_hint_dev);
     (void)hipFree(h->ef_visit_buf);
+    (void)hipFree(h->spec_wpos0);
+    (void)hipFree(h->spec_wposU);
     if (h->ins_host) (void)hipHostFree(h->ins_host);
     (void)hipFree(h->rows_pf);
     (void)hipFree(h->rows_qf);
@@ -789,6 +791,12 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
     if (out_first_id) *out_first_id = h->count;
     const uint32_t m = h->m, rw = 4 + h->gstride, ow = 4 + m;
     uint64_t done = 0, rec_out = 0;
+    // chunks of more than 4 points run as speculative parallel rounds (exact_kernels.hip: k_insert_spec); ZVDB_INSERT_SPEC=0: one wave, in order
+    const char *spec_env = getenv("ZVDB_INSERT_SPEC");
+    const bool spec = !(spec_env && spec_env[0] == '0') && m >= 1;
+    const uint32_t spec_bmax = 1024;
+    const size_t spec_rsb = round_up64((size_t)spec_bmax * insert_spec_rmax() * 8, 256), spec_rcb = round_up64((size_t)spec_bmax * 4, 256);
+    const size_t spec_extra = spec ? spec_rsb + spec_rcb + 256 : 0;
     {   // Everything that can fail for want of memory is reserved for ALL n points before the first launch, so that a
         // failure leaves the index as it was (the reference's insert leaves a consistent index on error: errdefer,
         // hnsw.zig:80): a later chunk must not fail after earlier chunks advanced count and the device lists.
@@ -813,7 +821,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
         ZV_CHECK(ensure_upper(h, h->up_count + ups));
         const uint64_t ncm = std::min<uint64_t>(8192, n);
         const size_t need = round_up64(ncm * dim * sizeof(float), 256) + round_up64(ncm * sizeof(InsertParam), 256) +
-                            round_up64(rec_chunk_max * rw * 4, 256) + 64;
+                            round_up64(rec_chunk_max * rw * 4, 256) + 64 + spec_extra;
         if (n > 4) { ZV_CHECK(ensure_pin(h, need)); ZV_CHECK(ensure_scratch(h, need)); }
         else ZV_CHECK(ensure_ins_block(h, need));
         ZV_CHECK(ensure_pin(h, (size_t)dim * 4 + 64));
@@ -861,6 +869,8 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                      rb = round_up64(totrec * rw * 4, 256);
         const uint64_t id0 = h->count;
         const unsigned char *res = nullptr;
+        bool spec_looped = false;
+        uint64_t spec_dbg_rounds = 0, spec_dbg_launched = 0;
         if (nc <= 4) {  // a call or two per point: everything through host-mapped memory, completion polled
             ZV_CHECK(ensure_ins_block(h, pb + qb + rb + 64));
             unsigned char *hb = static_cast<unsigned char *>(h->ins_host), *db = static_cast<unsigned char *>(h->ins_dev);
@@ -878,19 +888,90 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) ZV_HIP(hipStreamSynchronize(h->stream));
             res = hb + pb + qb;
         } else {
-            ZV_CHECK(ensure_pin(h, pb + qb + rb));
-            ZV_CHECK(ensure_scratch(h, pb + qb + rb));
+            ZV_CHECK(ensure_pin(h, pb + qb + rb + spec_extra));
+            ZV_CHECK(ensure_scratch(h, pb + qb + rb + spec_extra));
             unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr), *scr = static_cast<unsigned char *>(h->scratch);
             std::memcpy(pin, points + done * dim, nc * dim * sizeof(float));
             std::memcpy(pin + pb, prm.data(), nc * sizeof(InsertParam));
             ZV_HIP(hipMemcpyAsync(scr, pin, pb + qb, hipMemcpyHostToDevice, h->stream));
-            ZV_CHECK(launch_insert_full(h, (uint32_t)id0, (uint32_t)nc, reinterpret_cast<const float *>(scr),
-                                        reinterpret_cast<const InsertParam *>(scr + pb), reinterpret_cast<uint32_t *>(scr + pb + qb),
-                                        nullptr, 0u, h->stream));
+            if (!spec) {
+                ZV_CHECK(launch_insert_full(h, (uint32_t)id0, (uint32_t)nc, reinterpret_cast<const float *>(scr),
+                                            reinterpret_cast<const InsertParam *>(scr + pb), reinterpret_cast<uint32_t *>(scr + pb + qb),
+                                            nullptr, 0u, h->stream));
+            } else {
+                // per-list write stamps for every list the index can hold (sized once per call: all capacity was reserved above)
+                if (h->spec_cap0 < h->cap) {
+                    (void)hipFree(h->spec_wpos0);
+                    h->spec_wpos0 = nullptr; h->spec_cap0 = 0;
+                    ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->spec_wpos0), h->cap * 8));
+                    ZV_HIP(hipMemsetAsync(h->spec_wpos0, 0xFF, h->cap * 8, h->stream));
+                    h->spec_cap0 = h->cap;
+                }
+                if (h->spec_capU < std::max<uint64_t>(h->up_cap, 1)) {
+                    (void)hipFree(h->spec_wposU);
+                    h->spec_wposU = nullptr; h->spec_capU = 0;
+                    const uint64_t cu = std::max<uint64_t>(h->up_cap, 1);
+                    ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->spec_wposU), cu * 8));
+                    ZV_HIP(hipMemsetAsync(h->spec_wposU, 0xFF, cu * 8, h->stream));
+                    h->spec_capU = cu;
+                }
+                uint32_t *d_rset = reinterpret_cast<uint32_t *>(scr + pb + qb + rb), *d_rcnt = reinterpret_cast<uint32_t *>(scr + pb + qb + rb + spec_rsb);
+                uint32_t *d_cmin = reinterpret_cast<uint32_t *>(scr + pb + qb + rb + spec_rsb + spec_rcb);
+                volatile uint32_t *h_cmin = reinterpret_cast<volatile uint32_t *>(pin + pb + qb + rb);
+                uint64_t spec_rounds = 0, spec_launched = 0;
+                // one cooperative launch runs all rounds of the chunk (ZVDB_INSERT_SPEC=rounds: one round per three launches + a host sync)
+                bool looped = false;
+                if (!(spec_env && spec_env[0] == 'r')) {
+                    uint32_t lb = 32;
+                    if (const char *be = getenv("ZVDB_INSERT_SPEC_B")) lb = (uint32_t)std::max(1, std::min((int)spec_bmax, atoi(be)));
+                    const int rc = launch_insert_spec_loop(h, (uint32_t)id0, (uint32_t)nc, lb, reinterpret_cast<const float *>(scr),
+                                                           reinterpret_cast<const InsertParam *>(scr + pb), reinterpret_cast<uint32_t *>(scr + pb + qb),
+                                                           h->spec_wpos0, h->spec_wposU, d_rset, d_rcnt, d_cmin, h->spec_epoch + 1, h->stream);
+                    if (rc == ZVDB_OK) {
+                        looped = true;
+                        ZV_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h_cmin), d_cmin, 32, hipMemcpyDeviceToHost, h->stream));  // read after the sync below
+                        spec_launched = lb;
+                    } else {
+                        (void)hipGetLastError();  // (no cooperative launch here: the round-by-round form below)
+                    }
+                }
+                uint64_t pos = 0;
+                uint32_t bcur = 64;
+                while (!looped && pos < nc) {
+                    const uint32_t B = (uint32_t)std::min<uint64_t>(bcur, nc - pos);
+                    ZV_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_cmin), (int)B, 1, h->stream));
+                    h->spec_epoch += 1;
+                    ZV_CHECK(launch_insert_spec_round(h, (uint32_t)(id0 + pos), B, reinterpret_cast<const float *>(scr) + pos * dim,
+                                                      reinterpret_cast<const InsertParam *>(scr + pb) + pos, reinterpret_cast<uint32_t *>(scr + pb + qb),
+                                                      h->spec_wpos0, h->spec_wposU, h->spec_epoch, d_rset, d_rcnt, d_cmin, h->stream));
+                    ZV_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h_cmin), d_cmin, 4, hipMemcpyDeviceToHost, h->stream));
+                    ZV_HIP(hipStreamSynchronize(h->stream));
+                    const uint32_t c = *h_cmin;
+                    if (c == 0 || c > B) { set_error("speculative insert: bad commit count %u of %u", c, B); return ZVDB_ERR_HIP; }
+                    pos += c;
+                    bcur = std::max(32u, std::min(spec_bmax, 2 * c));
+                    spec_rounds += 1;
+                    spec_launched += B;
+                }
+                spec_looped = looped;
+                spec_dbg_rounds = spec_rounds; spec_dbg_launched = spec_launched;
+            }
             ZV_CHECK(finish_rows(h, id0, nc, h->stream));
             ZV_HIP(hipMemcpyAsync(pin + pb + qb, scr + pb + qb, totrec * rw * 4, hipMemcpyDeviceToHost, h->stream));
             ZV_HIP(hipStreamSynchronize(h->stream));
             res = pin + pb + qb;
+            if (spec_looped) {  // the persistent loop reports the rounds (= epochs) it used
+                const volatile uint32_t *ctl_h = reinterpret_cast<const volatile uint32_t *>(pin + pb + qb + rb);
+                if (ctl_h[5] != 0) { set_error("speculative insert: the round loop's grid barrier timed out"); return ZVDB_ERR_HIP; }
+                const uint32_t rounds = ctl_h[4];
+                h->spec_epoch += rounds;
+                spec_dbg_rounds = rounds;
+                spec_dbg_launched = spec_dbg_launched * rounds;
+            }
+            if (spec && getenv("ZVDB_INSERT_SPEC_DEBUG"))
+                fprintf(stderr, "[zvdb insert spec] chunk of %llu points at id %llu: %llu rounds%s, %llu point-slots launched (%.1f committed per round)\n",
+                        (unsigned long long)nc, (unsigned long long)id0, (unsigned long long)spec_dbg_rounds, spec_looped ? " in one cooperative launch" : "",
+                        (unsigned long long)spec_dbg_launched, (double)nc / (double)std::max<uint64_t>(spec_dbg_rounds, 1));
         }
         h->count += nc;
         h->up_count = up;

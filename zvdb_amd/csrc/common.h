@@ -156,6 +156,9 @@ struct zvdb_hip_index {
     uint32_t *guess_flag_dev = nullptr;   // its device alias
     mutable uint32_t *ef_hint_dev = nullptr;   // [16] largest visited-set fill seen per ef bucket (exact_kernels.hip: kEfTight)
     mutable uint32_t *ef_hint_host = nullptr;  // pinned copy, refreshed asynchronously after every ef launch
+    unsigned long long *spec_wpos0 = nullptr, *spec_wposU = nullptr;  // speculative insert: per-list write stamps (layer 0 / upper slots)
+    uint64_t spec_cap0 = 0, spec_capU = 0;
+    uint32_t spec_epoch = 0;
     mutable uint32_t *ef_visit_buf = nullptr;  // visited sets in global memory for searches whose safe table does not fit the LDS
     mutable size_t ef_visit_bytes = 0;
     float guess_adapt = 0.0f;
@@ -209,6 +212,14 @@ struct InsertParam { uint32_t level, slot, rec_off, maxlev_pre; };
 int launch_insert_full(const zvdb_hip_index *h, uint32_t first_owner, uint32_t n, const float *points, const InsertParam *params,
                        uint32_t *recs, uint32_t *seq_dst, uint32_t seq, hipStream_t s);
 int launch_copy_row(const float *src, float *dst, uint32_t dim, hipStream_t s);
+// one speculative round of B inserts (exact_kernels.hip: k_insert_spec / _check / _commit); *cmin (device, preset to B) <- points committed
+int launch_insert_spec_round(const zvdb_hip_index *h, uint32_t first_owner, uint32_t B, const float *points, const InsertParam *params,
+                             uint32_t *recs, unsigned long long *wpos0, unsigned long long *wposU, uint32_t epoch, uint32_t *rset,
+                             uint32_t *rcnt, uint32_t *cmin, hipStream_t s);
+int launch_insert_spec_loop(const zvdb_hip_index *h, uint32_t first_owner, uint32_t n_chunk, uint32_t B, const float *points,
+                            const InsertParam *params, uint32_t *recs, unsigned long long *wpos0, unsigned long long *wposU, uint32_t *rset,
+                            uint32_t *rcnt, uint32_t *ctl, uint32_t epoch, hipStream_t s);
+uint32_t insert_spec_rmax();
 // dst[0..n) <- src[0..n) (64-bit words), then *seq_dst = seq at system scope: publishes a result block to a polling host
 int launch_publish(unsigned long long *dst, const unsigned long long *src, uint32_t n, uint32_t *seq_dst, uint32_t seq, hipStream_t s);
 int ensure_ins_block(zvdb_hip_index *h, size_t bytes);

@@ -419,6 +419,335 @@ int launch_insert_full(const zvdb_hip_index *h, uint32_t first_owner, uint32_t n
     return ZVDB_OK;
 }
 
+// ---- the whole insert, SPECULATIVELY in parallel (same results as k_insert_full, insert by insert) --------------------------------
+// The reference's insert is one chain of dependent steps per point, and points must go in one after the other (each sees the
+// graph the previous ones left): on a GPU that is ~15 us of latency per point, a third of what one CPU core needs.  But what
+// insert i READS of the shared graph is small -- the lists along its greedy paths (one per hop) -- and what it WRITES to it is
+// smaller: one existing list per layer <= its level (its final ep's).  So a round takes the next B points and
+//   k_insert_spec    one wave per point, all against the graph as committed so far: the full insert (:73-117) with the list
+//                    writes held back as records, the set R of list ids it read kept, and every list it would write stamped
+//                    with its position in the round (wpos[list] = min position, tagged with the round's epoch);
+//   k_insert_check   point j is valid iff what it read is what a sequential run would have shown it, or would have led it the
+//                    same way: for every list of R_j stamped this round by a position j' < j -- a list it only SCANNED, to which
+//                    j' was merely appended (no shrink), is harmless unless j' is strictly closer to j's point than the best the
+//                    scan ended with (the appended entry is scanned last, strict '<', so nothing else about the hop changes: one
+//                    extra exact distance decides); the list it CONNECTED to, or a list that was shrunk (reordered), is a conflict.
+//                    c = the first invalid position;
+//   k_insert_commit  points < c write their lists (pairwise disjoint: two writers of one list conflict, the later one read it).
+// The host advances by c >= 1 (the first point of a round is always valid) and runs the next round from there; the points past c
+// are simply computed again.  (The reference's graphs are chains -- mean degree 1.6, ~30 hops per insert -- so the paths of a
+// round share most of their lists: stamp-only validation committed ~8 points per round at N = 100k, the scan rule above many more.)
+// Records, levels, slots, rows: exactly those of k_insert_full -- the host mirror and the tests do not see the difference.
+constexpr uint32_t kSpecRMax = 224;  // read-set capacity (lists read by one insert); more: the point is valid only as the first of a round
+__device__ __forceinline__ unsigned long long *spec_wpos(unsigned long long *wpos0, unsigned long long *wposU, uint32_t lid) {
+    return (lid & 0x80000000u) ? wposU + (lid & 0x7FFFFFFFu) : wpos0 + lid;
+}
+// COH: the shared graph arrays are read past the L1 (the persistent round loop below: other CUs write them between barriers)
+template <bool COH> __device__ __forceinline__ uint32_t ldc(const uint32_t *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH> __device__ __forceinline__ unsigned long long ldc64(const unsigned long long *p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+struct SpecArgs {
+    float *rows; uint32_t ld, dim; int metric;
+    uint32_t *adj, *deg, *adj_up, *deg_up, *lvl, *slot; uint32_t gstride, m;
+    uint32_t first_owner; const float *points; const InsertParam *params; uint32_t *recs;
+    unsigned long long *wpos0, *wposU; uint32_t *rset, *rcnt;
+};
+
+template <bool COH>
+__device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_t epoch_key, unsigned char *smem) {
+    float *rows = A.rows;
+    const uint32_t ld = A.ld, dim = A.dim, gstride = A.gstride, m = A.m;
+    const int metric = A.metric;
+    const int lane = threadIdx.x;
+    const uint32_t cap = (gstride + 1 + 3) & ~3u;
+    uint32_t *lst = reinterpret_cast<uint32_t *>(smem);       // [cap]
+    float *dst = reinterpret_cast<float *>(lst + cap);        // [cap]
+    uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
+    uint32_t *rs = srt + cap;                                 // [kSpecRMax] list ids read
+    float *rbd = reinterpret_cast<float *>(rs + kSpecRMax);   // [kSpecRMax] best distance each scan ended with
+    float *q = rbd + kSpecRMax;                               // [dim], 16-byte aligned (cap and kSpecRMax are multiples of 4)
+    const uint32_t rec_words = 4 + gstride;
+    const uint32_t owner = A.first_owner + b;
+    const uint32_t level = A.params[b].level, my_slot = A.params[b].slot, rec0 = A.params[b].rec_off, maxlev = A.params[b].maxlev_pre;
+    if (lane == 0) { A.lvl[owner] = level; A.slot[owner] = my_slot; }  // (nobody reaches `owner` before it is committed)
+    for (uint32_t i = lane; i < dim; i += kWave) {  // Node.init's copy (:24-26): to the row and to LDS
+        const float v = A.points[(size_t)b * dim + i];
+        rows[(size_t)owner * ld + i] = v;
+        q[i] = v;
+    }
+    __syncthreads();
+    uint32_t rn = 0;  // (wave-uniform)
+    uint32_t ep_cached = 0xFFFFFFFFu, ep_lvl = 0, ep_slot = 0;
+    // list of an EXISTING node at `layer` (nullptr: the node does not reach the layer); lid = its id in the stamp tables
+    auto list_of = [&](uint32_t node, uint32_t layer, const uint32_t *&dg, uint32_t &lid) -> const uint32_t * {
+        if (layer == 0) { dg = A.deg + node; lid = node; return A.adj + (size_t)node * gstride; }
+        if (node != ep_cached) { ep_cached = node; ep_lvl = ldc<COH>(A.lvl + node); ep_slot = ep_lvl ? ldc<COH>(A.slot + node) : 0u; }
+        if (ep_lvl < layer) return nullptr;
+        const uint32_t sl = ep_slot + layer - 1;
+        dg = A.deg_up + sl;
+        lid = 0x80000000u | sl;
+        return A.adj_up + (size_t)sl * gstride;
+    };
+    auto note_read = [&](uint32_t lid, float best_after_scan) {  // lid | 0x40000000: read to connect (its new contents derive from it)
+        if (rn < kSpecRMax) { if (lane == 0) { rs[rn] = lid; rbd[rn] = best_after_scan; } }
+        rn += 1;  // (past the capacity: counted, the check treats the point as unverifiable)
+    };
+    uint32_t ep = 0;  // the entry point is the first node, always (hnsw.zig:84, :111)
+    float cur = 0.0f;
+    if (lane == 0) cur = exact_dist_rt(metric, q, rows + (size_t)ep * ld, dim);  // :86
+    cur = __shfl(cur, 0);
+    for (uint32_t layer = 0; layer <= maxlev; ++layer) {  // :88
+        bool changed = true;
+        while (changed) {  // :90-104
+            changed = false;
+            const uint32_t *dgp = nullptr;
+            uint32_t lid = 0;
+            const uint32_t *al = list_of(ep, layer, dgp, lid);
+            if (!al) break;
+            const uint32_t nb0 = (uint32_t)lane < gstride ? ldc<COH>(al + lane) : 0u;
+            const uint32_t dg = min(ldc<COH>(dgp), gstride);
+            float best_d = cur;
+            uint32_t best_j = 0xFFFFFFFFu, best_id = ep;
+            for (uint32_t base = 0; base < dg; base += kWave) {
+                const uint32_t j = base + lane;
+                float d = 0.0f;
+                uint32_t nb = 0;
+                const bool act = j < dg;
+                if (act) {
+                    nb = base == 0 ? nb0 : ldc<COH>(al + j);
+                    d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
+                }
+                float md = act ? d : __builtin_inff();
+                uint32_t mj = act ? j : 0xFFFFFFFFu, mid = nb;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(md, off);
+                    const uint32_t oj = __shfl_xor(mj, off), oid = __shfl_xor(mid, off);
+                    if (od < md || (od == md && oj < mj)) { md = od; mj = oj; mid = oid; }
+                }
+                if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
+            }
+            note_read(lid, best_d);
+            if (best_j != 0xFFFFFFFFu) { ep = best_id; cur = best_d; changed = true; }
+        }
+        if (layer > level) continue;  // :106 -- above the new node's level only the scan runs
+        uint32_t *rec = A.recs + (size_t)(rec0 + layer) * rec_words;
+        // connect(owner, ep, layer) :119-141.  The owner's list is new: [ep] (one entry, no shrink).  ep's list, if ep has the layer:
+        // its committed list + owner, shrunk (:143-170) when it exceeds m -- kept in the record, written by the commit step.
+        const uint32_t *dgp = nullptr;
+        uint32_t lid = 0;
+        const uint32_t *al = list_of(ep, layer, dgp, lid);
+        uint32_t ep_n = 0xFFFFFFFFu;
+        if (al) {
+            note_read(lid | 0x40000000u, 0.0f);
+            const uint32_t n0 = min(ldc<COH>(dgp), gstride);
+            for (uint32_t i = lane; i < n0; i += kWave) lst[i] = ldc<COH>(al + i);
+            if (lane == 0) lst[n0] = owner;  // append
+            uint32_t n = n0 + 1;
+            const bool shrunk = n > m;
+            __syncthreads();
+            if (n > m) {  // shrinkConnections :143-170
+                const float *o = rows + (size_t)ep * ld;
+                for (uint32_t i = lane; i < n; i += kWave)
+                    dst[i] = lst[i] == owner ? exact_dist_rt(metric, o, q, dim) : exact_dist_rt(metric, o, rows + (size_t)lst[i] * ld, dim);
+                __syncthreads();
+                for (uint32_t i = lane; i < n; i += kWave) {
+                    const float di = dst[i];
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < n; ++j) {
+                        const float dj = dst[j];
+                        rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+                    }
+                    srt[rank] = lst[i];
+                }
+                __syncthreads();
+                n = m;
+                for (uint32_t i = lane; i < n; i += kWave) lst[i] = srt[i];
+                __syncthreads();
+            }
+            if (n > gstride) n = gstride;
+            for (uint32_t i = lane; i < n; i += kWave) rec[4 + i] = lst[i];
+            ep_n = n;
+            if (lane == 0) atomicMin(spec_wpos(A.wpos0, A.wposU, lid), ((unsigned long long)epoch_key << 32) | (b << 1) | (shrunk ? 1u : 0u));
+            __syncthreads();
+        }
+        if (lane == 0) {
+            rec[0] = ep;
+            rec[1] = 1u;  // the owner's list: [ep]
+            rec[2] = ep_n == 0xFFFFFFFFu ? 0u : ep_n;
+            rec[3] = ep_n == 0xFFFFFFFFu ? 0u : 1u;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < min(rn, kSpecRMax); i += kWave) {
+        A.rset[((size_t)b * kSpecRMax + i) * 2] = rs[i];
+        A.rset[((size_t)b * kSpecRMax + i) * 2 + 1] = __float_as_uint(rbd[i]);
+    }
+    if (lane == 0) A.rcnt[b] = rn;
+}
+
+// is position b of the round one a sequential run would have led another way?  (wave-uniform result; see k_insert_spec)
+template <bool COH>
+__device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32_t epoch_key) {
+    const int lane = threadIdx.x;
+    if (b == 0) return false;  // the first point of a round read the committed graph only
+    const uint32_t n = ldc<COH>(A.rcnt + b);
+    bool bad = n > kSpecRMax;
+    for (uint32_t i = lane; i < min(n, kSpecRMax); i += kWave) {
+        const uint32_t r = ldc<COH>(A.rset + ((size_t)b * kSpecRMax + i) * 2);
+        const unsigned long long v = ldc64<COH>(spec_wpos(A.wpos0, A.wposU, r & 0xBFFFFFFFu));
+        const uint32_t wb = ((uint32_t)v & 0x7FFFFFFFu) >> 1;
+        if ((uint32_t)(v >> 32) != epoch_key || wb >= b) continue;  // not written this round by an earlier point
+        if ((r & 0x40000000u) || ((uint32_t)v & 1u)) { bad = true; continue; }  // my connect list, or a list that was shrunk
+        // scanned only, and the writer was appended at its end: the hop is unchanged unless the writer beats the scan's best
+        const float d = exact_dist_rt(A.metric, A.rows + (size_t)(A.first_owner + b) * A.ld, A.rows + (size_t)(A.first_owner + wb) * A.ld, A.dim);
+        bad |= d < __uint_as_float(ldc<COH>(A.rset + ((size_t)b * kSpecRMax + i) * 2 + 1));
+    }
+    return __ballot(bad) != 0;
+}
+
+// position b writes what it recorded: ep's list and degree per layer (where ep has the layer), its own list [ep]
+template <bool COH>
+__device__ __forceinline__ void commit_body(const SpecArgs &A, uint32_t b) {
+    const int lane = threadIdx.x;
+    const uint32_t gstride = A.gstride;
+    const uint32_t owner = A.first_owner + b, level = A.params[b].level, my_slot = A.params[b].slot, rec0 = A.params[b].rec_off, maxlev = A.params[b].maxlev_pre;
+    const uint32_t rec_words = 4 + gstride;
+    for (uint32_t layer = 0; layer <= min(level, maxlev); ++layer) {
+        const uint32_t *rec = A.recs + (size_t)(rec0 + layer) * rec_words;
+        const uint32_t ep = ldc<COH>(rec + 0);
+        uint32_t *ol = layer == 0 ? A.adj + (size_t)owner * gstride : A.adj_up + (size_t)(my_slot + layer - 1) * gstride;
+        uint32_t *od = layer == 0 ? A.deg + owner : A.deg_up + (my_slot + layer - 1);
+        if (lane == 0) { ol[0] = ep; *od = 1u; }
+        if (ldc<COH>(rec + 3)) {
+            const uint32_t n = ldc<COH>(rec + 2);
+            const uint32_t es = layer == 0 ? 0u : ldc<COH>(A.slot + ep) + layer - 1;
+            uint32_t *el = layer == 0 ? A.adj + (size_t)ep * gstride : A.adj_up + (size_t)es * gstride;
+            uint32_t *ed = layer == 0 ? A.deg + ep : A.deg_up + es;
+            for (uint32_t i = lane; i < n; i += kWave) el[i] = ldc<COH>(rec + 4 + i);
+            if (lane == 0) *ed = n;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_insert_spec(SpecArgs A, uint32_t epoch_key) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    spec_body<false>(A, blockIdx.x, epoch_key, smem);
+}
+// c = first position of the round that a sequential run would have led another way; cmin starts at B
+__global__ __launch_bounds__(64) void k_insert_check(SpecArgs A, uint32_t epoch_key, uint32_t *cmin) {
+    if (check_body<false>(A, blockIdx.x, epoch_key) && threadIdx.x == 0) atomicMin(cmin, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_insert_commit(SpecArgs A, const uint32_t *__restrict__ cmin) {
+    if (blockIdx.x < *cmin) commit_body<false>(A, blockIdx.x);
+}
+
+// The rounds of a whole chunk in ONE cooperative launch of B workgroups (one wave each): speculate | check | commit with a grid
+// barrier between the phases, the next round starting at the first point not committed -- no host round trip per round (the
+// three-launch form above costs ~80 us per round, of which the GPU works ~35).  ctl: [0] barrier counter (zero at launch),
+// [1], [2] the rounds' commit counts (even / odd rounds, preset to B), [3] epoch counter (in: first epoch, out: next free one).
+// (returns false if the other workgroups never arrived -- ~10 s of polling: every workgroup then leaves the loop instead of
+// spinning for ever, ctl[5] tells the host; a cooperative launch keeps them co-resident, so this is a guard, not a path)
+__device__ __forceinline__ bool spec_grid_barrier(uint32_t *ctl, uint32_t nblocks, uint32_t &gen) {
+    __shared__ uint32_t ok_s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        gen += 1;
+        atomicAdd(ctl, 1u);
+        uint32_t spins = 0, ok = 1;
+        while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen * nblocks) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 25) || __hip_atomic_load(ctl + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(ctl + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        __threadfence();
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+__global__ __launch_bounds__(64) void k_insert_spec_loop(SpecArgs A0, uint32_t n_chunk, uint32_t *ctl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t B = gridDim.x, b = blockIdx.x;
+    const uint32_t epoch0 = __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t gen = 0, pos = 0, round = 0;
+    while (pos < n_chunk) {  // (pos, round: the same in every workgroup)
+        SpecArgs A = A0;
+        A.first_owner = A0.first_owner + pos;
+        A.points = A0.points + (size_t)pos * A0.dim;
+        A.params = A0.params + pos;
+        // (recs offsets are chunk-wide: params[].rec_off; rset / rcnt are per position of the round)
+        const uint32_t nb = min(B, n_chunk - pos);
+        const uint32_t key = 0xFFFFFFFFu - (epoch0 + round);
+        uint32_t *cm = ctl + 1 + (round & 1u);
+        if (b < nb) spec_body<true>(A, b, key, smem);
+        if (b == 0 && threadIdx.x == 0) __hip_atomic_store(ctl + 1 + ((round + 1) & 1u), B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!spec_grid_barrier(ctl, B, gen)) return;
+        if (b < nb && check_body<true>(A, b, key) && threadIdx.x == 0) atomicMin(cm, b);
+        if (!spec_grid_barrier(ctl, B, gen)) return;
+        const uint32_t c = min(__hip_atomic_load(cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nb);
+        if (b < c) commit_body<true>(A, b);
+        if (!spec_grid_barrier(ctl, B, gen)) return;
+        pos += c;  // c >= 1: position 0 is always valid
+        round += 1;
+    }
+    if (b == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(ctl + 3, epoch0 + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctl[4] = round;
+    }
+}
+
+static SpecArgs make_spec_args(const zvdb_hip_index *h, uint32_t first_owner, const float *points, const InsertParam *params, uint32_t *recs,
+                               unsigned long long *wpos0, unsigned long long *wposU, uint32_t *rset, uint32_t *rcnt) {
+    SpecArgs A;
+    A.rows = h->rows; A.ld = h->ld; A.dim = h->dim; A.metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
+    A.adj = h->adj; A.deg = h->deg; A.adj_up = h->adj_up; A.deg_up = h->deg_up; A.lvl = h->lvl; A.slot = h->slot; A.gstride = h->gstride; A.m = h->m;
+    A.first_owner = first_owner; A.points = points; A.params = params; A.recs = recs;
+    A.wpos0 = wpos0; A.wposU = wposU; A.rset = rset; A.rcnt = rcnt;
+    return A;
+}
+static size_t spec_lds_bytes(const zvdb_hip_index *h) {
+    return (3ull * ((h->gstride + 1 + 3) & ~3u) + 2 * kSpecRMax) * sizeof(uint32_t) + (size_t)h->dim * sizeof(float);
+}
+
+int launch_insert_spec_round(const zvdb_hip_index *h, uint32_t first_owner, uint32_t B, const float *points, const InsertParam *params,
+                             uint32_t *recs, unsigned long long *wpos0, unsigned long long *wposU, uint32_t epoch, uint32_t *rset,
+                             uint32_t *rcnt, uint32_t *cmin, hipStream_t s) {
+    const size_t lds = spec_lds_bytes(h);
+    ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_insert_spec), lds));
+    const uint32_t key = 0xFFFFFFFFu - epoch;
+    const SpecArgs A = make_spec_args(h, first_owner, points, params, recs, wpos0, wposU, rset, rcnt);
+    hipLaunchKernelGGL(k_insert_spec, dim3(B), dim3(64), lds, s, A, key);
+    hipLaunchKernelGGL(k_insert_check, dim3(B), dim3(64), 0, s, A, key, cmin);
+    hipLaunchKernelGGL(k_insert_commit, dim3(B), dim3(64), 0, s, A, cmin);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+// the whole chunk in one cooperative launch; ctl = 8 device words (see k_insert_spec_loop): set here; after it ran, ctl[4] = rounds used
+int launch_insert_spec_loop(const zvdb_hip_index *h, uint32_t first_owner, uint32_t n_chunk, uint32_t B, const float *points,
+                            const InsertParam *params, uint32_t *recs, unsigned long long *wpos0, unsigned long long *wposU, uint32_t *rset,
+                            uint32_t *rcnt, uint32_t *ctl, uint32_t epoch, hipStream_t s) {
+    const size_t lds = spec_lds_bytes(h);
+    ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_insert_spec_loop), lds));
+    const uint32_t init[6] = {0u, B, B, epoch, 0u, 0u};
+    ZV_HIP(hipMemcpyAsync(ctl, init, sizeof(init), hipMemcpyHostToDevice, s));
+    SpecArgs A = make_spec_args(h, first_owner, points, params, recs, wpos0, wposU, rset, rcnt);
+    void *args[] = {&A, &n_chunk, &ctl};
+    ZV_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_insert_spec_loop), dim3(B), dim3(64), args, (unsigned int)lds, s));
+    return ZVDB_OK;
+}
+uint32_t insert_spec_rmax() { return kSpecRMax; }
+
 __global__ __launch_bounds__(256) void k_copy_row(const float *__restrict__ src, float *__restrict__ dst, uint32_t dim) {
     for (uint32_t i = threadIdx.x; i < dim; i += 256) dst[i] = src[i];
 }
