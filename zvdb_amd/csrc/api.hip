@@ -929,7 +929,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                                                            h->spec_wpos0, h->spec_wposU, d_rset, d_rcnt, d_cmin, h->spec_epoch + 1, h->stream);
                     if (rc == ZVDB_OK) {
                         looped = true;
-                        ZV_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h_cmin), d_cmin, 32, hipMemcpyDeviceToHost, h->stream));  // read after the sync below
+                        ZV_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h_cmin), d_cmin, 48, hipMemcpyDeviceToHost, h->stream));  // read after the sync below
                         spec_launched = lb;
                     } else {
                         (void)hipGetLastError();  // (no cooperative launch here: the round-by-round form below)
@@ -967,6 +967,9 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                 h->spec_epoch += rounds;
                 spec_dbg_rounds = rounds;
                 spec_dbg_launched = spec_dbg_launched * rounds;
+                if (getenv("ZVDB_INSERT_SPEC_DEBUG"))
+                    fprintf(stderr, "[zvdb insert spec] rounds stopped by: same connect list %u, scanned list shrunk %u, appended point closer %u, read set overflow %u\n",
+                            ctl_h[8], ctl_h[9], ctl_h[10], ctl_h[11]);
             }
             if (spec && getenv("ZVDB_INSERT_SPEC_DEBUG"))
                 fprintf(stderr, "[zvdb insert spec] chunk of %llu points at id %llu: %llu rounds%s, %llu point-slots launched (%.1f committed per round)\n",

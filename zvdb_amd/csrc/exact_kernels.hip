@@ -593,20 +593,26 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
 
 // is position b of the round one a sequential run would have led another way?  (wave-uniform result; see k_insert_spec)
 template <bool COH>
-__device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32_t epoch_key) {
+__device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32_t epoch_key, uint32_t *why = nullptr) {
     const int lane = threadIdx.x;
     if (b == 0) return false;  // the first point of a round read the committed graph only
     const uint32_t n = ldc<COH>(A.rcnt + b);
     bool bad = n > kSpecRMax;
+    uint32_t cause = bad ? 8u : 0u;  // (diagnostic: 1 connect list, 2 shrunk list, 4 beaten by an appended point, 8 read-set overflow)
     for (uint32_t i = lane; i < min(n, kSpecRMax); i += kWave) {
         const uint32_t r = ldc<COH>(A.rset + ((size_t)b * kSpecRMax + i) * 2);
         const unsigned long long v = ldc64<COH>(spec_wpos(A.wpos0, A.wposU, r & 0xBFFFFFFFu));
         const uint32_t wb = ((uint32_t)v & 0x7FFFFFFFu) >> 1;
         if ((uint32_t)(v >> 32) != epoch_key || wb >= b) continue;  // not written this round by an earlier point
-        if ((r & 0x40000000u) || ((uint32_t)v & 1u)) { bad = true; continue; }  // my connect list, or a list that was shrunk
+        if ((r & 0x40000000u) || ((uint32_t)v & 1u)) { bad = true; cause |= (r & 0x40000000u) ? 1u : 2u; continue; }  // my connect list, or a list that was shrunk
         // scanned only, and the writer was appended at its end: the hop is unchanged unless the writer beats the scan's best
         const float d = exact_dist_rt(A.metric, A.rows + (size_t)(A.first_owner + b) * A.ld, A.rows + (size_t)(A.first_owner + wb) * A.ld, A.dim);
-        bad |= d < __uint_as_float(ldc<COH>(A.rset + ((size_t)b * kSpecRMax + i) * 2 + 1));
+        if (d < __uint_as_float(ldc<COH>(A.rset + ((size_t)b * kSpecRMax + i) * 2 + 1))) { bad = true; cause |= 4u; }
+    }
+    if (why) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cause |= __shfl_xor(cause, off);
+        *why = cause;
     }
     return __ballot(bad) != 0;
 }
@@ -692,9 +698,15 @@ __global__ __launch_bounds__(64) void k_insert_spec_loop(SpecArgs A0, uint32_t n
         if (b < nb) spec_body<true>(A, b, key, smem);
         if (b == 0 && threadIdx.x == 0) __hip_atomic_store(ctl + 1 + ((round + 1) & 1u), B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!spec_grid_barrier(ctl, B, gen)) return;
-        if (b < nb && check_body<true>(A, b, key) && threadIdx.x == 0) atomicMin(cm, b);
+        uint32_t why = 0;
+        const bool bad = b < nb && check_body<true>(A, b, key, &why);
+        if (bad && threadIdx.x == 0) atomicMin(cm, b);
         if (!spec_grid_barrier(ctl, B, gen)) return;
         const uint32_t c = min(__hip_atomic_load(cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nb);
+        if (bad && b == c && threadIdx.x == 0) {  // diagnostic: why the round stopped here (ctl[8 + cause bit])
+            for (uint32_t bit = 0; bit < 4; ++bit)
+                if (why & (1u << bit)) atomicAdd(ctl + 8 + bit, 1u);
+        }
         if (b < c) commit_body<true>(A, b);
         if (!spec_grid_barrier(ctl, B, gen)) return;
         pos += c;  // c >= 1: position 0 is always valid
@@ -739,7 +751,7 @@ int launch_insert_spec_loop(const zvdb_hip_index *h, uint32_t first_owner, uint3
                             uint32_t *rcnt, uint32_t *ctl, uint32_t epoch, hipStream_t s) {
     const size_t lds = spec_lds_bytes(h);
     ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_insert_spec_loop), lds));
-    const uint32_t init[6] = {0u, B, B, epoch, 0u, 0u};
+    const uint32_t init[12] = {0u, B, B, epoch, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     ZV_HIP(hipMemcpyAsync(ctl, init, sizeof(init), hipMemcpyHostToDevice, s));
     SpecArgs A = make_spec_args(h, first_owner, points, params, recs, wpos0, wposU, rset, rcnt);
     void *args[] = {&A, &n_chunk, &ctl};
