@@ -795,7 +795,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
     const char *spec_env = getenv("ZVDB_INSERT_SPEC");
     const bool spec = !(spec_env && spec_env[0] == '0') && m >= 1;
     const uint32_t spec_bmax = 1024;
-    const size_t spec_rsb = round_up64((size_t)spec_bmax * insert_spec_rmax() * 8, 256), spec_rcb = round_up64((size_t)spec_bmax * 4, 256);
+    const size_t spec_rsb = round_up64((size_t)spec_bmax * insert_spec_rmax() * 16, 256), spec_rcb = round_up64((size_t)spec_bmax * 4, 256);
     const size_t spec_extra = spec ? spec_rsb + spec_rcb + 256 : 0;
     {   // Everything that can fail for want of memory is reserved for ALL n points before the first launch, so that a
         // failure leaves the index as it was (the reference's insert leaves a consistent index on error: errdefer,
@@ -968,7 +968,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                 spec_dbg_rounds = rounds;
                 spec_dbg_launched = spec_dbg_launched * rounds;
                 if (getenv("ZVDB_INSERT_SPEC_DEBUG"))
-                    fprintf(stderr, "[zvdb insert spec] rounds stopped by: same connect list %u, scanned list shrunk %u, appended point closer %u, read set overflow %u\n",
+                    fprintf(stderr, "[zvdb insert spec] rounds stopped by: same connect list %u, re-scanned list leads elsewhere %u, appended point closer %u, read set overflow %u\n",
                             ctl_h[8], ctl_h[9], ctl_h[10], ctl_h[11]);
             }
             if (spec && getenv("ZVDB_INSERT_SPEC_DEBUG"))

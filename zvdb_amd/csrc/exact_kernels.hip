@@ -470,7 +470,9 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
     uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);  // [cap]
     uint32_t *rs = srt + cap;                                 // [kSpecRMax] list ids read
     float *rbd = reinterpret_cast<float *>(rs + kSpecRMax);   // [kSpecRMax] best distance each scan ended with
-    float *q = rbd + kSpecRMax;                               // [dim], 16-byte aligned (cap and kSpecRMax are multiples of 4)
+    uint32_t *rid = reinterpret_cast<uint32_t *>(rbd + kSpecRMax);  // [kSpecRMax] the node it moved to (0xFFFFFFFF: it stayed)
+    uint32_t *rly = rid + kSpecRMax;                          // [kSpecRMax] the list's layer
+    float *q = reinterpret_cast<float *>(rly + kSpecRMax);    // [dim], 16-byte aligned (cap and kSpecRMax are multiples of 4)
     const uint32_t rec_words = 4 + gstride;
     const uint32_t owner = A.first_owner + b;
     const uint32_t level = A.params[b].level, my_slot = A.params[b].slot, rec0 = A.params[b].rec_off, maxlev = A.params[b].maxlev_pre;
@@ -493,8 +495,8 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
         lid = 0x80000000u | sl;
         return A.adj_up + (size_t)sl * gstride;
     };
-    auto note_read = [&](uint32_t lid, float best_after_scan) {  // lid | 0x40000000: read to connect (its new contents derive from it)
-        if (rn < kSpecRMax) { if (lane == 0) { rs[rn] = lid; rbd[rn] = best_after_scan; } }
+    auto note_read = [&](uint32_t lid, float best_after_scan, uint32_t moved_to, uint32_t layer) {  // lid | 0x40000000: read to connect
+        if (rn < kSpecRMax) { if (lane == 0) { rs[rn] = lid; rbd[rn] = best_after_scan; rid[rn] = moved_to; rly[rn] = layer; } }
         rn += 1;  // (past the capacity: counted, the check treats the point as unverifiable)
     };
     uint32_t ep = 0;  // the entry point is the first node, always (hnsw.zig:84, :111)
@@ -532,7 +534,7 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
                 }
                 if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
             }
-            note_read(lid, best_d);
+            note_read(lid, best_d, best_j != 0xFFFFFFFFu ? best_id : 0xFFFFFFFFu, layer);
             if (best_j != 0xFFFFFFFFu) { ep = best_id; cur = best_d; changed = true; }
         }
         if (layer > level) continue;  // :106 -- above the new node's level only the scan runs
@@ -544,7 +546,7 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
         const uint32_t *al = list_of(ep, layer, dgp, lid);
         uint32_t ep_n = 0xFFFFFFFFu;
         if (al) {
-            note_read(lid | 0x40000000u, 0.0f);
+            note_read(lid | 0x40000000u, 0.0f, 0xFFFFFFFFu, layer);
             const uint32_t n0 = min(ldc<COH>(dgp), gstride);
             for (uint32_t i = lane; i < n0; i += kWave) lst[i] = ldc<COH>(al + i);
             if (lane == 0) lst[n0] = owner;  // append
@@ -585,29 +587,78 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
     }
     __syncthreads();
     for (uint32_t i = lane; i < min(rn, kSpecRMax); i += kWave) {
-        A.rset[((size_t)b * kSpecRMax + i) * 2] = rs[i];
-        A.rset[((size_t)b * kSpecRMax + i) * 2 + 1] = __float_as_uint(rbd[i]);
+        uint32_t *e = A.rset + ((size_t)b * kSpecRMax + i) * 4;
+        e[0] = rs[i];
+        e[1] = __float_as_uint(rbd[i]);
+        e[2] = rid[i];
+        e[3] = rly[i];
     }
     if (lane == 0) A.rcnt[b] = rn;
 }
 
 // is position b of the round one a sequential run would have led another way?  (wave-uniform result; see k_insert_spec)
+// A list b only scanned and that an earlier point SHRANK (reordered) is scanned again here, as the earlier point's record leaves it:
+// the hop is unchanged iff it ends on the same node at the same distance (or still finds nothing closer) -- every insert scans node
+// 0's list and one in ten ends there and shrinks it, so without this the rounds stop at the first such point.
 template <bool COH>
 __device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32_t epoch_key, uint32_t *why = nullptr) {
     const int lane = threadIdx.x;
     if (b == 0) return false;  // the first point of a round read the committed graph only
     const uint32_t n = ldc<COH>(A.rcnt + b);
     bool bad = n > kSpecRMax;
-    uint32_t cause = bad ? 8u : 0u;  // (diagnostic: 1 connect list, 2 shrunk list, 4 beaten by an appended point, 8 read-set overflow)
-    for (uint32_t i = lane; i < min(n, kSpecRMax); i += kWave) {
-        const uint32_t r = ldc<COH>(A.rset + ((size_t)b * kSpecRMax + i) * 2);
-        const unsigned long long v = ldc64<COH>(spec_wpos(A.wpos0, A.wposU, r & 0xBFFFFFFFu));
-        const uint32_t wb = ((uint32_t)v & 0x7FFFFFFFu) >> 1;
-        if ((uint32_t)(v >> 32) != epoch_key || wb >= b) continue;  // not written this round by an earlier point
-        if ((r & 0x40000000u) || ((uint32_t)v & 1u)) { bad = true; cause |= (r & 0x40000000u) ? 1u : 2u; continue; }  // my connect list, or a list that was shrunk
-        // scanned only, and the writer was appended at its end: the hop is unchanged unless the writer beats the scan's best
-        const float d = exact_dist_rt(A.metric, A.rows + (size_t)(A.first_owner + b) * A.ld, A.rows + (size_t)(A.first_owner + wb) * A.ld, A.dim);
-        if (d < __uint_as_float(ldc<COH>(A.rset + ((size_t)b * kSpecRMax + i) * 2 + 1))) { bad = true; cause |= 4u; }
+    uint32_t cause = bad ? 8u : 0u;  // (diagnostic: 1 connect list, 2 a re-scanned list leads elsewhere, 4 beaten by an appended point, 8 read-set overflow)
+    const float *myrow = A.rows + (size_t)(A.first_owner + b) * A.ld;
+    const uint32_t rec_words = 4 + A.gstride;
+    for (uint32_t i0 = 0; i0 < min(n, kSpecRMax); i0 += kWave) {
+        const uint32_t i = i0 + lane;
+        bool rescan = false;
+        uint32_t wb = 0, bid = 0, layer = 0;
+        float bd = 0.0f;
+        if (i < min(n, kSpecRMax)) {
+            const uint32_t *e = A.rset + ((size_t)b * kSpecRMax + i) * 4;
+            const uint32_t r = ldc<COH>(e);
+            const unsigned long long v = ldc64<COH>(spec_wpos(A.wpos0, A.wposU, r & 0xBFFFFFFFu));
+            wb = ((uint32_t)v & 0x7FFFFFFFu) >> 1;
+            if ((uint32_t)(v >> 32) == epoch_key && wb < b) {  // written this round by an earlier point
+                bd = __uint_as_float(ldc<COH>(e + 1));
+                if (r & 0x40000000u) { bad = true; cause |= 1u; }  // my connect list
+                else if ((uint32_t)v & 1u) { rescan = true; bid = ldc<COH>(e + 2); layer = ldc<COH>(e + 3); }  // shrunk: scan it again
+                else {  // the writer was appended at its end: the hop is unchanged unless the writer beats the scan's best
+                    const float d = exact_dist_rt(A.metric, myrow, A.rows + (size_t)(A.first_owner + wb) * A.ld, A.dim);
+                    if (d < bd) { bad = true; cause |= 4u; }
+                }
+            }
+        }
+        unsigned long long todo = __ballot(rescan);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t wbl = (uint32_t)__shfl((int)wb, l), bidl = (uint32_t)__shfl((int)bid, l), lyl = (uint32_t)__shfl((int)layer, l);
+            const float bdl = __shfl(bd, l);
+            const uint32_t *rec = A.recs + (size_t)(A.params[wbl].rec_off + lyl) * rec_words;  // the list as the earlier point leaves it
+            const uint32_t ln = min(ldc<COH>(rec + 2), A.gstride);
+            float md = __builtin_inff();
+            uint32_t mj = 0xFFFFFFFFu, mid = 0;
+            for (uint32_t base = 0; base < ln; base += kWave) {  // (the scan of spec_body: strict '<', the earliest of equal minima)
+                const uint32_t j = base + lane;
+                float d = __builtin_inff();
+                uint32_t x = 0, jj = 0xFFFFFFFFu;
+                if (j < ln) {
+                    x = ldc<COH>(rec + 4 + j);
+                    d = exact_dist_rt(A.metric, myrow, A.rows + (size_t)x * A.ld, A.dim);
+                    jj = j;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(d, off);
+                    const uint32_t oj = __shfl_xor(jj, off), ox = __shfl_xor(x, off);
+                    if (od < d || (od == d && oj < jj)) { d = od; jj = oj; x = ox; }
+                }
+                if (jj != 0xFFFFFFFFu && d < md) { md = d; mj = jj; mid = x; }
+            }
+            const bool same = bidl == 0xFFFFFFFFu ? !(mj != 0xFFFFFFFFu && md < bdl) : (mj != 0xFFFFFFFFu && mid == bidl && md == bdl);
+            if (!same) { bad = true; cause |= 2u; }
+        }
     }
     if (why) {
 #pragma unroll
@@ -728,7 +779,7 @@ static SpecArgs make_spec_args(const zvdb_hip_index *h, uint32_t first_owner, co
     return A;
 }
 static size_t spec_lds_bytes(const zvdb_hip_index *h) {
-    return (3ull * ((h->gstride + 1 + 3) & ~3u) + 2 * kSpecRMax) * sizeof(uint32_t) + (size_t)h->dim * sizeof(float);
+    return (3ull * ((h->gstride + 1 + 3) & ~3u) + 4 * kSpecRMax) * sizeof(uint32_t) + (size_t)h->dim * sizeof(float);
 }
 
 int launch_insert_spec_round(const zvdb_hip_index *h, uint32_t first_owner, uint32_t B, const float *points, const InsertParam *params,
