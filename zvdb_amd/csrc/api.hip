@@ -795,7 +795,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
     const char *spec_env = getenv("ZVDB_INSERT_SPEC");
     const bool spec = !(spec_env && spec_env[0] == '0') && m >= 1;
     const uint32_t spec_bmax = 1024;
-    const size_t spec_rsb = round_up64((size_t)spec_bmax * insert_spec_rmax() * 16, 256), spec_rcb = round_up64((size_t)spec_bmax * 4, 256);
+    const size_t spec_rsb = round_up64((size_t)spec_bmax * insert_spec_rmax() * 16, 256), spec_rcb = round_up64((size_t)spec_bmax * 8, 256);  // read counts [1024] + deferred-connect masks [1024]
     const size_t spec_extra = spec ? spec_rsb + spec_rcb + 256 : 0;
     {   // Everything that can fail for want of memory is reserved for ALL n points before the first launch, so that a
         // failure leaves the index as it was (the reference's insert leaves a consistent index on error: errdefer,
@@ -929,7 +929,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                                                            h->spec_wpos0, h->spec_wposU, d_rset, d_rcnt, d_cmin, h->spec_epoch + 1, h->stream);
                     if (rc == ZVDB_OK) {
                         looped = true;
-                        ZV_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h_cmin), d_cmin, 48, hipMemcpyDeviceToHost, h->stream));  // read after the sync below
+                        ZV_HIP(hipMemcpyAsync(const_cast<uint32_t *>(h_cmin), d_cmin, 52, hipMemcpyDeviceToHost, h->stream));  // read after the sync below
                         spec_launched = lb;
                     } else {
                         (void)hipGetLastError();  // (no cooperative launch here: the round-by-round form below)
@@ -968,8 +968,8 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                 spec_dbg_rounds = rounds;
                 spec_dbg_launched = spec_dbg_launched * rounds;
                 if (getenv("ZVDB_INSERT_SPEC_DEBUG"))
-                    fprintf(stderr, "[zvdb insert spec] rounds stopped by: same connect list %u, re-scanned list leads elsewhere %u, appended point closer %u, read set overflow %u\n",
-                            ctl_h[8], ctl_h[9], ctl_h[10], ctl_h[11]);
+                    fprintf(stderr, "[zvdb insert spec] rounds stopped by: a scanned list with two earlier writers %u, re-scanned list leads elsewhere %u, appended point closer %u, read set overflow %u; deferred connects redone %u\n",
+                            ctl_h[8], ctl_h[9], ctl_h[10], ctl_h[11], ctl_h[12]);
             }
             if (spec && getenv("ZVDB_INSERT_SPEC_DEBUG"))
                 fprintf(stderr, "[zvdb insert spec] chunk of %llu points at id %llu: %llu rounds%s, %llu point-slots launched (%.1f committed per round)\n",

@@ -451,11 +451,31 @@ template <bool COH> __device__ __forceinline__ unsigned long long ldc64(const un
     if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
 }
+// stamp of a list: [round key : 32 | second-smallest writer position : 11 (0x7FF none) | smallest : 11 | the smallest one shrank it : 1]
+__device__ __forceinline__ void spec_stamp(unsigned long long *p, uint32_t key, uint32_t b, uint32_t shrunk) {
+    unsigned long long old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        uint32_t lo;
+        if ((uint32_t)(old >> 32) != key) {
+            lo = (0x7FFu << 12) | (b << 1) | shrunk;  // first writer of this round (whatever an older round left is void)
+        } else {
+            uint32_t m1 = ((uint32_t)old >> 1) & 0x7FFu, s1 = (uint32_t)old & 1u, m2 = ((uint32_t)old >> 12) & 0x7FFu;
+            if (b < m1) { m2 = m1; m1 = b; s1 = shrunk; }
+            else if (b != m1 && b < m2) m2 = b;
+            lo = (m2 << 12) | (m1 << 1) | s1;
+        }
+        const unsigned long long nv = ((unsigned long long)key << 32) | lo;
+        if (nv == old) return;
+        const unsigned long long seen = atomicCAS(p, old, nv);
+        if (seen == old) return;
+        old = seen;
+    }
+}
 struct SpecArgs {
     float *rows; uint32_t ld, dim; int metric;
     uint32_t *adj, *deg, *adj_up, *deg_up, *lvl, *slot; uint32_t gstride, m;
     uint32_t first_owner; const float *points; const InsertParam *params; uint32_t *recs;
-    unsigned long long *wpos0, *wposU; uint32_t *rset, *rcnt;
+    unsigned long long *wpos0, *wposU; uint32_t *rset, *rcnt, *defer;
 };
 
 template <bool COH>
@@ -476,7 +496,7 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
     const uint32_t rec_words = 4 + gstride;
     const uint32_t owner = A.first_owner + b;
     const uint32_t level = A.params[b].level, my_slot = A.params[b].slot, rec0 = A.params[b].rec_off, maxlev = A.params[b].maxlev_pre;
-    if (lane == 0) { A.lvl[owner] = level; A.slot[owner] = my_slot; }  // (nobody reaches `owner` before it is committed)
+    if (lane == 0) { A.lvl[owner] = level; A.slot[owner] = my_slot; A.defer[b] = 0u; }  // (nobody reaches `owner` before it is committed)
     for (uint32_t i = lane; i < dim; i += kWave) {  // Node.init's copy (:24-26): to the row and to LDS
         const float v = A.points[(size_t)b * dim + i];
         rows[(size_t)owner * ld + i] = v;
@@ -575,7 +595,7 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
             if (n > gstride) n = gstride;
             for (uint32_t i = lane; i < n; i += kWave) rec[4 + i] = lst[i];
             ep_n = n;
-            if (lane == 0) atomicMin(spec_wpos(A.wpos0, A.wposU, lid), ((unsigned long long)epoch_key << 32) | (b << 1) | (shrunk ? 1u : 0u));
+            if (lane == 0) spec_stamp(spec_wpos(A.wpos0, A.wposU, lid), epoch_key, b, shrunk ? 1u : 0u);
             __syncthreads();
         }
         if (lane == 0) {
@@ -600,8 +620,13 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
 // A list b only scanned and that an earlier point SHRANK (reordered) is scanned again here, as the earlier point's record leaves it:
 // the hop is unchanged iff it ends on the same node at the same distance (or still finds nothing closer) -- every insert scans node
 // 0's list and one in ten ends there and shrinks it, so without this the rounds stop at the first such point.
-template <bool COH>
-__device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32_t epoch_key, uint32_t *why = nullptr) {
+// HUB (the cooperative loop): a point whose CONNECT list an earlier point of the round wrote too -- both end on the same node, the
+// reference's graphs are full of such hubs -- is not a conflict: its trajectory is checked like any other (the scan of that list
+// included), only its record of the list is void; the bit of that layer is set in defer[b], the commit step leaves the list
+// alone, and after it ONE workgroup redoes the deferred connects in position order on the lists as they then are (k_insert_spec_loop).
+// What a scan can still not be checked against is a list with TWO earlier writers (the second one's list exists only after the commit).
+template <bool COH, bool HUB>
+__device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32_t epoch_key, uint32_t *why = nullptr, uint32_t *any_deferred = nullptr) {
     const int lane = threadIdx.x;
     if (b == 0) return false;  // the first point of a round read the committed graph only
     const uint32_t n = ldc<COH>(A.rcnt + b);
@@ -618,10 +643,15 @@ __device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32
             const uint32_t *e = A.rset + ((size_t)b * kSpecRMax + i) * 4;
             const uint32_t r = ldc<COH>(e);
             const unsigned long long v = ldc64<COH>(spec_wpos(A.wpos0, A.wposU, r & 0xBFFFFFFFu));
-            wb = ((uint32_t)v & 0x7FFFFFFFu) >> 1;
+            wb = ((uint32_t)v >> 1) & 0x7FFu;
+            const uint32_t wb2 = ((uint32_t)v >> 12) & 0x7FFu;
             if ((uint32_t)(v >> 32) == epoch_key && wb < b) {  // written this round by an earlier point
                 bd = __uint_as_float(ldc<COH>(e + 1));
-                if (r & 0x40000000u) { bad = true; cause |= 1u; }  // my connect list
+                if (r & 0x40000000u) {  // my connect list
+                    if constexpr (HUB) { atomicOr(A.defer + b, 1u << ldc<COH>(e + 3)); if (any_deferred) atomicOr(any_deferred, 1u); }
+                    else { bad = true; cause |= 1u; }
+                }
+                else if (wb2 < b) { bad = true; cause |= 1u; }  // scanned, and two earlier points wrote it
                 else if ((uint32_t)v & 1u) { rescan = true; bid = ldc<COH>(e + 2); layer = ldc<COH>(e + 3); }  // shrunk: scan it again
                 else {  // the writer was appended at its end: the hop is unchanged unless the writer beats the scan's best
                     const float d = exact_dist_rt(A.metric, myrow, A.rows + (size_t)(A.first_owner + wb) * A.ld, A.dim);
@@ -669,10 +699,11 @@ __device__ __forceinline__ bool check_body(const SpecArgs &A, uint32_t b, uint32
 }
 
 // position b writes what it recorded: ep's list and degree per layer (where ep has the layer), its own list [ep]
-template <bool COH>
+template <bool COH, bool HUB>
 __device__ __forceinline__ void commit_body(const SpecArgs &A, uint32_t b) {
     const int lane = threadIdx.x;
     const uint32_t gstride = A.gstride;
+    const uint32_t deferred = HUB ? ldc<COH>(A.defer + b) : 0u;
     const uint32_t owner = A.first_owner + b, level = A.params[b].level, my_slot = A.params[b].slot, rec0 = A.params[b].rec_off, maxlev = A.params[b].maxlev_pre;
     const uint32_t rec_words = 4 + gstride;
     for (uint32_t layer = 0; layer <= min(level, maxlev); ++layer) {
@@ -681,7 +712,7 @@ __device__ __forceinline__ void commit_body(const SpecArgs &A, uint32_t b) {
         uint32_t *ol = layer == 0 ? A.adj + (size_t)owner * gstride : A.adj_up + (size_t)(my_slot + layer - 1) * gstride;
         uint32_t *od = layer == 0 ? A.deg + owner : A.deg_up + (my_slot + layer - 1);
         if (lane == 0) { ol[0] = ep; *od = 1u; }
-        if (ldc<COH>(rec + 3)) {
+        if (ldc<COH>(rec + 3) && !((deferred >> layer) & 1u)) {
             const uint32_t n = ldc<COH>(rec + 2);
             const uint32_t es = layer == 0 ? 0u : ldc<COH>(A.slot + ep) + layer - 1;
             uint32_t *el = layer == 0 ? A.adj + (size_t)ep * gstride : A.adj_up + (size_t)es * gstride;
@@ -692,22 +723,68 @@ __device__ __forceinline__ void commit_body(const SpecArgs &A, uint32_t b) {
     }
 }
 
+// a deferred connect of position b at `layer`, on ep's list AS IT IS NOW: append, shrink (:143-170), write it and put it in b's record
+__device__ __forceinline__ void spec_merge_one(const SpecArgs &A, uint32_t b, uint32_t layer, unsigned char *smem) {
+    const int lane = threadIdx.x;
+    const uint32_t gstride = A.gstride, m = A.m, cap = (gstride + 1 + 3) & ~3u;
+    uint32_t *lst = reinterpret_cast<uint32_t *>(smem);
+    float *dst = reinterpret_cast<float *>(lst + cap);
+    uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);
+    const uint32_t owner = A.first_owner + b;
+    uint32_t *rec = A.recs + (size_t)(A.params[b].rec_off + layer) * (4 + gstride);
+    const uint32_t ep = ldc<true>(rec);
+    const uint32_t es = layer == 0 ? 0u : ldc<true>(A.slot + ep) + layer - 1;
+    uint32_t *el = layer == 0 ? A.adj + (size_t)ep * gstride : A.adj_up + (size_t)es * gstride;
+    uint32_t *ed = layer == 0 ? A.deg + ep : A.deg_up + es;
+    const uint32_t n0 = min(ldc<true>(ed), gstride);
+    __syncthreads();
+    for (uint32_t i = lane; i < n0; i += kWave) lst[i] = ldc<true>(el + i);
+    if (lane == 0) lst[n0] = owner;
+    uint32_t n = n0 + 1;
+    __syncthreads();
+    if (n > m) {
+        const float *o = A.rows + (size_t)ep * A.ld;
+        for (uint32_t i = lane; i < n; i += kWave) dst[i] = exact_dist_rt(A.metric, o, A.rows + (size_t)lst[i] * A.ld, A.dim);
+        __syncthreads();
+        for (uint32_t i = lane; i < n; i += kWave) {
+            const float di = dst[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const float dj = dst[j];
+                rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+            }
+            srt[rank] = lst[i];
+        }
+        __syncthreads();
+        n = m;
+        for (uint32_t i = lane; i < n; i += kWave) lst[i] = srt[i];
+        __syncthreads();
+    }
+    if (n > gstride) n = gstride;
+    for (uint32_t i = lane; i < n; i += kWave) { el[i] = lst[i]; rec[4 + i] = lst[i]; }
+    if (lane == 0) { *ed = n; rec[2] = n; }
+    __threadfence();  // the next deferred connect may be on the same list
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void k_insert_spec(SpecArgs A, uint32_t epoch_key) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     spec_body<false>(A, blockIdx.x, epoch_key, smem);
 }
 // c = first position of the round that a sequential run would have led another way; cmin starts at B
 __global__ __launch_bounds__(64) void k_insert_check(SpecArgs A, uint32_t epoch_key, uint32_t *cmin) {
-    if (check_body<false>(A, blockIdx.x, epoch_key) && threadIdx.x == 0) atomicMin(cmin, blockIdx.x);
+    if (check_body<false, false>(A, blockIdx.x, epoch_key) && threadIdx.x == 0) atomicMin(cmin, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_insert_commit(SpecArgs A, const uint32_t *__restrict__ cmin) {
-    if (blockIdx.x < *cmin) commit_body<false>(A, blockIdx.x);
+    if (blockIdx.x < *cmin) commit_body<false, false>(A, blockIdx.x);
 }
 
 // The rounds of a whole chunk in ONE cooperative launch of B workgroups (one wave each): speculate | check | commit with a grid
-// barrier between the phases, the next round starting at the first point not committed -- no host round trip per round (the
-// three-launch form above costs ~80 us per round, of which the GPU works ~35).  ctl: [0] barrier counter (zero at launch),
-// [1], [2] the rounds' commit counts (even / odd rounds, preset to B), [3] epoch counter (in: first epoch, out: next free one).
+// barrier between the phases (and, in rounds that deferred a connect, a fourth phase: workgroup 0 redoes them in order), the next
+// round starting at the first point not committed -- no host round trip per round (the three-launch form above costs ~80 us per
+// round, of which the GPU works ~35).  ctl: [0] barrier counter (zero at launch), [1], [2] the rounds' commit counts (even / odd
+// rounds, preset to B), [3] first epoch, [4] out: rounds, [5] barrier time-out, [6], [7] "a connect was deferred" (even / odd
+// rounds), [8..11] what stopped the rounds, [12] deferred connects redone.
 // (returns false if the other workgroups never arrived -- ~10 s of polling: every workgroup then leaves the loop instead of
 // spinning for ever, ctl[5] tells the host; a cooperative launch keeps them co-resident, so this is a guard, not a path)
 __device__ __forceinline__ bool spec_grid_barrier(uint32_t *ctl, uint32_t nblocks, uint32_t &gen) {
@@ -747,10 +824,13 @@ __global__ __launch_bounds__(64) void k_insert_spec_loop(SpecArgs A0, uint32_t n
         const uint32_t key = 0xFFFFFFFFu - (epoch0 + round);
         uint32_t *cm = ctl + 1 + (round & 1u);
         if (b < nb) spec_body<true>(A, b, key, smem);
-        if (b == 0 && threadIdx.x == 0) __hip_atomic_store(ctl + 1 + ((round + 1) & 1u), B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b == 0 && threadIdx.x == 0) {
+            __hip_atomic_store(ctl + 1 + ((round + 1) & 1u), B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctl + 6 + ((round + 1) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (!spec_grid_barrier(ctl, B, gen)) return;
         uint32_t why = 0;
-        const bool bad = b < nb && check_body<true>(A, b, key, &why);
+        const bool bad = b < nb && check_body<true, true>(A, b, key, &why, ctl + 6 + (round & 1u));
         if (bad && threadIdx.x == 0) atomicMin(cm, b);
         if (!spec_grid_barrier(ctl, B, gen)) return;
         const uint32_t c = min(__hip_atomic_load(cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nb);
@@ -758,8 +838,25 @@ __global__ __launch_bounds__(64) void k_insert_spec_loop(SpecArgs A0, uint32_t n
             for (uint32_t bit = 0; bit < 4; ++bit)
                 if (why & (1u << bit)) atomicAdd(ctl + 8 + bit, 1u);
         }
-        if (b < c) commit_body<true>(A, b);
+        const bool any_deferred = __hip_atomic_load(ctl + 6 + (round & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (b < c) commit_body<true, true>(A, b);
         if (!spec_grid_barrier(ctl, B, gen)) return;
+        if (any_deferred) {  // (the same in every workgroup) the deferred connects of the committed points, in position order
+            if (b == 0) {
+                uint32_t redone = 0;
+                for (uint32_t j = 1; j < c; ++j) {
+                    uint32_t dm = ldc<true>(A.defer + j);
+                    while (dm) {
+                        const uint32_t layer = (uint32_t)__builtin_ctz(dm);
+                        dm &= dm - 1;
+                        spec_merge_one(A, j, layer, smem);
+                        redone += 1;
+                    }
+                }
+                if (threadIdx.x == 0 && redone) atomicAdd(ctl + 12, redone);
+            }
+            if (!spec_grid_barrier(ctl, B, gen)) return;
+        }
         pos += c;  // c >= 1: position 0 is always valid
         round += 1;
     }
@@ -775,7 +872,7 @@ static SpecArgs make_spec_args(const zvdb_hip_index *h, uint32_t first_owner, co
     A.rows = h->rows; A.ld = h->ld; A.dim = h->dim; A.metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     A.adj = h->adj; A.deg = h->deg; A.adj_up = h->adj_up; A.deg_up = h->deg_up; A.lvl = h->lvl; A.slot = h->slot; A.gstride = h->gstride; A.m = h->m;
     A.first_owner = first_owner; A.points = points; A.params = params; A.recs = recs;
-    A.wpos0 = wpos0; A.wposU = wposU; A.rset = rset; A.rcnt = rcnt;
+    A.wpos0 = wpos0; A.wposU = wposU; A.rset = rset; A.rcnt = rcnt; A.defer = rcnt + 1024;  // (rcnt and defer share one block: [1024] each)
     return A;
 }
 static size_t spec_lds_bytes(const zvdb_hip_index *h) {
@@ -802,7 +899,7 @@ int launch_insert_spec_loop(const zvdb_hip_index *h, uint32_t first_owner, uint3
                             uint32_t *rcnt, uint32_t *ctl, uint32_t epoch, hipStream_t s) {
     const size_t lds = spec_lds_bytes(h);
     ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_insert_spec_loop), lds));
-    const uint32_t init[12] = {0u, B, B, epoch, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const uint32_t init[13] = {0u, B, B, epoch, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     ZV_HIP(hipMemcpyAsync(ctl, init, sizeof(init), hipMemcpyHostToDevice, s));
     SpecArgs A = make_spec_args(h, first_owner, points, params, recs, wpos0, wposU, rset, rcnt);
     void *args[] = {&A, &n_chunk, &ctl};
