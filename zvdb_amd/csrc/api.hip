@@ -922,7 +922,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                 // one cooperative launch runs all rounds of the chunk (ZVDB_INSERT_SPEC=rounds: one round per three launches + a host sync)
                 bool looped = false;
                 if (!(spec_env && spec_env[0] == 'r')) {
-                    uint32_t lb = 32;
+                    uint32_t lb = 48;  // (measured 200k x 128: 32 -> 204k, 48 -> 257k, 64 -> 252k, 96 -> 219k inserts/s)
                     if (const char *be = getenv("ZVDB_INSERT_SPEC_B")) lb = (uint32_t)std::max(1, std::min((int)spec_bmax, atoi(be)));
                     const int rc = launch_insert_spec_loop(h, (uint32_t)id0, (uint32_t)nc, lb, reinterpret_cast<const float *>(scr),
                                                            reinterpret_cast<const InsertParam *>(scr + pb), reinterpret_cast<uint32_t *>(scr + pb + qb),
