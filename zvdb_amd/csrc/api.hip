@@ -793,7 +793,8 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
     uint64_t done = 0, rec_out = 0;
     // chunks of more than 4 points run as speculative parallel rounds (exact_kernels.hip: k_insert_spec); ZVDB_INSERT_SPEC=0: one wave, in order
     const char *spec_env = getenv("ZVDB_INSERT_SPEC");
-    const bool spec = !(spec_env && spec_env[0] == '0') && m >= 1;
+    // (list ids carry two flag bits: shards beyond 2^30 rows or upper-layer slots fall back to the in-order kernel)
+    const bool spec = !(spec_env && spec_env[0] == '0') && m >= 1 && h->count + n < (1ull << 30) && h->up_count + 32ull * n < (1ull << 30);
     const uint32_t spec_bmax = 1024;
     const size_t spec_rsb = round_up64((size_t)spec_bmax * insert_spec_rmax() * 16, 256), spec_rcb = round_up64((size_t)spec_bmax * 8, 256);  // read counts [1024] + deferred-connect masks [1024]
     const size_t spec_extra = spec ? spec_rsb + spec_rcb + 256 : 0;
