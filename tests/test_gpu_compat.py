@@ -292,11 +292,18 @@ def test_fused_insert_under_exact_ties(zv, oracle, n, d, m):
             assert np.array_equal(ri, gi) and np.array_equal(rd, gd)
 
 
+@pytest.mark.parametrize("form", ["", "rounds", "0"])
 @pytest.mark.parametrize("n,d,m,ties", [(3000, 32, 16, False), (700, 2, 3, True), (9000, 8, 4, False)])
-def test_insert_many_equals_sequential_inserts(zv, oracle, n, d, m, ties):
-    """HNSW.insert_many (zvdb_hip_insert_batch_layer0: a chunk of inserts inside ONE launch, each seeing the lists its
-    predecessors left) builds the graph of n insert() calls: identical to the oracle's on every layer, device mirror
-    included; also when the index already holds points and when a chunk boundary (8192) falls inside the batch."""
+def test_insert_many_equals_sequential_inserts(zv, oracle, monkeypatch, n, d, m, ties, form):
+    """HNSW.insert_many (zvdb_hip_insert_batch: a chunk of inserts, each seeing the lists its predecessors left) builds the
+    graph of n insert() calls: identical to the oracle's on every layer, device mirror included; also when the index already
+    holds points and when a chunk boundary (8192) falls inside the batch.  In all three forms of the bulk insert
+    (ZVDB_INSERT_SPEC): speculative parallel rounds in one cooperative launch (default), round by round from the host, and
+    one wave in order -- on tie-heavy data with tiny m too, where nearly every point of a round ends on the same few nodes."""
+    if form:
+        monkeypatch.setenv("ZVDB_INSERT_SPEC", form)
+    else:
+        monkeypatch.delenv("ZVDB_INSERT_SPEC", raising=False)
     rng = np.random.default_rng(n)
     V = rng.random((n, d), dtype=np.float32)
     if ties:
