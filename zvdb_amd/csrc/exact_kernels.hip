@@ -1495,7 +1495,9 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
 // the host asynchronously after every launch); once known, the batch first runs with a table of 2.5 x that (kEfTight: a
 // query that fills it stops, marks its count kEfAgain and writes nothing else) and a second launch with the safe table
 // serves exactly the marked queries (kEfRetry).  Results and counters are those of a single safe pass.
-constexpr uint32_t kEfSingle = 0, kEfTight = 1, kEfRetry = 2, kEfAgain = 0xFFFFFFFFu;
+// pass: kEfSingle all queries, a full table is an error (stats[2]); kEfTight all queries, a query that fills its table marks
+// itself (count = kEfAgain) for the next launch; kEfRetry only the marked, full table = error; kEfRetryMark only the marked, marks again.
+constexpr uint32_t kEfSingle = 0, kEfTight = 1, kEfRetry = 2, kEfRetryMark = 3, kEfAgain = 0xFFFFFFFFu;
 __device__ unsigned long long g_ef_prof[10];
 // GH: the visited set lives in GLOBAL memory (ghash: one pre-zeroed table of 2^hash_bits slots per query of the launch, query
 // index = block + qoff) -- the safe pass of searches whose safe table does not fit the LDS (ef * stride beyond ~12k)
@@ -1507,10 +1509,11 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
-    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint, uint32_t *ghash, uint32_t qoff) {
+    uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t *ghash, uint32_t qoff,
+    uint32_t *dyn_ctr /* GH: tables handed out on demand (the net pass), else table = block */, uint32_t dyn_max) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t qi = blockIdx.x + qoff;
-    if (pass == kEfRetry && out_count[qi] != kEfAgain) return;  // served by the tight pass
+    if ((pass == kEfRetry || pass == kEfRetryMark) && out_count[qi] != kEfAgain) return;  // served by an earlier pass
     if (entries) entry = entries[qi];
     float *q = reinterpret_cast<float *>(smem);
     uint64_t *wk = reinterpret_cast<uint64_t *>(q + dim_pad);          // [2][efp]
@@ -1519,12 +1522,28 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t *lds_hash = hist + 256;
     float *nb_d = reinterpret_cast<float *>(lds_hash + (GH ? 0u : (1u << hash_bits)));
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
-    uint32_t *hash;  // (one address space per instantiation: LDS atomics or global atomics)
-    if constexpr (GH) hash = ghash + ((size_t)blockIdx.x << hash_bits);
-    else hash = lds_hash;
-
     const int lane = threadIdx.x;
     const int t = lane & 15;
+    uint32_t *hash;  // (one address space per instantiation: LDS atomics or global atomics)
+    if constexpr (GH) {
+        if (dyn_ctr) {  // the net pass: few queries get here, each takes the next free table and clears it
+            uint32_t tslot = 0;
+            if (lane == 0) tslot = atomicAdd(dyn_ctr, 1u);
+            tslot = (uint32_t)__builtin_amdgcn_readfirstlane((int)tslot);
+            if (tslot >= dyn_max) {  // more stragglers than tables: reported, not served
+                for (uint32_t i = lane; i < k; i += kWave) { out_ids[(size_t)qi * k + i] = ~0ull; out_dist[(size_t)qi * k + i] = __builtin_inff(); }
+                if (lane == 0) { out_count[qi] = 0; if (stats) atomicAdd(&stats[2], 1ull); }
+                return;
+            }
+            hash = ghash + ((size_t)tslot << hash_bits);
+            for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
+            __threadfence();
+        } else {
+            hash = ghash + ((size_t)blockIdx.x << hash_bits);
+        }
+    } else {
+        hash = lds_hash;
+    }
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
     if constexpr (!GH)
@@ -1575,7 +1594,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
                 __syncthreads();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
-                if (overflow && pass == kEfTight) {  // the safe-table launch behind this one serves the query
+                if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
                     if (lane == 0) out_count[qi] = kEfAgain;
                     return;
                 }
@@ -1775,9 +1794,10 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
-    uint32_t pass /* kEfSingle / kEfTight / kEfRetry */, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */) {
+    uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */,
+    uint32_t * /* dyn_ctr */, uint32_t /* dyn_max */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (pass == kEfRetry && out_count[blockIdx.x] != kEfAgain) return;  // served by the tight pass
+    if ((pass == kEfRetry || pass == kEfRetryMark) && out_count[blockIdx.x] != kEfAgain) return;  // served by an earlier pass
     if (entries) entry = entries[blockIdx.x];
     float *q = reinterpret_cast<float *>(smem);
     uint64_t *Wt = reinterpret_cast<uint64_t *>(q + dim_pad);    // [64 EPL] merge scatter buffer: keys ...
@@ -1907,7 +1927,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                 const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
                 sync_w();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
-                if (overflow && pass == kEfTight) {  // the safe-table launch behind this one serves the query
+                if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
                     if (lane == 0) out_count[qi] = kEfAgain;
                     release_helpers();
                     return;
@@ -2199,7 +2219,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
-                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u);
+                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, static_cast<uint32_t *>(nullptr), 0u);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
@@ -2218,16 +2238,41 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                 ZV_HIP(hipMemsetAsync(h->ef_visit_buf, 0, (size_t)nc * tb, s));
                 hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(nc), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                    d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, gbits, efp, d_entries,
-                                   pass, h->ef_hint_dev + bucket, h->ef_visit_buf, (uint32_t)q0);
+                                   pass, h->ef_hint_dev + bucket, h->ef_visit_buf, (uint32_t)q0, static_cast<uint32_t *>(nullptr), 0u);
                 ZV_HIP(hipGetLastError());
             }
             return ZVDB_OK;
         };
+        // the net under the LDS passes: a query that fills even the safe LDS table (small ef: the way from the entry node to the
+        // query's region alone can visit more than 2 ef stride nodes -- one query in ~5,000 at ef = 16 on a 500k-row shard, found by
+        // tools/soak_graph.py) marks itself once more and is served here, visited set in global memory, tables handed out on demand
+        auto go_net = [&]() -> int {
+            const uint32_t nbits = bits_for(std::min<uint64_t>(std::max<uint64_t>(N, 1), std::max<uint64_t>((uint64_t)ef * h->gstride * 16, 65536)));
+            const size_t tb = 4ull << nbits;
+            const uint32_t dyn_max = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (1ull << 30) / tb));
+            if (h->ef_visit_bytes < 256 + (size_t)dyn_max * tb) {
+                if (h->ef_visit_buf) { ZV_HIP(hipStreamSynchronize(s)); (void)hipFree(h->ef_visit_buf); h->ef_visit_buf = nullptr; h->ef_visit_bytes = 0; }
+                ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_visit_buf), 256 + (size_t)dyn_max * tb));
+                h->ef_visit_bytes = 256 + (size_t)dyn_max * tb;
+            }
+            uint32_t *ctr = h->ef_visit_buf + (h->ef_visit_bytes / 4 - 64);  // (the last 256 bytes of the block)
+            ZV_HIP(hipMemsetAsync(ctr, 0, 4, s));
+            const size_t lds = 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 8ull * kWave;
+            ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 0, true>), lds));
+            hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
+                               d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, nbits, efp, d_entries,
+                               (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_visit_buf, 0u, ctr, dyn_max);
+            ZV_HIP(hipGetLastError());
+            return ZVDB_OK;
+        };
         auto go = [&](auto kern, uint32_t wparam) -> int {
             if (two_pass) ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight));
-            const uint32_t pass = two_pass ? kEfRetry : kEfSingle;
-            if (safe_global) { ZV_CHECK(go_global(pass)); }
-            else { ZV_CHECK(go1(kern, wparam, hash_bits, pass)); }
+            if (safe_global) {
+                ZV_CHECK(go_global(two_pass ? kEfRetry : kEfSingle));
+            } else {
+                ZV_CHECK(go1(kern, wparam, hash_bits, two_pass ? kEfRetryMark : kEfTight));
+                ZV_CHECK(go_net());
+            }
             ZV_HIP(hipMemcpyAsync(h->ef_hint_host, h->ef_hint_dev, 64, hipMemcpyDeviceToHost, s));  // read by a LATER call, never waited for
             return ZVDB_OK;
         };
