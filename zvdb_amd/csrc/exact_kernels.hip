@@ -8,9 +8,12 @@
 // Kernels (all wave64, gfx950):
 //   k_exact_distances   K1/K5  a1 at the call sites hnsw.zig:86,:96,:160-161
 //   k_greedy_layer0     a2     insert's steepest-descent scan at layer 0 (hnsw.zig:88-104)
-//   k_search_compat     a5/a6  search (hnsw.zig:194-236): one wave per query
-//   k_search_ef         ext.   ef-mode beam search (spec: oracle/zvdb_oracle.h)
-//   k_rerank            K5     exact re-rank + (dist,id) top-k of brute-force candidates
+//   k_insert_layer0 / k_insert_full      a2-a4  the insert (hnsw.zig:73-117), one wave, n points per launch in order
+//   k_insert_spec[_loop] / _check / _commit     the same insert for a round of points speculatively in parallel (bulk calls)
+//   k_search_compat[_fast]      a5/a6  search (hnsw.zig:194-236): one wave per query
+//   k_search_ef_reg / k_search_ef       ext.   ef-mode beam search (spec: oracle/zvdb_oracle.h): beam in registers / in LDS
+//   k_descend           ext.   entry descent through the bulk graph's upper layers
+//   k_rerank[_staged]   K5     exact re-rank + (dist,id) top-k of brute-force candidates
 #include <cstring>
 #include "common.h"
 #include "wave_select.h"
