@@ -201,9 +201,12 @@ int zvdb_hip_insert_batch_layer0(zvdb_hip_index *h, const float *points, uint32_
                                  uint64_t *out_first_id, uint64_t *out_ep, float *out_ep_dist, uint64_t *out_ep_lists,
                                  uint32_t *out_ep_n, uint32_t *out_owner_n);
 /* The WHOLE of insert (hnsw.zig:73-117), every layer, for n points per call: the device holds each node's level and all
- * of its lists, and one launch per chunk of 8,192 points runs the inserts one after the other -- append the point, then
- * per layer 0..max_level the greedy scan (:90-104) and, up to the point's own level, connect (:106-108) with both
+ * of its lists, and one launch per chunk of 8,192 points runs the inserts -- append the point, then per layer
+ * 0..max_level the greedy scan (:90-104) and, up to the point's own level, connect (:106-108) with both
  * shrinkConnections -- each insert seeing what its predecessors left: the graph of n reference inserts in this order.
+ * (Chunks of more than 4 points run as speculative parallel rounds: a round's points are inserted concurrently against
+ * the committed graph, everything each one read is validated against what the earlier ones of the round wrote, the valid
+ * prefix commits in order and the rest runs again -- the same graph and the same records, bit for bit.)
  * levels[i] = the level randomLevel() (:172-180) drew for point i (the caller draws it: the binding owns the RNG).
  * The entry point is the first node (:84, :111).  For the host mirror: out_nrec[i] records for point i, one per layer
  * 0..min(level, max_level before it), each 4 + m words {ep, owner_n, ep_n, ep_has_layer, ep's list after the connect}:
