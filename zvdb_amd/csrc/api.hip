@@ -1434,6 +1434,7 @@ int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *
         if (h->rows_p) b += h->cap_p * h->ldp + h->cap_p * 4;
         if (h->rows_pf) b += h->cap_pf * fp4s_ksteps(h->dim) * 32 + h->cap_pf * 4;
         if (h->rows_hf) b += h->cap_hf * bf16s_ksteps(h->dim) * 32 + (h->cap_hf + 64) * 4;
+        b += h->ef_visit_bytes + (h->spec_cap0 + h->spec_capU) * 8;  // ef-search net / global visited tables, speculative-insert stamps
         *out_resident_bytes = b;
     }
     return ZVDB_OK;
