@@ -445,7 +445,8 @@ constexpr uint32_t kSpecRMax = 224;  // read-set capacity (lists read by one ins
 __device__ __forceinline__ unsigned long long *spec_wpos(unsigned long long *wpos0, unsigned long long *wposU, uint32_t lid) {
     return (lid & 0x80000000u) ? wposU + (lid & 0x7FFFFFFFu) : wpos0 + lid;
 }
-// COH: the shared graph arrays are read past the L1 (the persistent round loop below: other CUs write them between barriers)
+// COH = true reads past the L1 (agent-scope atomic loads).  Not needed by the round loop below -- its grid barriers fence at agent
+// scope -- and kept only as the switch to flip if a platform's fences ever turn out weaker than the memory model says.
 template <bool COH> __device__ __forceinline__ uint32_t ldc(const uint32_t *p) {
     if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
@@ -735,13 +736,13 @@ __device__ __forceinline__ void spec_merge_one(const SpecArgs &A, uint32_t b, ui
     uint32_t *srt = reinterpret_cast<uint32_t *>(dst + cap);
     const uint32_t owner = A.first_owner + b;
     uint32_t *rec = A.recs + (size_t)(A.params[b].rec_off + layer) * (4 + gstride);
-    const uint32_t ep = ldc<true>(rec);
-    const uint32_t es = layer == 0 ? 0u : ldc<true>(A.slot + ep) + layer - 1;
+    const uint32_t ep = ldc<false>(rec);
+    const uint32_t es = layer == 0 ? 0u : ldc<false>(A.slot + ep) + layer - 1;
     uint32_t *el = layer == 0 ? A.adj + (size_t)ep * gstride : A.adj_up + (size_t)es * gstride;
     uint32_t *ed = layer == 0 ? A.deg + ep : A.deg_up + es;
-    const uint32_t n0 = min(ldc<true>(ed), gstride);
+    const uint32_t n0 = min(ldc<false>(ed), gstride);
     __syncthreads();
-    for (uint32_t i = lane; i < n0; i += kWave) lst[i] = ldc<true>(el + i);
+    for (uint32_t i = lane; i < n0; i += kWave) lst[i] = ldc<false>(el + i);
     if (lane == 0) lst[n0] = owner;
     uint32_t n = n0 + 1;
     __syncthreads();
@@ -826,14 +827,16 @@ __global__ __launch_bounds__(64) void k_insert_spec_loop(SpecArgs A0, uint32_t n
         const uint32_t nb = min(B, n_chunk - pos);
         const uint32_t key = 0xFFFFFFFFu - (epoch0 + round);
         uint32_t *cm = ctl + 1 + (round & 1u);
-        if (b < nb) spec_body<true>(A, b, key, smem);
+        // (plain loads throughout: every phase starts behind a grid barrier whose agent-scope fences -- release before the arrival,
+        // acquire after the last one -- make the other workgroups' writes of the previous phase visible, across XCDs too)
+        if (b < nb) spec_body<false>(A, b, key, smem);
         if (b == 0 && threadIdx.x == 0) {
             __hip_atomic_store(ctl + 1 + ((round + 1) & 1u), B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ctl + 6 + ((round + 1) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!spec_grid_barrier(ctl, B, gen)) return;
         uint32_t why = 0;
-        const bool bad = b < nb && check_body<true, true>(A, b, key, &why, ctl + 6 + (round & 1u));
+        const bool bad = b < nb && check_body<false, true>(A, b, key, &why, ctl + 6 + (round & 1u));
         if (bad && threadIdx.x == 0) atomicMin(cm, b);
         if (!spec_grid_barrier(ctl, B, gen)) return;
         const uint32_t c = min(__hip_atomic_load(cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nb);
@@ -842,13 +845,13 @@ __global__ __launch_bounds__(64) void k_insert_spec_loop(SpecArgs A0, uint32_t n
                 if (why & (1u << bit)) atomicAdd(ctl + 8 + bit, 1u);
         }
         const bool any_deferred = __hip_atomic_load(ctl + 6 + (round & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        if (b < c) commit_body<true, true>(A, b);
+        if (b < c) commit_body<false, true>(A, b);
         if (!spec_grid_barrier(ctl, B, gen)) return;
         if (any_deferred) {  // (the same in every workgroup) the deferred connects of the committed points, in position order
             if (b == 0) {
                 uint32_t redone = 0;
                 for (uint32_t j = 1; j < c; ++j) {
-                    uint32_t dm = ldc<true>(A.defer + j);
+                    uint32_t dm = A.defer[j];
                     while (dm) {
                         const uint32_t layer = (uint32_t)__builtin_ctz(dm);
                         dm &= dm - 1;
