@@ -2174,10 +2174,10 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     uint32_t hash_bits = bits_for(want);  // the SAFE table
     if (const char *hb_env = getenv("ZVDB_EF_HASH_BITS")) hash_bits = (uint32_t)std::max(8, std::min(15, atoi(hb_env)));  // (experiment)
     const uint32_t efp = round_up(ef, kWave), kpad = round_up(std::max(k, 1u), kWave);
-    // beam in registers up to ef = 512 (k_search_ef_reg), in LDS beyond (k_search_ef); ZVDB_EF_BEAM=lds forces the LDS kernel
+    // beam in registers up to ef = 1024 (k_search_ef_reg), in LDS beyond (k_search_ef); ZVDB_EF_BEAM=lds forces the LDS kernel
     const char *beam_env = getenv("ZVDB_EF_BEAM");  // (read per call: the parity test switches it)
     const bool beam_lds = beam_env && beam_env[0] == 'l';
-    const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : 0;
+    const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : ef <= 1024 ? 16 : 0;
     auto lds_bytes = [&](uint32_t hb) -> size_t {
         if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad + 16;
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
@@ -2286,7 +2286,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             unsigned long long zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, got[10];
             ZV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ef_prof), zero, sizeof(zero)));
             ZV_CHECK(epl == 2 ? go(k_search_ef_reg<RT, 2, 1, 1>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 1, 1>, kpad)
-                     : epl == 8 ? go(k_search_ef_reg<RT, 8, 1, 1>, kpad) : go(k_search_ef<RT, 1>, efp));
+                     : epl == 8 ? go(k_search_ef_reg<RT, 8, 1, 1>, kpad) : epl == 16 ? go(k_search_ef_reg<RT, 16, 1, 0>, kpad) : go(k_search_ef<RT, 1>, efp));
             ZV_HIP(hipStreamSynchronize(s));
             ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
             const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
@@ -2301,13 +2301,14 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         // 1.67M, 4 waves 0.69M (8 rows per wave step: half the waves idle on 16-entry lists; with the 16-lane walk 0.94M / 1.20M / 1.29M)
         uint32_t wpq = sizeof(RT) == 2 ? 2 : 4;
         if (const char *we = getenv("ZVDB_EF_WPQ")) wpq = (uint32_t)atoi(we);  // (1, 2, 4: experiment / tests; read per call)
-        if (epl == 8 && wpq == 4) wpq = 2;
+        if (epl >= 8 && wpq == 4) wpq = 2;
         if (epl == 0 || (wpq != 2 && wpq != 4)) wpq = 1;
         wpq_launch = wpq;
         if (wpq == 4) return epl == 2 ? go(k_search_ef_reg<RT, 2, 4>, kpad) : go(k_search_ef_reg<RT, 4, 4>, kpad);
-        if (wpq == 2) return epl == 2 ? go(k_search_ef_reg<RT, 2, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 2>, kpad) : go(k_search_ef_reg<RT, 8, 2>, kpad);
+        if (wpq == 2) return epl == 2 ? go(k_search_ef_reg<RT, 2, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 2>, kpad)
+                             : epl == 8 ? go(k_search_ef_reg<RT, 8, 2>, kpad) : go(k_search_ef_reg<RT, 16, 2>, kpad);
         return epl == 2 ? go(k_search_ef_reg<RT, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4>, kpad)
-               : epl == 8 ? go(k_search_ef_reg<RT, 8>, kpad) : go(k_search_ef<RT>, efp);
+               : epl == 8 ? go(k_search_ef_reg<RT, 8>, kpad) : epl == 16 ? go(k_search_ef_reg<RT, 16>, kpad) : go(k_search_ef<RT>, efp);
     });
 }
 
