@@ -19,8 +19,14 @@
  *     (mirrors the global mutex of hnsw.zig:74-75,:195-196);
  *   - "host" entry points take host pointers and synchronise before returning;
  *     "_dev" entry points take DEVICE pointers + a hipStream_t (as void*) and
- *     only enqueue work (no allocation, no sync): they are what bench.py and
- *     the multi-GPU path call with torch-owned device memory;
+ *     only enqueue work: they are what bench.py and the multi-GPU path call
+ *     with torch-owned device memory.  Index-owned scratch they need is
+ *     allocated the FIRST time a call of a given shape needs it (hipMalloc, and a
+ *     device synchronise when a smaller buffer is replaced) -- the brute-force
+ *     workspace is the caller's (zvdb_hip_bruteforce_workspace), the graph
+ *     search's scratch can be taken ahead of time with
+ *     zvdb_hip_search_graph_reserve; after that a _dev call allocates nothing
+ *     and does not synchronise;
  *   - without a HIP device every entry point that needs one fails with
  *     ZVDB_ERR_NO_DEVICE.  There is no CPU fallback.
  */
@@ -227,7 +233,12 @@ int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, floa
  *             set lives in LDS, sized from the fills the index has seen for this ef (a query that
  *             outgrows it is re-run by a second launch with the safe size); when the safe size
  *             does not fit (ef * stride beyond ~12k) that launch keeps the visited sets in an
- *             index-owned device buffer of up to 2 GiB, allocated on first need.
+ *             index-owned device buffer of up to 2 GiB, allocated on first need; otherwise a last
+ *             16-workgroup launch serves the rare query that fills even the safe LDS table from a
+ *             small index-owned pool of global tables (16 tables of >= 16 ef stride slots: 4 MiB at
+ *             ef <= 256 / stride 16, 32 MiB at ef = 1024 / stride 32).  Searches of one index that
+ *             are launched on different streams are ordered among themselves (they share that
+ *             scratch); searches of different indexes are independent.
  * Outputs: out_ids[nq*k], out_dist[nq*k], out_count[nq] (count may be < k:
  * test_hnsw.zig:122-125; unused slots are id = UINT64_MAX, dist = +inf).
  * stats may be NULL. */
@@ -271,6 +282,10 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
                               uint32_t k, uint32_t ef, uint64_t entry, uint64_t id_offset,
                               void *d_ids, void *d_dist, void *d_count, void *d_stats,
                               void *stream);
+/* Takes, ahead of time, every index-owned buffer a zvdb_hip_search_graph_dev call with up to nq queries, this k and this
+ * ef (0 = reference-compat) allocates on first need -- so that the searches themselves only enqueue kernels (no hipMalloc,
+ * no synchronise: e.g. under stream capture).  Buffers only grow; reserving again with smaller sizes is a no-op. */
+int zvdb_hip_search_graph_reserve(zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t ef);
 /* C1 consumer: merge G all-gathered per-shard lists ([G][nq][k] ids/dist,
  * [G][nq] counts, device memory) into the global top-k by (dist, id). */
 int zvdb_hip_merge_topk_dev(const void *d_ids, const void *d_dist, const void *d_count,

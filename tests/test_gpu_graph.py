@@ -121,3 +121,166 @@ def test_on_disk_format_round_trip(zv, oracle, tmp_path, kind):
         f.truncate(len(raw) // 2)
     with pytest.raises(zv.ZvdbError):
         zv.Index.load(path)
+
+
+@pytest.mark.parametrize("env", [
+    {"ZVDB_EF_GLOBAL_VISITED": "1"},                      # safe pass with the visited sets in the index-owned global buffer
+    {"ZVDB_EF_GLOBAL_VISITED": "1", "ZVDB_EF_TWO_PASS": "0"},
+    {"ZVDB_EF_HASH_BITS": "8", "ZVDB_EF_TWO_PASS": "0"},  # safe LDS table forced tiny: most queries are served by the net (work list + table pool)
+    {},
+])
+def test_ef_search_from_two_streams_shares_the_index_scratch(zv, oracle, env, monkeypatch):
+    """ef searches launched on two streams of ONE index share its scratch (global visited tables, the net's work list and table
+    pool): each search waits for the previous user's marker (exact_kernels.hip: ef_scratch_begin / _end).  Results, launched
+    back to back on two streams, equal the single-stream results and the oracle's -- in every mode that uses that scratch."""
+    import torch
+    n, d, m, k, ef, nq = 6000, 32, 8, 10, 48, 1500
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    idx = zv.Index(m=m)
+    idx.add(V)
+    idx.build_knn_graph(m)
+    dev = torch.device("cuda", 0)
+    Qa = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    Qb = oracle.uniform_rows(0xC0FFEE, nq, nq, d)
+    qa, qb = torch.from_numpy(Qa).to(dev), torch.from_numpy(Qb).to(dev)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    idx.search_graph_reserve(nq, k, ef)
+
+    def run(q, stream):
+        ids = torch.empty((nq, k), dtype=torch.int64, device=dev); dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        cnt = torch.empty((nq,), dtype=torch.int32, device=dev); st = torch.zeros((3,), dtype=torch.int64, device=dev)
+        with torch.cuda.stream(stream):
+            st.zero_()
+        idx.search_graph_dev(q.data_ptr(), nq, d, k, ef, 0, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), stream.cuda_stream)
+        return ids, dd, cnt, st
+
+    s0 = torch.cuda.current_stream()
+    ra = run(qa, s0); rb = run(qb, s0)
+    torch.cuda.synchronize()
+    want = [t.cpu().numpy().copy() for t in ra + rb]
+    assert want[3][2] == 0 and want[7][2] == 0, "a visited set overflowed"
+    # the single-stream results are the host entry point's (which the fuzz sweeps hold to the oracle); spot-check the oracle here too
+    ref = oracle.HNSW(m, 200)
+    for r in V:
+        ref.insert(r, 0)
+    for i in range(n):
+        nb = idx.get_neighbors(i)
+        ref.set_neighbors(i, 0, [int(x) for x in nb])
+    for qi in range(0, nq, 97):
+        ri, rd = ref.search_ef(Qa[qi], k, ef)
+        assert np.array_equal(want[0][qi, :len(ri)].astype(np.uint64), ri) and np.array_equal(want[1][qi, :len(ri)], rd)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(s0); s2.wait_stream(s0)
+    for _ in range(8):
+        ga = run(qa, s1); gb = run(qb, s2)
+        torch.cuda.synchronize()
+        got = [t.cpu().numpy() for t in ga + gb]
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+
+
+def _file_header(raw):
+    """The 256-byte header of the on-disk format (api.hip: ZvdbFileHeader) as a dict of (offset, struct format, value)."""
+    import struct
+    names32 = ["version", "dim", "ld", "ldh", "metric", "m", "ef_construction", "gstride", "flags", "max_level", "bulk_graph", "bulk_top"]
+    names64 = ["count", "up_count", "off_rows", "off_norm", "off_adj", "off_deg", "off_lvl", "off_slot", "off_adj_up", "off_deg_up", "file_bytes"]
+    out, off = {}, 8
+    for nm in names32:
+        out[nm] = (off, "<I", struct.unpack_from("<I", raw, off)[0]); off += 4
+    for nm in names64:
+        out[nm] = (off, "<Q", struct.unpack_from("<Q", raw, off)[0]); off += 8
+    return out
+
+
+def test_load_rejects_corrupt_and_hostile_files(zv, oracle, tmp_path):
+    """zvdb_hip_load trusts nothing in the file: header fields outside their domains, a section table that is not the one the
+    fields imply, a size that differs from the header's, and -- after the upload -- any index the graph kernels would follow
+    out of bounds (degree > stride, neighbour id >= count, level > max_level, upper-layer slots past up_count) all end in
+    ZVDB_ERR_INVALID, not in a device fault.  Each case is one field or one word of a valid file changed."""
+    import struct
+    n, d = 3000, 32
+    V = oracle.uniform_rows(91, 0, n, d)
+    idx = zv.Index(m=8, graph_stride=16)
+    idx.add(V)
+    idx.build_graph(8, 32, zv.BF_I8, 5)
+    good = str(tmp_path / "good.zvdb")
+    idx.save(good)
+    raw = open(good, "rb").read()
+    hd = _file_header(raw)
+    assert hd["count"][2] == n and hd["up_count"][2] > 0 and hd["bulk_graph"][2] == 1
+    zv.Index.load(good)  # the unmodified file loads
+
+    def refused(mutated, what):
+        p = str(tmp_path / "bad.zvdb")
+        with open(p, "wb") as f:
+            f.write(mutated)
+        with pytest.raises(zv.ZvdbError) as e:
+            zv.Index.load(p)
+        assert "corrupt index file" in str(e.value) or "not a zvdb-hip index file" in str(e.value), (what, str(e.value))
+
+    def with_field(name, value):
+        off, fmt, _ = hd[name]
+        b = bytearray(raw)
+        struct.pack_into(fmt, b, off, value)
+        return bytes(b)
+
+    def with_word(section, index, value):  # one u32 of a section
+        b = bytearray(raw)
+        struct.pack_into("<I", b, hd[section][2] + 4 * index, value)
+        return bytes(b)
+
+    # (1) header domains
+    refused(with_field("flags", 0x80), "unknown flag bit")
+    refused(with_field("metric", 7), "metric")
+    refused(with_field("max_level", 40), "max_level > 31")
+    refused(with_field("bulk_top", n), "entry node >= count")
+    refused(with_field("gstride", 0), "zero stride")
+    refused(with_field("count", 2**40), "absurd row count (overflowing sizes)")
+    refused(with_field("up_count", 2**63), "absurd upper-row count")
+    # (2) section table / size
+    refused(with_field("off_adj", hd["off_adj"][2] + 256), "shifted section")
+    refused(with_field("off_rows", 0), "section over the header")
+    refused(with_field("file_bytes", hd["file_bytes"][2] + 256), "size mismatch")
+    refused(raw + b"\0" * 256, "padded file")
+    refused(raw[:len(raw) - 256], "truncated file")
+    refused(with_field("count", n - 1), "count that no longer matches the table")
+    # (3) graph contents (the header stays consistent: only the kernel can see these)
+    refused(with_word("off_deg", 17, 17), "degree > stride")
+    refused(with_word("off_adj", 5 * 16 + 0, n + 3), "neighbour id out of range")
+    refused(with_word("off_adj", 9 * 16 + 0, 0xFFFFFFFF), "neighbour id out of range (max)")
+    refused(with_word("off_lvl", 3, 31), "level above max_level" if hd["max_level"][2] < 31 else "slots out of range")
+    refused(with_word("off_deg_up", 0, 99), "upper degree > stride")
+    refused(with_word("off_adj_up", 0, n), "upper neighbour id out of range")
+    # a node WITH upper layers whose slot points past the upper rows
+    lv = np.frombuffer(raw, dtype="<u4", count=n, offset=hd["off_lvl"][2])
+    top = int(np.argmax(lv))
+    assert lv[top] >= 1
+    refused(with_word("off_slot", top, int(hd["up_count"][2])), "upper-layer slot past up_count")
+
+
+def test_descend_is_refused_once_the_bulk_graph_is_stale(zv, oracle):
+    """The bulk graph's upper layers describe the index only as the build left it: after rows are added, or layer 0 is replaced
+    (upload_graph / set_neighbors / build_knn_graph), ZVDB_ENTRY_DESCEND is an error instead of a descent through stale layers,
+    and graph_info stops reporting the old entry; a rebuild restores it."""
+    n, d = 2000, 24
+    V = oracle.uniform_rows(5, 0, n + 100, d)
+    Q = oracle.uniform_rows(6, 0, 8, d)
+    idx = zv.Index(m=8, graph_stride=16)
+    idx.add(V[:n])
+    idx.build_graph(8, 32, zv.BF_I8, 3)
+    entry, maxlev = idx.graph_info()
+    idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
+    idx.add(V[n:])                                            # rows the descent could never reach
+    with pytest.raises(zv.ZvdbError):
+        idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
+    assert idx.graph_info()[0] == 0
+    idx.search_graph(Q, 5, ef=32, entry=0)                    # a plain entry still works
+    idx.build_graph(8, 32, zv.BF_I8, 3)
+    idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
+    idx.build_knn_graph(8)                                    # layer 0 replaced under the upper layers
+    with pytest.raises(zv.ZvdbError):
+        idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
+    idx.build_graph(8, 32, zv.BF_I8, 3)
+    idx.set_neighbors(7, [1, 2, 3])
+    with pytest.raises(zv.ZvdbError):
+        idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)

@@ -1,5 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+# the harness is built here, from its source (no binary in the tree)
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $R/tools/bf16_regq_bench.hip -o $R/tools/bf16_regq_bench
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_regq -o p --output-format csv -- $R/tools/bf16_regq_bench 10000000 > $R/gpurun_out/pmc_regq.log 2>&1
 python3 - <<PY
 import csv, glob

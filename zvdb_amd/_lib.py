@@ -56,6 +56,7 @@ HIP_SYMBOLS = [
     ("zvdb_hip_insert_layer0", _i32, [_vp, _f32p, _u32, _u64, _u64p, _u64p, _f32p, _u64p, _u32p, _u32p, _u64p]),
     ("zvdb_hip_search_graph", _i32, [_vp, _f32p, _u32, _u32, _u32, _u32, _u64, _u64p, _f32p, _u32p,
                                       C.POINTER(SearchStats)]),
+    ("zvdb_hip_search_graph_reserve", _i32, [_vp, _u32, _u32, _u32]),
     ("zvdb_hip_search_bruteforce", _i32, [_vp, _f32p, _u32, _u32, _u32, _u32, _u64p, _f32p, _u32p]),
     ("zvdb_hip_bruteforce_workspace", _i32, [_vp, _u32, _u32, _u32, _u64p]),
     ("zvdb_hip_search_bruteforce_dev", _i32, [_vp, _vp, _u32, _u32, _u32, _u32, _u64, _vp, _u64, _vp, _vp,

@@ -2,9 +2,11 @@
 // plus the host-side plumbing they share: error string, staging buffers, capacity growth.
 #include <cstdarg>
 #include <cstring>
+#include <string>
 #include <algorithm>
 
 #include "common.h"
+#include <sys/stat.h>
 
 #include <sys/types.h>
 #include <unistd.h>
@@ -95,6 +97,11 @@ int ensure_capacity(zvdb_hip_index *h, uint64_t want) {
     h->cap = ncap;
     return ZVDB_OK;
 }
+
+// The bulk graph's upper layers describe the index only while its rows and lists are the ones the build left: rows added
+// afterwards would be unreachable from the descent, lists replaced by upload_graph / set_neighbors / build_knn_graph are not the
+// ones the upper layers were selected over.  Those calls drop the flag; added rows are caught by the count.
+static bool bulk_graph_valid(const zvdb_hip_index *h) { return h->bulk_graph && h->bulk_count == h->count; }
 
 // tie_buf is shared by every compat search on this index, whatever stream it is launched on: a search waits for the
 // previous one's last kernel before it touches the flags, and leaves its own marker behind
@@ -318,6 +325,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     if (h->ef_hint_host) (void)hipHostFree(h->ef_hint_host);
     (void)hipFree(h->ef_hint_dev);
     (void)hipFree(h->ef_visit_buf);
+    (void)hipFree(h->ef_net_buf);
+    if (h->ef_event) (void)hipEventDestroy(h->ef_event);
     (void)hipFree(h->spec_wpos0);
     (void)hipFree(h->spec_wposU);
     if (h->ins_host) (void)hipHostFree(h->ins_host);
@@ -460,6 +469,7 @@ int zvdb_hip_set_neighbors(zvdb_hip_index *h, uint64_t node, const uint64_t *ids
         set_error("NodeNotFound: node %llu", (unsigned long long)node);
         return ZVDB_ERR_NODE_NOT_FOUND;
     }
+    h->bulk_graph = false;
     if (n > h->gstride) {
         set_error("neighbour list of %u exceeds the device stride %u", n, h->gstride);
         return ZVDB_ERR_INVALID;
@@ -489,6 +499,7 @@ int zvdb_hip_upload_graph(zvdb_hip_index *h, const uint32_t *adj, const uint32_t
     ZV_CHECK(use_device(h));
     ZV_ARG(n <= h->count, "graph has more nodes than the index has rows");
     ZV_ARG(stride <= h->gstride, "graph stride exceeds the device stride");
+    h->bulk_graph = false;
     ef_hint_reset(h, h->stream);
     for (uint64_t i = 0; i < n; ++i) {
         ZV_ARG(deg[i] <= stride, "degree exceeds stride");
@@ -1028,8 +1039,8 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
     ZV_ARG(h->count > 0 && k > 0, "search_graph_dev needs a non-empty index and k > 0");
     const bool descend = entry == ZVDB_ENTRY_DESCEND;
     if (descend) {
-        if (ef == 0 || !h->bulk_graph) {
-            set_error("ZVDB_ENTRY_DESCEND needs ef > 0 and a graph built by zvdb_hip_build_graph");
+        if (ef == 0 || !bulk_graph_valid(h)) {
+            set_error("ZVDB_ENTRY_DESCEND needs ef > 0 and a graph built by zvdb_hip_build_graph over the index as it is now (no rows added, no lists replaced since)");
             return ZVDB_ERR_INVALID;
         }
         entry = h->bulk_top;
@@ -1062,6 +1073,17 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
     timing_end(h, s);
     if ((ef == 0 || descend) && rc == ZVDB_OK) ZV_CHECK(tie_end(h, s));
     return rc;
+}
+
+int zvdb_hip_search_graph_reserve(zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t ef) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    ZV_CHECK(use_device(h));
+    ZV_ARG(nq > 0 && k > 0 && h->dim > 0, "search_graph_reserve needs nq > 0, k > 0 and a dimensioned index");
+    ZV_CHECK(ensure_tie(h, nq));  // compat flags / descent entries
+    if (ef > 0)
+        ZV_CHECK(launch_search_ef(h, nullptr, nq, k, ef, 0u, 0ull, nullptr, nullptr, nullptr, nullptr, h->stream, nullptr, true));
+    return ZVDB_OK;
 }
 
 int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, uint32_t dim,
@@ -1130,8 +1152,8 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
         // unlock-free inner call: we already hold the mutex, so call the launchers directly
         const bool descend = entry == ZVDB_ENTRY_DESCEND;
         if (descend) {
-            if (ef == 0 || !h->bulk_graph) {
-                set_error("ZVDB_ENTRY_DESCEND needs ef > 0 and a graph built by zvdb_hip_build_graph");
+            if (ef == 0 || !bulk_graph_valid(h)) {
+                set_error("ZVDB_ENTRY_DESCEND needs ef > 0 and a graph built by zvdb_hip_build_graph over the index as it is now (no rows added, no lists replaced since)");
                 return ZVDB_ERR_INVALID;
             }
             entry = h->bulk_top;
@@ -1243,6 +1265,7 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode) 
     ZV_ARG(mode <= ZVDB_BF_FP4, "unknown brute-force mode");
     ZV_ARG(degree >= 1 && degree <= h->gstride, "degree must be in [1, graph_stride]");
     if (h->count == 0) return ZVDB_OK;
+    h->bulk_graph = false;
     ef_hint_reset(h, h->stream);
     const uint32_t k = degree + 1;  // the row itself is (one of) its own nearest
     const uint32_t B = 1024;        // rows per search batch
@@ -1281,7 +1304,23 @@ int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction
         ZV_HIP(hipMemsetAsync(h->deg, 0, 4, h->stream));
         ZV_HIP(hipStreamSynchronize(h->stream));
     }
-    return build_bulk_graph(h, M, ef_construction, mode, level_seed, ensure_upper);
+    // The build writes levels, slots and lists in place (a second copy of a 10M-row graph is what it cannot afford): a build that
+    // fails midway (e.g. out of memory in an upper-layer sub-index) must not leave half of the new graph under the old header.
+    // It leaves the index WITHOUT a graph: empty lists on every layer, no levels -- rows untouched, every search well defined.
+    h->bulk_graph = false;
+    const int rc = build_bulk_graph(h, M, ef_construction, mode, level_seed, ensure_upper);
+    if (rc != ZVDB_OK) {
+        const std::string why = zvdb_hip_last_error();
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipMemsetAsync(h->deg, 0, h->count * 4, h->stream);
+        if (h->lvl) (void)hipMemsetAsync(h->lvl, 0, h->count * 4, h->stream);
+        if (h->slot) (void)hipMemsetAsync(h->slot, 0, h->count * 4, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+        h->up_count = 0;
+        h->max_level = 0;
+        set_error("%s (the index is left without a graph)", why.c_str());
+    }
+    return rc;
 }
 
 
@@ -1374,6 +1413,36 @@ int zvdb_hip_load(const char *path, int32_t device, zvdb_hip_index **out) {
         set_error("%s is not a zvdb-hip index file (version 1)", path);
         return ZVDB_ERR_INVALID;
     }
+    // The file is input from outside: nothing in it is trusted.  (1) Header fields against their domains; (2) the section table
+    // against the ONE layout the fields imply (the writer's arithmetic, overflow-checked) and against the file's real size;
+    // (3) after the upload, one kernel over every index the graph kernels follow without a bounds test (k_validate_graph).
+    {
+        auto bad = [&](const char *what) { fclose(f); set_error("%s: corrupt index file (%s)", path, what); return ZVDB_ERR_INVALID; };
+        if (hd.flags & ~(ZVDB_FLAG_BF16_MIRROR | ZVDB_FLAG_BF16_ROWS)) return bad("unknown flags");
+        if (hd.metric > ZVDB_METRIC_COSINE) return bad("metric");
+        if (hd.dim > (1u << 20) || hd.ld > (1u << 21) || hd.ldh > (1u << 21)) return bad("dimension");
+        if (hd.gstride == 0 || hd.gstride > 4096 || hd.m == 0 || hd.m > hd.gstride) return bad("m / graph stride");
+        if (hd.count > 0xFFFFFFF0ull || hd.up_count > 0xFFFFFFF0ull) return bad("row count");
+        if (hd.count == 0 && hd.up_count != 0) return bad("upper layers without rows");
+        if (hd.count && hd.dim == 0) return bad("rows without a dimension");
+        if (hd.max_level > 31) return bad("max_level");  // hnsw.zig:172-180 caps the level at 31
+        if (hd.bulk_graph > 1 || (hd.count ? hd.bulk_top >= hd.count : hd.bulk_top != 0)) return bad("entry node");
+        const bool hbf = (hd.flags & ZVDB_FLAG_BF16_ROWS) != 0;
+        const unsigned __int128 lim = (unsigned __int128)1 << 62;
+        unsigned __int128 off = 256;
+        bool ok = true;
+        auto place = [&](unsigned __int128 bytes, uint64_t got) {
+            if (bytes > lim || off > lim) { ok = false; return; }
+            if ((uint64_t)off != got) ok = false;
+            off = (off + bytes + 255) / 256 * 256;
+        };
+        const unsigned __int128 n = hd.count, up = hd.up_count, rowb = hbf ? (unsigned __int128)hd.ldh * 2 : (unsigned __int128)hd.ld * 4;
+        place(n * rowb, hd.off_rows); place(n * 4, hd.off_norm); place(n * hd.gstride * 4, hd.off_adj); place(n * 4, hd.off_deg);
+        place(n * 4, hd.off_lvl); place(n * 4, hd.off_slot); place(up * hd.gstride * 4, hd.off_adj_up); place(up * 4, hd.off_deg_up);
+        if (!ok || off > lim || (uint64_t)off != hd.file_bytes) return bad("section table");
+        struct stat st{};
+        if (fstat(fileno(f), &st) != 0 || (uint64_t)st.st_size != hd.file_bytes) return bad("file size differs from the header's");
+    }
     zvdb_hip_config cfg{};
     cfg.abi_version = ZVDB_HIP_ABI_VERSION; cfg.dim = hd.dim; cfg.metric = hd.metric; cfg.m = hd.m; cfg.ef_construction = hd.ef_construction;
     cfg.device = device; cfg.flags = hd.flags; cfg.graph_stride = hd.gstride; cfg.capacity = hd.count;
@@ -1403,10 +1472,24 @@ int zvdb_hip_load(const char *path, int32_t device, zvdb_hip_index **out) {
                     rc = launch_finalize_rows(h, 0, n, h->stream);  // norms + the optional row-major bf16 mirror, from the rows
                 }
             }
+            if (rc == ZVDB_OK) {  // (3) the graph's indices
+                uint32_t *d_bad = nullptr, bad = 0;
+                if (hipMalloc(reinterpret_cast<void **>(&d_bad), 4) != hipSuccess) rc = ZVDB_ERR_OOM;
+                if (rc == ZVDB_OK && hipMemsetAsync(d_bad, 0, 4, h->stream) != hipSuccess) rc = ZVDB_ERR_HIP;
+                if (rc == ZVDB_OK) rc = launch_validate_graph(h, n, hd.up_count, hd.max_level, d_bad, h->stream);
+                if (rc == ZVDB_OK && hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = ZVDB_ERR_HIP;
+                if (rc == ZVDB_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = ZVDB_ERR_HIP;
+                (void)hipFree(d_bad);
+                if (rc == ZVDB_OK && bad) {
+                    set_error("%s: corrupt index file (graph:%s%s%s%s)", path, bad & 1 ? " degree > stride" : "", bad & 2 ? " neighbour id out of range" : "",
+                              bad & 4 ? " level > max_level" : "", bad & 8 ? " upper-layer slot out of range" : "");
+                    rc = ZVDB_ERR_INVALID;
+                }
+            }
             if (rc == ZVDB_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = ZVDB_ERR_HIP;
         }
         if (rc == ZVDB_OK) {
-            h->count = n; h->up_count = hd.up_count; h->max_level = hd.max_level; h->bulk_graph = hd.bulk_graph != 0; h->bulk_top = hd.bulk_top;
+            h->count = n; h->up_count = hd.up_count; h->max_level = hd.max_level; h->bulk_graph = hd.bulk_graph != 0; h->bulk_top = hd.bulk_top; h->bulk_count = n;
         }
     }
     fclose(f);
@@ -1434,7 +1517,7 @@ int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *
         if (h->rows_p) b += h->cap_p * h->ldp + h->cap_p * 4;
         if (h->rows_pf) b += h->cap_pf * fp4s_ksteps(h->dim) * 32 + h->cap_pf * 4;
         if (h->rows_hf) b += h->cap_hf * bf16s_ksteps(h->dim) * 32 + (h->cap_hf + 64) * 4;
-        b += h->ef_visit_bytes + (h->spec_cap0 + h->spec_capU) * 8;  // ef-search net / global visited tables, speculative-insert stamps
+        b += h->ef_visit_bytes + (h->ef_net_list_words + h->ef_net_table_words) * 4 + (h->spec_cap0 + h->spec_capU) * 8;  // ef-search net / global visited tables, speculative-insert stamps
         *out_resident_bytes = b;
     }
     return ZVDB_OK;
@@ -1443,7 +1526,7 @@ int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *
 int zvdb_hip_graph_info(zvdb_hip_index *h, uint64_t *out_entry, uint32_t *out_max_level) {
     ZV_ARG(h, "null argument");
     std::lock_guard<std::mutex> g(h->mu);
-    if (out_entry) *out_entry = h->bulk_graph ? h->bulk_top : 0;
+    if (out_entry) *out_entry = bulk_graph_valid(h) ? h->bulk_top : 0;
     if (out_max_level) *out_max_level = h->max_level;
     return ZVDB_OK;
 }

@@ -118,6 +118,7 @@ struct zvdb_hip_index {
     uint32_t max_level = 0;  // over the nodes inserted through zvdb_hip_insert_batch / of the bulk graph
     bool bulk_graph = false;  // zvdb_hip_build_graph ran: every layer is the bulk graph's, bulk_top its entry node
     uint32_t bulk_top = 0;
+    uint64_t bulk_count = 0;  // rows the bulk graph was built over: ZVDB_ENTRY_DESCEND is refused once count differs (api.hip: bulk_graph_valid)
     uint32_t *tie_buf = nullptr;  // [tie_cap] per-query "equal minima" flags of k_search_compat_fast
     uint64_t tie_cap = 0;
     hipEvent_t tie_event = nullptr;  // end of the last launch pair that used tie_buf: the next one (any stream) waits for it
@@ -161,6 +162,10 @@ struct zvdb_hip_index {
     uint32_t spec_epoch = 0;
     mutable uint32_t *ef_visit_buf = nullptr;  // visited sets in global memory for searches whose safe table does not fit the LDS
     mutable size_t ef_visit_bytes = 0;
+    mutable uint32_t *ef_net_buf = nullptr;  // the net under the LDS passes: [work list: ef_net_list_words][kEfNetBlocks tables]
+    mutable size_t ef_net_list_words = 0, ef_net_table_words = 0;
+    mutable hipEvent_t ef_event = nullptr;   // end of the last ef search that used the buffers above: the next one (any stream) waits for it
+    mutable bool ef_event_set = false;
     float guess_adapt = 0.0f;
     // zvdb_hip_insert_layer0: host-mapped [row | result] block -- the kernels read the point and write the result through
     // it, so an insert submits no copy-engine transfers (each costs ~10 us for a few hundred bytes)
@@ -234,7 +239,8 @@ void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s);
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
                      float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s,
-                     const uint32_t *d_entries = nullptr /* per-query entry nodes (launch_descend) */);
+                     const uint32_t *d_entries = nullptr /* per-query entry nodes (launch_descend) */,
+                     bool reserve_only = false /* allocate what a launch of this shape needs, launch nothing */);
 int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
                    unsigned long long *d_stats, hipStream_t s);
 // exact re-rank of candidate lists: cand[nq][kc] u32 (0xFFFFFFFF = empty) -> top-k by (dist,id)
@@ -255,6 +261,7 @@ int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s);
 int fp4_range(zvdb_hip_index *h, hipStream_t s);  // sets p_mid / p_scale from the rows' value range
 int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const uint32_t *d_cnt, uint32_t k,
                           uint64_t r0, uint32_t n, uint32_t degree, hipStream_t s);
+int launch_validate_graph(const zvdb_hip_index *h, uint64_t n, uint64_t up_count, uint32_t max_level, uint32_t *d_bad, hipStream_t s);
 int launch_merge_topk(const uint64_t *d_ids, const float *d_dist, const uint32_t *d_count,
                       uint32_t G, uint32_t nq, uint32_t k, uint64_t *o_ids, float *o_dist,
                       uint32_t *o_count, hipStream_t s);

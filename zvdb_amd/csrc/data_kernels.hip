@@ -440,6 +440,43 @@ int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const 
     return ZVDB_OK;
 }
 
+// Structural check of a graph that came from OUTSIDE (zvdb_hip_load): every index the search / descent / insert kernels use
+// without a bounds test.  Thread i < n: node i (degree, layer-0 ids, level, its upper-layer slots); thread n + r: upper row r
+// (degree, ids).  bad[0] = OR of: 1 degree > stride, 2 neighbour id >= n, 4 level > max_level, 8 upper slots out of range.
+__global__ __launch_bounds__(256) void k_validate_graph(uint64_t n, uint32_t gstride, uint64_t up_count, uint32_t max_level,
+                                                        const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg,
+                                                        const uint32_t *__restrict__ lvl, const uint32_t *__restrict__ slot,
+                                                        const uint32_t *__restrict__ adj_up, const uint32_t *__restrict__ deg_up,
+                                                        uint32_t *__restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t b = 0;
+    if (i < n) {
+        const uint32_t dg = deg[i];
+        if (dg > gstride) b |= 1u;
+        for (uint32_t j = 0; j < min(dg, gstride); ++j)
+            if (adj[i * gstride + j] >= n) b |= 2u;
+        const uint32_t lv = lvl[i];
+        if (lv > max_level) b |= 4u;
+        if (lv > 0 && (uint64_t)slot[i] + lv > up_count) b |= 8u;
+    } else if (i < n + up_count) {
+        const uint64_t r = i - n;
+        const uint32_t dg = deg_up[r];
+        if (dg > gstride) b |= 1u;
+        for (uint32_t j = 0; j < min(dg, gstride); ++j)
+            if (adj_up[r * gstride + j] >= n) b |= 2u;
+    }
+    if (b) atomicOr(bad, b);
+}
+
+int launch_validate_graph(const zvdb_hip_index *h, uint64_t n, uint64_t up_count, uint32_t max_level, uint32_t *d_bad, hipStream_t s) {
+    const uint64_t tot = n + up_count;
+    if (tot == 0) return ZVDB_OK;
+    hipLaunchKernelGGL(k_validate_graph, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, s, n, h->gstride, up_count, max_level, h->adj, h->deg,
+                       h->lvl, h->slot, h->adj_up, h->deg_up, d_bad);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 // C1 consumer: global top-k of G all-gathered shard lists, order (dist, id).  One wave per
 // query; rank by counting over the <= G*k live candidates held in LDS.
 // rank g's arrays start at ids0 + g*rs_i, dist0 + g*rs_d, count0 + g*rs_c (byte strides)

@@ -1507,18 +1507,25 @@ constexpr uint32_t kEfSingle = 0, kEfTight = 1, kEfRetry = 2, kEfRetryMark = 3, 
 __device__ unsigned long long g_ef_prof[10];
 // GH: the visited set lives in GLOBAL memory (ghash: one pre-zeroed table of 2^hash_bits slots per query of the launch, query
 // index = block + qoff) -- the safe pass of searches whose safe table does not fit the LDS (ef * stride beyond ~12k)
-template <typename RT, int PROF = 0, bool GH = false>
-__global__ __launch_bounds__(64) void k_search_ef(
+// The net's work list (index-owned, zeroed by the host before the last LDS pass of a call): [0] = queries appended, [1] = pop
+// cursor of the net launch, [2 ...] = query indices.  The LAST LDS pass of a call appends every query it marks; the net launch is
+// kEfNetBlocks workgroups that pop queries until the list is empty, each on its own global visited table.
+constexpr uint32_t kEfNetBlocks = 16;
+__device__ __forceinline__ void ef_mark_again(uint32_t *out_count, uint32_t qi, uint32_t *net_list) {  // (one lane)
+    out_count[qi] = kEfAgain;
+    if (net_list) net_list[2 + atomicAdd(net_list, 1u)] = qi;
+}
+
+// one query of the LDS-beam search; hash_g: the query's visited table when GH (pre-zeroed), unused otherwise
+template <typename RT, int PROF, bool GH>
+__device__ __forceinline__ void ef_search_one(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
-    uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
-    uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t *ghash, uint32_t qoff,
-    uint32_t *dyn_ctr /* GH: tables handed out on demand (the net pass), else table = block */, uint32_t dyn_max) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t qi = blockIdx.x + qoff;
+    uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries, uint32_t pass, uint32_t *__restrict__ fill_hint,
+    uint32_t *hash_g, uint32_t qi, uint32_t *net_list, unsigned char *smem) {
     if ((pass == kEfRetry || pass == kEfRetryMark) && out_count[qi] != kEfAgain) return;  // served by an earlier pass
     if (entries) entry = entries[qi];
     float *q = reinterpret_cast<float *>(smem);
@@ -1531,25 +1538,8 @@ __global__ __launch_bounds__(64) void k_search_ef(
     const int lane = threadIdx.x;
     const int t = lane & 15;
     uint32_t *hash;  // (one address space per instantiation: LDS atomics or global atomics)
-    if constexpr (GH) {
-        if (dyn_ctr) {  // the net pass: few queries get here, each takes the next free table and clears it
-            uint32_t tslot = 0;
-            if (lane == 0) tslot = atomicAdd(dyn_ctr, 1u);
-            tslot = (uint32_t)__builtin_amdgcn_readfirstlane((int)tslot);
-            if (tslot >= dyn_max) {  // more stragglers than tables: reported, not served
-                for (uint32_t i = lane; i < k; i += kWave) { out_ids[(size_t)qi * k + i] = ~0ull; out_dist[(size_t)qi * k + i] = __builtin_inff(); }
-                if (lane == 0) { out_count[qi] = 0; if (stats) atomicAdd(&stats[2], 1ull); }
-                return;
-            }
-            hash = ghash + ((size_t)tslot << hash_bits);
-            for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
-            __threadfence();
-        } else {
-            hash = ghash + ((size_t)blockIdx.x << hash_bits);
-        }
-    } else {
-        hash = lds_hash;
-    }
+    if constexpr (GH) hash = hash_g;
+    else hash = lds_hash;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
     if constexpr (!GH)
@@ -1601,7 +1591,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 __syncthreads();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
                 if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
-                    if (lane == 0) out_count[qi] = kEfAgain;
+                    if (lane == 0) ef_mark_again(out_count, qi, net_list);
                     return;
                 }
                 // (1) one lane per neighbour: visited test-and-set; fb = fresh list positions
@@ -1764,6 +1754,46 @@ __global__ __launch_bounds__(64) void k_search_ef(
     }
 }
 
+// launch forms of ef_search_one.  LDS tables (GH = false): block = query.  GH, net_list == nullptr: the global safe pass, block =
+// query (+ qoff), table = block (pre-zeroed by the host).  GH, net_list != nullptr: the NET -- each of the kEfNetBlocks workgroups
+// owns one table and serves queries popped from the work list (clearing the table per query) until the list is empty.
+template <typename RT, int PROF = 0, bool GH = false>
+__global__ __launch_bounds__(64) void k_search_ef(
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
+    uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
+    uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
+    uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
+    uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
+    uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t *ghash, uint32_t qoff,
+    uint32_t *net_list /* LDS passes: marks are appended here (may be null); GH: non-null = the net launch */, uint32_t /* unused */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (GH) {
+        uint32_t *table = ghash + ((size_t)blockIdx.x << hash_bits);
+        if (net_list) {
+            const uint32_t total = __hip_atomic_load(net_list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (;;) {
+                uint32_t i = 0;
+                if (threadIdx.x == 0) i = atomicAdd(net_list + 1, 1u);
+                i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+                if (i >= total) return;
+                const uint32_t qi = net_list[2 + i];
+                for (uint32_t j = threadIdx.x; j < (1u << hash_bits); j += kWave) table[j] = 0;
+                __threadfence();
+                __syncthreads();
+                ef_search_one<RT, PROF, true>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, ef, entry, id_offset, out_ids, out_dist, out_count,
+                                              stats, dim_pad, hash_bits, efp, entries, pass, fill_hint, table, qi, nullptr, smem);
+                __syncthreads();
+            }
+        }
+        ef_search_one<RT, PROF, true>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, ef, entry, id_offset, out_ids, out_dist, out_count, stats,
+                                      dim_pad, hash_bits, efp, entries, pass, fill_hint, table, blockIdx.x + qoff, nullptr, smem);
+    } else {
+        ef_search_one<RT, PROF, false>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, ef, entry, id_offset, out_ids, out_dist, out_count, stats,
+                                       dim_pad, hash_bits, efp, entries, pass, fill_hint, nullptr, blockIdx.x + qoff, net_list, smem);
+    }
+}
+
 // ---- ef-mode beam search, beam in REGISTERS (ef <= 64 EPL) ---------------------------------------------------------------------
 // Same search, same results as k_search_ef above (keys are distinct, so "the ef best of the union" is one set however it is
 // held); what changes is where W lives.  The profile of the LDS-set kernel (ZVDB_EF_PROF=1, 1M x 768, ef = 128) put a third
@@ -1801,7 +1831,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
     uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */,
-    uint32_t * /* dyn_ctr */, uint32_t /* dyn_max */) {
+    uint32_t *net_list /* marks are appended here (the last LDS pass of a call; else null) */, uint32_t /* unused */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((pass == kEfRetry || pass == kEfRetryMark) && out_count[blockIdx.x] != kEfAgain) return;  // served by an earlier pass
     if (entries) entry = entries[blockIdx.x];
@@ -1934,7 +1964,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                 sync_w();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
                 if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
-                    if (lane == 0) out_count[qi] = kEfAgain;
+                    if (lane == 0) ef_mark_again(out_count, qi, net_list);
                     release_helpers();
                     return;
                 }
@@ -2158,9 +2188,48 @@ int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq,
     });
 }
 
+// ---- index-owned scratch of the ef search (all mutable members of the index; callers hold h->mu) -------------------------------
+static int ef_scratch_begin(const zvdb_hip_index *h, hipStream_t s) {
+    if (!h->ef_event) ZV_HIP(hipEventCreateWithFlags(&h->ef_event, hipEventDisableTiming));
+    if (h->ef_event_set) ZV_HIP(hipStreamWaitEvent(s, h->ef_event, 0));
+    return ZVDB_OK;
+}
+static int ef_scratch_end(const zvdb_hip_index *h, hipStream_t s) {
+    ZV_HIP(hipEventRecord(h->ef_event, s));
+    h->ef_event_set = true;
+    return ZVDB_OK;
+}
+// (re)allocation frees a buffer other streams may still be reading: wait for the whole device first (rare: sizes only grow)
+static int ef_reserve_visit(const zvdb_hip_index *h, size_t bytes) {
+    if (h->ef_visit_bytes >= bytes) return ZVDB_OK;
+    if (h->ef_visit_buf) { ZV_HIP(hipDeviceSynchronize()); (void)hipFree(h->ef_visit_buf); h->ef_visit_buf = nullptr; h->ef_visit_bytes = 0; }
+    ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_visit_buf), bytes));
+    h->ef_visit_bytes = bytes;
+    return ZVDB_OK;
+}
+// table of the net: >= 16 ef stride slots (a straggler that filled the safe LDS table of 1.5 ef stride)
+static uint32_t ef_net_bits(const zvdb_hip_index *h, uint32_t ef) {
+    const uint64_t N = h->count;
+    return bits_for(std::min<uint64_t>(std::max<uint64_t>(N, 1), std::max<uint64_t>((uint64_t)ef * h->gstride * 16, 65536)));
+}
+// the net's buffer: [list: 2 + nq words, padded to 256 B][kEfNetBlocks tables of 4 << bits bytes] -- 4 MiB at ef <= 256 / stride
+// 16, 32 MiB at ef = 1024 / stride 32 (before: 256 tables, up to 1 GiB, taken by the first search whether or not it needed them)
+static int ef_reserve_net(const zvdb_hip_index *h, uint32_t nq, uint32_t ef) {
+    const size_t list_words = round_up64((uint64_t)nq + 2, 64);
+    const size_t table_words = (size_t)kEfNetBlocks << ef_net_bits(h, ef);
+    if (h->ef_net_list_words >= list_words && h->ef_net_table_words >= table_words) return ZVDB_OK;
+    const size_t lw = std::max(list_words, h->ef_net_list_words), tw = std::max(table_words, h->ef_net_table_words);
+    if (h->ef_net_buf) { ZV_HIP(hipDeviceSynchronize()); (void)hipFree(h->ef_net_buf); h->ef_net_buf = nullptr; h->ef_net_list_words = h->ef_net_table_words = 0; }
+    ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_net_buf), (lw + tw) * sizeof(uint32_t)));
+    h->ef_net_list_words = lw;
+    h->ef_net_table_words = tw;
+    return ZVDB_OK;
+}
+
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
-                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, const uint32_t *d_entries) {
+                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, const uint32_t *d_entries,
+                     bool reserve_only) {
     if (nq == 0) return ZVDB_OK;
     if (ef < k) ef = k;
     const uint64_t N = h->count;
@@ -2220,23 +2289,19 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
         uint32_t wpq_launch = 1;
-        auto go1 = [&](auto kern, uint32_t wparam, uint32_t hb, uint32_t pass) -> int {
+        auto go1 = [&](auto kern, uint32_t wparam, uint32_t hb, uint32_t pass, uint32_t *net_list) -> int {
             const size_t lds = lds_bytes(hb);
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
-                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, static_cast<uint32_t *>(nullptr), 0u);
+                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, net_list, 0u);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
         auto go_global = [&](uint32_t pass) -> int {  // the safe pass with the visited sets in global memory
             const size_t tb = 4ull << gbits;
             const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(nq, (2ull << 30) / tb));
-            if (h->ef_visit_bytes < chunk * tb) {
-                if (h->ef_visit_buf) { ZV_HIP(hipStreamSynchronize(s)); (void)hipFree(h->ef_visit_buf); h->ef_visit_buf = nullptr; h->ef_visit_bytes = 0; }
-                ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_visit_buf), chunk * tb));
-                h->ef_visit_bytes = chunk * tb;
-            }
+            ZV_CHECK(ef_reserve_visit(h, chunk * tb));
             const size_t lds = 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 8ull * kWave;
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 0, true>), lds));
             for (uint64_t q0 = 0; q0 < nq; q0 += chunk) {
@@ -2251,35 +2316,39 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         };
         // the net under the LDS passes: a query that fills even the safe LDS table (small ef: the way from the entry node to the
         // query's region alone can visit more than 2 ef stride nodes -- one query in ~5,000 at ef = 16 on a 500k-row shard, found by
-        // tools/soak_graph.py) marks itself once more and is served here, visited set in global memory, tables handed out on demand
+        // tools/soak_graph.py) is appended to the index's work list by the last LDS pass and served here, visited set in global
+        // memory: kEfNetBlocks workgroups, one table each, pop the list until it is empty (an empty list costs one 16-block launch)
         auto go_net = [&]() -> int {
-            const uint32_t nbits = bits_for(std::min<uint64_t>(std::max<uint64_t>(N, 1), std::max<uint64_t>((uint64_t)ef * h->gstride * 16, 65536)));
-            const size_t tb = 4ull << nbits;
-            const uint32_t dyn_max = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (1ull << 30) / tb));
-            if (h->ef_visit_bytes < 256 + (size_t)dyn_max * tb) {
-                if (h->ef_visit_buf) { ZV_HIP(hipStreamSynchronize(s)); (void)hipFree(h->ef_visit_buf); h->ef_visit_buf = nullptr; h->ef_visit_bytes = 0; }
-                ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_visit_buf), 256 + (size_t)dyn_max * tb));
-                h->ef_visit_bytes = 256 + (size_t)dyn_max * tb;
-            }
-            uint32_t *ctr = h->ef_visit_buf + (h->ef_visit_bytes / 4 - 64);  // (the last 256 bytes of the block)
-            ZV_HIP(hipMemsetAsync(ctr, 0, 4, s));
             const size_t lds = 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 8ull * kWave;
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 0, true>), lds));
-            hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
-                               d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, nbits, efp, d_entries,
-                               (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_visit_buf, 0u, ctr, dyn_max);
+            hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(kEfNetBlocks), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride,
+                               (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, ef_net_bits(h, ef), efp, d_entries,
+                               (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_net_buf + h->ef_net_list_words, 0u, h->ef_net_buf, 0u);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
+        // Index-owned scratch (global visited tables, the net's list and tables) is shared by every ef search on this index whatever
+        // stream it is launched on: a search waits for the previous user's last launch (ef_scratch_begin) and records its own
+        // (ef_scratch_end) -- the chain tie_buf has (api.hip).  h->mu serialises the host-side enqueue only.
         auto go = [&](auto kern, uint32_t wparam) -> int {
-            if (two_pass) ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight));
+            if (safe_global) {
+                const size_t tb = 4ull << gbits;
+                ZV_CHECK(ef_reserve_visit(h, std::max<uint64_t>(1, std::min<uint64_t>(nq, (2ull << 30) / tb)) * tb));
+            } else {
+                ZV_CHECK(ef_reserve_net(h, nq, ef));
+            }
+            if (reserve_only) return ZVDB_OK;  // (zvdb_hip_search_graph_reserve: everything a launch of this shape allocates)
+            ZV_CHECK(ef_scratch_begin(h, s));
+            if (two_pass) ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight, nullptr));
             if (safe_global) {
                 ZV_CHECK(go_global(two_pass ? kEfRetry : kEfSingle));
             } else {
-                ZV_CHECK(go1(kern, wparam, hash_bits, two_pass ? kEfRetryMark : kEfTight));
+                ZV_HIP(hipMemsetAsync(h->ef_net_buf, 0, 8, s));  // list count + pop cursor
+                ZV_CHECK(go1(kern, wparam, hash_bits, two_pass ? kEfRetryMark : kEfTight, h->ef_net_buf));
                 ZV_CHECK(go_net());
             }
             ZV_HIP(hipMemcpyAsync(h->ef_hint_host, h->ef_hint_dev, 64, hipMemcpyDeviceToHost, s));  // read by a LATER call, never waited for
+            ZV_CHECK(ef_scratch_end(h, s));
             return ZVDB_OK;
         };
         if (prof) {  // diagnostic build of the same kernel: per-phase cycles, printed after a synchronise

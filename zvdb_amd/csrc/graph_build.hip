@@ -427,6 +427,7 @@ int build_bulk_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, ui
     h->max_level = maxlev;
     h->up_count = up;
     h->bulk_top = top;
+    h->bulk_count = N;
     h->bulk_graph = true;
     return ZVDB_OK;
 }

@@ -208,6 +208,10 @@ class Index:
         check(self._L.zvdb_hip_search_graph_dev(self._h, q_ptr, nq, dim, k, ef, entry, id_offset, ids_ptr,
                                                 dist_ptr, cnt_ptr, stats_ptr, stream))
 
+    def search_graph_reserve(self, nq: int, k: int, ef: int) -> None:
+        """Takes every index-owned buffer a later search_graph_dev of this shape would allocate on first need."""
+        check(self._L.zvdb_hip_search_graph_reserve(self._h, nq, k, ef))
+
     def set_shard_count(self, shards: int) -> None:
         """This index is one of `shards` id-range shards (zvdb_hip_index_set_shard_count): the fp4 screen keeps its
         share of the survivor budget."""
