@@ -11,7 +11,7 @@
 // fragment (conflict-free ds_read_b128 at base + immediate) and multiplies it with its own B registers.  Operand bytes per
 // flop are half those of the staged 256 x 256 tile (only the corpus moves; L2 -> LDS at full MFMA rate: 16 B/clk/CU instead
 // of 32, which is what capped the staged kernel at 0.42 of peak), the steady state has ONE barrier per 32-row group
-// (3,072 MFMA cycles) and its LDS-DMA issues are spread over the k-loop (one piece per 8 fragments).
+// (3,072 MFMA cycles) and its LDS-DMA issues are spread over the first 60 % of the k-loop (one piece per 5 fragments).
 // MFMA shape: v_mfma_f32_16x16x32_bf16 -- the chip is power-limited on random bf16 data and holds a ~10 % higher clock on
 // this shape than on 32x32x16 (tools/bf16_regq_bench.hip: 1.54 vs 1.44 PFLOP/s for the same loop; profiles/r2/).
 //
@@ -23,6 +23,7 @@
 // sums): acc = -key, pass <=> acc > -tau.  Selection state (per-(workgroup, query) kept list + append buffer in global
 // memory, exact (key, id) radix select) is shared with the other scan kernels (bf_select.h); a wave owns its 32 queries,
 // so appends and prune rounds need no workgroup rendezvous.
+#include <vector>
 #include "common.h"
 #include "wave_select.h"
 #include "bf_select.h"
@@ -34,7 +35,7 @@ namespace zvdb {
 namespace {
 
 constexpr int BH_NW = 8;                  // waves per workgroup (2 per SIMD)
-constexpr int BH_R = 6;                   // A-fragment register ring (reads in flight per wave)
+constexpr int BH_R = 6;                   // A-fragment register ring (reads in flight per wave; 5: -1.6 %, measured)
 constexpr int BH_CAP = NSUB * SUBCAP;     // append-buffer entries per (workgroup, query)
 constexpr int BH_HW = 384, BH_MARK = 64;  // prune request mark; queries above MARK are pruned in a round
 constexpr uint32_t BH_SAMPLE_GROUPS = 8;  // moments mode: 32-row groups sampled per stream
@@ -73,6 +74,17 @@ __device__ __forceinline__ void bh_lgkm_drain(u32x4 (&a)[BH_R]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
 }
 template <int N> __device__ __forceinline__ void bh_lgkm_wait(u32x4 &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+
+// LDS-DMA in the saddr form: uniform base (SGPR pair) + 32-bit lane offset, LDS destination through M0.  Inline asm because
+// hipcc builds a 64-bit vector address per piece from the builtin (a v_lshl_add_u64 and two more VGPRs in a loop that has none
+// to spare): +3 % QPS at 10M x 768 (profiles/r3/bf16_stream_ab.txt).  These operations are invisible to hipcc's waitcnt pass;
+// the ring's vmcnt bookkeeping is the explicit s_waitcnt pair at the top of the unit loop.
+__device__ __forceinline__ void bh_dma16(uint32_t voff, gbytes_t sbase, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void bh_dma4(uint32_t voff, gbytes_t sbase, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
 
 // Exact prune of the calling wave's 32 queries whose append buffer passed MARK.  Out of line and cold on purpose: the scan
 // keeps 192 VGPRs of query fragments live, and an inlined radix select pushes the allocator into spilling them in the hot
@@ -114,11 +126,13 @@ __device__ __attribute__((noinline, cold)) void bh_prune_wave(uint64_t *kept, ui
 template <int KS, int NG, bool MOM, int KPV = KP, int GATED = 0>
 __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     const unsigned char *__restrict__ Qf /* Layout16, [query block of 16][K2][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
-    const float *__restrict__ vnorm /* [rows padded]: sum v'^2 (0: dot / cosine), +inf past N */, uint32_t N, uint32_t nq, uint32_t QT,
+    const float *__restrict__ vnorm /* [rows padded]: -1/2 sum v'^2 (-0: dot / cosine), -inf past N */, uint32_t N, uint32_t nq, uint32_t QT,
     uint32_t S, uint32_t U /* units of NG groups */, uint64_t *__restrict__ cand, uint64_t *__restrict__ partial,
     uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt,
     uint32_t max_units, const uint32_t *__restrict__ gate, float *__restrict__ mom) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
+    unsigned long long t_begin = 0;
+    if constexpr (!MOM) { if (mom) t_begin = __builtin_amdgcn_s_memrealtime(); }  // (ZVDB_BF16S_STAMPS=1 diagnostic: per-workgroup begin / end)
     using Geo = BhGeo<KS, NG>;
     constexpr int F = Geo::F, P = Geo::P, NP = Geo::NP, K2 = KS / 2, R = BH_R;
     constexpr uint32_t SLOT = Geo::SLOT;
@@ -162,26 +176,23 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
         if (tid < 4) ctl[tid] = 0;
     }
 
-    // B operand: my 32 queries = 2 blocks of 16, every k-step, for the whole launch
-    u32x4 B[KS];
-    {
-        const unsigned char *qsrc = Qf + ((size_t)(qt * (T2 / 16) + 2 * wave) * K2) * 1024 + lane * 16;
-#pragma unroll
-        for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
-    }
-    const uint32_t lane16 = (uint32_t)lane * 16;
+    // B operand: my 32 queries = 2 blocks of 16, every k-step
+    u32x4 B[KS];  // (loaded at every entry of the unit loop, below)
+    const unsigned char *qsrc = Qf + ((size_t)(qt * (T2 / 16) + 2 * wave) * K2) * 1024 + lane * 16;
+    const uint32_t lane16 = (uint32_t)lane * 16, lane4 = (uint32_t)lane * 4;
+    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
     auto dma_unit = [&](uint32_t u, uint32_t slot) {  // prologue form: all pieces back to back
         const gbytes_t src = uniform_ptr(Vf + (size_t)u * F * 1024);
-        unsigned char *dst = smem + slot * SLOT;
+        const uint32_t dst = lds0 + slot * SLOT;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const uint32_t piece = (uint32_t)wave + (uint32_t)BH_NW * p;
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + piece * 1024 + lane16), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+            bh_dma16(lane16, src + piece * 1024, dst + piece * 1024);
         }
         if (wave == 0) {
+            const gbytes_t nsrc = uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)u * NG * 32));
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-                __builtin_amdgcn_global_load_lds((gptr_t)(vnorm + (size_t)u * NG * 32 + p * 64 + lane), (lptr_t)(dst + F * 1024 + p * 256), 4, 0, 0);
+            for (int p = 0; p < NP; ++p) bh_dma4(lane4, nsrc + p * 256, dst + F * 1024 + p * 256);
         }
     };
     if (n > 0) {
@@ -190,36 +201,41 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     }
     asm volatile("" ::: "memory");
     __syncthreads();  // selection state initialised (also drains the prologue loads; once per launch)
-    // NOTE: __syncthreads() waited for the two prologue units as well; the steady state below never drains the VMEM queue.
 
     float thr0 = 0.0f, thr1 = 0.0f;  // -tau of my two queries (B set 0: query 32 wave + fc; set 1: + 16)
-    if constexpr (!MOM) {
-        thr0 = -tau_f[wave * 32 + fc];
-        thr1 = -tau_f[wave * 32 + 16 + fc];
-    }
     float ms1[2] = {0.0f, 0.0f}, ms2[2] = {0.0f, 0.0f};  // moments mode
     uint32_t mrows = 0;
 
     const uint32_t lds_state = (uint32_t)(size_t)(lptr_t)tau_f;
-    auto prune_mine = [&]() {
-        bh_prune_wave<KPV>(kept, tau_g, kp, lds_state);
-        thr0 = -tau_f[wave * 32 + fc];
-        thr1 = -tau_f[wave * 32 + 16 + fc];
-    };
 
-    uint32_t slot = 0;
-    const uint32_t lds0 = (uint32_t)(size_t)(lptr_t)smem;
-    for (uint32_t it = 0; it < n; ++it) {
-        if (it > 0) {  // (the first unit was drained by the __syncthreads above)
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-            __builtin_amdgcn_s_barrier();
+    // The unit loop is entered once per launch and once more after every prune round of this wave.  A prune is a CALL (header of
+    // bh_prune_wave) and nothing of the loop's register state lives across it: inside the loop hipcc spilled the query fragments
+    // around the call and re-loaded them on the way back.  So the loop is LEFT for a prune, and every entry loads the fragments
+    // and the bounds afresh and drains the counters once, ahead of the loop.
+    uint32_t slot = 0, it = 0;
+    while (it < n) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
+        if constexpr (!MOM) {
+            thr0 = -tau_f[wave * 32 + fc];
+            thr1 = -tau_f[wave * 32 + 16 + fc];
         }
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0), as an instruction the waitcnt pass sees
+        bool want_prune = false;
+        do {
+        // unit `it` has landed: my pieces of it (all but the P (+ NP) youngest operations: those are unit it + 1's), then everyone's
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+        __builtin_amdgcn_s_barrier();  // (the first one of a launch is redundant: the __syncthreads above)
+        // ... and my pieces of unit it + 1 as well.  Not needed for correctness; it keeps the QT workgroups of a stream within one
+        // unit of each other, so that the L2 serves three of them from the fetch of the first: +2 % QPS (A/B on one box,
+        // profiles/r3/bf16_stream_ab.txt; round 2's build had this wait by accident -- hipcc placed it for a spill re-load)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the unit fetched during this one: it + 2 (past the stream end: a harmless re-read of its last unit)
         const uint32_t un = min(u0 + it + 2, u1 - 1);
-        const gbytes_t nsrc = uniform_ptr(Vf + (size_t)un * F * 1024);
-        unsigned char *ndst = smem + (slot >= 1 ? slot - 1 : 2) * SLOT;
-        const float *nnorm = vnorm + (size_t)un * NG * 32 + lane;
+        const gbytes_t nsrc = uniform_ptr(Vf + (size_t)un * F * 1024 + (size_t)wave * 1024);
+        const uint32_t ndst = lds0 + (slot >= 1 ? slot - 1 : 2) * SLOT + (uint32_t)wave * 1024;
+        const gbytes_t nnorm = uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)un * NG * 32));
         const uint32_t base = lds0 + slot * SLOT + lane16;
         const uint32_t nbase = lds0 + slot * SLOT + F * 1024 + 16 * fq;
         // norms of the unit's rows: group gi, row block rb -> rows 16 rb + 4 fq + [0, 4) of the group
@@ -241,9 +257,9 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
             constexpr int GI = FI / KS, WI = FI % KS, RB = WI / K2, JJ = WI % K2;
             constexpr int SL = FI % R;
             constexpr int W = (F - 1 - FI) < (R - 1) ? (F - 1 - FI) : (R - 1);  // younger reads allowed in flight
-            if constexpr (JJ == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { acc[RB][0][r] = -0.5f * nv[GI][RB][r]; acc[RB][1][r] = acc[RB][0][r]; }
+            if constexpr (JJ == 0) {  // (the mirror holds the start value ready-made: -|v'|^2 / 2)
+                acc[RB][0] = nv[GI][RB];
+                acc[RB][1] = nv[GI][RB];
             }
             bh_lgkm_wait<W>(A[SL]);
             __builtin_amdgcn_sched_barrier(0);
@@ -251,15 +267,19 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
             acc[RB][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[SL]), __builtin_bit_cast(bf16x8, B[K2 + JJ]), acc[RB][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (FI + R < F) bh_lds_read128<(FI + R) * 1024>(A[SL], base);
-            if constexpr (FI % 8 == 2) {  // this wave's piece FI / 8 of the unit being fetched
-                const uint32_t piece = (uint32_t)wave + (uint32_t)BH_NW * (FI / 8);
-                __builtin_amdgcn_global_load_lds((gptr_t)(nsrc + piece * 1024 + lane16), (lptr_t)(ndst + piece * 1024), 16, 0, 0);
+            // this wave's pieces of the unit being fetched: one every DSTEP fragments from fragment 2 on, the norms behind the last.
+            // 48-fragment units issue theirs in the first 60 % of the loop, so that the wait behind the next barrier finds them
+            // landed: steps of 8 / 6 / 4 / 5: 93.4k / 93.3k / 94.5k / 95.3k QPS on one box (profiles/r3/bf16_stream_ab.txt; a
+            // placement also moves hipcc's register allocation, the loop has no VGPR to spare -- re-measure after any change here)
+            constexpr int DSTEP = F == 48 ? 5 : 8, NORM_AT = F == 48 ? 30 : F - 3;
+            if constexpr (FI % DSTEP == 2 && FI / DSTEP < P) {
+                constexpr uint32_t POFF = (uint32_t)BH_NW * (FI / DSTEP) * 1024;  // piece = wave + 8 (FI / DSTEP)
+                bh_dma16(lane16, nsrc + POFF, ndst + POFF);
             }
-            if constexpr (FI == F - 3) {
+            if constexpr (FI == NORM_AT) {
                 if (wave == 0) {
 #pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        __builtin_amdgcn_global_load_lds((gptr_t)(nnorm + p * 64), (lptr_t)(ndst + F * 1024 + p * 256), 4, 0, 0);
+                    for (int p = 0; p < NP; ++p) bh_dma4(lane4, nnorm + p * 256, ndst + F * 1024 + p * 256);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -299,12 +319,17 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
                                         need |= sl == (uint32_t)BH_HW;
                                     }
                                 }
-                        if (__ballot(need)) prune_mine();
+                        if (__ballot(need)) want_prune = true;  // (<= 32 NG more appends per query before the loop is left: BH_CAP holds them)
                     }
                 }
             }
         });
         slot = slot == 2 ? 0 : slot + 1;
+        ++it;
+        } while (it < n && !want_prune);
+        if constexpr (!MOM) {
+            if (want_prune) bh_prune_wave<KPV>(kept, tau_g, kp, lds_state);
+        }
     }
 
     if constexpr (MOM) {
@@ -326,6 +351,13 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done with the ring: it becomes the per-wave select scratch of the stream end
+    if constexpr (!MOM) {
+        if (mom && tid == 0) {
+            unsigned long long *st = reinterpret_cast<unsigned long long *>(mom) + 2 * (size_t)b;
+            st[0] = t_begin;
+            st[1] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
     {   // stream end: lane-per-query copy when nothing needs selecting, else the radix select
         unsigned char *selw = smem + wave * sel_scratch_bytes<KPV>();
         const uint32_t q = (uint32_t)wave * 32 + (uint32_t)(lane & 31);
@@ -419,7 +451,8 @@ __global__ __launch_bounds__(256) void k_bf16_pack_frag(const RT *__restrict__ s
     *reinterpret_cast<u32x4 *>(out + u * 16) = w;
 }
 
-// norm[r] = sum over the bf16-rounded row of v'^2 (L2; 0 for dot / cosine), +inf for r >= n: one wave per row
+// norm[r] = -1/2 sum over the bf16-rounded row of v'^2 (L2; -0 for dot / cosine), -inf for r >= n: one wave per row.  This IS the
+// accumulator's start value (header: keys), stored ready-made (the halving is exact): the scan copies it, no multiply (+1 % QPS)
 template <typename RT>
 __global__ __launch_bounds__(256) void k_bf16_frag_norms(const RT *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n, uint64_t n_pad,
                                                          int l2, float *__restrict__ norm) {
@@ -427,7 +460,7 @@ __global__ __launch_bounds__(256) void k_bf16_frag_norms(const RT *__restrict__ 
     const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_pad) return;
     if (r >= n) {
-        if (lane == 0) norm[r] = __builtin_inff();
+        if (lane == 0) norm[r] = -__builtin_inff();
         return;
     }
     float sacc = 0.0f;
@@ -440,7 +473,7 @@ __global__ __launch_bounds__(256) void k_bf16_frag_norms(const RT *__restrict__ 
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sacc += __shfl_xor(sacc, off);
     }
-    if (lane == 0) norm[r] = sacc;
+    if (lane == 0) norm[r] = -0.5f * sacc;
 }
 
 template <int KS, int NG, bool MOM, int KPV>
@@ -532,6 +565,29 @@ int launch_bf16s_prep_queries(const zvdb_hip_index *h, const float *d_queries, u
 int launch_bf16s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand,
                       uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate,
                       uint32_t kpv, hipStream_t s) {
+    static const bool stamps = [] { const char *e = getenv("ZVDB_BF16S_STAMPS"); return e && e[0] == '1'; }();
+    if (stamps && !gate && kpv == (uint32_t)KP) {  // diagnostic (synchronises): when each workgroup of the scan began and ended, per XCD
+        static unsigned long long *d_st = nullptr;
+        const uint32_t nb = QT * S;
+        if (!d_st) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&d_st), 2 * 4096 * sizeof(unsigned long long)));
+        ZV_CHECK((bh_launch<false, KP>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, reinterpret_cast<float *>(d_st), s)));
+        std::vector<unsigned long long> st(2 * nb);
+        ZV_HIP(hipStreamSynchronize(s));
+        ZV_HIP(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (uint32_t b = 0; b < nb; ++b) { t0 = std::min(t0, st[2 * b]); t1 = std::max(t1, st[2 * b + 1]); }
+        double xs[8] = {0}, xe[8] = {0}, xmax[8] = {0};
+        for (uint32_t b = 0; b < nb; ++b) {
+            const double e = (double)(st[2 * b + 1] - t0) * 0.01, bg = (double)(st[2 * b] - t0) * 0.01;  // 100 MHz -> us
+            xs[b & 7] += bg; xe[b & 7] += e; xmax[b & 7] = std::max(xmax[b & 7], e);
+        }
+        fprintf(stderr, "[zvdb bf16s stamps] %u workgroups, span %.1f us; per XCD (block %% 8) mean begin / mean end / last end (us):", nb, (double)(t1 - t0) * 0.01);
+        for (int x = 0; x < 8; ++x) fprintf(stderr, "  %d: %.0f / %.0f / %.0f", x, xs[x] / (nb / 8), xe[x] / (nb / 8), xmax[x]);
+        double emin = 1e30, emax = 0, esum = 0;
+        for (uint32_t b = 0; b < nb; ++b) { const double e = (double)(st[2 * b + 1] - t0) * 0.01; emin = std::min(emin, e); emax = std::max(emax, e); esum += e; }
+        fprintf(stderr, "\n[zvdb bf16s stamps] workgroup end times: min %.0f, mean %.0f, max %.0f us\n", emin, esum / nb, emax);
+        return ZVDB_OK;
+    }
     if (kpv == (uint32_t)KPMAX) return bh_launch<false, KPMAX>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     if (kpv == (uint32_t)KPW) return bh_launch<false, KPW>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     return bh_launch<false, KP>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
