@@ -322,6 +322,7 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->rows_p);
     (void)hipFree(h->norm_p);
     if (h->guess_flag_host) (void)hipHostFree(h->guess_flag_host);
+    if (h->bal_host) (void)hipHostFree(h->bal_host);
     if (h->ef_hint_host) (void)hipHostFree(h->ef_hint_host);
     (void)hipFree(h->ef_hint_dev);
     (void)hipFree(h->ef_visit_buf);

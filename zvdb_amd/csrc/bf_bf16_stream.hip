@@ -24,6 +24,8 @@
 // memory, exact (key, id) radix select) is shared with the other scan kernels (bf_select.h); a wave owns its 32 queries,
 // so appends and prune rounds need no workgroup rendezvous.
 #include <vector>
+#include <cmath>
+#include <cstring>
 #include "common.h"
 #include "wave_select.h"
 #include "bf_select.h"
@@ -123,16 +125,20 @@ __device__ __attribute__((noinline, cold)) void bh_prune_wave(uint64_t *kept, ui
 // KS = 16-element k-steps per row (KS / 2 MFMA k-steps of 32); NG = 32-row groups per ring slot; MOM: moments mode (sum of
 // key, key^2 per query over a sample instead of selecting); GATED = 1: the same code under its own symbol for the gated
 // repair launch (a no-op unless the verification failed), so that profiler statistics do not average no-ops into the scan
+// units per XCD: XCD x (= blockIdx % 8 under round-robin placement) scans units [off[x], off[x + 1]), split evenly over its S / 8
+// streams; off[8] == 0: an even split over all S streams
+struct BhSplit { uint32_t off[9]; uint32_t tag; };  // tag: this launch's number mod 64, returned with the durations
+
 template <int KS, int NG, bool MOM, int KPV = KP, int GATED = 0>
 __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     const unsigned char *__restrict__ Qf /* Layout16, [query block of 16][K2][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
     const float *__restrict__ vnorm /* [rows padded]: -1/2 sum v'^2 (-0: dot / cosine), -inf past N */, uint32_t N, uint32_t nq, uint32_t QT,
     uint32_t S, uint32_t U /* units of NG groups */, uint64_t *__restrict__ cand, uint64_t *__restrict__ partial,
     uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt,
-    uint32_t max_units, const uint32_t *__restrict__ gate, float *__restrict__ mom) {
+    uint32_t max_units, const uint32_t *__restrict__ gate, float *__restrict__ mom, BhSplit split, uint32_t *__restrict__ dur_out) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
     unsigned long long t_begin = 0;
-    if constexpr (!MOM) { if (mom) t_begin = __builtin_amdgcn_s_memrealtime(); }  // (ZVDB_BF16S_STAMPS=1 diagnostic: per-workgroup begin / end)
+    if (dur_out) t_begin = __builtin_amdgcn_s_memrealtime();
     using Geo = BhGeo<KS, NG>;
     constexpr int F = Geo::F, P = Geo::P, NP = Geo::NP, K2 = KS / 2, R = BH_R;
     constexpr uint32_t SLOT = Geo::SLOT;
@@ -155,9 +161,16 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     const uint32_t x = b & 7, jb = b >> 3;
     const uint32_t qt = jb % QT;
     const uint32_t s = (jb / QT) * 8 + x;
-    const uint32_t per = (U + S - 1) / S;
-    const uint32_t u0 = min(s * per, U);
-    const uint32_t u1 = min(u0 + (max_units ? min(per, max_units) : per), U);
+    uint32_t per = (U + S - 1) / S, ulo = s * per, uhi = U;
+    if (split.off[8]) {  // my XCD's range, my stream's share of it (ids still ascend along a stream)
+        const uint32_t nsx = S >> 3;
+        ulo = split.off[x];
+        uhi = split.off[x + 1];
+        per = (uhi - ulo + nsx - 1) / nsx;
+        ulo += (jb / QT) * per;
+    }
+    const uint32_t u0 = min(ulo, uhi);
+    const uint32_t u1 = min(u0 + (max_units ? min(per, max_units) : per), uhi);
     const uint32_t n = u1 - u0;
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
     uint64_t *kept = cand + (size_t)b * BLKV_ENTRIES;
@@ -352,13 +365,8 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every wave is done with the ring: it becomes the per-wave select scratch of the stream end
-    if constexpr (!MOM) {
-        if (mom && tid == 0) {
-            unsigned long long *st = reinterpret_cast<unsigned long long *>(mom) + 2 * (size_t)b;
-            st[0] = t_begin;
-            st[1] = __builtin_amdgcn_s_memrealtime();
-        }
-    }
+    if (dur_out && tid == 0)  // (host-mapped: read by a later launch; 100 MHz ticks under the launch's tag)
+        dur_out[b] = (split.tag << 24) | (uint32_t)min((unsigned long long)0xFFFFFFull, __builtin_amdgcn_s_memrealtime() - t_begin);
     {   // stream end: lane-per-query copy when nothing needs selecting, else the radix select
         unsigned char *selw = smem + wave * sel_scratch_bytes<KPV>();
         const uint32_t q = (uint32_t)wave * 32 + (uint32_t)(lane & 31);
@@ -480,14 +488,14 @@ __global__ __launch_bounds__(256) void k_bf16_frag_norms(const RT *__restrict__ 
 template <int KS, int NG, bool MOM, int KPV>
 int bh_launch_geo(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand,
                   uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, uint32_t max_units,
-                  const uint32_t *gate, float *mom, hipStream_t s) {
+                  const uint32_t *gate, float *mom, hipStream_t s, const BhSplit &split, uint32_t *dur_out) {
     constexpr uint32_t lds = bh_lds_bytes<KS, NG, KPV>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     const uint32_t G = (uint32_t)((h->count + 31) / 32), U = (G + NG - 1) / NG;
     auto go = [&](auto kern) -> int {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_hf, h->norm_hf, (uint32_t)h->count, nq, QT, S, U, cand, partial,
-                           tau_g, kp, list_base, Stot, pcnt, max_units, gate, mom);
+                           tau_g, kp, list_base, Stot, pcnt, max_units, gate, mom, split, dur_out);
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
     };
@@ -500,13 +508,13 @@ int bh_launch_geo(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t n
 template <bool MOM, int KPV>
 int bh_launch(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand, uint64_t *partial,
               uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, uint32_t sample_groups, const uint32_t *gate,
-              float *mom, hipStream_t s) {
+              float *mom, hipStream_t s, const BhSplit &split = BhSplit{}, uint32_t *dur_out = nullptr) {
     const uint32_t KS = bf16s_ksteps(h->dim);
     auto mu = [&](uint32_t ng) { return sample_groups ? (sample_groups + ng - 1) / ng : 0u; };
-    if (KS == 8) return bh_launch_geo<8, 6, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(6), gate, mom, s);
-    if (KS == 16) return bh_launch_geo<16, 3, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(3), gate, mom, s);
-    if (KS == 32) return bh_launch_geo<32, 1, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(1), gate, mom, s);
-    return bh_launch_geo<48, 1, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(1), gate, mom, s);
+    if (KS == 8) return bh_launch_geo<8, 6, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(6), gate, mom, s, split, dur_out);
+    if (KS == 16) return bh_launch_geo<16, 3, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(3), gate, mom, s, split, dur_out);
+    if (KS == 32) return bh_launch_geo<32, 1, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(1), gate, mom, s, split, dur_out);
+    return bh_launch_geo<48, 1, MOM, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, mu(1), gate, mom, s, split, dur_out);
 }
 
 }  // namespace
@@ -562,36 +570,78 @@ int launch_bf16s_prep_queries(const zvdb_hip_index *h, const float *d_queries, u
     return ZVDB_OK;
 }
 
+// Adaptive split of the scan's units over the 8 XCDs.  Under the power limit the XCDs of one device run this kernel at clocks a
+// few per cent apart (profiles/r3/bf16_stream_workgroup_end_times.txt: the same XCDs finish 3 - 6 % early launch after launch),
+// and a launch ends with its slowest workgroup.  Every workgroup leaves its duration in host-mapped memory; here the durations of
+// an EARLIER launch (whatever has arrived: nothing is waited for) turn into per-XCD speeds = units / mean duration, the shares
+// follow them with damping 1/2, and the next launch runs with the new split.  Results do not depend on the split (every row is
+// scanned once; the merged lists hold the exact k' best keys either way).  ZVDB_BF16S_BALANCE=0: even split.
+static int bh_balance(const zvdb_hip_index *h, uint32_t QT, uint32_t S, BhSplit *split, uint32_t **dur_out) {
+    static const bool off = [] { const char *e = getenv("ZVDB_BF16S_BALANCE"); return e && e[0] == '0'; }();
+    static const bool dbg = [] { const char *e = getenv("ZVDB_BF16S_BALANCE"); return e && e[0] == 'v'; }();
+    const uint32_t nb = QT * S, G = (uint32_t)((h->count + 31) / 32);
+    const uint32_t NG = bf16s_groups_per_unit(bf16s_ksteps(h->dim)), U = (G + NG - 1) / NG;
+    if (off || S % 8 != 0 || nb > 4096 || U < 64 * S) return ZVDB_OK;  // (short streams: nothing to balance)
+    if (!h->bal_host) {
+        ZV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->bal_host), 4096 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+        if (!h->bal_host) { set_error("hipHostMalloc returned no block"); return ZVDB_ERR_OOM; }
+        std::memset(h->bal_host, 0, 4096 * sizeof(uint32_t));
+        ZV_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->bal_dev), h->bal_host, 0));
+    }
+    if (h->bal_nb == nb) {
+        // durations of ONE earlier launch (all under the same tag: launches are queued ahead of the device, the newest complete set
+        // may be several launches old) against the split THAT launch ran with
+        const uint32_t tag = __atomic_load_n(h->bal_host, __ATOMIC_RELAXED) >> 24;
+        const uint32_t *ho = h->bal_hist[tag & 63];
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool all = ho[8] == U;
+        for (uint32_t b = 0; b < nb && all; ++b) {
+            const uint32_t d = __atomic_load_n(h->bal_host + b, __ATOMIC_RELAXED);
+            if ((d >> 24) != tag || (d & 0xFFFFFFu) == 0) all = false;
+            t[b & 7] += (double)(d & 0xFFFFFFu);
+        }
+        if (all) {
+            double speed[8], sum = 0.0;
+            for (int x = 0; x < 8; ++x) { speed[x] = (double)(ho[x + 1] - ho[x]) / t[x]; sum += speed[x]; }
+            double wsum = 0.0;
+            for (int x = 0; x < 8; ++x) { h->bal_w[x] = 0.5f * h->bal_w[x] + 0.5f * (float)(speed[x] / sum * 8.0); wsum += h->bal_w[x]; }
+            for (int x = 0; x < 8; ++x) h->bal_w[x] = std::min(1.15f, std::max(0.85f, (float)(h->bal_w[x] / wsum * 8.0)));
+            if (dbg) fprintf(stderr, "[zvdb bf16s balance] tag %u shares %.3f %.3f %.3f %.3f %.3f %.3f %.3f %.3f\n", tag, h->bal_w[0], h->bal_w[1], h->bal_w[2],
+                             h->bal_w[3], h->bal_w[4], h->bal_w[5], h->bal_w[6], h->bal_w[7]);
+        }
+    } else {
+        for (int x = 0; x < 8; ++x) h->bal_w[x] = 1.0f;
+        std::memset(h->bal_hist, 0, sizeof(h->bal_hist));
+    }
+    h->bal_seq = (h->bal_seq + 1) & 63;
+    if (h->bal_seq == 0) h->bal_seq = 1;  // (tag 0 = "nothing written yet")
+    uint32_t *off8 = h->bal_hist[h->bal_seq];
+    double wsum = 0.0, acc = 0.0;
+    for (int x = 0; x < 8; ++x) wsum += h->bal_w[x];
+    off8[0] = 0;
+    for (int x = 0; x < 8; ++x) {
+        acc += h->bal_w[x];
+        off8[x + 1] = x == 7 ? U : std::max(off8[x], (uint32_t)std::llround((double)U * acc / wsum));
+    }
+    h->bal_nb = nb;
+    for (int x = 0; x < 9; ++x) split->off[x] = off8[x];
+    split->tag = h->bal_seq;
+    *dur_out = h->bal_dev;
+    return ZVDB_OK;
+}
+
 // QT = tiles of 256 queries; S = streams (QT * S workgroups, one per CU)
 int launch_bf16s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand,
                       uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate,
                       uint32_t kpv, hipStream_t s) {
-    static const bool stamps = [] { const char *e = getenv("ZVDB_BF16S_STAMPS"); return e && e[0] == '1'; }();
-    if (stamps && !gate && kpv == (uint32_t)KP) {  // diagnostic (synchronises): when each workgroup of the scan began and ended, per XCD
-        static unsigned long long *d_st = nullptr;
-        const uint32_t nb = QT * S;
-        if (!d_st) ZV_HIP(hipMalloc(reinterpret_cast<void **>(&d_st), 2 * 4096 * sizeof(unsigned long long)));
-        ZV_CHECK((bh_launch<false, KP>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, reinterpret_cast<float *>(d_st), s)));
-        std::vector<unsigned long long> st(2 * nb);
-        ZV_HIP(hipStreamSynchronize(s));
-        ZV_HIP(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (uint32_t b = 0; b < nb; ++b) { t0 = std::min(t0, st[2 * b]); t1 = std::max(t1, st[2 * b + 1]); }
-        double xs[8] = {0}, xe[8] = {0}, xmax[8] = {0};
-        for (uint32_t b = 0; b < nb; ++b) {
-            const double e = (double)(st[2 * b + 1] - t0) * 0.01, bg = (double)(st[2 * b] - t0) * 0.01;  // 100 MHz -> us
-            xs[b & 7] += bg; xe[b & 7] += e; xmax[b & 7] = std::max(xmax[b & 7], e);
-        }
-        fprintf(stderr, "[zvdb bf16s stamps] %u workgroups, span %.1f us; per XCD (block %% 8) mean begin / mean end / last end (us):", nb, (double)(t1 - t0) * 0.01);
-        for (int x = 0; x < 8; ++x) fprintf(stderr, "  %d: %.0f / %.0f / %.0f", x, xs[x] / (nb / 8), xe[x] / (nb / 8), xmax[x]);
-        double emin = 1e30, emax = 0, esum = 0;
-        for (uint32_t b = 0; b < nb; ++b) { const double e = (double)(st[2 * b + 1] - t0) * 0.01; emin = std::min(emin, e); emax = std::max(emax, e); esum += e; }
-        fprintf(stderr, "\n[zvdb bf16s stamps] workgroup end times: min %.0f, mean %.0f, max %.0f us\n", emin, esum / nb, emax);
-        return ZVDB_OK;
-    }
-    if (kpv == (uint32_t)KPMAX) return bh_launch<false, KPMAX>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
-    if (kpv == (uint32_t)KPW) return bh_launch<false, KPW>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
-    return bh_launch<false, KP>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+    // the main scan of the guessed-threshold pipeline runs with the adaptive per-XCD split (bh_balance); the gated repair scan with
+    // an even one
+    BhSplit split{};
+    uint32_t *dur = nullptr;
+    if (!gate) ZV_CHECK(bh_balance(h, QT, S, &split, &dur));
+    if (kpv == (uint32_t)KPMAX) return bh_launch<false, KPMAX>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s, split, dur);
+    if (kpv == (uint32_t)KPW) return bh_launch<false, KPW>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s, split, dur);
+    return bh_launch<false, KP>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s, split, dur);
 }
 
 int launch_bf16s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, float *mom, float z,
