@@ -142,7 +142,12 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
         "i, d, c = idx.search_bruteforce(Q, 10, zv.BF_FP4)\n"
         "e, ed, _ = idx.search_bruteforce(Q, 10, zv.BF_F32)\n"
         "i8, d8, _ = idx.search_bruteforce(Q, 10, zv.BF_I8)\n"
-        "np.savez(sys.argv[1], i=i, d=d, c=c, e=e, ed=ed, i8=i8, d8=d8)\n")
+        # rows wider than the bf16 stream kernel takes: the STAGED kernel's bf16 and fp32 screens (guessed thresholds from a row sample)
+        "del idx; wide = zv.Index(metric=zv.METRIC_DOT if sys.argv[2] == 'dot' else zv.METRIC_L2SQ, flags=zv.FLAG_BF16_MIRROR); wide.add_synthetic(540_000, 800, 0x5EED)\n"
+        "Qw = oracle.uniform_rows(0xC0FFEE, 0, 40, 800)\n"
+        "wb, wbd, _ = wide.search_bruteforce(Qw, 10, zv.BF_BF16)\n"
+        "wf, wfd, _ = wide.search_bruteforce(Qw, 10, zv.BF_F32)\n"
+        "np.savez(sys.argv[1], i=i, d=d, c=c, e=e, ed=ed, i8=i8, d8=d8, wb=wb, wbd=wbd, wf=wf, wfd=wfd)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for name, env in {"guess": {}, "cascade": {"ZVDB_BF_GUESS": "0"}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"}, "shape16": {"ZVDB_BF_FP4_SHAPE": "16"},
@@ -166,6 +171,12 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
         assert np.array_equal(res[name]["d8"], base["d8"]), name
     if metric == "l2":
         assert np.array_equal(base["i8"], base["e"]) and np.array_equal(base["d8"], base["ed"])
+    # the staged kernel's float screens ride the pipeline too (thresholds guessed from a 4,096-row sample, k_sample_guess): the
+    # fp32 screen on the 96-d shard and both float screens on 800-d rows return the cascade's results under every variant
+    for name in res:
+        for key in ("e", "ed", "wb", "wbd", "wf", "wfd"):
+            assert np.array_equal(res[name][key], base[key]), (name, key)
+    assert np.array_equal(base["wb"], base["wf"]) and np.array_equal(base["wbd"], base["wfd"])
 
 
 def test_bruteforce_fp4_ragged_large_and_incremental(zv, oracle):

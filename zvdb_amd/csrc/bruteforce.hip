@@ -15,6 +15,7 @@
 #include "common.h"
 #include "wave_select.h"
 #include "bf_select.h"
+#include "row_types.h"
 
 namespace zvdb {
 
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(NI == 4 ? 256 : 512, NI == 4 ? 1 : 2) void k_bf_sca
     uint32_t nq, int alpha_i, uint32_t QT, uint32_t S, uint32_t NT, uint64_t *__restrict__ cand,
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t t_first,
     uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, uint32_t rot_tab, uint32_t dbg_in,
-    unsigned long long *__restrict__ dbgbuf) {
+    unsigned long long *__restrict__ dbgbuf, const uint32_t *__restrict__ gate /* non-null: a no-op unless *gate (the repair scan) */) {
+    if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
     const uint32_t dbg = DBG ? dbg_in : 0u;  // all diagnostics compile out of the production instantiation
     using acc_t = typename AccT<MODE>::type;
     constexpr bool INT = MODE == 2;
@@ -781,18 +783,124 @@ uint32_t rot_table(uint32_t KT) {
     return t;
 }
 
+// Guessed thresholds for the STAGED kernel's float screens (fp32, bf16 on rows wider than the stream kernel takes): mean and
+// variance of the screen key |v|^2 / 2 - q.v (dot / cosine: -q.v) per query over a sample of the shard's rows, evenly strided
+// -> tau = mean + z sigma (k_bf16_guess's rule).  Plain fp32 arithmetic on the stored rows: a guess needs no more (the bf16
+// screen's keys differ from these by its rounding, far below sigma), and what a guess gets wrong is verified and repaired.
+// One workgroup = 4 queries (held in LDS) x nsamp rows, 8 lanes per row.
+constexpr int SG_Q = 4, SG_SPLIT = 16;
+// grid (ceil(nq / SG_Q), SG_SPLIT): workgroup (g, p) takes steps p, p + SG_SPLIT, ... of the sample (32 rows per step) -- a walk is
+// one dependent memory round trip per step, so the sample is cut into SG_SPLIT short chains; k_sample_tau adds the partial sums.
+template <typename RT>
+__global__ __launch_bounds__(256) void k_sample_guess(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, const float *__restrict__ norm /* null: dot */,
+                                                      uint32_t N, const float *__restrict__ queries, uint32_t nq, uint32_t nsamp, float z,
+                                                      uint32_t *__restrict__ verify_flag, double *__restrict__ part /* [SG_SPLIT][nq pad SG_Q][2] */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);                      // [SG_Q][ld], zero padded like the rows (ld: a multiple of 32)
+    double *red = reinterpret_cast<double *>(q + (size_t)SG_Q * ld);  // [4 waves][SG_Q][2]
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
+    const uint32_t q0 = blockIdx.x * SG_Q;
+    for (uint32_t i = threadIdx.x; i < SG_Q * ld; i += 256) {
+        const uint32_t qi = q0 + i / ld, c = i % ld;
+        q[i] = (qi < nq && c < dim) ? queries[(size_t)qi * dim + c] : 0.0f;
+    }
+    __syncthreads();
+    // the sample: runs of 64 consecutive rows, evenly spread (single rows strided over the shard cost a page walk each: 4,096
+    // rows of a 1M x 128 shard took 100 us, the runs take 25 us); sample row i = (i / 64) * bstep + i % 64
+    const uint32_t ns = min(nsamp, N) / 64 * 64 ? min(nsamp, N) / 64 * 64 : min(nsamp, N), bstep = ns >= 64 ? N / (ns / 64) : 1u;
+    float f1[SG_Q], f2[SG_Q];  // per thread: <= nsamp / (32 SG_SPLIT) keys (the sums go to double below)
+#pragma unroll
+    for (int j = 0; j < SG_Q; ++j) f1[j] = f2[j] = 0.0f;
+    // 8 lanes per row: lane g of a group walks elements 4 g + 32 i + [0, 4) (a group reads 128 contiguous bytes of fp32 rows per
+    // step), 32 rows per workgroup step; the group's partial dot products meet in its lane 0 (xor 4, 2, 1)
+    const uint32_t g8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    for (uint32_t i0 = 32 * blockIdx.y; i0 < ns; i0 += 32 * SG_SPLIT) {
+        const uint32_t i = i0 + grp;
+        const bool live = i < ns;
+        const uint32_t r = live ? (ns >= 64 ? (i >> 6) * bstep + (i & 63) : i) : 0u;
+        const RT *v = rows + (size_t)r * ld;
+        float d[SG_Q];
+#pragma unroll
+        for (int j = 0; j < SG_Q; ++j) d[j] = 0.0f;
+        for (uint32_t c0 = 4 * g8; c0 < ld; c0 += 32) {
+            const float4 e = row_load4(v + c0);
+#pragma unroll
+            for (int j = 0; j < SG_Q; ++j) {
+                const float4 qq = *reinterpret_cast<const float4 *>(q + j * ld + c0);
+                d[j] += e.x * qq.x + e.y * qq.y + e.z * qq.z + e.w * qq.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SG_Q; ++j) {
+            d[j] += __shfl_xor(d[j], 4);
+            d[j] += __shfl_xor(d[j], 2);
+            d[j] += __shfl_xor(d[j], 1);
+        }
+        if (live && g8 == 0) {
+            const float hn = norm ? 0.5f * norm[r] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < SG_Q; ++j) {
+                const float key = hn - d[j];
+                f1[j] += key;
+                f2[j] += key * key;
+            }
+        }
+    }
+    double s1[SG_Q], s2[SG_Q];
+#pragma unroll
+    for (int j = 0; j < SG_Q; ++j) { s1[j] = (double)f1[j]; s2[j] = (double)f2[j]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < SG_Q; ++j) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s1[j] += __shfl_xor(s1[j], off);
+            s2[j] += __shfl_xor(s2[j], off);
+        }
+        if (lane == 0) { red[(wave * SG_Q + j) * 2] = s1[j]; red[(wave * SG_Q + j) * 2 + 1] = s2[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < SG_Q * 2) {  // (plain stores: an agent-scope fence per workgroup -- the "last one reduces" pattern -- cost 65 us here)
+        double a = 0.0;
+        for (int w = 0; w < 4; ++w) a += red[w * SG_Q * 2 + threadIdx.x];
+        part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SG_Q * 2 + threadIdx.x] = a;
+    }
+}
+
+// partial sums -> tau = mean + z sigma per query (k_bf16_guess's rule)
+__global__ __launch_bounds__(256) void k_sample_tau(const double *__restrict__ part, uint32_t groups, uint32_t nq, uint32_t ns, float z,
+                                                    uint32_t *__restrict__ tau_g) {
+    const uint32_t qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    double a = 0.0, b = 0.0;
+    for (uint32_t p = 0; p < (uint32_t)SG_SPLIT; ++p) {
+        const double *pp = part + ((size_t)p * groups * SG_Q + qi) * 2;
+        a += pp[0];
+        b += pp[1];
+    }
+    uint32_t out = 0xFFFFFFFFu;  // no bound
+    if (ns >= 64) {
+        const double mu = a / ns, var = b / ns - mu * mu;
+        if (var > 0.0) {
+            const float tk = (float)(mu + (double)z * sqrt(var));
+            if (tk == tk && fabsf(tk) < 3.0e38f) out = f32_key(tk);
+        }
+    }
+    tau_g[qi] = out;
+}
+
 template <int MODE, int NI, int KBV, int KPV = KP>
 int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char *rows, const void *vn,
                  uint32_t N, uint32_t nq, int alpha_i, uint64_t *cand, uint64_t *partial, uint32_t *tau_g,
                  uint32_t kp, uint32_t t_first, uint32_t nt, uint32_t list_base, uint32_t Stot, uint32_t *pcnt,
-                 hipStream_t s) {
-    unsigned long long *dbgbuf = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);
+                 hipStream_t s, const uint32_t *gate = nullptr, unsigned long long *dbg_area = nullptr) {
+    unsigned long long *dbgbuf = dbg_area ? dbg_area : reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);
     if constexpr (KPV != KP) {  // wide lists: production build only
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, false, NI, KBV, KPV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         hipLaunchKernelGGL((k_bf_scan5<MODE, false, NI, KBV, KPV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
-                           list_base, Stot, pcnt, rot_table(p.row_bytes / KBV), 0u, dbgbuf);
+                           list_base, Stot, pcnt, rot_table(p.row_bytes / KBV), 0u, dbgbuf, gate);
         return ZVDB_OK;
     }
     if (debug_flags()) {
@@ -801,13 +909,13 @@ int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char
         hipLaunchKernelGGL((k_bf_scan5<MODE, true, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial,
                            (debug_flags() & 2) ? nullptr : tau_g, kp, t_first, list_base, Stot, pcnt, rot_table(p.row_bytes / KBV),
-                           debug_flags(), dbgbuf);
+                           debug_flags(), dbgbuf, gate);
     } else {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_scan5<MODE, false, NI, KBV>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4));
         hipLaunchKernelGGL((k_bf_scan5<MODE, false, NI, KBV>), dim3(p.QT * p.S), dim3(NI == 4 ? 256 : 512), LDS4, s, q_op, rows, p.row_bytes,
                            p.row_bytes / KBV, vn, N, nq, alpha_i, p.QT, p.S, nt, cand, partial, tau_g, kp, t_first,
-                           list_base, Stot, pcnt, rot_table(p.row_bytes / KBV), 0u, dbgbuf);
+                           list_base, Stot, pcnt, rot_table(p.row_bytes / KBV), 0u, dbgbuf, gate);
     }
     return ZVDB_OK;
 }
@@ -915,7 +1023,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                   "ZVDB_BF_I8 with dim <= 768, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
         return ZVDB_ERR_UNSUPPORTED;
     }
-    if (!guess_pipe) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
+    // The float screens of the STAGED kernel (fp32; bf16 on rows the stream kernel does not take) ride the same guessed +
+    // verified thresholds on shards of >= 8 tiles per stream: the cascade below spends a flooded tile per stream, a merge
+    // and a second partial scan on learning what a 4,096-row sample predicts (BASELINE configs[1], 1M x 128 fp32 at batch
+    // 256: pass A 187 us + merges 90 us of a 1.03 ms step, and pass C runs against the loose bound of 4,096 rows).
+    const bool staged_guess = !guess_pipe && !stream_route && !guess_off && (mode == ZVDB_BF_F32 || mode == ZVDB_BF_BF16) &&
+                              kpv == (uint32_t)KP && p.NT >= 8 * p.S && !debug_flags();
+    if (!guess_pipe && !staged_guess) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
     {
@@ -964,7 +1078,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         // than kp candidates has no proof that it holds the kp best -> (4) gated repair scan + merge re-read the corpus
         // for those queries with no bound (exact; no-ops when the guess held, which is the common case).  A guess that
         // is too loose is self-correcting (the append buffers fill and the prune rounds tighten the bound).
-        if (guess_pipe) {
+        float z = 0.0f;
+        if (guess_pipe || staged_guess) {
             static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
             static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
             // candidates admitted per query: 6 per survivor wanted (384 for the usual 64; fewer survivors, fewer appends)
@@ -981,7 +1096,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 __atomic_store_n(h->guess_flag_host, 0u, __ATOMIC_RELAXED);
                 h->guess_adapt = std::min(2.0f, h->guess_adapt + 0.5f);
             }
-            const float z = (float)(norm_quantile(tail) + zshift + (zshift == 0.0 ? (double)h->guess_adapt : 0.0));
+            z = (float)(norm_quantile(tail) + zshift + (zshift == 0.0 ? (double)h->guess_adapt : 0.0));
+        }
+        if (guess_pipe) {
             uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
             uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
             uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
@@ -1013,6 +1130,44 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, kpv, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids,
                                (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv);
+            timing_end(h, s);
+            ZV_HIP(hipGetLastError());
+            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+        }
+        if (staged_guess) {
+            uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
+            uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
+            uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
+            unsigned long long *dbg_area = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);  // (never written in production builds)
+            static const uint32_t nsamp_env = [] { const char *e = getenv("ZVDB_BF_SAMPLE"); return e ? (uint32_t)atoi(e) : 0u; }();  // (tuning)
+            const uint32_t nsamp = nsamp_env ? nsamp_env : 4096;
+            ZV_CHECK(rows_dispatch(h, [&](auto rws, uint32_t ld) -> int {
+                using RT = row_elem_t<decltype(rws)>;
+                const size_t lds = (size_t)SG_Q * ld * 4 + 4 * SG_Q * 2 * 8 + 16;
+                if (lds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sample_guess<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                const uint32_t groups = (nq + SG_Q - 1) / SG_Q;
+                double *part = reinterpret_cast<double *>(cand);  // (cand is free until the scan)
+                const uint32_t ns_eff = std::min(nsamp, N) >= 64 ? std::min(nsamp, N) / 64 * 64 : std::min(nsamp, N);
+                hipLaunchKernelGGL(k_sample_guess<RT>, dim3(groups, SG_SPLIT), dim3(256), lds, s, rws, ld, h->dim,
+                                   l2 ? ((h->flags & ZVDB_FLAG_BF16_ROWS) ? h->norm_h : h->norm) : (const float *)nullptr, N, d_queries_exact, nq, nsamp, z, vflag, part);
+                hipLaunchKernelGGL(k_sample_tau, dim3((nq + 255) / 256), dim3(256), 0, s, part, groups, nq, ns_eff, z, tau_g);
+                ZV_HIP(hipGetLastError());
+                return ZVDB_OK;
+            }));
+            auto scan1 = [&](uint32_t *tau, uint32_t list_base, const uint32_t *gate) -> int {
+                if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
+                return launch_scan5<0, 2, 128>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
+            };
+            ZV_CHECK(scan1(tau_g, 0, nullptr));
+            const uint32_t cap = kp + 64 * kpv;
+            const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
+            if (mlds > 64 * 1024)
+                ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 1, vflag, defq,
+                               h->guess_flag_dev, kpv);
+            ZV_CHECK(scan1(tau_rep, p.S, vflag));
+            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, (uint32_t *)nullptr, kp, cap, p.S, 2, vflag,
+                               defq, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
             return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
