@@ -37,7 +37,7 @@ namespace zvdb {
 namespace {
 
 constexpr int BH_NW = 8;                  // waves per workgroup (2 per SIMD)
-constexpr int BH_R = 6;                   // A-fragment register ring (reads in flight per wave; 5: -1.6 %, measured)
+constexpr int BH_R = 6;                   // A-fragment register ring (reads in flight per wave; 5: -1.6 %, 7: -3.4 %, 8 spills: measured)
 constexpr int BH_CAP = NSUB * SUBCAP;     // append-buffer entries per (workgroup, query)
 constexpr int BH_HW = 384, BH_MARK = 64;  // prune request mark; queries above MARK are pruned in a round
 constexpr uint32_t BH_SAMPLE_GROUPS = 8;  // moments mode: 32-row groups sampled per stream
@@ -225,6 +225,9 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     // bh_prune_wave) and nothing of the loop's register state lives across it: inside the loop hipcc spilled the query fragments
     // around the call and re-loaded them on the way back.  So the loop is LEFT for a prune, and every entry loads the fragments
     // and the bounds afresh and drains the counters once, ahead of the loop.
+    // static priority for the younger half of the workgroup, the arbitration loser of every SIMD pair otherwise
+    // (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): +0.4 .. 0.9 % (profiles/r3/bf16_stream_ab.txt)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     uint32_t slot = 0, it = 0;
     while (it < n) {
 #pragma unroll
