@@ -1028,7 +1028,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // and a second partial scan on learning what a 4,096-row sample predicts (BASELINE configs[1], 1M x 128 fp32 at batch
     // 256: pass A 187 us + merges 90 us of a 1.03 ms step, and pass C runs against the loose bound of 4,096 rows).
     const bool staged_guess = !guess_pipe && !stream_route && !guess_off && (mode == ZVDB_BF_F32 || mode == ZVDB_BF_BF16) &&
-                              kpv == (uint32_t)KP && p.NT >= 8 * p.S && !debug_flags();
+                              kpv == (uint32_t)KP && p.NT >= 8 * p.S && !(debug_flags() & ~(16u | 32u));
     if (!guess_pipe && !staged_guess) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
@@ -1159,6 +1159,16 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 return launch_scan5<0, 2, 128>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
             };
             ZV_CHECK(scan1(tau_g, 0, nullptr));
+            if (debug_flags() & (16 | 32)) {  // diagnostic build of the scan: counters / cycle sums of the one pass
+                unsigned long long c[12];
+                ZV_HIP(hipMemcpyAsync(c, dbg_area, sizeof(c), hipMemcpyDeviceToHost, s));
+                ZV_HIP(hipStreamSynchronize(s));
+                const double nb = (double)p.QT * p.S;
+                fprintf(stderr, "[zvdb dbg] guessed-threshold pass (tiles %u, streams %u): wave-tiles %llu, with-pass %llu, prunes %llu, appends %llu | cycles/blk (wave 0): "
+                        "kernel %.0f, phaseA %.0f, phaseB %.0f; slice loop: wait+barrier %.0f, reads+DMA issue %.0f, k-steps %.0f\n",
+                        p.NT, p.S, c[0], c[1], c[2], c[3], c[4] / nb, c[6] / nb, c[7] / nb, c[9] / nb, c[10] / nb, c[11] / nb);
+                ZV_HIP(hipMemsetAsync(dbg_area, 0, 128, s));
+            }
             const uint32_t cap = kp + 64 * kpv;
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             if (mlds > 64 * 1024)
