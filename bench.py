@@ -529,7 +529,7 @@ def main():
         achieved = flops / kavg / 1e12 if kavg > 0 else 0.0
         peak = PEAK_TFLOPS[args.mode]
         traffic, traffic_src = None, None
-        for rnd in ("r2", "r1"):
+        for rnd in ("r3", "r2", "r1"):
             tf = os.path.join(ROOT, "profiles", rnd, "traffic_10Mx768.json")
             if world == 1 and traffic is None and os.path.exists(tf):
                 tj = json.load(open(tf)).get(args.mode)
@@ -574,7 +574,7 @@ def main():
                 "timed_regions": kern_n,
                 "region": ("per step: sample-moments launch + threshold guess + ONE scan of the whole shard (stream kernel) + verifying merge "
                            "+ gated repair scan/merge (no-ops when the guess held); the scan is ~99 % of the region "
-                           "(profiles/r2/: rocprofv3 kernel stats of this command)" if args.mode in ("fp4", "i8", "bf16") else
+                           "(profiles/r3/: rocprofv3 kernel stats of this command)" if args.mode in ("fp4", "i8", "bf16") else
                            "per step: 3 launches of the scan kernel (threshold cascade passes A/B/C) + 2 threshold merges"),
                 "peak_note": ("spec dense fp4 MFMA peak; tools/mfma_peak_bench.hip measures 6.7 PFLOP/s for back-to-back "
                               "v_mfma_scale_f32_32x32x64_f8f6f4 on random operands (the chip lowers its clock under load)" if args.mode == "fp4" else
