@@ -575,7 +575,8 @@ def main():
                 "region": ("per step: sample-moments launch + threshold guess + ONE scan of the whole shard (stream kernel) + verifying merge "
                            "+ gated repair scan/merge (no-ops when the guess held); the scan is ~99 % of the region "
                            "(profiles/r3/: rocprofv3 kernel stats of this command)" if args.mode in ("fp4", "i8", "bf16") else
-                           "per step: 3 launches of the scan kernel (threshold cascade passes A/B/C) + 2 threshold merges"),
+                           "per step: row-sample moments (k_sample_guess) + thresholds + ONE scan of the whole shard (staged 256 x 256 kernel) + verifying "
+                           "merge + gated repair scan/merge (no-ops when the guess held)"),
                 "peak_note": ("spec dense fp4 MFMA peak; tools/mfma_peak_bench.hip measures 6.7 PFLOP/s for back-to-back "
                               "v_mfma_scale_f32_32x32x64_f8f6f4 on random operands (the chip lowers its clock under load)" if args.mode == "fp4" else
                               "spec dense bf16 MFMA peak (2.4 GHz); on random bf16 operands the chip is power-limited: the bare "
