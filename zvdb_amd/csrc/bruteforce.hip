@@ -1156,6 +1156,12 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             }));
             auto scan1 = [&](uint32_t *tau, uint32_t list_base, const uint32_t *gate) -> int {
                 if (mode == ZVDB_BF_BF16) return launch_scan5<1, 2, 128>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
+                // one query tile: no other workgroup shares a stream's L2 lines, every slice is an HBM round trip -- the 64-byte slices'
+                // 4-stage ring (three in flight) covers it better than two 128-byte stages: +3 % at 1M x 128, +2 % at 256-d
+                // (ZVDB_BF_F32_KBV=128 / 64 forces either)
+                static const int kbv_env = [] { const char *e = getenv("ZVDB_BF_F32_KBV"); return e ? atoi(e) : 0; }();
+                const bool kbv64 = kbv_env ? kbv_env == 64 : p.QT == 1;
+                if (kbv64) return launch_scan5<0, 2, 64>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
                 return launch_scan5<0, 2, 128>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
             };
             ZV_CHECK(scan1(tau_g, 0, nullptr));
