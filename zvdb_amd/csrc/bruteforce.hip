@@ -964,7 +964,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
     // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
     // (from 8 tiles = 64 row groups per stream: BASELINE configs[1], 1M x 128 at batch 256 = 256 streams of 15 tiles, rides it)
-    const bool sb = mode == ZVDB_BF_BF16 && bf16s_eligible(h) && !guess_off && p.NT >= 8 * p.S && !(debug_flags() & 64);
+    // (smaller shards with k beyond the staged kernel's 112: one flooding scan of the stream kernel, like the int8 route)
+    const bool sb_big = !guess_off && p.NT >= 8 * p.S;
+    const bool sb = mode == ZVDB_BF_BF16 && bf16s_eligible(h) && !(debug_flags() & 64) && (sb_big || k > (uint32_t)KPW - 16);
     if (sb) ZV_CHECK(ensure_bf16_frag_mirror(h, s));
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
@@ -1008,7 +1010,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t nlists = p.S, stot_lists = p.S;
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
-    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4) && big8) || sb;
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4) && big8) || (sb && sb_big);
     // k' = 64 survivors per query (one per lane of the selects) carry k <= 48 (56 with the exact fp32 screen); the stream
     // kernels also run with k' = 128 (two entries per lane), which carries k <= 112 -- on large shards inside the guessed-
     // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
@@ -1020,7 +1022,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const uint32_t kpv = !wide_k ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
     if (k > (kpv != (uint32_t)KP ? kpv - 16 : kmax)) {
         set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d on the stream routes: "
-                  "ZVDB_BF_I8 with dim <= 768, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
+                  "ZVDB_BF_I8 / ZVDB_BF_BF16 with dim <= 768, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
         return ZVDB_ERR_UNSUPPORTED;
     }
     // The float screens of the STAGED kernel (fp32; bf16 on rows the stream kernel does not take) ride the same guessed +
@@ -1193,6 +1195,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             const uint32_t SS = t128 ? p.S8 : p.S;
             if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            else if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
             const uint32_t cap = kp + 64 * kpv;
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
