@@ -1422,7 +1422,7 @@ int zvdb_hip_load(const char *path, int32_t device, zvdb_hip_index **out) {
         if (hd.flags & ~(ZVDB_FLAG_BF16_MIRROR | ZVDB_FLAG_BF16_ROWS)) return bad("unknown flags");
         if (hd.metric > ZVDB_METRIC_COSINE) return bad("metric");
         if (hd.dim > (1u << 20) || hd.ld > (1u << 21) || hd.ldh > (1u << 21)) return bad("dimension");
-        if (hd.gstride == 0 || hd.gstride > 4096 || hd.m == 0 || hd.m > hd.gstride) return bad("m / graph stride");
+        if (hd.gstride == 0 || hd.gstride > 4096 || hd.m == 0 || hd.m > 4096) return bad("m / graph stride");  // (zvdb_hip_create's domains; m may exceed the stride)
         if (hd.count > 0xFFFFFFF0ull || hd.up_count > 0xFFFFFFF0ull) return bad("row count");
         if (hd.count == 0 && hd.up_count != 0) return bad("upper layers without rows");
         if (hd.count && hd.dim == 0) return bad("rows without a dimension");
