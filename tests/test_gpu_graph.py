@@ -284,3 +284,19 @@ def test_descend_is_refused_once_the_bulk_graph_is_stale(zv, oracle):
     idx.set_neighbors(7, [1, 2, 3])
     with pytest.raises(zv.ZvdbError):
         idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
+
+
+def test_load_accepts_every_index_create_accepts(zv, oracle, tmp_path):
+    """m may exceed the device stride (zvdb_hip_create allows it; the bulk build's upper-layer sub-indexes are such): the loader's
+    header checks follow create's domains, not a narrower guess."""
+    V = oracle.uniform_rows(3, 0, 800, 16)
+    idx = zv.Index(m=16, graph_stride=8)
+    idx.add(V)
+    idx.build_knn_graph(8)
+    path = str(tmp_path / "m_gt_stride.zvdb")
+    idx.save(path)
+    got = zv.Index.load(path)
+    Q = oracle.uniform_rows(4, 0, 8, 16)
+    a = idx.search_graph(Q, 5, ef=16)
+    b = got.search_graph(Q, 5, ef=16)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
