@@ -1030,7 +1030,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // and a second partial scan on learning what a 4,096-row sample predicts (BASELINE configs[1], 1M x 128 fp32 at batch
     // 256: pass A 187 us + merges 90 us of a 1.03 ms step, and pass C runs against the loose bound of 4,096 rows).
     const bool staged_guess = !guess_pipe && !stream_route && !guess_off && (mode == ZVDB_BF_F32 || mode == ZVDB_BF_BF16) &&
-                              kpv == (uint32_t)KP && p.NT >= 8 * p.S && !(debug_flags() & ~(16u | 32u));
+                              kpv == (uint32_t)KP && p.NT >= 8 * p.S && !(debug_flags() & ~(16u | 32u)) &&
+                              (size_t)SG_Q * std::max(h->ld, h->ldh) * 4 <= 128 * 1024;  // (k_sample_guess keeps 4 padded queries in LDS)
     if (!guess_pipe && !staged_guess) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     timing_begin(h, s);
