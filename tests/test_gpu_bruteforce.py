@@ -435,3 +435,24 @@ def test_exact_screens_on_dense_low_dimensional_rows(zv, oracle, n, d, nq, k):
     for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
         ids, dist, _ = idx.search_bruteforce(Q, k, mode)
         assert np.array_equal(ids, ri) and np.array_equal(dist, rd), mode
+
+
+def test_bf16_stream_results_do_not_depend_on_the_adaptive_xcd_split(zv, oracle):
+    """The bf16 stream scan re-splits its rows over the 8 XCDs from the workgroup durations of earlier launches (bh_balance): every
+    launch may run with a different partition of the rows into streams.  The results may not move: 30 launches of one batch, each
+    synchronised so that the next one sees fresh durations, return the first launch's ids and distances, which are the int8 route's
+    and (sampled) the oracle's exact top-k."""
+    n, d, nq, k = 1_000_000, 64, 1024, 10
+    idx = zv.Index(flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(n, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    first = idx.search_bruteforce(Q, k, zv.BF_BF16)
+    for _ in range(30):
+        again = idx.search_bruteforce(Q, k, zv.BF_BF16)
+        assert all(np.array_equal(a, b) for a, b in zip(first, again))
+    i8 = idx.search_bruteforce(Q, k, zv.BF_I8)
+    assert np.array_equal(first[0], i8[0]) and np.array_equal(first[1], i8[1])
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    sel = [0, 511, 1023]
+    ri, rd, _ = oracle.bruteforce_topk(V, Q[sel], k)
+    assert np.array_equal(first[0][sel], ri) and np.array_equal(first[1][sel], rd)
