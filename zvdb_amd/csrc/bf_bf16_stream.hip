@@ -127,7 +127,7 @@ __device__ __attribute__((noinline, cold)) void bh_prune_wave(uint64_t *kept, ui
 // repair launch (a no-op unless the verification failed), so that profiler statistics do not average no-ops into the scan
 // units per XCD: XCD x (= blockIdx % 8 under round-robin placement) scans units [off[x], off[x + 1]), split evenly over its S / 8
 // streams; off[8] == 0: an even split over all S streams
-struct BhSplit { uint32_t off[9]; uint32_t tag; };  // tag: this launch's number mod 64, returned with the durations
+struct BhSplit { uint32_t off[9]; uint32_t tag; };  // tag: this launch's number (1 .. 255, cyclic), returned with the durations
 
 template <int KS, int NG, bool MOM, int KPV = KP, int GATED = 0>
 __global__ __launch_bounds__(512, 2) void k_bf16_stream(
@@ -595,7 +595,7 @@ static int bh_balance(const zvdb_hip_index *h, uint32_t QT, uint32_t S, BhSplit 
         // durations of ONE earlier launch (all under the same tag: launches are queued ahead of the device, the newest complete set
         // may be several launches old) against the split THAT launch ran with
         const uint32_t tag = __atomic_load_n(h->bal_host, __ATOMIC_RELAXED) >> 24;
-        const uint32_t *ho = h->bal_hist[tag & 63];
+        const uint32_t *ho = h->bal_hist[tag & 255];
         double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool all = ho[8] == U;
         for (uint32_t b = 0; b < nb && all; ++b) {
@@ -616,8 +616,8 @@ static int bh_balance(const zvdb_hip_index *h, uint32_t QT, uint32_t S, BhSplit 
         for (int x = 0; x < 8; ++x) h->bal_w[x] = 1.0f;
         std::memset(h->bal_hist, 0, sizeof(h->bal_hist));
     }
-    h->bal_seq = (h->bal_seq + 1) & 63;
-    if (h->bal_seq == 0) h->bal_seq = 1;  // (tag 0 = "nothing written yet")
+    h->bal_seq = (h->bal_seq + 1) & 255;  // (a caller more than 254 scans ahead of the device would pair durations with a later
+    if (h->bal_seq == 0) h->bal_seq = 1;  //  launch's split: the shares are clamped to +-15 % and damped, the results unaffected; tag 0 = "nothing written yet")
     uint32_t *off8 = h->bal_hist[h->bal_seq];
     double wsum = 0.0, acc = 0.0;
     for (int x = 0; x < 8; ++x) wsum += h->bal_w[x];

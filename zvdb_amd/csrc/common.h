@@ -172,7 +172,7 @@ struct zvdb_hip_index {
     // next launch reads whatever has arrived (no synchronisation) -- bf_bf16_stream.hip: bh_balance
     mutable uint32_t *bal_host = nullptr, *bal_dev = nullptr;  // [4096] durations (100 MHz ticks) of the last scan's workgroups
     mutable float bal_w[8] = {1, 1, 1, 1, 1, 1, 1, 1};        // relative share of the units per XCD
-    mutable uint32_t bal_hist[64][9] = {};  // the splits (units per XCD, prefix form) of the last 64 scans, by launch tag
+    mutable uint32_t bal_hist[256][9] = {};  // the splits (units per XCD, prefix form) of the last 255 scans, by launch tag (1 .. 255)
     mutable uint32_t bal_nb = 0, bal_seq = 0;  // workgroups of those scans; tag of the last one
     // zvdb_hip_insert_layer0: host-mapped [row | result] block -- the kernels read the point and write the result through
     // it, so an insert submits no copy-engine transfers (each costs ~10 us for a few hundred bytes)
