@@ -286,8 +286,10 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
             if constexpr (FI + R < F) bh_lds_read128<(FI + R) * 1024>(A[SL], base);
             // this wave's pieces of the unit being fetched: one every DSTEP fragments from fragment 2 on, the norms behind the last.
             // 48-fragment units issue theirs in the first 60 % of the loop, so that the wait behind the next barrier finds them
-            // landed: steps of 8 / 6 / 4 / 5: 93.4k / 93.3k / 94.5k / 95.3k QPS on one box (profiles/r3/bf16_stream_ab.txt; a
-            // placement also moves hipcc's register allocation, the loop has no VGPR to spare -- re-measure after any change here)
+            // landed: steps of 8 / 7 / 6 / 5 / 4 in the final loop structure: 95.0k / 94.4k / 97.9k / 98.9k / 98.9k QPS on one box, with
+            // 2 x FETCH_SIZE = 15.4 / 48.2 / 19.9 / 16.8 / 18.1 GB per scan for 15.4 GB of corpus (profiles/r3/bf16_stream_ab.txt): how well
+            // the 4 query-tile workgroups of a stream share their fetches depends on the placement too.  A placement also moves
+            // hipcc's register allocation (the loop has no VGPR to spare) -- re-measure after any change here
             constexpr int DSTEP = F == 48 ? 5 : 8, NORM_AT = F == 48 ? 30 : F - 3;
             if constexpr (FI % DSTEP == 2 && FI / DSTEP < P) {
                 constexpr uint32_t POFF = (uint32_t)BH_NW * (FI / DSTEP) * 1024;  // piece = wave + 8 (FI / DSTEP)
