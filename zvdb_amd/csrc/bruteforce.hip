@@ -1135,7 +1135,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp);
         }
         if (staged_guess) {
             uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
@@ -1189,7 +1189,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                defq, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp);
         }
         if (kpv != (uint32_t)KP && stream_route) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
             const bool t128 = s8 || s4;
@@ -1205,7 +1205,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp);
         }
         if (p.NT >= 4 * p.S && !(debug_flags() & 64)) {
             // pass A streams: every workgroup of pass A floods one tile (256 candidates per query, 8-byte

@@ -253,7 +253,8 @@ int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq,
 // exact re-rank of candidate lists: cand[nq][kc] u32 (0xFFFFFFFF = empty) -> top-k by (dist,id)
 int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, const uint32_t *d_cand,
                   uint32_t kc, uint32_t k, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
-                  uint32_t *d_count, hipStream_t s);
+                  uint32_t *d_count, hipStream_t s,
+                  uint32_t kp_valid = 0 /* > 0: the lists hold at most this many candidates (compacted to the front) */);
 
 // ---- data_kernels.hip -------------------------------------------------------
 int launch_fill_synthetic(float *d_out, uint64_t nrows, uint32_t dim, uint32_t ld, uint64_t seed,

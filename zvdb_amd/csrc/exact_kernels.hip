@@ -2470,21 +2470,39 @@ __global__ __launch_bounds__(64) void k_rerank(const RT *__restrict__ rows, uint
 // reference's (hnsw.zig:182-192): one lane, strictly ascending k, sub / mul / add, no contraction.
 typedef const __attribute__((address_space(1))) void *rr_gptr_t;
 typedef __attribute__((address_space(3))) void *rr_lptr_t;
-// KC = 64 or 128 candidates per query (KC / 64 batches of 64 rows through the same two stage buffers).  RT = stored row
-// element: a 256-byte chunk holds 64 fp32 / 128 bf16 elements, a 16-byte piece 4 / 8.
-template <int KC, typename RT>
+// LDS-DMA by inline asm (per-lane 64-bit source address, wave-uniform LDS destination through M0).  With the builtin, hipcc's
+// waitcnt pass puts s_waitcnt vmcnt(0) in front of EVERY LDS read of the walk below -- it cannot prove the reads disjoint from
+// the DMA of the next chunk, which is in flight by design -- so fetch and walk ran strictly one after the other (r2 measured
+// "deeper staging changes nothing" for exactly this reason).  The kernel waits for its chunks itself.
+__device__ __forceinline__ void rr_dma16(const unsigned char *src, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+// KC = 64 / 128 / 256 candidates per query (KC / 64 batches of 64 rows through the same two stage buffers).  RT = stored row
+// element.  CHB = bytes of a row fetched per step (256 / 512 / 1024): one LDS-DMA instruction moves 1 KiB = 1024 / CHB rows x CHB
+// contiguous bytes, so a larger CHB reads longer runs of a row at once (a 16-byte piece holds 4 fp32 / 8 bf16 elements).  SR =
+// rows staged per batch: 64, or 32 when the lists hold at most 32 candidates (the brute-force routes at k <= 16: the host knows) --
+// then CHB = 512 fits the same 32 KiB of LDS (4 workgroups per CU) as 64 rows of 256 bytes.  Measured in the headline step (1,024
+// queries x 32 candidates x 3 KiB rows; rocprofv3 stats of `bench.py --mode bf16`): round 2's kernel 71.6 us; with the waits and the walk fixed (below) 41.7 us
+// (256 B x 64 rows), 40.3 us (512 B x 32 rows), 61.5 us (1 KiB x 32 rows: half the workgroups per CU); four stage buffers with three
+// chunks in flight 43.3 us -- what is left is the rate of 100 MB of scattered 256 .. 512-byte pieces (~3 TB/s), not round trips.
+template <int KC, typename RT, int CHB = 256, int SR = 64>
 __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
                                                       const float *__restrict__ queries, const uint32_t *__restrict__ cand,
                                                       uint32_t k, uint64_t id_offset, uint64_t *__restrict__ out_ids,
                                                       float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
-                                                      uint32_t dim_pad /* multiple of 64 */) {
+                                                      uint32_t dim_pad /* multiple of a chunk's elements */) {
     constexpr uint32_t kc = KC;
     constexpr int NB = KC / 64;
-    constexpr int RR_CH = 256 / (int)sizeof(RT);  // elements per chunk
+    constexpr int LPR = CHB / 16;                 // lanes per row of a DMA instruction = 16-byte pieces per chunk
+    constexpr int RPI = 64 / LPR;                 // rows per DMA instruction
+    constexpr int NINS = SR / RPI;                // DMA instructions per chunk
+    constexpr int RR_CH = CHB / (int)sizeof(RT);  // elements per chunk
     constexpr int EPP = 16 / (int)sizeof(RT);     // elements per 16-byte piece
+    constexpr uint32_t BUF = (uint32_t)SR * CHB;  // bytes of one stage buffer
+    static_assert(SR == 64 || (SR == 32 && KC == 64), "32 staged rows: single batch only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *stage = smem;                                              // [2][64 rows][256 B]
-    float *q = reinterpret_cast<float *>(smem + 2 * 64 * 256);               // [dim_pad], zero padded
+    unsigned char *stage = smem;                                              // [2][SR rows][CHB]
+    float *q = reinterpret_cast<float *>(smem + 2 * BUF);                     // [dim_pad], zero padded
     float *cd = q + dim_pad;
     uint32_t *ci = reinterpret_cast<uint32_t *>(cd + kc);
     const int lane = threadIdx.x;
@@ -2492,7 +2510,7 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
 #pragma unroll
-    for (int bt = 0; bt < NB; ++bt) ci[lane + 64 * bt] = cand[(size_t)qi * kc + lane + 64 * bt];
+    for (int bt = 0; bt < NB; ++bt) ci[lane + 64 * bt] = (SR == 64 || lane < SR) ? cand[(size_t)qi * kc + lane + 64 * bt] : 0xFFFFFFFFu;
     __syncthreads();
     {   // drop duplicate ids (keep the first copy)
         bool dup[NB];
@@ -2511,65 +2529,65 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
             if (dup[bt]) ci[lane + 64 * bt] = 0xFFFFFFFFu;
         __syncthreads();
     }
-    const uint32_t nch = (ld + RR_CH - 1) / RR_CH;
+    const uint32_t nch = (ld * (uint32_t)sizeof(RT) + CHB - 1) / CHB;
     const uint32_t row_bytes = ld * (uint32_t)sizeof(RT);
+    const uint32_t stage_lds = (uint32_t)(size_t)(rr_lptr_t)stage;
 #pragma unroll 1
     for (int bt = 0; bt < NB; ++bt) {
-        // DMA side: instruction t fills rows 4t .. 4t+3 of this batch; this lane serves row 4t + (lane >> 4), position lane & 15
-        uint32_t src_off[16];  // byte offset of my piece inside a chunk of row (4t + lane/16), before the chunk offset
-        const RT *src_row[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint32_t r = 4 * t + (lane >> 4);
-            const uint32_t id = ci[64 * bt + r];
-            src_row[t] = rows + (size_t)(id == 0xFFFFFFFFu ? 0u : id) * ld;
-            src_off[t] = (((uint32_t)lane & 15u) ^ (r & 15u)) << 4;
-        }
+        // DMA side: instruction t fills rows RPI t .. RPI t + RPI - 1 of this batch; this lane serves row RPI t + lane / LPR, piece
+        // lane % LPR -- of the SOURCE piece (lane % LPR) ^ (row % LPR): the swizzle that makes the walk's reads conflict-free
         // slots past the last valid candidate of the batch (lists are compacted to the front: a shard that keeps fewer than
         // 64 survivors leaves a ~0 tail) are not fetched at all: whole DMA instructions drop out, wave-uniformly
         const unsigned long long vmask = __ballot(ci[64 * bt + lane] != 0xFFFFFFFFu);
-        const int nt_used = vmask ? (64 - __builtin_clzll(vmask) + 3) / 4 : 0;
+        const int nvalid = vmask ? 64 - __builtin_clzll(vmask) : 0;
+        const int nt_used = min((nvalid + RPI - 1) / RPI, NINS);
         auto issue = [&](uint32_t c, uint32_t buf) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
+#pragma unroll 8
+            for (int t = 0; t < NINS; ++t) {
                 if (t >= nt_used) break;
+                const uint32_t r = (uint32_t)RPI * t + ((uint32_t)lane / LPR);
+                const uint32_t id = ci[64 * bt + r];
+                const unsigned char *src_row = reinterpret_cast<const unsigned char *>(rows + (size_t)(id == 0xFFFFFFFFu ? 0u : id) * ld);
                 // the row's last chunk may be short (ld is a multiple of 32 floats): stay inside the row
-                const uint32_t off = min(c * 256u + src_off[t], row_bytes - 16);
-                __builtin_amdgcn_global_load_lds((rr_gptr_t)(reinterpret_cast<const unsigned char *>(src_row[t]) + off),
-                                                 (rr_lptr_t)(stage + buf * (64 * 256) + t * 1024), 16, 0, 0);
+                const uint32_t off = min(c * (uint32_t)CHB + ((((uint32_t)lane % LPR) ^ (r % LPR)) << 4), row_bytes - 16);
+                rr_dma16(src_row + off, (uint32_t)__builtin_amdgcn_readfirstlane((int)(stage_lds + buf * BUF + t * 1024)));
             }
         };
-        const uint32_t my_id = ci[64 * bt + lane];
+        const uint32_t my_id = lane < SR ? ci[64 * bt + lane] : 0xFFFFFFFFu;
         float sum = 0.0f;
         issue(0, 0);
         for (uint32_t c = 0; c < nch; ++c) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c has landed (single wave: no barrier needed)
             if (c + 1 < nch) issue(c + 1, (c + 1) & 1);
-            const unsigned char *mine = stage + (c & 1) * (64 * 256) + lane * 256;
+            const unsigned char *mine = stage + (c & 1) * BUF + (lane & (SR - 1)) * CHB;
             const uint32_t k0 = c * RR_CH;
-            const uint32_t kend = min(dim, k0 + RR_CH);
+            // Elements [dim, ld) are zero in the row (padding) and in q: they add +0.0, which changes nothing -- so a chunk that lies
+            // inside the row is walked whole, without a test per element; only the row's last, short chunk (ld is a multiple of 32
+            // fp32 / 64 bf16 elements, not of a chunk) stops at the row's end, a whole piece at a time.  The sum stays the
+            // reference's: one element after the other, each operation rounded (this file is built without contraction).
+            auto walk = [&](auto l2c, auto fullc) {
+                constexpr bool L2 = decltype(l2c)::value, FULL = decltype(fullc)::value;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const uint32_t kk = k0 + EPP * p;
-                if (kk >= kend) break;
-                float vv[EPP], aa[EPP];
-                if constexpr (sizeof(RT) == 4) {
-                    const float4 v = *reinterpret_cast<const float4 *>(mine + ((p ^ (lane & 15)) << 4));
-                    vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
-                } else {
-                    const uint4 w = *reinterpret_cast<const uint4 *>(mine + ((p ^ (lane & 15)) << 4));
-                    vv[0] = bf16_lo(w.x); vv[1] = bf16_hi(w.x); vv[2] = bf16_lo(w.y); vv[3] = bf16_hi(w.y);
-                    vv[4] = bf16_lo(w.z); vv[5] = bf16_hi(w.z); vv[6] = bf16_lo(w.w); vv[7] = bf16_hi(w.w);
-                }
+                for (int p = 0; p < LPR; ++p) {
+                    const uint32_t kk = k0 + EPP * p;
+                    if constexpr (!FULL) { if (kk >= ld) break; }
+                    float vv[EPP], aa[EPP];
+                    if constexpr (sizeof(RT) == 4) {
+                        const float4 v = *reinterpret_cast<const float4 *>(mine + ((p ^ (lane & (LPR - 1))) << 4));
+                        vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
+                    } else {
+                        const uint4 w = *reinterpret_cast<const uint4 *>(mine + ((p ^ (lane & (LPR - 1))) << 4));
+                        vv[0] = bf16_lo(w.x); vv[1] = bf16_hi(w.x); vv[2] = bf16_lo(w.y); vv[3] = bf16_hi(w.y);
+                        vv[4] = bf16_lo(w.z); vv[5] = bf16_hi(w.z); vv[6] = bf16_lo(w.w); vv[7] = bf16_hi(w.w);
+                    }
 #pragma unroll
-                for (int e4 = 0; e4 < EPP; e4 += 4) {
-                    const float4 a = *reinterpret_cast<const float4 *>(q + kk + e4);
-                    aa[e4] = a.x; aa[e4 + 1] = a.y; aa[e4 + 2] = a.z; aa[e4 + 3] = a.w;
-                }
+                    for (int e4 = 0; e4 < EPP; e4 += 4) {
+                        const float4 a = *reinterpret_cast<const float4 *>(q + kk + e4);
+                        aa[e4] = a.x; aa[e4 + 1] = a.y; aa[e4 + 2] = a.z; aa[e4 + 3] = a.w;
+                    }
 #pragma unroll
-                for (int e = 0; e < EPP; ++e) {
-                    if (kk + e < kend) {
-                        if (metric == ZVDB_METRIC_L2SQ) {
+                    for (int e = 0; e < EPP; ++e) {
+                        if constexpr (L2) {
                             float t = aa[e] - vv[e];
                             t = t * t;
                             sum = sum + t;
@@ -2579,9 +2597,12 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
                         }
                     }
                 }
-            }
+            };
+            const bool full = k0 + RR_CH <= ld;
+            if (metric == ZVDB_METRIC_L2SQ) { if (full) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{}); }
+            else { if (full) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{}); }
         }
-        cd[64 * bt + lane] = my_id == 0xFFFFFFFFu ? __builtin_inff() : (metric == ZVDB_METRIC_L2SQ ? sum : -sum);
+        cd[64 * bt + lane] = my_id == 0xFFFFFFFFu ? __builtin_inff() : (metric == ZVDB_METRIC_L2SQ ? sum : -sum);  // (lanes >= SR: no row, +inf)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads of the stage are done before the next batch refills it
     }
     __syncthreads();
@@ -2614,22 +2635,25 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
 
 int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, const uint32_t *d_cand,
                   uint32_t kc, uint32_t k, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
-                  uint32_t *d_count, hipStream_t s) {
+                  uint32_t *d_count, hipStream_t s, uint32_t kp_valid) {
     if (nq == 0) return ZVDB_OK;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool staged_off = [] { const char *e = getenv("ZVDB_RERANK"); return e && e[0] == 'v' && e[1] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
         if ((kc == 64 || kc == 128 || kc == 256) && ld * sizeof(RT) >= 256 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
-            const uint32_t dp = round_up(h->dim, 256 / (uint32_t)sizeof(RT));  // q is read a whole chunk at a time
-            const size_t lds2 = 2 * 64 * 256 + 4ull * (dp + 2ull * kc);
-            auto go = [&](auto kern) -> int {
+            auto go_geo = [&](auto kern, uint32_t chb, uint32_t sr) -> int {
+                const uint32_t dp = round_up(h->dim, chb / (uint32_t)sizeof(RT));  // q is read a whole chunk at a time
+                const size_t lds2 = 2ull * sr * chb + 4ull * (dp + 2ull * kc);
                 ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds2));
                 hipLaunchKernelGGL(kern, dim3(nq), dim3(64), lds2, s, rows, ld, h->dim, metric, d_queries, d_cand, k, id_offset, d_ids, d_dist,
                                    d_count, dp);
                 ZV_HIP(hipGetLastError());
                 return ZVDB_OK;
             };
+            auto go = [&](auto kern) -> int { return go_geo(kern, 256, 64); };
+            // lists of at most 32 candidates (the caller says so: k <= 16 on the exact screens): 32 staged rows, longer runs per row
+            if (kc == 64 && kp_valid && kp_valid <= 32 && ld * sizeof(RT) >= 1024) return go_geo(k_rerank_staged<64, RT, 512, 32>, 512, 32);
             if (kc == 64) return go(k_rerank_staged<64, RT>);
             if (kc == 128) return go(k_rerank_staged<128, RT>);
             return go(k_rerank_staged<256, RT>);
