@@ -154,6 +154,13 @@ def reference_harness(zv):
         if qi < 200:
             first.append((ri, rd))
     t_cpu = time.perf_counter() - t0
+    # beyond the reference: the same searches query-parallel on T OS threads -- the reference serialises search on one
+    # mutex (hnsw.zig:195-196) and its "multi-threaded" benchmark spawns no threads; a read-only search parallelises trivially
+    T = max(1, min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    pi, pd, pn = ref.search_many(Q, K, threads=T)
+    t_par = time.perf_counter() - t0
+    par_same = all(np.array_equal(ri, pi[qi, :len(ri)]) and np.array_equal(rd, pd[qi, :len(ri)]) for qi, (ri, rd) in enumerate(first))
     h = zv.HNSW(16, 200)
     t0 = time.perf_counter()
     h.insert_many(V, np.zeros(P, dtype=np.int32))  # (levels 0: unobservable through search; the oracle above got the same)
@@ -168,7 +175,9 @@ def reference_harness(zv):
                   "source": "benchmarks/shared_benchmarks.zig:61-125, single_threaded_benchmarks.zig:28-33"},
         "cpu": {"kind": "port", "cores": 1, "nproc": os.cpu_count(), **cpu,
                 "thread_labels": {str(t): cpu for t in (2, 4, 8)},
-                "thread_labels_note": "multi_threaded_benchmarks.zig:8-19 passes the thread count as a label only (no std.Thread.spawn; one global mutex)"},
+                "thread_labels_note": "multi_threaded_benchmarks.zig:8-19 passes the thread count as a label only (no std.Thread.spawn; one global mutex)",
+                "beyond_reference_query_parallel": {"threads": T, "search_qps": NQ / t_par, "same_results_as_1_thread_first_200": bool(par_same),
+                                                    "note": "read-only searches split over OS threads (no global mutex): not what the reference does"}},
         "gpu": {"search_qps_batched_host_api": NQ / t_gpu, "insert_many_pts_per_s": P / t_ins_gpu,
                 "bit_exact_vs_oracle_first_200_queries": bool(same)},
         "reference_published": {"search_qps": 2678.13, "insert_pts_per_s": 8392.22, "source": "benchmarks/benchmark.md:102-113 (unstated CPU)"},

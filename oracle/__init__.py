@@ -71,6 +71,8 @@ def lib():
     L.orc_hnsw_insert.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_int]
     L.orc_hnsw_search.restype = C.c_size_t
     L.orc_hnsw_search.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, u64p, f32p]
+    L.orc_hnsw_search_many.restype = None
+    L.orc_hnsw_search_many.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p, u64p]
     L.orc_hnsw_search_ef_ex.restype = C.c_size_t
     L.orc_hnsw_search_ef_ex.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, u64p, f32p]
     L.orc_hnsw_search_ef.restype = C.c_size_t
@@ -189,6 +191,29 @@ class HNSW:
         n = self._L.orc_hnsw_search(self._h, _p(q, C.c_float), q.size, k,
                                     _p(ids, C.c_uint64), _p(dist, C.c_float))
         return ids[:n].copy(), dist[:n].copy()
+
+    def search_many(self, queries, k: int, threads: int = 1):
+        """k-NN of every row of `queries` (reference-compat search, no counters), the queries split over `threads` OS threads
+        (ctypes releases the GIL; the search is read-only).  Returns ids [nq, k], dist [nq, k], n [nq]."""
+        import threading
+        Q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, d = Q.shape
+        ids = np.zeros((nq, max(k, 1)), dtype=np.uint64)
+        dist = np.zeros((nq, max(k, 1)), dtype=np.float32)
+        n = np.zeros(nq, dtype=np.uint64)
+        threads = max(1, min(threads, nq))
+        parts = [(t * nq // threads, (t + 1) * nq // threads) for t in range(threads)]
+
+        def work(a, b):
+            if b > a:
+                self._L.orc_hnsw_search_many(self._h, _p(Q[a:b], C.c_float), b - a, d, k, _p(ids[a:b], C.c_uint64),
+                                             _p(dist[a:b], C.c_float), _p(n[a:b], C.c_uint64))
+        th = [threading.Thread(target=work, args=p) for p in parts]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return ids, dist, n
 
     def search_ef(self, query, k: int, ef: int, metric: int = 0, entry: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         """ef-mode beam search (extension; the spec of k_search_ef): metric 0 = squared L2, 1 = inner product."""

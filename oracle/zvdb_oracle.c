@@ -348,26 +348,28 @@ static cand_t pq_remove(pqueue *q) {
     return top;
 }
 
-/* search -- hnsw.zig:194-236 */
-size_t orc_hnsw_search(orc_hnsw *h, const float *query, size_t d, size_t k,
-                       uint64_t *out_ids, float *out_dist) {
+/* search -- hnsw.zig:194-236.  ctr: the index's counters, or NULL (orc_hnsw_search_many: several threads search one index) */
+static inline size_t hnsw_search_body(const orc_hnsw *h, orc_counters *ctr, const float *query, size_t d, size_t k,
+                                      uint64_t *out_ids, float *out_dist, unsigned char *scratch) {
     if (!h->has_entry || k == 0) return 0;         /* :201; k = 0 -> loop never runs */
     if (d != h->dim) return 0;
     size_t nres = 0;
     pqueue q = {0, 0, 0};
-    unsigned char *visited = (unsigned char *)calloc(h->count, 1); /* :205 (set of ids) */
+    /* :205 (set of ids).  scratch: a caller-owned all-zero array of h->count bytes, handed back all-zero (orc_hnsw_search_many: a
+     * calloc / free of it per query serialises threads in the allocator and the kernel's page handling) */
+    unsigned char *visited = scratch ? scratch : (unsigned char *)calloc(h->count, 1);
     if (!visited) return 0;
 
     cand_t seed;
     seed.id = h->entry_point;
     seed.distance = orc_distance_f32(query, h->nodes[h->entry_point].point, d); /* :208 */
-    h->ctr.search_dist_evals += 1;
+    if (ctr) ctr->search_dist_evals += 1;
     pq_add(&q, seed);
     visited[h->entry_point] = 1;                                                 /* :209 */
 
     while (q.len > 0 && nres < k) {                                              /* :211 */
         const cand_t cur = pq_remove(&q);                                        /* :212 */
-        h->ctr.search_pops += 1;
+        if (ctr) ctr->search_pops += 1;
         out_ids[nres] = cur.id;                                                  /* :213-214 */
         out_dist[nres] = cur.distance;
         nres += 1;
@@ -378,14 +380,19 @@ size_t orc_hnsw_search(orc_hnsw *h, const float *query, size_t d, size_t k,
                 cand_t c;
                 c.id = nb;
                 c.distance = orc_distance_f32(query, h->nodes[nb].point, d);     /* :219 */
-                h->ctr.search_dist_evals += 1;
+                if (ctr) ctr->search_dist_evals += 1;
                 pq_add(&q, c);                                                   /* :220 */
                 visited[nb] = 1;                                                 /* :221 */
             }
         }
     }
+    if (scratch) {  /* every id marked is one that was pushed: popped (out_ids) or still queued */
+        for (size_t i = 0; i < nres; ++i) scratch[out_ids[i]] = 0;
+        for (size_t i = 0; i < q.len; ++i) scratch[q.items[i].id] = 0;
+    } else {
+        free(visited);
+    }
     free(q.items);
-    free(visited);
 
     /* final stable insertion sort by distance(query, point) -- :227-233.  The
      * comparator recomputes the same two values on every call (:230); the
@@ -393,7 +400,7 @@ size_t orc_hnsw_search(orc_hnsw *h, const float *query, size_t d, size_t k,
     for (size_t i = 1; i < nres; ++i) {
         size_t j = i;
         while (j > 0) {
-            h->ctr.sort_dist_evals += 2;
+            if (ctr) ctr->sort_dist_evals += 2;
             if (!(out_dist[j] < out_dist[j - 1])) break;
             const float td = out_dist[j]; out_dist[j] = out_dist[j - 1]; out_dist[j - 1] = td;
             const uint64_t ti = out_ids[j]; out_ids[j] = out_ids[j - 1]; out_ids[j - 1] = ti;
@@ -401,6 +408,21 @@ size_t orc_hnsw_search(orc_hnsw *h, const float *query, size_t d, size_t k,
         }
     }
     return nres;                                                                 /* :235 */
+}
+
+size_t orc_hnsw_search(orc_hnsw *h, const float *query, size_t d, size_t k,
+                       uint64_t *out_ids, float *out_dist) {
+    return hnsw_search_body(h, &h->ctr, query, d, k, out_ids, out_dist, NULL);
+}
+
+/* nq searches in one call, read-only (no counters): what one thread of a query-parallel CPU baseline runs (bench.py: "beyond
+ * the reference", whose search takes one global mutex, hnsw.zig:195-196).  out arrays: nq * k entries, out_n: nq. */
+void orc_hnsw_search_many(const orc_hnsw *h, const float *queries, size_t nq, size_t d, size_t k,
+                          uint64_t *out_ids, float *out_dist, uint64_t *out_n) {
+    unsigned char *scratch = (unsigned char *)calloc(h->count ? h->count : 1, 1);
+    for (size_t i = 0; i < nq; ++i)
+        out_n[i] = scratch ? hnsw_search_body(h, NULL, queries + i * d, d, k, out_ids + i * k, out_dist + i * k, scratch) : 0;
+    free(scratch);
 }
 
 /* ef-mode beam search (EXTENSION; specification in zvdb_oracle.h). */

@@ -67,6 +67,10 @@ int orc_hnsw_insert(orc_hnsw *h, const float *point, size_t d, int level);
  * order). out arrays need k entries. */
 size_t orc_hnsw_search(orc_hnsw *h, const float *query, size_t d, size_t k,
                        uint64_t *out_ids, float *out_dist);
+/* nq such searches in one call without touching the counters: read-only on the index, so several threads may run it on one index
+ * (the query-parallel CPU baseline of bench.py -- beyond the reference, which serialises searches on one mutex, hnsw.zig:195-196) */
+void orc_hnsw_search_many(const orc_hnsw *h, const float *queries, size_t nq, size_t d, size_t k,
+                          uint64_t *out_ids, float *out_dist, uint64_t *out_n);
 
 /* 16-way blocked squared-L2 used by the ef-mode TRAVERSAL (extension): the 4-float chunk c of the
  * rows goes to partial sum (c mod 16), each partial accumulates its chunks in increasing order

@@ -179,3 +179,18 @@ def test_synthetic_stream_is_uniform_and_reproducible(oracle):
     assert abs(a.mean() - 0.5) < 0.01 and abs(a.var() - 1 / 12) < 0.005
     b = oracle.fill_uniform(0x5EED, 5000, 100)
     assert np.array_equal(a[5000:5100], b)
+
+
+def test_search_many_equals_single_searches_on_any_thread_count(oracle):
+    """orc_hnsw_search_many (the query-parallel CPU baseline of bench.py) is the reference-compat search without counters: the
+    same ids, distances and result counts as one orc_hnsw_search per query, on 1 thread and on 4."""
+    V = oracle.uniform_rows(11, 0, 600, 12)
+    h = oracle.HNSW(4, 200)
+    for r in V:
+        h.insert(r, 0)
+    Q = oracle.uniform_rows(12, 0, 37, 12)
+    want = [h.search(q, 7) for q in Q]
+    for threads in (1, 4):
+        ids, dist, n = h.search_many(Q, 7, threads=threads)
+        for qi, (ri, rd) in enumerate(want):
+            assert int(n[qi]) == len(ri) and np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)
