@@ -165,6 +165,10 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
         if (!MOM && lds_load_u32(ctl) != 0) round();
         const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g_begin + wave + I8_NW * it));
         if (g >= g_end) continue;
+        // (hipcc waits for this load with s_waitcnt vmcnt(0) at the top of EVERY step -- its first use sits behind the loop's back
+        // edge -- which also drains the A fragments in flight.  Requesting it by inline asm and waiting with vmcnt(KS) instead (r3,
+        // profiles/r3/bf16_stream_ab.txt: r3_ab17) made the int8 scan 2.7 % SLOWER and left the fp4 scan unchanged: as in the bf16
+        // kernel, the drain keeps the query-tile workgroups of a stream close enough to share their fetches in the L2.)
         const int32_t vn_mine = vn_next;  // loaded one step ahead (see bf_fp4_stream.hip)
         if (vnorm) vn_next = vnorm[(size_t)32 * min(g + I8_NW, g_last) + fr];
         // accumulator start = -(|v'|^2 >> 1) of the register's corpus row; rows past N: INT_MAX >> 1 ~ 2^30, never pass
