@@ -456,3 +456,41 @@ def test_bf16_stream_results_do_not_depend_on_the_adaptive_xcd_split(zv, oracle)
     sel = [0, 511, 1023]
     ri, rd, _ = oracle.bruteforce_topk(V, Q[sel], k)
     assert np.array_equal(first[0][sel], ri) and np.array_equal(first[1][sel], rd)
+
+
+def test_bruteforce_dev_from_two_streams_with_two_workspaces(zv, oracle):
+    """zvdb_hip_search_bruteforce_dev keeps its per-call state in the CALLER's workspace: two batches launched on two streams of one
+    index, each with a workspace of its own, return what the same calls return one after the other -- on the bf16 stream route
+    (guessed thresholds, adaptive split: the index-side state they share is host bookkeeping under the handle's mutex) and on the
+    int8 route."""
+    import torch
+    n, d, nq, k = 600_000, 64, 512, 10
+    idx = zv.Index(flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(n, d, 0x5EED)
+    dev = torch.device("cuda", 0)
+    qa = torch.from_numpy(oracle.uniform_rows(0xC0FFEE, 0, nq, d)).to(dev)
+    qb = torch.from_numpy(oracle.uniform_rows(0xC0FFEE, nq, nq, d)).to(dev)
+    for mode in (zv.BF_BF16, zv.BF_I8):
+        wsb = idx.bruteforce_workspace(nq, k, mode)
+        ws = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+        def run(q, w, stream):
+            ids = torch.empty((nq, k), dtype=torch.int64, device=dev); dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            cnt = torch.empty((nq,), dtype=torch.int32, device=dev)
+            idx.search_bruteforce_dev(q.data_ptr(), nq, d, k, mode, 0, w.data_ptr(), wsb, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), stream.cuda_stream)
+            return ids, dd, cnt
+
+        s0 = torch.cuda.current_stream()
+        ra = run(qa, ws[0], s0); rb = run(qb, ws[1], s0)
+        torch.cuda.synchronize()
+        want = [t.cpu().numpy().copy() for t in ra + rb]
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        s1.wait_stream(s0); s2.wait_stream(s0)
+        for _ in range(6):
+            ga = run(qa, ws[0], s1); gb = run(qb, ws[1], s2)
+            torch.cuda.synchronize()
+            got = [t.cpu().numpy() for t in ga + gb]
+            assert all(np.array_equal(a, b) for a, b in zip(want, got)), mode
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    ri, rd, _ = oracle.bruteforce_topk(V, qa[:3].cpu().numpy(), k)
+    assert np.array_equal(want[0][:3].astype(np.uint64), ri) and np.array_equal(want[1][:3], rd)
