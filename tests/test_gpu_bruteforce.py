@@ -257,8 +257,18 @@ def test_bruteforce_k_up_to_112_on_the_staged_routes(zv, oracle, n, d, nq, k):
         assert np.all(np.diff(d4[qi, :c]) >= 0)
         for e in range(0, c, 13):
             assert oracle.distance(Q[qi], V[int(a4[qi, e])]) == d4[qi, e]
-    with pytest.raises(zv.ZvdbError):
-        idx.search_bruteforce(Q, 113, zv.BF_F32)
+    if d > 128:
+        with pytest.raises(zv.ZvdbError):
+            idx.search_bruteforce(Q, 113, zv.BF_F32)
+    else:  # (fp32 rows of <= 128 dimensions have a stream route of their own since r3: k <= 240, as one flooding scan on small shards)
+        kk = min(200, n)
+        ri2, rd2, rc2 = oracle.bruteforce_topk(V, Q[sel], kk)
+        ids, dist, cnt = idx.search_bruteforce(Q, kk, zv.BF_F32)
+        assert np.all(cnt == kk)
+        for j, qi in enumerate(sel):
+            assert np.array_equal(ids[qi], ri2[j]) and np.array_equal(dist[qi], rd2[j]), qi
+        with pytest.raises(zv.ZvdbError):
+            idx.search_bruteforce(Q, 241, zv.BF_F32)
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(5000, 64, 40, 100), (129, 200, 3, 112), (70, 32, 5, 100), (30000, 96, 300, 64),
@@ -356,7 +366,14 @@ def test_bruteforce_limits(zv, oracle):
     idx = zv.Index()
     idx.add(oracle.uniform_rows(1, 0, 10, 8))
     with pytest.raises(zv.ZvdbError):
-        idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 113)       # k > k' - margin (k' = 128)
+        idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 241)       # k > k' - margin (k' = 256: the stream routes' widest lists)
+    wide = zv.Index()
+    wide.add(oracle.uniform_rows(1, 0, 10, 200))
+    with pytest.raises(zv.ZvdbError):
+        wide.search_bruteforce(oracle.uniform_rows(2, 0, 1, 200), 113)    # fp32 rows beyond 128 dimensions: the staged kernel, k' = 128
+    ids, dist, cnt = idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 113)  # (fp32, dim <= 128: served; k > N returns N)
+    ri, rd, _ = oracle.bruteforce_topk(oracle.uniform_rows(1, 0, 10, 8), oracle.uniform_rows(2, 0, 1, 8), 10)
+    assert cnt[0] == 10 and np.array_equal(ids[0, :10], ri[0]) and np.array_equal(dist[0, :10], rd[0])
     with pytest.raises(zv.ZvdbError):
         idx.search_bruteforce(oracle.uniform_rows(2, 0, 1, 8), 5, zv.BF_BF16)  # no mirror
     empty = zv.Index(dim=8)

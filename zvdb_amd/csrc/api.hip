@@ -325,6 +325,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     if (h->bal_host) (void)hipHostFree(h->bal_host);
     if (h->ef_hint_host) (void)hipHostFree(h->ef_hint_host);
     (void)hipFree(h->ef_hint_dev);
+    (void)hipFree(h->rows_ff);
+    (void)hipFree(h->norm_ff);
     (void)hipFree(h->ef_visit_buf);
     (void)hipFree(h->ef_net_buf);
     if (h->ef_event) (void)hipEventDestroy(h->ef_event);
@@ -1518,6 +1520,7 @@ int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *
         if (h->rows_p) b += h->cap_p * h->ldp + h->cap_p * 4;
         if (h->rows_pf) b += h->cap_pf * fp4s_ksteps(h->dim) * 32 + h->cap_pf * 4;
         if (h->rows_hf) b += h->cap_hf * bf16s_ksteps(h->dim) * 32 + (h->cap_hf + 64) * 4;
+        if (h->rows_ff) b += h->cap_ff * f32s_ksteps(h->dim) * 32 + h->cap_ff * 4;
         b += h->ef_visit_bytes + (h->ef_net_list_words + h->ef_net_table_words) * 4 + (h->spec_cap0 + h->spec_capU) * 8;  // ef-search net / global visited tables, speculative-insert stamps
         *out_resident_bytes = b;
     }

@@ -9,6 +9,13 @@
 // the (key, id) radix select is shared (bf_select.h).  The result is the exact k' best by int8 key -- identical to
 // the staged kernel's (tested) -- so with k' >= k + margin the final top-k is the exact one (recall 1.0 in bench.py).
 //
+// MODE 0 (r3) instantiates it for the EXACT-ARITHMETIC fp32 screen on short rows (dim <= 128: BASELINE configs[1], 1M x 128 at batch
+// 256): v_mfma_f32_32x32x2_f32 takes one fp32 per lane, so a 16-byte fragment piece feeds 4 MFMAs and a k-step covers 8 elements
+// (lane l: elements 8 j + 4 (l >> 5) + [0, 4) of row / query l & 31); KS = 8 / 16 (dim <= 64 / 128): the 128-query tile is 32 / 64
+// KiB of LDS.  The staged 256 x 256 kernel streams BOTH operands through LDS and, with one query tile, shares the corpus stream
+// with nobody: 0.68 of the fp32-MFMA peak at that shape; here only the corpus moves, HBM -> registers.  It reads a fragment-order
+// fp32 mirror (rows_ff: the rows' bytes once more -- which is why this route is for short rows).
+//
 // MODE 3 instantiates the same 128-query geometry for the fp4 screen (v_mfma_scale_f32_32x32x64_f8f6f4, fp32 keys): a
 // 32-byte k-step then covers 64 elements, so KS = 24 is a 1536-d row -- the dimensions the 256-query fp4 kernel
 // (bf_fp4_stream.hip, KS <= 12) cannot keep resident.  It reads the fp4 fragment-order mirror built there.
@@ -34,6 +41,7 @@ using i32x8 = __attribute__((ext_vector_type(8))) int;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 template <int MODE> struct Acc128 { using type = i32x16; };
 template <> struct Acc128<3> { using type = f32x16; };
+template <> struct Acc128<0> { using type = f32x16; };
 
 
 __host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS, uint32_t sel_bytes = SEL_SCRATCH) {
@@ -41,7 +49,7 @@ __host__ __device__ inline uint32_t i8s_lds_bytes(uint32_t KS, uint32_t sel_byte
 }
 
 // KS = 32-byte (32-element) k-steps per row; MOM: moments mode (sum of key, key^2 per query instead of selecting)
-// MODE: 2 = int8 (int keys), 3 = fp4 (fp32 keys)
+// MODE: 2 = int8 (int keys), 3 = fp4 (fp32 keys), 0 = fp32 (fp32 keys; a k-step = 8 elements)
 // GATED = 1: the same code under its own symbol for the gated repair launch (see k_fp4_stream)
 template <int MODE, int KS, bool MOM, int KPV = KP, int GATED = 0>
 __global__ __launch_bounds__(512, 2) void k_i8_stream(
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
     uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all, uint32_t kp, uint32_t list_base, uint32_t Stot,
     uint32_t *__restrict__ pcnt, uint32_t max_tiles, const uint32_t *__restrict__ gate, float *__restrict__ mom) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
-    constexpr int I8_RING = KS % I8_RING_MAX == 0 ? I8_RING_MAX : 6;
+    constexpr int I8_RING = KS % I8_RING_MAX == 0 ? I8_RING_MAX : KS % 8 == 0 ? 8 : 6;
     static_assert(KS % I8_RING == 0 && KS % 2 == 0, "ring wrap / set parity");
     constexpr bool INT = MODE == 2;
     using acc_t = typename Acc128<MODE>::type;
@@ -208,6 +216,11 @@ __global__ __launch_bounds__(512, 2) void k_i8_stream(
                 const i32x4 xb = __builtin_bit_cast(i32x4, BS[f]);
                 if constexpr (INT) {
                     acc[f] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa, xb, J == 0 ? init : acc[f], 0, 0, 0);
+                } else if constexpr (MODE == 0) {  // four 2-deep fp32 MFMAs per piece: component c = elements 8 J + c (lanes < 32), + 4 (lanes >= 32)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(xa.x), __int_as_float(xb.x), J == 0 ? init : acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(xa.y), __int_as_float(xb.y), acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(xa.z), __int_as_float(xb.z), acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(xa.w), __int_as_float(xb.w), acc[f], 0, 0, 0);
                 } else {
                     const i32x8 wa = {xa.x, xa.y, xa.z, xa.w, 0, 0, 0, 0}, wb = {xb.x, xb.y, xb.z, xb.w, 0, 0, 0, 0};
                     acc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, wb, J == 0 ? init : acc[f], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
@@ -427,15 +440,47 @@ __global__ __launch_bounds__(256) void k_i8_norms(const RT *__restrict__ rows, u
     if (lane == 0) norm[r] = s;
 }
 
+// fp32 rows (or queries) -> fragment order of MODE 0: unit (group of 32 rows, k-step j, lane l) = the 4 fp32 of row 32 g + (l & 31),
+// elements 8 j + 4 (l >> 5) + [0, 4); rows >= n and elements >= dim are 0
+template <typename RT>
+__global__ __launch_bounds__(256) void k_f32_pack_frag(const RT *__restrict__ src, uint32_t dim, uint32_t ld, uint64_t n, uint64_t units,
+                                                       uint32_t KS, unsigned char *__restrict__ out) {
+    const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const uint32_t l = (uint32_t)(u & 63);
+    const uint64_t gj = u >> 6;
+    const uint32_t j = (uint32_t)(gj % KS);
+    const uint64_t row = (gj / KS) * 32 + (l & 31);
+    const uint32_t k0 = 8 * j + 4 * (l >> 5);
+    u32x4 w = {0, 0, 0, 0};
+    if (row < n) {
+        const RT *v = src + row * ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (k0 + e < dim) w[e] = __float_as_uint(row_elem(v, k0 + e));
+    }
+    *reinterpret_cast<u32x4 *>(out + u * 16) = w;
+}
+// the screen's |v|^2 per row (the index's fp32 norms; 0: dot / cosine), +inf past n
+__global__ __launch_bounds__(256) void k_f32_frag_norms(const float *__restrict__ norm_in, uint64_t n, uint64_t n_pad, int l2, float *__restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_pad) return;
+    out[r] = r >= n ? __builtin_inff() : (l2 ? norm_in[r] : 0.0f);
+}
+
+}  // namespace
+uint32_t f32s_ksteps(uint32_t dim);
+namespace {
+
 template <int MODE, bool MOM, int KPV = KP>
 int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
                      uint32_t *pcnt, uint32_t max_tiles, const uint32_t *gate, float *mom, hipStream_t s) {
-    const uint32_t KS = MODE == 2 ? i8s_ksteps(h->dim) : fp4s128_ksteps(h->dim);
+    const uint32_t KS = MODE == 2 ? i8s_ksteps(h->dim) : MODE == 0 ? f32s_ksteps(h->dim) : fp4s128_ksteps(h->dim);
     const uint32_t lds = i8s_lds_bytes(KS, (uint32_t)sel_scratch_bytes<KPV>());
     const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
-    const void *vn = !l2 ? nullptr : MODE == 2 ? (const void *)h->norm_qf : (const void *)h->norm_pf;
-    const unsigned char *rows = MODE == 2 ? h->rows_qf : h->rows_pf;
+    const void *vn = !l2 ? nullptr : MODE == 2 ? (const void *)h->norm_qf : MODE == 0 ? (const void *)h->norm_ff : (const void *)h->norm_pf;
+    const unsigned char *rows = MODE == 2 ? h->rows_qf : MODE == 0 ? h->rows_ff : h->rows_pf;
     auto go = [&](auto kern) -> int {
         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(QT * S), dim3(512), lds, s, q_op, rows, vn, (uint32_t)h->count, nq, QT, S, nt, cand,
@@ -453,6 +498,9 @@ int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
         if (KS == 6) ZV_CHECK(go(k_i8_stream<2, 6, MOM, KPV>));
         else if (KS == 12) ZV_CHECK(go(k_i8_stream<2, 12, MOM, KPV>));
         else ZV_CHECK(go(k_i8_stream<2, 24, MOM, KPV>));
+    } else if constexpr (MODE == 0) {
+        if (KS == 8) ZV_CHECK(go(k_i8_stream<0, 8, MOM, KPV>));
+        else ZV_CHECK(go(k_i8_stream<0, 16, MOM, KPV>));
     } else {
         if (KS == 18) ZV_CHECK(go(k_i8_stream<3, 18, MOM, KPV>));
         else ZV_CHECK(go(k_i8_stream<3, 24, MOM, KPV>));
@@ -551,6 +599,64 @@ int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint
         return launch_i8_stream<3, false, KPW>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     return launch_i8_stream<3, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
+// ---- the same 128-query kernel with fp32 MFMAs on a fragment-order fp32 mirror: dim <= 128 (KS = 8, 16) -------------------------
+uint32_t f32s_ksteps(uint32_t dim) { return dim <= 64 ? 8u : 16u; }
+bool f32s_eligible(const zvdb_hip_index *h) {
+    static const bool off = [] { const char *e = getenv("ZVDB_BF_F32_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    return !off && h->dim > 4 && h->dim <= 128;
+}
+uint64_t f32s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad) { return (uint64_t)nq_pad * f32s_ksteps(h->dim) * 32; }
+int ensure_f32_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
+    if (h->rows_ff && h->count_ff == h->count) return ZVDB_OK;
+    if (h->count == 0) return ZVDB_OK;
+    const uint32_t KS = f32s_ksteps(h->dim);
+    const uint64_t rows_pad = round_up64(h->count, 256);
+    if (h->cap_ff < rows_pad) {
+        if (h->rows_ff) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_ff)); ZV_HIP(hipFree(h->norm_ff)); }
+        h->rows_ff = nullptr;
+        h->norm_ff = nullptr;
+        const uint64_t ncap = round_up64(std::max<uint64_t>(h->count, h->cap), 256);
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->rows_ff), ncap * KS * 32));
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->norm_ff), ncap * sizeof(float)));
+        h->cap_ff = ncap;
+    }
+    const uint64_t units = rows_pad / 32 * KS * 64;
+    const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = row_elem_t<decltype(rows)>;
+        hipLaunchKernelGGL(k_f32_pack_frag<RT>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, rows, h->dim, ld, h->count, units, KS, h->rows_ff);
+        hipLaunchKernelGGL(k_f32_frag_norms, dim3((uint32_t)((rows_pad + 255) / 256)), dim3(256), 0, s, (h->flags & ZVDB_FLAG_BF16_ROWS) ? h->norm_h : h->norm,
+                           h->count, rows_pad, l2 ? 1 : 0, h->norm_ff);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
+    h->count_ff = h->count;
+    return ZVDB_OK;
+}
+int launch_f32s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op, hipStream_t s) {
+    const uint32_t KS = f32s_ksteps(h->dim);
+    const uint64_t units = (uint64_t)nq_pad / 32 * KS * 64;
+    hipLaunchKernelGGL(k_f32_pack_frag<float>, dim3((uint32_t)((units + 255) / 256)), dim3(256), 0, s, d_queries, h->dim, h->dim, (uint64_t)nq, units, KS, q_op);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+int launch_f32s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
+                     uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s) {
+    if (kpv == (uint32_t)KPMAX)
+        return launch_i8_stream<0, false, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+    if (kpv == (uint32_t)KPW)
+        return launch_i8_stream<0, false, KPW>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+    return launch_i8_stream<0, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
+}
+int launch_f32s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                      float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
+    ZV_CHECK((launch_i8_stream<0, true>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s)));
+    hipLaunchKernelGGL(k_i8_guess, dim3(QT * I8_TQ), dim3(64), 0, s, mom, QT * S, QT, S, nq, z, 0, tau_g, verify_flag);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 int launch_fp4s128_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                          float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
     ZV_CHECK((launch_i8_stream<3, true>(h, q_op, nq, QT, S, nt, nullptr, nullptr, nullptr, 0u, 0u, 0u, nullptr, 1u, nullptr, mom, s)));

@@ -755,6 +755,7 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     off += round_up64(std::max<uint64_t>((uint64_t)p.nq_pad * p.row_bytes,
                                          mode == ZVDB_BF_FP4 && (fp4s_eligible(h) || fp4s128_eligible(h)) ? fp4s_query_bytes(h, p.nq_pad)
                                          : mode == ZVDB_BF_I8 && i8s_eligible(h) ? i8s_query_bytes(h, p.nq_pad)
+                                         : mode == ZVDB_BF_F32 && f32s_eligible(h) ? f32s_query_bytes(h, p.nq_pad)
                                          : mode == ZVDB_BF_BF16 && bf16s_eligible(h) ? bf16s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
     off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap,
@@ -961,6 +962,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
     const bool s4 = mode == ZVDB_BF_FP4 && !f7 && fp4s128_eligible(h) && (big8 || wide_k);
+    // fp32, dim <= 128: the 128-query stream kernel with fp32 MFMAs on a fragment-order fp32 mirror (bf_i8_stream.hip, MODE 0) -- the
+    // staged kernel streams both operands through LDS and reaches 0.68 of the fp32-MFMA peak at BASELINE configs[1]
+    const bool sf = mode == ZVDB_BF_F32 && f32s_eligible(h) && (big8 || k > (uint32_t)KPW - 16);
     // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
     // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
     // (from 8 tiles = 64 row groups per stream: BASELINE configs[1], 1M x 128 at batch 256 = 256 streams of 15 tiles, rides it)
@@ -968,6 +972,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool sb_big = !guess_off && p.NT >= 8 * p.S;
     const bool sb = mode == ZVDB_BF_BF16 && bf16s_eligible(h) && !(debug_flags() & 64) && (sb_big || k > (uint32_t)KPW - 16);
     if (sb) ZV_CHECK(ensure_bf16_frag_mirror(h, s));
+    if (sf) ZV_CHECK(ensure_f32_frag_mirror(h, s));
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
     if (ws_bytes < p.total) {
@@ -997,6 +1002,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         ZV_CHECK(launch_bf16s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else if (s8) {
         ZV_CHECK(launch_i8s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
+    } else if (sf) {
+        ZV_CHECK(launch_f32s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else {
         const uint64_t total = (uint64_t)p.nq_pad * p.row_elems;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);
@@ -1010,11 +1017,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t nlists = p.S, stot_lists = p.S;
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
-    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4) && big8) || (sb && sb_big);
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4 || sf) && big8) || (sb && sb_big);
     // k' = 64 survivors per query (one per lane of the selects) carry k <= 48 (56 with the exact fp32 screen); the stream
     // kernels also run with k' = 128 (two entries per lane), which carries k <= 112 -- on large shards inside the guessed-
     // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
-    const bool stream_route = f7 || s8 || s4 || sb;
+    const bool stream_route = f7 || s8 || s4 || sb || sf;
     // (the staged kernel has the same two list widths; the v1 kernel kept for A/B has only k' = 64)
     // The stream kernels go on to k' = 256 (four entries per lane): k <= 240, and the fp4 screen uses it from k > 64
     // (recall@100: 0.84 with 128 survivors).
@@ -1022,7 +1029,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const uint32_t kpv = !wide_k ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
     if (k > (kpv != (uint32_t)KP ? kpv - 16 : kmax)) {
         set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d on the stream routes: "
-                  "ZVDB_BF_I8 / ZVDB_BF_BF16 with dim <= 768, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
+                  "ZVDB_BF_I8 / ZVDB_BF_BF16 with dim <= 768, ZVDB_BF_F32 with dim <= 128, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
         return ZVDB_ERR_UNSUPPORTED;
     }
     // The float screens of the STAGED kernel (fp32; bf16 on rows the stream kernel does not take) ride the same guessed +
@@ -1105,7 +1112,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
             uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
             uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
-            const bool t128 = s8 || s4;               // 128-query tiles (QT8 x S8 workgroups)
+            const bool t128 = s8 || s4 || sf;         // 128-query tiles (QT8 x S8 workgroups)
             const uint32_t SS = t128 ? p.S8 : p.S;  // streams = lists per query and scan
             float *mom = reinterpret_cast<float *>(cand);  // (cand is free until the scan)
             if (sb) {
@@ -1114,6 +1121,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             } else if (s8) {
                 ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            } else if (sf) {
+                ZV_CHECK(launch_f32s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
+                ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             } else if (s4) {
                 ZV_CHECK(launch_fp4s128_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
@@ -1129,6 +1139,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv);
             if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
+            else if (sf) ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, kpv, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids,
@@ -1192,9 +1203,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp);
         }
         if (kpv != (uint32_t)KP && stream_route) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
-            const bool t128 = s8 || s4;
+            const bool t128 = s8 || s4 || sf;
             const uint32_t SS = t128 ? p.S8 : p.S;
             if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            else if (sf) ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));

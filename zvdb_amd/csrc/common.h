@@ -140,6 +140,10 @@ struct zvdb_hip_index {
     unsigned char *rows_hf = nullptr;
     float *norm_hf = nullptr;  // [cap_hf + 64] sum of the squared bf16 values (0: dot / cosine), +inf past count
     uint64_t cap_hf = 0, count_hf = 0;
+    // fp32 rows in MFMA fragment order for the fp32 stream screen (bf_i8_stream.hip, MODE 0; dim <= 128, lazy): [group of 32 rows][KS][64][16 B]
+    unsigned char *rows_ff = nullptr;
+    float *norm_ff = nullptr;  // [cap_ff] sum v^2 (0: dot / cosine), +inf past count
+    uint64_t cap_ff = 0, count_ff = 0;
     // fp4 (E2M1) scalar-quantised mirror for ZVDB_BF_FP4 (lazy, like the int8 one)
     unsigned char *rows_p = nullptr;  // [cap_p][ldp] bytes, 2 codes per byte (low nibble = even element), ldp = round_up(dim, 256) / 2
     float *norm_p = nullptr;          // [cap_p] sum of the squared fp4 VALUES (exact in fp32)
@@ -284,6 +288,16 @@ uint32_t i8s_ksteps(uint32_t dim);
 uint64_t i8s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad);
 int i8_range(zvdb_hip_index *h, hipStream_t s);  // sets q_lo / q_inv from the rows' value range (data_kernels.hip)
 int ensure_i8_frag_mirror(zvdb_hip_index *h, hipStream_t s);
+uint32_t f32s_ksteps(uint32_t dim);
+bool f32s_eligible(const zvdb_hip_index *h);
+uint64_t f32s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad);
+int ensure_f32_frag_mirror(zvdb_hip_index *h, hipStream_t s);
+int launch_f32s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op, hipStream_t s);
+int launch_f32s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                     uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
+                     uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s);
+int launch_f32s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
+                      float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
 int launch_i8s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op,
                             hipStream_t s);
 int launch_i8s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
