@@ -964,7 +964,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool s4 = mode == ZVDB_BF_FP4 && !f7 && fp4s128_eligible(h) && (big8 || wide_k);
     // fp32, dim <= 128: the 128-query stream kernel with fp32 MFMAs on a fragment-order fp32 mirror (bf_i8_stream.hip, MODE 0) -- the
     // staged kernel streams both operands through LDS and reaches 0.68 of the fp32-MFMA peak at BASELINE configs[1]
-    const bool sf = mode == ZVDB_BF_F32 && f32s_eligible(h) && (big8 || k > (uint32_t)KPW - 16);
+    // -- measured: +13 % at 64 dimensions, +0 .. 5 % at 128 (both designs sit at ~0.68 there: DESIGN 3, K4), for a mirror as large as
+    // the rows; so: by default up to 64 dimensions, and wherever k > 112 needs its wider lists; ZVDB_BF_F32_KERNEL=stream: up to 128
+    static const bool sf_wide = [] { const char *e = getenv("ZVDB_BF_F32_KERNEL"); return e && e[0] == 's'; }();
+    const bool sf = mode == ZVDB_BF_F32 && f32s_eligible(h) && ((big8 && (h->dim <= 64 || sf_wide)) || k > (uint32_t)KPW - 16);
     // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
     // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
     // (from 8 tiles = 64 row groups per stream: BASELINE configs[1], 1M x 128 at batch 256 = 256 streams of 15 tiles, rides it)
