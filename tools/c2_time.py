@@ -1,7 +1,7 @@
 import sys, time
 sys.path.insert(0, '/root/repo')
 import torch, zvdb_amd as zv, numpy as np
-N2, D2, B2, K = 1_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 128, 256, 10
+N2, D2, B2, K = (int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000), int(sys.argv[1]) if len(sys.argv) > 1 else 128, 256, 10
 dev = torch.device("cuda", 0)
 idx = zv.Index(dim=D2, capacity=N2)
 idx.add_synthetic(N2, D2, 0x5EED)
