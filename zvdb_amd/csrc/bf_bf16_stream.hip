@@ -24,6 +24,7 @@
 // memory, exact (key, id) radix select) is shared with the other scan kernels (bf_select.h); a wave owns its 32 queries,
 // so appends and prune rounds need no workgroup rendezvous.
 #include <vector>
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 #include "common.h"
@@ -37,7 +38,8 @@ namespace zvdb {
 namespace {
 
 constexpr int BH_NW = 8;                  // waves per workgroup (2 per SIMD)
-constexpr int BH_R = 6;                   // A-fragment register ring (reads in flight per wave; 5: -1.6 %, 7: -3.4 %, 8 spills: measured)
+constexpr int BH_R = 6;                   // A-fragment register ring of the plain loop (reads in flight per wave; 5: -1.6 %, 7: -3.4 %, 8 spills: measured)
+constexpr int BH_RF = 4;                  // ... of the flow loop (the ring is never empty there; 6 spills a query fragment: -17 %)
 constexpr int BH_CAP = NSUB * SUBCAP;     // append-buffer entries per (workgroup, query)
 constexpr int BH_HW = 384, BH_MARK = 64;  // prune request mark; queries above MARK are pruned in a round
 constexpr uint32_t BH_SAMPLE_GROUPS = 8;  // moments mode: 32-row groups sampled per stream
@@ -71,10 +73,13 @@ template <int O0, int O1> __device__ __forceinline__ void bh_lds_read_norms(f32x
 template <int N> __device__ __forceinline__ void bh_lgkm_wait2(f32x4 &a, f32x4 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 // every outstanding LDS read has landed: ties ALL ring registers, so that code behind it (the cold append / prune path, which may
 // spill or copy registers around its call) only ever sees landed values
-__device__ __forceinline__ void bh_lgkm_drain(u32x4 (&a)[BH_R]) {
-    static_assert(BH_R == 6, "operand list below");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+template <int R> __device__ __forceinline__ void bh_lgkm_drain(u32x4 (&a)[R]) {
+    static_assert(R == 6 || R == 4, "operand list below");
+    if constexpr (R == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[R - 1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
 }
+template <int N> __device__ __forceinline__ void bh_lgkm_wait2(u32x4 &d, f32x4 &a) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(d), "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void bh_lgkm_wait3(u32x4 &d, f32x4 &a, f32x4 &b) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(d), "+v"(a), "+v"(b) : "n"(N)); }
 template <int N> __device__ __forceinline__ void bh_lgkm_wait(u32x4 &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
 
 // LDS-DMA in the saddr form: uniform base (SGPR pair) + 32-bit lane offset, LDS destination through M0.  Inline asm because
@@ -140,7 +145,9 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     unsigned long long t_begin = 0;
     if (dur_out) t_begin = __builtin_amdgcn_s_memrealtime();
     using Geo = BhGeo<KS, NG>;
-    constexpr int F = Geo::F, P = Geo::P, NP = Geo::NP, K2 = KS / 2, R = BH_R;
+    constexpr int F = Geo::F, P = Geo::P, NP = Geo::NP, K2 = KS / 2;
+    constexpr bool FLOW = NG == 1 && F % BH_RF == 0 && !MOM;  // (the 768-d geometry; see the unit loops below)
+    constexpr int R = FLOW ? BH_RF : BH_R;
     constexpr uint32_t SLOT = Geo::SLOT;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     float *tau_f = reinterpret_cast<float *>(smem + 3 * SLOT);  // exclusive bound: pass <=> key < tau
@@ -148,7 +155,6 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     uint32_t *nkept = cnt + T2;
     uint32_t *subw = nkept + T2;                                 // per wave: prune_query's view of one append buffer
     uint32_t *ctl = subw + BH_NW * NSUB;                         // [0] lock of the shared select scratch
-    unsigned char *sel = reinterpret_cast<unsigned char *>(ctl + 4);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -212,8 +218,8 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
         dma_unit(u0, 0);
         dma_unit(min(u0 + 1, u1 - 1), 1);
     }
-    asm volatile("" ::: "memory");
-    __syncthreads();  // selection state initialised (also drains the prologue loads; once per launch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // selection state initialised, the prologue's units landed
 
     float thr0 = 0.0f, thr1 = 0.0f;  // -tau of my two queries (B set 0: query 32 wave + fc; set 1: + 16)
     float ms1[2] = {0.0f, 0.0f}, ms2[2] = {0.0f, 0.0f};  // moments mode
@@ -225,10 +231,119 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
     // bh_prune_wave) and nothing of the loop's register state lives across it: inside the loop hipcc spilled the query fragments
     // around the call and re-loaded them on the way back.  So the loop is LEFT for a prune, and every entry loads the fragments
     // and the bounds afresh and drains the counters once, ahead of the loop.
-    // static priority for the younger half of the workgroup, the arbitration loser of every SIMD pair otherwise
+    // Static priority for the younger half of the workgroup, the arbitration loser of every SIMD pair otherwise
     // (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): +0.4 .. 0.9 % (profiles/r3/bf16_stream_ab.txt)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     uint32_t slot = 0, it = 0;
+    if constexpr (FLOW) {
+    // FLOW loop (one 32-row group per unit, F a multiple of the ring depth: the 768-d geometry).  Two differences to the plain loop
+    // below, +3 .. 5 % QPS together (profiles/r3/bf16_stream_ab.txt, r3_ab20 .. 22):
+    // (1) the A ring and the norms run AHEAD of the barrier -- the first R fragments and the start values of unit it + 1 are
+    //     requested in the tail of unit it, so the MFMAs behind the barrier start on operands that are already in registers.
+    //     Legal because every wave drains ALL its pieces (units <= it + 1) ahead of the barrier at the top of unit it: behind
+    //     that barrier unit it + 1 is complete in LDS.  (Ring depth 4: with 6 the loop spills a query fragment.)
+    // (2) selection per ROW BLOCK, a few fragments after the block's last MFMA, in the shadow of the MFMAs that follow
+    //     (MI355X_MICROARCH.md, "Two waves per SIMD", item 9: partners that reach their vector work together leave the matrix
+    //     pipe idle): row block 0 behind fragment K2 + 3; row block 1 behind fragment 3 of the NEXT unit -- its accumulators are
+    //     free until fragment K2, their start values are read straight into them behind the selection.
+    u32x4 A[R];
+    f32x4 nv0;         // start values of row block 0 (requested a unit ahead); row block 1's are read straight into its accumulators
+    f32x4 acc[2][2];   // [row block][B set]
+    while (it < n) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
+        thr0 = -tau_f[wave * 32 + fc];
+        thr1 = -tau_f[wave * 32 + 16 + fc];
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0), as an instruction the waitcnt pass sees
+        {   // prime the ring with unit `it` (visible: its pieces were drained ahead of a barrier this wave has passed)
+            const uint32_t base = lds0 + slot * SLOT + lane16;
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(nv0) : "v"(lds0 + slot * SLOT + F * 1024 + 16 * fq));
+            static_for<R>([&](auto jc) { constexpr int J = decltype(jc)::value; bh_lds_read128<J * 1024>(A[J], base); });
+        }
+        bool want_prune = false;
+        acc[1][0] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};  // (no row block pending)
+        acc[1][1] = acc[1][0];
+        // selection of one finished row block (16 rows x my 32 queries): the rare pass path appends to the queries' buffers
+        auto select_rb = [&](auto rbc, uint32_t row0) {
+            constexpr int rb = decltype(rbc)::value;
+            const float m0 = fmaxf(fmaxf(acc[rb][0][0], acc[rb][0][1]), fmaxf(acc[rb][0][2], acc[rb][0][3]));
+            const float m1 = fmaxf(fmaxf(acc[rb][1][0], acc[rb][1][1]), fmaxf(acc[rb][1][2], acc[rb][1][3]));
+            if (__ballot(m0 > thr0 || m1 > thr1)) {  // (__builtin_expect moves this path out of line: -2 %)
+                bh_lgkm_drain(A);  // (the ring holds reads in flight: the append path may move registers)
+                asm volatile("" : "+v"(nv0));
+                bool need = false;
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (acc[rb][qb][r] > (qb ? thr1 : thr0)) {
+                            uint32_t q = (uint32_t)wave * 32 + (uint32_t)qb * 16 + fc;
+                            const uint32_t sl = atomicAdd(cnt + q, 1u);
+                            const uint32_t id = row0 + 16u * rb + 4u * fq + (uint32_t)r;
+                            if (sl < (uint32_t)BH_CAP) subs[(size_t)q * BH_CAP + sl] = ((uint64_t)f32_key(-acc[rb][qb][r]) << 32) | id;
+                            need |= sl == (uint32_t)BH_HW;
+                        }
+                    }
+                if (__ballot(need)) want_prune = true;
+            }
+        };
+        do {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of units it and it + 1
+        __builtin_amdgcn_s_barrier();                      // ... everyone's; and everyone is done reading unit it - 1
+        const uint32_t un = min(u0 + it + 2, u1 - 1);
+        const gbytes_t nsrc = uniform_ptr(Vf + (size_t)un * F * 1024 + (size_t)wave * 1024);
+        const uint32_t ndst = lds0 + (slot >= 1 ? slot - 1 : 2) * SLOT + (uint32_t)wave * 1024;
+        const gbytes_t nnorm = uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)un * NG * 32));
+        const uint32_t base = lds0 + slot * SLOT + lane16;
+        const uint32_t nslot = slot == 2 ? 0 : slot + 1;
+        const uint32_t xbase = lds0 + nslot * SLOT + lane16;               // unit it + 1 (past the stream end: stale bytes, never used)
+        const uint32_t nbase = lds0 + slot * SLOT + F * 1024 + 16 * fq;
+        const uint32_t xnbase = lds0 + nslot * SLOT + F * 1024 + 16 * fq;
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<F>([&](auto fcn) {
+            constexpr int FI = decltype(fcn)::value;
+            constexpr int WI = FI % KS, RB = WI / K2, JJ = WI % K2;
+            constexpr int SL = FI % R;
+            if constexpr (FI == 0) bh_lgkm_wait2<R - 1>(A[SL], nv0);              // (requested ahead of the ring)
+            else if constexpr (FI == K2) bh_lgkm_wait3<R - 1>(A[SL], acc[1][0], acc[1][1]);  // (requested at fragment 6)
+            else bh_lgkm_wait<R - 1>(A[SL]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FI == 0) {
+                acc[0][0] = nv0;
+                acc[0][1] = nv0;
+            }
+            acc[RB][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[SL]), __builtin_bit_cast(bf16x8, B[JJ]), acc[RB][0], 0, 0, 0);
+            acc[RB][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[SL]), __builtin_bit_cast(bf16x8, B[K2 + JJ]), acc[RB][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FI == 6) bh_lds_read_norms<64, 64>(acc[1][0], acc[1][1], nbase);
+            if constexpr (FI == F - R - 1) asm volatile("ds_read_b128 %0, %1" : "=&v"(nv0) : "v"(xnbase));  // (dead since fragment 0)
+            if constexpr (FI + R < F) bh_lds_read128<(FI + R) * 1024>(A[SL], base);
+            else bh_lds_read128<(FI + R - F) * 1024>(A[SL], xbase);
+            // (placement of the pieces re-swept in this loop: steps of 4 from 0 / 4 from 2 / 6 from 1: -2.8 / -20 / -2.2 %)
+            constexpr int DSTEP = 5, NORM_AT = 30;
+            if constexpr (FI % DSTEP == 2 && FI / DSTEP < P) {
+                constexpr uint32_t POFF = (uint32_t)BH_NW * (FI / DSTEP) * 1024;  // piece = wave + 8 (FI / DSTEP)
+                bh_dma16(lane16, nsrc + POFF, ndst + POFF);
+            }
+            if constexpr (FI == NORM_AT) {
+                if (wave == 0) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bh_dma4(lane4, nnorm + p * 256, ndst + F * 1024 + p * 256);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (FI == K2 + 3) select_rb(std::integral_constant<int, 0>{}, 32u * (u0 + it));       // (at + 8: -5 %)
+            if constexpr (FI == 3) select_rb(std::integral_constant<int, 1>{}, 32u * (u0 + it) - 32u);  // the previous unit's
+        });
+        slot = nslot;
+        ++it;
+        } while (it < n && !want_prune);
+        select_rb(std::integral_constant<int, 1>{}, 32u * (u0 + it) - 32u);  // the last unit's row block 1
+        bh_lgkm_drain(A);
+        asm volatile("" : "+v"(nv0));
+        if (want_prune) bh_prune_wave<KPV>(kept, tau_g, kp, lds_state);
+    }
+    } else {
     while (it < n) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
@@ -349,6 +464,8 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
         if constexpr (!MOM) {
             if (want_prune) bh_prune_wave<KPV>(kept, tau_g, kp, lds_state);
         }
+    }
+
     }
 
     if constexpr (MOM) {
