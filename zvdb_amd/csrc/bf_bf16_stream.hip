@@ -12,6 +12,8 @@
 // flop are half those of the staged 256 x 256 tile (only the corpus moves; L2 -> LDS at full MFMA rate: 16 B/clk/CU instead
 // of 32, which is what capped the staged kernel at 0.42 of peak), the steady state has ONE barrier per 32-row group
 // (3,072 MFMA cycles) and its LDS-DMA issues are spread over the first 60 % of the k-loop (one piece per 5 fragments).
+// In the 512- / 768-d geometries (one group per unit) the operand ring runs AHEAD of that barrier and the selection of a
+// 16-row block sits a few fragments behind the block, in the shadow of the following MFMAs ("FLOW loop", in the kernel).
 // MFMA shape: v_mfma_f32_16x16x32_bf16 -- the chip is power-limited on random bf16 data and holds a ~10 % higher clock on
 // this shape than on 32x32x16 (tools/bf16_regq_bench.hip: 1.54 vs 1.44 PFLOP/s for the same loop; profiles/r2/).
 //
