@@ -590,7 +590,7 @@ def main():
                               "v_mfma_scale_f32_32x32x64_f8f6f4 on random operands (the chip lowers its clock under load)" if args.mode == "fp4" else
                               "spec dense bf16 MFMA peak (2.4 GHz); on random bf16 operands the chip is power-limited: the bare "
                               "v_mfma_f32_32x32x16_bf16 loop holds 1.99 PFLOP/s (profiles/r1/mfma_peak_bench.txt) and this kernel's loop "
-                              "runs at 1.75-1.80 GHz in-kernel (profiles/r2/bf16_regq_ablation.txt)" if args.mode == "bf16" else None),
+                              "holds ~1.85 GHz with the MFMA pipes busy 0.82 of the cycles (rocprofv3 SQ counters: profiles/r3/pmc_mfma_utilisation_bf16_stream.txt)" if args.mode == "bf16" else None),
                 "hbm_achieved_GBps": float(n_local) * D * ELT_BYTES[args.mode] / kavg / 1e9 if kavg > 0 else 0.0,
                 "hbm_peak_GBps": 8000.0,
                 "algorithmic_flops_per_launch": flops,
