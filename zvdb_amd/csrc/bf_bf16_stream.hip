@@ -273,6 +273,12 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
             if (__ballot(m0 > thr0 || m1 > thr1)) {  // (__builtin_expect moves this path out of line: -2 %)
                 bh_lgkm_drain(A);  // (the ring holds reads in flight: the append path may move registers)
                 asm volatile("" : "+v"(nv0));
+                // lane-derived values of this rare path are re-derived HERE from an opaque copy of lane16: hoisted out of the unit
+                // loop they cost VGPRs the loop does not have -- hipcc spilled them and re-loaded them in this path, each re-load
+                // behind an s_waitcnt vmcnt(0) that also waits for the LDS-DMA pieces in flight (30 scratch operations -> none)
+                uint32_t l16 = lane16, one = 1u;
+                asm volatile("" : "+v"(l16), "+v"(one));
+                const uint32_t fc = (l16 >> 4) & 15u, fq = l16 >> 8;
                 bool need = false;
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
                     for (int r = 0; r < 4; ++r) {
                         if (acc[rb][qb][r] > (qb ? thr1 : thr0)) {
                             uint32_t q = (uint32_t)wave * 32 + (uint32_t)qb * 16 + fc;
-                            const uint32_t sl = atomicAdd(cnt + q, 1u);
+                            const uint32_t sl = atomicAdd(cnt + q, one);
                             const uint32_t id = row0 + 16u * rb + 4u * fq + (uint32_t)r;
                             if (sl < (uint32_t)BH_CAP) subs[(size_t)q * BH_CAP + sl] = ((uint64_t)f32_key(-acc[rb][qb][r]) << 32) | id;
                             need |= sl == (uint32_t)BH_HW;
