@@ -734,8 +734,18 @@ static int bh_balance(const zvdb_hip_index *h, uint32_t QT, uint32_t S, BhSplit 
             double speed[8], sum = 0.0;
             for (int x = 0; x < 8; ++x) { speed[x] = (double)(ho[x + 1] - ho[x]) / t[x]; sum += speed[x]; }
             double wsum = 0.0;
-            for (int x = 0; x < 8; ++x) { h->bal_w[x] = 0.5f * h->bal_w[x] + 0.5f * (float)(speed[x] / sum * 8.0); wsum += h->bal_w[x]; }
+            for (int x = 0; x < 8; ++x) { h->bal_w[x] = 0.5f * h->bal_w[x] + 0.5f * (float)(speed[x] / sum * 8.0); wsum += h->bal_w[x]; }  // (gain 0.5 / 0.75 / 1: no difference)
             for (int x = 0; x < 8; ++x) h->bal_w[x] = std::min(1.15f, std::max(0.85f, (float)(h->bal_w[x] / wsum * 8.0)));
+            if (dbg) {
+                double dmax = 0.0, dsum = 0.0, xmax[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xmin[8] = {1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30, 1e30};
+                for (uint32_t b = 0; b < nb; ++b) {
+                    const double d = (double)(__atomic_load_n(h->bal_host + b, __ATOMIC_RELAXED) & 0xFFFFFFu);
+                    dmax = std::max(dmax, d); dsum += d; xmax[b & 7] = std::max(xmax[b & 7], d); xmin[b & 7] = std::min(xmin[b & 7], d);
+                }
+                fprintf(stderr, "[zvdb bf16s balance] tag %u slowest workgroup / mean = %.4f; per XCD max/mean-of-all:", tag, dmax / (dsum / nb));
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.3f(min %.3f)", xmax[x] / (dsum / nb), xmin[x] / (dsum / nb));
+                fprintf(stderr, "\n");
+            }
             if (dbg) fprintf(stderr, "[zvdb bf16s balance] tag %u shares %.3f %.3f %.3f %.3f %.3f %.3f %.3f %.3f\n", tag, h->bal_w[0], h->bal_w[1], h->bal_w[2],
                              h->bal_w[3], h->bal_w[4], h->bal_w[5], h->bal_w[6], h->bal_w[7]);
         }
