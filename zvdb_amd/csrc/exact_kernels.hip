@@ -1014,6 +1014,28 @@ __device__ __forceinline__ bool hash_insert_atomic(uint32_t *tab, uint32_t bits,
     }
 }
 
+// The same table with ANY slot count (k_search_ef_reg: the LDS a query's table takes sets the queries per CU, and a power of two
+// wastes up to half of it): home slot = high half of hash x size, probing wraps at size.
+__device__ __forceinline__ uint32_t hashn_slot(uint32_t id, uint32_t size) { return __umulhi(id * 2654435761u, size); }
+__device__ __forceinline__ void hashn_insert_uniform(uint32_t *tab, uint32_t size, uint32_t id) {
+    uint32_t s = hashn_slot(id, size);
+    for (;;) {
+        const uint32_t v = tab[s];
+        if (v == 0) { tab[s] = id + 1; return; }
+        if (v == id + 1) return;
+        s = s + 1 == size ? 0 : s + 1;
+    }
+}
+__device__ __forceinline__ bool hashn_insert_atomic(uint32_t *tab, uint32_t size, uint32_t id) {
+    uint32_t s = hashn_slot(id, size);
+    for (;;) {
+        const uint32_t old = atomicCAS(&tab[s], 0u, id + 1);
+        if (old == 0) return true;
+        if (old == id + 1) return false;
+        s = s + 1 == size ? 0 : s + 1;
+    }
+}
+
 // Frontier: Zig std.PriorityQueue (std/priority_queue.zig, Zig >= 0.13) restated on two LDS
 // arrays; executed wave-uniformly (every lane performs the same reads and writes) so the
 // pop order -- including the order of exactly equal distances -- is the oracle's.
@@ -1829,7 +1851,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
-    uint32_t hash_bits, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
+    uint32_t hash_size /* slots of the visited table: any count >= 256 */, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
     uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */,
     uint32_t *net_list /* marks are appended here (the last LDS pass of a call; else null) */, uint32_t /* unused */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1839,7 +1861,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint64_t *Wt = reinterpret_cast<uint64_t *>(q + dim_pad);    // [64 EPL] merge scatter buffer: keys ...
     uint32_t *Ft = reinterpret_cast<uint32_t *>(Wt + kWave * EPL);  // [64 EPL] ... and expanded flags
     uint32_t *hash = Ft + kWave * EPL;
-    float *nb_d = reinterpret_cast<float *>(hash + (1u << hash_bits));
+    float *nb_d = reinterpret_cast<float *>(hash + hash_size);
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
     uint32_t *R = nb_i + kWave;                          // [kpad] result ids
     float *RD = reinterpret_cast<float *>(R + kpad);     // [kpad] their exact distances
@@ -1850,7 +1872,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = threadIdx.x; i < dim_pad; i += kWave * WPQ) q[i] = i < dim ? qg[i] : 0.0f;
-    for (uint32_t i = threadIdx.x; i < (1u << hash_bits); i += kWave * WPQ) hash[i] = 0;
+    for (uint32_t i = threadIdx.x; i < hash_size; i += kWave * WPQ) hash[i] = 0;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
     constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : 4 / WPQ;  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32)
@@ -1887,7 +1909,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
     auto stamp = [&](int ph) { if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); pf[ph] += n - pt; pt = n; } };
     if constexpr (PROF) pt = __builtin_amdgcn_s_memtime();
-    const uint32_t hash_limit = (1u << hash_bits) - (1u << (hash_bits - 2));  // 75 % load cap
+    const uint32_t hash_limit = hash_size - hash_size / 8;  // 87.5 % load cap (the tight table is sized for <= 74 % at the largest fill seen)
     uint32_t hash_used = 0;
     bool overflow = false;
 
@@ -1929,7 +1951,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                                                     : blocked16_dist<ZVDB_METRIC_DOT>(q, erow, nchunks, t);
         insert_sorted(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)f32_key(d0)) << 32) | entry);
         evals = 1;
-        hash_insert_uniform(hash, hash_bits, entry);
+        hashn_insert_uniform(hash, hash_size, entry);
         hash_used = 1;
         sync_w();
         for (;;) {
@@ -1972,7 +1994,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                 bool fresh1 = false;
                 if ((uint32_t)lane < cnt && !overflow) {
                     nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
-                    fresh1 = hash_insert_atomic(hash, hash_bits, nbl);
+                    fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
                 }
                 // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
                 // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
@@ -2247,10 +2269,11 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     const char *beam_env = getenv("ZVDB_EF_BEAM");  // (read per call: the parity test switches it)
     const bool beam_lds = beam_env && beam_env[0] == 'l';
     const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : ef <= 1024 ? 16 : 0;
-    auto lds_bytes = [&](uint32_t hb) -> size_t {
-        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * (1ull << hb) + 8ull * kWave + 8ull * kpad + 16;
-        return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * (1ull << hb) + 8ull * kWave;
+    auto lds_slots = [&](uint64_t slots) -> size_t {  // LDS of a query with a visited table of `slots` entries
+        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * slots + 8ull * kWave + 8ull * kpad + 16;
+        return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * slots + 8ull * kWave;
     };
+    auto lds_bytes = [&](uint32_t hb) -> size_t { return lds_slots(1ull << hb); };
     // A safe table that leaves fewer than two workgroups per CU (ef * stride beyond ~12k) does not go to the LDS at all: the safe
     // pass then keeps the visited sets in GLOBAL memory (k_search_ef<GH>: a pre-zeroed table of >= 8 ef stride slots per query in
     // an index-owned buffer, the batch in chunks of <= 2 GiB) -- slower per pop, but it serves only what the tight LDS pass
@@ -2283,14 +2306,38 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         if (tight_bits > lds_cap_bits) tight_bits = safe_rank;                      // (does not fit the LDS: no tight pass)
         tight_bits = std::min(tight_bits, safe_rank);
     }
-    const bool two_pass = tight_bits < safe_rank;
+    // Register-beam kernel: the tight table takes ANY slot count, chosen for the queries per CU it allows.  A query is one chain of
+    // dependent pops (latency), so throughput = queries in flight x a rate per query, and a batch runs in ceil(nq / (CUs x queries per
+    // CU)) rounds: 1,024 queries at ef = 256 on 1536-d bf16 rows ran as two rounds of 512 on 64-KB (2^14-slot) tables that were 22 %
+    // full.  Rule: the MOST queries per CU (up to what the kernel's VGPRs allow) whose table still holds the largest fill seen at
+    // <= 74 % load (cap 87.5 %: beyond it the safe pass serves the query, as before), never more slots than 2.5 x that fill.
+    uint32_t tight_slots = 0;
+    if (epl && seen && !tp_env) {
+        uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
+        if (const char *we = getenv("ZVDB_EF_WPQ")) wq = (uint32_t)atoi(we);
+        if (epl >= 8 && wq == 4) wq = 2;
+        const uint32_t vlim = wq == 2 ? 6u : 4u;  // workgroups per CU the kernels' registers allow (2 waves x 160 VGPRs: 6; 4 x 128 or 1 x 256+: 4)
+        const uint64_t smin = (uint64_t)seen * 27 / 20 + 64, spref = (uint64_t)seen * 5 / 2 + 128;
+        for (uint32_t g = vlim; g >= 1 && !tight_slots; --g) {
+            const size_t per = (160u * 1024u) / g;
+            if (per <= lds_slots(0) + 4 * smin) continue;
+            const uint64_t fit = ((per - lds_slots(0)) / 4) & ~63ull;
+            if (fit >= smin) tight_slots = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(fit, spref), 1ull << 15);
+        }
+        if (tight_slots && !safe_global && tight_slots >= (1u << hash_bits)) tight_slots = 0;  // (the safe table is no larger: one pass)
+        if (tight_slots) tight_bits = 0;  // (marks "sized in slots" below)
+    }
+    const bool two_pass = tight_slots ? true : tight_bits < safe_rank;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
         uint32_t wpq_launch = 1;
         auto go1 = [&](auto kern, uint32_t wparam, uint32_t hb, uint32_t pass, uint32_t *net_list) -> int {
-            const size_t lds = lds_bytes(hb);
+            // hb: table size as a power of two; the tight pass of the register-beam kernel may carry a slot count instead (hb == 0)
+            const uint32_t slots = hb ? (1u << hb) : tight_slots;
+            const size_t lds = lds_slots(slots);
+            if (epl) hb = slots;  // (k_search_ef_reg takes slots, k_search_ef bits)
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
@@ -2360,9 +2407,9 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
             const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
             fprintf(stderr, "[zvdb ef prof] %llu queries, %.1f pops each; shader cycles per POP: next-scan %.0f, list+visited %.0f, distances %.0f, beam update %.0f; "
-                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop; visited table 2^%u (safe 2^%u%s)\n", got[7], np / nw,
+                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop; visited table %u slots (safe 2^%u%s)\n", got[7], np / nw,
                     got[0] / np, got[1] / np, got[2] / np, got[3] / np, got[4] / nw, got[5] / nw, (got[0] + got[1] + got[2] + got[3] + got[4] + got[5]) / nw,
-                    got[8] / np, got[9] / np, two_pass ? tight_bits : (safe_global ? gbits : hash_bits), safe_global ? gbits : hash_bits, safe_global ? " global" : "");
+                    got[8] / np, got[9] / np, two_pass ? (tight_slots ? tight_slots : 1u << tight_bits) : 1u << (safe_global ? gbits : hash_bits), safe_global ? gbits : hash_bits, safe_global ? " global" : "");
             return ZVDB_OK;
         }
         // waves per query.  Measured at 1M x 768, M = 16, ef = 128, batch 1,024 / 4,096 / 16,384 (QPS): fp32 rows 1 wave 775k / 901k /
