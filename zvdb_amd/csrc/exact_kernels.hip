@@ -2316,7 +2316,8 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
         if (const char *we = getenv("ZVDB_EF_WPQ")) wq = (uint32_t)atoi(we);
         if (epl >= 8 && wq == 4) wq = 2;
-        const uint32_t vlim = wq == 2 ? 6u : 4u;  // workgroups per CU the kernels' registers allow (2 waves x 160 VGPRs: 6; 4 x 128 or 1 x 256+: 4)
+        // workgroups per CU the kernels' registers allow: 2 waves x <= 160 VGPRs (EPL <= 4): 6; 2 x 172 .. 200 (EPL 8, 16), 4 x 128, 1 x 256+: 4
+        const uint32_t vlim = (wq == 2 && epl <= 4) ? 6u : 4u;
         const uint64_t smin = (uint64_t)seen * 27 / 20 + 64, spref = (uint64_t)seen * 5 / 2 + 128;
         for (uint32_t g = vlim; g >= 1 && !tight_slots; --g) {
             const size_t per = (160u * 1024u) / g;
