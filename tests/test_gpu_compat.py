@@ -189,7 +189,7 @@ def test_exact_ties_follow_oracle_heap_order(zv, oracle):
         assert np.array_equal(ids[qi, :cnt[qi]], ri) and np.array_equal(dist[qi, :cnt[qi]], rd)
 
 
-def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle):
+def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle, monkeypatch):
     n, d, m = 4000, 48, 12
     V = oracle.uniform_rows(31, 0, n, d)
     nn, _, _ = oracle.bruteforce_topk(V, V, m + 1)
@@ -208,14 +208,21 @@ def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle):
     idx.upload_graph(adj, deg)
     Q = oracle.uniform_rows(32, 0, 64, d)
     for k, ef in ((10, 10), (10, 64), (25, 200)):
-        ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
-        ref.reset_counters()
-        for qi, q in enumerate(Q):
-            ri, rd = ref.search_ef(q, k, ef)
-            assert cnt[qi] == len(ri)
-            assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)
-        c = ref.counters()
-        assert (ev, pp) == (c.search_dist_evals, c.search_pops)
+        # 1st call: the safe visited table (no fill seen yet for this ef); 2nd: the tight table sized IN SLOTS from the fill the
+        # first call left (exact_kernels.hip: launch_search_ef); 3rd / 4th: tight tables forced so small that most queries fill
+        # them and are served again by the safe pass -- a power-of-two one and one of 300 slots.  Same results, same counters.
+        for env in (None, None, "t8", "s300"):
+            if env: monkeypatch.setenv("ZVDB_EF_TWO_PASS", env)
+            else: monkeypatch.delenv("ZVDB_EF_TWO_PASS", raising=False)
+            ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
+            ref.reset_counters()
+            for qi, q in enumerate(Q):
+                ri, rd = ref.search_ef(q, k, ef)
+                assert cnt[qi] == len(ri)
+                assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)
+            c = ref.counters()
+            assert (ev, pp) == (c.search_dist_evals, c.search_pops), env
+        monkeypatch.delenv("ZVDB_EF_TWO_PASS", raising=False)
 
 
 def test_greedy_layer0_seam(zv, oracle):

@@ -2312,7 +2312,11 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // full.  Rule: the MOST queries per CU (up to what the kernel's VGPRs allow) whose table still holds the largest fill seen at
     // <= 74 % load (cap 87.5 %: beyond it the safe pass serves the query, as before), never more slots than 2.5 x that fill.
     uint32_t tight_slots = 0;
-    if (epl && seen && !tp_env) {
+    if (epl && tp_env && tp_env[0] == 's') {  // "s<slots>": force a tight table of that many slots (tests: overflow + retry on a non-power-of-two table)
+        tight_slots = (uint32_t)std::max(64, std::min(1 << 15, atoi(tp_env + 1)));
+        if (lds_slots(tight_slots) > 160 * 1024) tight_slots = 0;
+        if (tight_slots) tight_bits = 0;
+    } else if (epl && seen && !tp_env) {
         uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
         if (const char *we = getenv("ZVDB_EF_WPQ")) wq = (uint32_t)atoi(we);
         if (epl >= 8 && wq == 4) wq = 2;
