@@ -2323,11 +2323,21 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         // workgroups per CU the kernels' registers allow: 2 waves x <= 160 VGPRs (EPL <= 4): 6; 2 x 172 .. 200 (EPL 8, 16), 4 x 128, 1 x 256+: 4
         const uint32_t vlim = (wq == 2 && epl <= 4) ? 6u : 4u;
         const uint64_t smin = (uint64_t)seen * 27 / 20 + 64, spref = (uint64_t)seen * 5 / 2 + 128;
-        for (uint32_t g = vlim; g >= 1 && !tight_slots; --g) {
+        static const uint32_t ncu = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(v, 1); }();
+        auto fit_of = [&](uint32_t g) -> uint64_t {  // slots a table may take with g queries per CU (0: the fill does not fit)
             const size_t per = (160u * 1024u) / g;
-            if (per <= lds_slots(0) + 4 * smin) continue;
+            if (per <= lds_slots(0) + 4 * smin) return 0;
             const uint64_t fit = ((per - lds_slots(0)) / 4) & ~63ull;
-            if (fit >= smin) tight_slots = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(fit, spref), 1ull << 15);
+            return fit >= smin ? fit : 0;
+        };
+        uint32_t gmax = 0;
+        for (uint32_t g = vlim; g >= 1 && !gmax; --g) if (fit_of(g)) gmax = g;
+        if (gmax) {
+            // ... and of those, the FEWEST queries per CU that take no more rounds for this batch (a larger table probes less)
+            const uint32_t rounds = (nq + ncu * gmax - 1) / (ncu * gmax);
+            uint32_t g = gmax;
+            while (g > 1 && fit_of(g - 1) && (nq + ncu * (g - 1) - 1) / (ncu * (g - 1)) == rounds) --g;
+            tight_slots = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(fit_of(g), spref), 1ull << 15);
         }
         if (tight_slots && !safe_global && tight_slots >= (1u << hash_bits)) tight_slots = 0;  // (the safe table is no larger: one pass)
         if (tight_slots) tight_bits = 0;  // (marks "sized in slots" below)
