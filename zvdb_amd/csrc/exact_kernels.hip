@@ -2316,13 +2316,16 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         tight_slots = (uint32_t)std::max(64, std::min(1 << 15, atoi(tp_env + 1)));
         if (lds_slots(tight_slots) > 160 * 1024) tight_slots = 0;
         if (tight_slots) tight_bits = 0;
-    } else if (epl && seen && !tp_env) {
+    } else if (epl && !tp_env) {
+        // (no fill seen yet for this ef on this index: the first batch assumes ef * stride / 2 -- about what searches visit --
+        // instead of running whole on the safe table; a query that visits more is served by the safe pass like any other overflow)
+        const uint32_t seen_eff = seen ? seen : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride / 2);
         uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
         if (const char *we = getenv("ZVDB_EF_WPQ")) wq = (uint32_t)atoi(we);
         if (epl >= 8 && wq == 4) wq = 2;
         // workgroups per CU the kernels' registers allow: 2 waves x <= 160 VGPRs (EPL <= 4): 6; 2 x 172 .. 200 (EPL 8, 16), 4 x 128, 1 x 256+: 4
         const uint32_t vlim = (wq == 2 && epl <= 4) ? 6u : 4u;
-        const uint64_t smin = (uint64_t)seen * 27 / 20 + 64, spref = (uint64_t)seen * 5 / 2 + 128;
+        const uint64_t smin = (uint64_t)seen_eff * 27 / 20 + 64, spref = (uint64_t)seen_eff * 5 / 2 + 128;
         static const uint32_t ncu = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(v, 1); }();
         auto fit_of = [&](uint32_t g) -> uint64_t {  // slots a table may take with g queries per CU (0: the fill does not fit)
             const size_t per = (160u * 1024u) / g;
