@@ -76,7 +76,8 @@ if only != "bulk":
     t0 = time.perf_counter(); idx.build_knn_graph(2 * M, zv.BF_I8); t1 = time.perf_counter()
     print(f" directed exact {2 * M}-NN lists, entry node 0 (build {t1 - t0:.2f} s)")
     sweep("knn(2M)  ", 0)
-t0 = time.perf_counter(); idx.build_graph(M, efc, zv.BF_I8, 7); t1 = time.perf_counter()
+bmode = {"i8": zv.BF_I8, "fp4": zv.BF_FP4, "bf16": zv.BF_BF16, "f32": zv.BF_F32}[os.environ.get("ZVDB_PROBE_BUILD", "i8")]  # screen of the build's kNN pass
+t0 = time.perf_counter(); idx.build_graph(M, efc, bmode, 7); t1 = time.perf_counter()
 deg = np.array([len(idx.get_neighbors(i)) for i in range(0, N, max(1, N // 2000))])
 e, ml = idx.graph_info()
 print(f" bulk graph M={M} (cap {2 * M}), build {t1 - t0:.2f} s = {N / (t1 - t0):.0f} rows/s, mean layer-0 degree {deg.mean():.1f}, max level {ml}, entry {e}")
