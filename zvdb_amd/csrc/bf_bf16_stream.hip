@@ -44,7 +44,7 @@ constexpr int BH_R = 6;                   // A-fragment register ring of the pla
 constexpr int BH_RF = 4;                  // ... of the flow loop (the ring is never empty there; 6 spills a query fragment: -17 %)
 constexpr int BH_CAP = NSUB * SUBCAP;     // append-buffer entries per (workgroup, query)
 constexpr int BH_HW = 384, BH_MARK = 64;  // prune request mark; queries above MARK are pruned in a round
-constexpr uint32_t BH_SAMPLE_GROUPS = 8;  // moments mode: 32-row groups sampled per stream
+constexpr uint32_t BH_SAMPLE_GROUPS = 4;  // moments mode: 32-row groups sampled per stream (8: the launch takes 28 instead of 20 us, the guess is no better)
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
