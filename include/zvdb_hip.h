@@ -159,6 +159,10 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode);
  *            2 M links with the same heuristic (graph_stride >= 2 M; M <= 32);
  *   layer L  the M exact nearest among the nodes whose level reaches L;
  *   entry    the first node of the highest level (zvdb_hip_graph_info).
+ * `mode` = enum zvdb_bf_mode of the screen behind the nearest-neighbour lists: the exact screens (ZVDB_BF_F32 / _BF16 / _I8)
+ * give the oracle's graph; ZVDB_BF_FP4 (approximate candidates, exact re-rank) builds wide shards faster -- beyond 768
+ * dimensions the exact screens run on the staged kernels: 12.5M x 1536 bf16 rows build in 226 s instead of 335 and answer the
+ * same recall (profiles/r3/).
  * Replaces every layer of the index's graph.  Search it with zvdb_hip_search_graph(ef > 0, entry = ZVDB_ENTRY_DESCEND):
  * a greedy descent through the upper layers picks each query's layer-0 entry, then the ef-mode beam search runs. */
 int zvdb_hip_build_graph(zvdb_hip_index *h, uint32_t M, uint32_t ef_construction, uint32_t mode, uint64_t level_seed);
