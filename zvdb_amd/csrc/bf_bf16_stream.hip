@@ -327,7 +327,9 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
             if constexpr (FI == F - R - 1) asm volatile("ds_read_b128 %0, %1" : "=&v"(nv0) : "v"(xnbase));  // (dead since fragment 0)
             if constexpr (FI + R < F) bh_lds_read128<(FI + R) * 1024>(A[SL], base);
             else bh_lds_read128<(FI + R - F) * 1024>(A[SL], xbase);
-            // (placement of the pieces re-swept in this loop: steps of 4 from 0 / 4 from 2 / 6 from 1: -2.8 / -20 / -2.2 %)
+            // (placement of the pieces re-swept in this loop: steps of 4 from 0 / 4 from 2 / 6 from 1: -2.8 / -20 / -2.2 %; steps of 5 from
+            // fragment 0 / 1 / 3 / 4 instead of 2: +0.8 / -4.3 / -0.5 / -1.3 % -- but from fragment 0 the four query-tile workgroups of a
+            // stream share their fetches less: 2 x FETCH_SIZE 17.9 - 18.9 GB per scan instead of 15.5 - 16.0.  Kept at 2.)
             constexpr int DSTEP = 5, NORM_AT = 30;
             if constexpr (FI % DSTEP == 2 && FI / DSTEP < P) {
                 constexpr uint32_t POFF = (uint32_t)BH_NW * (FI / DSTEP) * 1024;  // piece = wave + 8 (FI / DSTEP)
