@@ -169,6 +169,22 @@ def reference_harness(zv):
     gi, gd, gc = h.index.search_graph(Q, K)   # one batched launch through the host API (PCIe included)
     t_gpu = time.perf_counter() - t0
     same = all(np.array_equal(ri, gi[qi, :len(ri)]) and np.array_equal(rd, gd[qi, :len(ri)]) for qi, (ri, rd) in enumerate(first))
+    # the reference's own CALLING pattern (shared_benchmarks.zig:68-72: ONE point per insert call; :104-109: ONE query per search
+    # call) through the drop-in API -- latency-bound on a GPU, reported next to the bulk numbers whether or not it beats the CPU port
+    NPC, NQC = 20_000, 3_000
+    h1 = zv.HNSW(16, 200)
+    t0 = time.perf_counter()
+    for r in V[:NPC]:
+        h1.insert(r, _level=0)
+    t_ins_call = time.perf_counter() - t0
+    del h1
+    t0 = time.perf_counter()
+    pc_same = True
+    for qi in range(NQC):
+        ci, cd = h.search_ids(Q[qi], K)
+        if qi < 200 and not (np.array_equal(first[qi][0], ci) and np.array_equal(first[qi][1], cd)):
+            pc_same = False
+    t_call = time.perf_counter() - t0
     cpu = {"search_qps": NQ / t_cpu, "insert_pts_per_s": P / t_ins_cpu}
     return {
         "shape": {"points": P, "dim": D, "queries": NQ, "k": K, "m": 16, "ef_construction": 200,
@@ -179,9 +195,132 @@ def reference_harness(zv):
                 "beyond_reference_query_parallel": {"threads": T, "search_qps": NQ / t_par, "same_results_as_1_thread_first_200": bool(par_same),
                                                     "note": "read-only searches split over OS threads (no global mutex): not what the reference does"}},
         "gpu": {"search_qps_batched_host_api": NQ / t_gpu, "insert_many_pts_per_s": P / t_ins_gpu,
-                "bit_exact_vs_oracle_first_200_queries": bool(same)},
+                "bit_exact_vs_oracle_first_200_queries": bool(same),
+                "search_per_call_qps": NQC / t_call, "search_per_call_us": t_call / NQC * 1e6, "search_per_call_queries": NQC,
+                "search_per_call_bit_exact_first_200": bool(pc_same),
+                "insert_per_call_pts_per_s": NPC / t_ins_call, "insert_per_call_us": t_ins_call / NPC * 1e6, "insert_per_call_points": NPC,
+                "per_call_note": "one point / one query per API call through the Python mirror of HNSW(T) (the reference's calling pattern); "
+                                 "the bulk numbers beside them are insert_many / one batched search of all queries"},
         "reference_published": {"search_qps": 2678.13, "insert_pts_per_s": 8392.22, "source": "benchmarks/benchmark.md:102-113 (unstated CPU)"},
     }
+
+
+def make_rows(zv, torch, g, n, dim, structured, dev, stream, nq):
+    """Fills index g with n rows and returns nq queries of the same distribution (device tensor).  structured = rows of intrinsic
+    rank 12 + 1 % noise (data that HAS neighbourhoods; seeded, generated on the device); else the benchmark's own generator,
+    i.i.d. U[0,1) coordinates (shared_benchmarks.zig:53-59)."""
+    q = torch.empty((nq, dim), dtype=torch.float32, device=dev)
+    if structured:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(5)
+        A = torch.rand((12, dim), generator=gen, device=dev) - 0.5
+        for r0 in range(0, n, 200_000):
+            c = min(200_000, n - r0)
+            rows = (torch.rand((c, 12), generator=gen, device=dev) @ A + 0.01 * torch.randn((c, dim), generator=gen, device=dev)).contiguous()
+            torch.cuda.synchronize()
+            g.add_dev(rows.data_ptr(), c, dim, stream)
+            torch.cuda.synchronize()
+        q.copy_(torch.rand((nq, 12), generator=gen, device=dev) @ A + 0.01 * torch.randn((nq, dim), generator=gen, device=dev))
+        torch.cuda.synchronize()
+    else:
+        g.add_synthetic(n, dim, CORPUS_SEED)
+        zv.fill_synthetic_dev(q.data_ptr(), nq, dim, QUERY_SEED, 0, stream)
+    return q
+
+
+def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16_rows=False, M=16, efc=64, reps=5):
+    """The graph route (BASELINE configs[2]-[4]: HNSW M = 16, efSearch) on one GPU: bulk HNSW graph built on the device (M = 16:
+    heuristic forward links over the `efc` exact nearest + reverse links, cut to 2 M; upper layers), ef-mode beam search entered by
+    hierarchical descent (spec = the oracle, bit-exact: tests/test_gpu_graph.py), recall@k against the exact brute-force route of the
+    same index.  Roofline: HBM random gather, algorithmic bytes = E d sizeof(elt) + P M0 4 per query with E / P counted by
+    the kernel (the oracle counts the same), over the search kernel's own launch time (HIP events on the launch stream)."""
+    import numpy as np
+    g = zv.Index(dim=dim, capacity=rows, m=2 * M, graph_stride=2 * M,
+                 flags=zv.FLAG_BF16_MIRROR | (zv.FLAG_BF16_ROWS if bf16_rows else 0))
+    qg = make_rows(zv, torch, g, rows, dim, structured, dev, stream, batch)
+    t0 = time.perf_counter()
+    g.build_graph(M, efc, zv.BF_I8, 7)
+    t_build = time.perf_counter() - t0
+    ids = torch.empty((batch, k), dtype=torch.int64, device=dev)
+    dd = torch.empty((batch, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty((batch,), dtype=torch.int32, device=dev)
+    st = torch.zeros(4, dtype=torch.int64, device=dev)
+    wsb = g.bruteforce_workspace(batch, k, zv.BF_I8)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    for _ in range(3):  # (the certificate's survivor level settles over the first batches)
+        g.search_bruteforce_dev(qg.data_ptr(), batch, dim, k, zv.BF_I8, 0, ws.data_ptr(), wsb, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), stream)
+    torch.cuda.synchronize()
+    gt = ids.cpu().numpy().copy()
+    del ws
+    elt = 2 if bf16_rows else 4
+    out = {"rows": rows, "dim": dim, "row_dtype": "bf16" if bf16_rows else "f32", "M": M, "ef_construction": efc, "layer0_cap": 2 * M, "batch": batch, "k": k,
+           "build_s": t_build, "build_rows_per_s": rows / t_build, "entry": "hierarchical descent (ZVDB_ENTRY_DESCEND)",
+           "data": ("rows of intrinsic rank 12 + 1 % noise (seeded, generated on the device) -- NOT the benchmark's generator" if structured
+                    else "i.i.d. U[0,1) coordinates (the benchmark's generator, shared_benchmarks.zig:53-59)"),
+           "recall_ground_truth": "int8 brute-force route of the same index (certified exact)", "ef": {}}
+    g.search_graph_reserve(batch, k, max(efs))
+    for ef in efs:
+        for _ in range(2):
+            g.search_graph_dev(qg.data_ptr(), batch, dim, k, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
+        st.zero_()
+        g.search_graph_dev(qg.data_ptr(), batch, dim, k, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = ids.cpu().numpy()
+        rec = float(np.mean([len(set(got[i]) & set(gt[i])) / k for i in range(batch)]))
+        ev, pp = int(st[0].item()), int(st[1].item())
+        g.timing_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.search_graph_dev(qg.data_ptr(), batch, dim, k, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / reps
+        kms, kn = g.timing_read()
+        g.timing_enable(False)
+        kavg = kms / max(kn, 1) * 1e-3
+        nbytes = ev * dim * elt + pp * 2 * M * 4
+        out["ef"][str(ef)] = {
+            "qps": batch / el, "ms_per_batch": el * 1e3, f"recall_at_{k}": rec, "dist_evals_per_query": ev / batch, "pops_per_query": pp / batch,
+            "roofline": {"bound": "hbm", "kernel": "k_search_ef_reg (exact_kernels.hip; + k_descend ahead of it, outside the timed kernel)",
+                         "kernel_ms_avg": kavg * 1e3, "timed_launches": kn, "achieved": nbytes / kavg / 1e9 if kavg > 0 else 0.0, "peak": 8000.0,
+                         "unit": "GB/s", "frac": nbytes / kavg / 8e12 if kavg > 0 else 0.0,
+                         "algorithmic_bytes_per_launch": nbytes, "bytes_rule": "E d sizeof(elt) + P M0 4 (SURVEY 8d), E / P counted in-kernel"}}
+    return out
+
+
+def c2_leg(zv, torch, dev, stream, k, modes=("f32",), steps=20):
+    """BASELINE configs[1]: 1M x 128 fp32 brute force, batch 256 (MFMA distance kernel + wavefront top-k), per exact screen."""
+    N2, D2, B2 = 1_000_000, 128, 256
+    MODES = {"bf16": zv.BF_BF16, "f32": zv.BF_F32, "i8": zv.BF_I8}
+    idx = zv.Index(dim=D2, capacity=N2, flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(N2, D2, CORPUS_SEED)
+    q = torch.empty((B2, D2), dtype=torch.float32, device=dev)
+    zv.fill_synthetic_dev(q.data_ptr(), B2, D2, QUERY_SEED, 0, stream)
+    ws_b = max(idx.bruteforce_workspace(B2, k, MODES[m]) for m in modes)
+    ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
+    ids = torch.empty((B2, k), dtype=torch.int64, device=dev)
+    dd = torch.empty((B2, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B2,), dtype=torch.int32, device=dev)
+    out = {"rows": N2, "dim": D2, "batch": B2, "k": k}
+    for name in modes:
+        m = MODES[name]
+        for _ in range(4):
+            idx.search_bruteforce_dev(q.data_ptr(), B2, D2, k, m, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), stream)
+        torch.cuda.synchronize()
+        idx.timing_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            idx.search_bruteforce_dev(q.data_ptr(), B2, D2, k, m, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), stream)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kms, kn = idx.timing_read()
+        idx.timing_enable(False)
+        ach = 2.0 * B2 * N2 * D2 / (kms / kn * 1e-3) / 1e12
+        out[name] = {"qps": B2 * steps / el, "ms_per_batch": el / steps * 1e3,
+                     "roofline": {"bound": "mfma", "kernel": "k_bf_scan5<f32> / k_i8_stream<0> (fp32 MFMA)" if name == "f32" else KERNEL_NAMES[name],
+                                  "kernel_ms_avg": kms / kn, "timed_regions": kn, "achieved": ach, "peak": PEAK_TFLOPS[name],
+                                  "unit": "TFLOP/s" if name != "i8" else "TOP/s", "frac": ach / PEAK_TFLOPS[name]}}
+    out["certificate"] = idx.cert_info()
+    return out, idx, q, ws, ws_b, ids, dd, cnt
 
 
 def extras(args, zv, torch):
@@ -193,34 +332,10 @@ def extras(args, zv, torch):
     out = {}
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
-    # ---- BASELINE configs[1]: 1M x 128 fp32 brute force, batch 256, fp32-MFMA screen ---------------
-    N2, D2, B2, K = 1_000_000, 128, 256, args.k
-    idx = zv.Index(dim=D2, capacity=N2, flags=zv.FLAG_BF16_MIRROR)
-    idx.add_synthetic(N2, D2, CORPUS_SEED)
-    q = torch.empty((B2, D2), dtype=torch.float32, device=dev)
-    zv.fill_synthetic_dev(q.data_ptr(), B2, D2, QUERY_SEED, 0, stream)
-    ws_b = max(idx.bruteforce_workspace(B2, K, m) for m in (zv.BF_F32, zv.BF_BF16, zv.BF_I8))
-    ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
-    ids = torch.empty((B2, K), dtype=torch.int64, device=dev)
-    dd = torch.empty((B2, K), dtype=torch.float32, device=dev)
-    cnt = torch.empty((B2,), dtype=torch.int32, device=dev)
-    c2 = {}
-    for name, m in (("f32", zv.BF_F32), ("bf16", zv.BF_BF16), ("i8", zv.BF_I8)):
-        for _ in range(3):
-            idx.search_bruteforce_dev(q.data_ptr(), B2, D2, K, m, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(),
-                                      cnt.data_ptr(), stream)
-        torch.cuda.synchronize()
-        idx.timing_enable(True)
-        t0 = time.perf_counter()
-        for _ in range(20):
-            idx.search_bruteforce_dev(q.data_ptr(), B2, D2, K, m, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(),
-                                      cnt.data_ptr(), stream)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        kms, kn = idx.timing_read()
-        idx.timing_enable(False)
-        c2[name] = {"qps": B2 * 20 / el, "ms_per_batch": el / 20 * 1e3, "scan_ms": kms / kn,
-                    "achieved_tflops": 2.0 * B2 * N2 * D2 / (kms / kn * 1e-3) / 1e12}
+    # ---- BASELINE configs[1]: 1M x 128 fp32 brute force, batch 256, every exact screen ---------------
+    K = args.k
+    c2, idx, q, ws, ws_b, ids, dd, cnt = c2_leg(zv, torch, dev, stream, K, modes=("f32", "bf16", "i8"))
+    N2, D2, B2 = c2["rows"], c2["dim"], c2["batch"]
     # exactness spot check of the f32 leg against the oracle on 4 queries
     Vh = oracle.uniform_rows(CORPUS_SEED, 0, N2, D2)
     qh = q.cpu().numpy()
@@ -231,7 +346,7 @@ def extras(args, zv, torch):
     c2["oracle_check"] = bool(np.array_equal(ids.cpu().numpy()[:4].astype(np.uint64), ri)
                               and np.array_equal(dd.cpu().numpy()[:4], rd))
     out["c2_1Mx128_batch256"] = c2
-    del idx
+    del idx, ws
 
     # ---- the reference's own benchmark shape: compat-mode search (hnsw.zig:194-236) ---------------------
     # benchmarks/shared_benchmarks.zig:90-125: index of P points (untimed build), then timed k = 10 searches.
@@ -301,64 +416,11 @@ def extras(args, zv, torch):
     # over the 64 exact nearest + reverse links, cut to 32; upper layers), ef-mode beam search entered by hierarchical
     # descent (extension; spec = oracle), recall vs the brute-force route.  On i.i.d. uniform 768-d rows no graph reaches the
     # bar (profiles/r2/graph_recall_*.txt hold the curves, incl. data with neighbourhood structure where it does) ------------
-    NG, DG, BG = args.extras_graph_rows, 768, 1024
-
-    def graph_leg(structured):
-        g = zv.Index(dim=DG, capacity=NG, m=32, graph_stride=32, flags=zv.FLAG_BF16_MIRROR)
-        qg = torch.empty((BG, DG), dtype=torch.float32, device=dev)
-        if structured:  # rows = Z A + 0.01 noise, Z ~ U[0,1)^(N x 12): data that HAS neighbourhoods (tests/manual/graph_recall_probe.py)
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(5)
-            A = torch.rand((12, DG), generator=gen, device=dev) - 0.5
-            for r0 in range(0, NG, 200_000):
-                n = min(200_000, NG - r0)
-                rows = (torch.rand((n, 12), generator=gen, device=dev) @ A + 0.01 * torch.randn((n, DG), generator=gen, device=dev)).contiguous()
-                torch.cuda.synchronize()
-                g.add_dev(rows.data_ptr(), n, DG, stream)
-                torch.cuda.synchronize()
-            qg.copy_(torch.rand((BG, 12), generator=gen, device=dev) @ A + 0.01 * torch.randn((BG, DG), generator=gen, device=dev))
-            torch.cuda.synchronize()
-        else:
-            g.add_synthetic(NG, DG, CORPUS_SEED)
-            zv.fill_synthetic_dev(qg.data_ptr(), BG, DG, QUERY_SEED, 0, stream)
-        t0 = time.perf_counter()
-        g.build_graph(16, 64, zv.BF_I8, 7)
-        t_build = time.perf_counter() - t0
-        ids = torch.empty((BG, K), dtype=torch.int64, device=dev)
-        dd = torch.empty((BG, K), dtype=torch.float32, device=dev)
-        cnt = torch.empty((BG,), dtype=torch.int32, device=dev)
-        st = torch.zeros(4, dtype=torch.int64, device=dev)
-        wsb = g.bruteforce_workspace(BG, K, zv.BF_I8)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        g.search_bruteforce_dev(qg.data_ptr(), BG, DG, K, zv.BF_I8, 0, ws.data_ptr(), wsb, ids.data_ptr(), dd.data_ptr(),
-                                cnt.data_ptr(), stream)
-        torch.cuda.synchronize()
-        gt = ids.cpu().numpy().copy()
-        graph = {"rows": NG, "dim": DG, "M": 16, "ef_construction": 64, "layer0_cap": 32, "batch": BG, "graph_build_s": t_build,
-                 "graph_build_rows_per_s": NG / t_build, "entry": "hierarchical descent (ZVDB_ENTRY_DESCEND)",
-                 "data": "rows of intrinsic rank 12 + 1 % noise (seeded, generated on the device)" if structured else "i.i.d. U[0,1) coordinates (the benchmark's generator)",
-                 "ef": {}}
-        for ef in (64, 128, 256):
-            st.zero_()
-            g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(),
-                               st.data_ptr(), stream)
-            torch.cuda.synchronize()
-            got = ids.cpu().numpy()
-            rec = float(np.mean([len(set(got[i]) & set(gt[i])) / K for i in range(BG)]))
-            ev = int(st[0].item())
-            t0 = time.perf_counter()
-            for _ in range(3):
-                g.search_graph_dev(qg.data_ptr(), BG, DG, K, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
-            torch.cuda.synchronize()
-            el = (time.perf_counter() - t0) / 3
-            graph["ef"][str(ef)] = {"qps": BG / el, "ms_per_batch": el * 1e3, "recall_at_10": rec,
-                                    "dist_evals_per_query": ev / BG, "algorithmic_GBps": ev * DG * 4 / el / 1e9,
-                                    "hbm_frac_of_8TBps": ev * DG * 4 / el / 8e12}
-        return graph
-
-    out["graph_route_ef_mode"] = graph_leg(False)
+    NG = args.extras_graph_rows
+    out["graph_route_ef_mode"] = graph_leg(zv, torch, dev, stream, NG, 768, 1024, K, (64, 128, 256), False)
     # the same route on rows with neighbourhood structure (what embeddings look like): here the graph clears the metric's recall bar
-    out["graph_route_ef_mode_structured_rows"] = graph_leg(True)
+    out["graph_route_ef_mode_structured_rows"] = graph_leg(zv, torch, dev, stream, NG, 768, 1024, K, (64, 128, 256), True)
+    out["graph_route_ef_mode_structured_bf16_rows"] = graph_leg(zv, torch, dev, stream, NG, 768, 1024, K, (64, 128, 256), True, bf16_rows=True)
 
     # ---- k sweep of the reference's benchmark (single_threaded_benchmarks.zig:28-33: k in {10, 25, 50, 100}) on the brute-force
     # routes: int8 = exact top-k (k' = 64 survivors up to k = 48, 128 beyond), fp4 = approximate, recall measured against int8 ----
@@ -550,6 +612,21 @@ def main():
                                         "achieved": ach2, "peak": PEAK_TFLOPS[name], "unit": "TFLOP/s" if name != "i8" else "TOP/s",
                                         "frac": ach2 / PEAK_TFLOPS[name]}}
 
+    cert = idx.cert_info()  # certificate counters of the headline index (all legs so far)
+    if auto and not args.no_paths and world == 1 and not args.rehearse_shard_of and rank == 0:
+        # the routes BASELINE configs[1]-[2] name, bounded (1M rows), each with its own roofline object: the graph route on the
+        # benchmark's generator (where no graph reaches the recall bar: SURVEY 7 predicted it, profiles/r2/graph_recall_*.txt hold the
+        # curves) and on rows with neighbourhood structure (where it does); configs[1] on the fp32-MFMA screen
+        ws = None  # (the headline's workspace is no longer needed)
+        for nm, structured, hb in (("graph_ef128_1Mx768_uniform", False, False), ("graph_ef128_1Mx768_rank12", True, False),
+                                   ("graph_ef128_1Mx768_rank12_bf16rows", True, True)):
+            gl = graph_leg(zv, torch, dev, stream, 1_000_000, 768, 1024, K, (128,), structured, bf16_rows=hb)
+            e = gl.pop("ef")["128"]
+            paths[nm] = {"value": e["qps"], "unit": "QPS", "ef": 128, **{kk: vv for kk, vv in e.items() if kk != "qps"}, **gl}
+        c2 = c2_leg(zv, torch, dev, stream, K, modes=("f32",))[0]
+        paths["c2_1Mx128_b256_f32"] = {"value": c2["f32"]["qps"], "unit": "QPS", "rows": c2["rows"], "dim": c2["dim"], "batch": c2["batch"],
+                                       "ms_per_batch": c2["f32"]["ms_per_batch"], "roofline": c2["f32"]["roofline"], "certificate": c2["certificate"]}
+
     if rank == 0:
         qps = B * args.steps / elapsed
         flops = 2.0 * B * n_local * D  # algorithmic flops of one scan launch on this rank
@@ -594,7 +671,9 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s" if args.mode != "i8" else "TOP/s",
                 "screen": ("approximate 4-bit screen: recall_at_10 above is measured, not guaranteed" if args.mode == "fp4"
-                           else "screen keeps the exact top-k whenever they are among the k' best screen keys"),
+                           else "certified: per query the re-rank proves that no row outside the k' survivors can enter the top-k "
+                                "(bound on the screen's rounding, zvdb_amd/csrc/bf_cert.h), else the query is recomputed by an exact scan "
+                                "inside the same call -- see `certificate`"),
                 "frac": achieved / peak,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
@@ -616,6 +695,9 @@ def main():
                 "algorithmic_bytes_per_launch": float(n_local) * D * ELT_BYTES[args.mode],
             },
         }
+        out["certificate"] = {**cert, "survivors_kept": {0: "32 (k <= 16) / 64", 1: 64, 2: 128, 3: 256}[cert["level"]],
+                              "note": "queries = all that went through the certificate on the headline index (every leg); repaired = recomputed by the "
+                                      "exact scan (expected only while the survivor level settles in the warm-up)"}
         if headline_note:
             out["headline_note"] = headline_note
         if paths:

@@ -61,6 +61,8 @@ enum zvdb_metric {
 
 /* brute-force contraction modes (a10; no reference symbol) */
 enum zvdb_bf_mode {
+    /* The first three are exact AND certified (ZVDB_OPT_CERTIFY below): per query either a proof that no row the screen
+     * left out can enter the top-k, or an exact scan of all rows in the reference's arithmetic. */
     ZVDB_BF_F32 = 0,  /* fp32 MFMA (v_mfma_f32_32x32x2_f32) screen + exact fp32 re-rank */
     ZVDB_BF_BF16 = 1, /* bf16 MFMA screen over the bf16 mirror + exact fp32 re-rank */
     ZVDB_BF_I8 = 2,   /* int8 MFMA (v_mfma_i32_32x32x32_i8) screen over a scalar-quantised mirror
@@ -254,6 +256,8 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
 /* ---- a10: brute-force Q x V^T + fused top-k (no reference symbol) --------- */
 /* For each query the k smallest distances over all rows, ascending, ties by
  * lower id; final distances are recomputed in exact reference arithmetic.
+ * ZVDB_BF_F32 / _BF16 / _I8 are CERTIFIED (ZVDB_OPT_CERTIFY, on by default): the ids are proven to be the exact
+ * top-k per query, or recomputed by an exact scan inside the same call.
  * k <= 112 on every route and dimension (k <= 48, 56 with ZVDB_BF_F32, keep
  * k' = 64 survivors per query; larger k -- the approximate ZVDB_BF_FP4 screen
  * from k > 32 -- keep k' = 128); k <= 240 on the stream routes (ZVDB_BF_I8 and
@@ -311,12 +315,69 @@ int zvdb_hip_index_set_shard_count(zvdb_hip_index *h, uint32_t shards);
  * never guaranteed, on this route -- ZVDB_BF_I8 / _BF16 / _F32 are the exact ones. */
 int zvdb_hip_index_set_screen_survivors(zvdb_hip_index *h, uint32_t survivors);
 
+/* Index options (behaviour that used to hang on environment variables lives here: an embedded library is configured by its
+ * caller, not by the process environment). */
+enum zvdb_option {
+    /* 1 (default) / 0: certify the results of the exact brute-force screens (ZVDB_BF_F32 / _BF16 / _I8).  With it every query's
+     * result is PROVEN to be the k smallest reference distances (hnsw.zig:182-192; ties by lower id) or recomputed: the re-rank
+     * compares the k-th exact distance with the k'-th survivor's screen key through a bound on everything the screen rounds
+     * (bf16 operands: residual norms measured when the mirror is built; int8 codes likewise; MFMA accumulation: one ulp per
+     * step in any order; the reference sum's own rounding) -- zvdb_amd/csrc/bf_cert.h states the inequality.  A query the
+     * bound cannot certify is recomputed inside the same call by an exact scan of every row in the reference's arithmetic
+     * (no screen involved), and the index keeps more survivors (64, 128, 256) for the following batches so that the proof
+     * goes through without it.  Without it the exact screens return the true top-k "whenever it is among the k' best screen keys",
+     * unchecked.  ZVDB_BF_FP4 is approximate by design and never certified. */
+    ZVDB_OPT_CERTIFY = 1,
+    /* 0 .. 3: survivors kept per query from the first batch on (0: as few as the route allows and adapt; 1: 64; 2: 128; 3: 256) */
+    ZVDB_OPT_CERT_MIN_LEVEL = 2,
+    /* 1: every query is sent through the exact scan whatever the certificate says (tests of the repair path; results are the
+     * same by definition, only slower) */
+    ZVDB_OPT_CERT_FORCE_REPAIR = 3
+};
+int zvdb_hip_index_set_option(zvdb_hip_index *h, uint32_t option, uint64_t value);
+
+typedef struct zvdb_hip_cert_info {
+    uint64_t queries;  /* queries that went through the certificate */
+    uint64_t batches;
+    uint64_t repaired; /* of them: recomputed by the exact scan (read without synchronising: launches still running are not counted) */
+    uint32_t level;    /* survivors currently kept: 0 = the route's minimum (32 for k <= 16, else 64), 1 = 64, 2 = 128, 3 = 256 */
+    uint32_t enabled;
+} zvdb_hip_cert_info;
+int zvdb_hip_bruteforce_cert_info(zvdb_hip_index *h, zvdb_hip_cert_info *out);
+
 /* Same merge over ONE all-gathered byte buffer: rank g's chunk starts at g * rank_stride_bytes and
  * holds ids u64[nq*k] at offset 0, dist f32[nq*k] at nq*k*8, count u32[nq] at nq*k*12 (so a rank
  * sends its three result arrays with a single collective). */
 int zvdb_hip_merge_topk_packed_dev(const void *d_packed, uint64_t rank_stride_bytes, uint32_t G,
                                    uint32_t nq, uint32_t k, void *d_out_ids, void *d_out_dist,
                                    void *d_out_count, void *stream);
+
+/* ---- the multi-GPU step behind the ABI (the reference is single-node: no counterpart) -------------------
+ * One process per GPU, the index sharded by vector-id range (ids are dense insertion order, hnsw.zig:77; a shard's first
+ * global id is its id_offset).  A communicator wraps one RCCL rank: rank 0 obtains the unique id (zvdb_hip_comm_unique_id)
+ * and hands its ZVDB_COMM_ID_BYTES bytes to the other ranks by any channel it has (a file, a socket, MPI, torch.distributed);
+ * every rank then calls zvdb_hip_comm_create (collective: returns once all `world` ranks have joined).  RCCL is bound at run
+ * time (librccl.so.1, xGMI inside a node); ZVDB_ERR_UNSUPPORTED if it cannot be loaded.
+ * The sharded searches run the local search on this rank's shard, ONE all-gather of the packed per-shard top-k
+ * (nq k 12 + nq 4 bytes per rank) and the k-way merge by (distance, id) -- everything enqueued on the caller's stream, no host
+ * round trip; every rank ends with the same global top-k in d_ids / d_dist / d_count (layouts of the unsharded *_dev calls).
+ * Exactness: the union of exact per-shard top-k lists contains the exact global top-k, so the brute-force routes stay exact
+ * (and certified) when sharded; the graph route's recall is the per-shard recall. */
+typedef struct zvdb_hip_comm zvdb_hip_comm; /* opaque */
+#define ZVDB_COMM_ID_BYTES 128
+#define ZVDB_SHARDED_GRAPH 0xFFFFFFFFu /* `mode` of zvdb_hip_sharded_workspace for the graph route */
+int zvdb_hip_comm_unique_id(void *out_id /* ZVDB_COMM_ID_BYTES bytes */);
+int zvdb_hip_comm_create(uint32_t rank, uint32_t world, const void *unique_id, int32_t device /* -1 = current */, zvdb_hip_comm **out);
+void zvdb_hip_comm_destroy(zvdb_hip_comm *c);
+int zvdb_hip_comm_info(zvdb_hip_comm *c, uint32_t *out_rank, uint32_t *out_world);
+/* bytes of device workspace the sharded calls need (packed send + receive buffers + the local search's own workspace) */
+int zvdb_hip_sharded_workspace(zvdb_hip_index *h, zvdb_hip_comm *c, uint32_t nq, uint32_t k, uint32_t mode, uint64_t *out_bytes);
+int zvdb_hip_search_bruteforce_sharded_dev(zvdb_hip_index *h, zvdb_hip_comm *c, const void *d_queries, uint32_t nq, uint32_t dim,
+                                           uint32_t k, uint32_t mode, uint64_t id_offset, void *d_workspace, uint64_t workspace_bytes,
+                                           void *d_ids, void *d_dist, void *d_count, void *stream);
+int zvdb_hip_search_graph_sharded_dev(zvdb_hip_index *h, zvdb_hip_comm *c, const void *d_queries, uint32_t nq, uint32_t dim,
+                                      uint32_t k, uint32_t ef, uint64_t entry, uint64_t id_offset, void *d_workspace,
+                                      uint64_t workspace_bytes, void *d_ids, void *d_dist, void *d_count, void *d_stats, void *stream);
 
 /* Kernel timing hook for bench.py's roofline object: the library records HIP
  * events around the dominant kernel of the last *_dev brute-force/graph call

@@ -1,6 +1,8 @@
 # one-off randomized parity sweep of the ef-mode beam search (extension; specification = the oracle's search_ef) on random
 # kNN graphs: ids, distances, counts and evaluation / pop counters bit for bit, on fp32 and on bf16 rows, through BOTH beam
-# kernels (registers for ef <= 512, LDS beyond or with ZVDB_EF_BEAM=lds).  usage: python tests/manual/fuzz_ef.py [cases] [seed]
+# kernels (registers for ef <= 512, LDS beyond or with ZVDB_EF_BEAM=lds); both metrics of the spec (squared L2 and inner product,
+# orc_hnsw_search_ef_ex's `metric`), k up to 100, rows up to 1536 dimensions (BASELINE configs[4]: 1536-d, k = 100, ef = 256).
+# usage: python tests/manual/fuzz_ef.py [cases] [seed]
 import sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, oracle, zvdb_amd as zv
@@ -9,16 +11,18 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for c in range(cases):
     n = int(rng.choice([50, 300, 2000, 6000]))
-    d = int(rng.choice([3, 16, 48, 64, 100, 128, 200, 256, 320, 512, 768, 800]))
+    d = int(rng.choice([3, 16, 48, 64, 100, 128, 200, 256, 320, 512, 768, 800, 1024, 1536]))
     if d >= 512: n = min(n, 2000)
+    dot = bool(rng.random() < 0.4)  # inner-product metric (rows and queries centred on 0)
     m = int(rng.choice([2, 4, 8, 12, 16, 32]))
     m = min(m, n - 1)
     ties = bool(rng.random() < 0.25)
     hb = bool(rng.random() < 0.5)  # bf16 row storage
-    V = rng.random((n, d), dtype=np.float32)
+    V = rng.random((n, d), dtype=np.float32) - np.float32(0.5 if dot else 0.0)
     if ties: V = np.floor(V * 4).astype(np.float32)
     if hb: V = oracle.bf16_round(V)
-    nn, _, _ = oracle.bruteforce_topk(V, V, m + 1)
+    om = 1 if dot else 0
+    nn, _, _ = oracle.bruteforce_topk(V, V, m + 1, om)
     ref = oracle.HNSW(m, 200)
     for r in V: ref.insert(r, 0)
     adj = np.zeros((n, m), dtype=np.uint32); deg = np.zeros(n, dtype=np.uint32)
@@ -26,14 +30,14 @@ for c in range(cases):
         nb = [int(x) for x in nn[i] if int(x) != i][:m]
         ref.set_neighbors(i, 0, nb)
         adj[i, :len(nb)] = nb; deg[i] = len(nb)
-    idx = zv.Index(m=m, flags=zv.FLAG_BF16_ROWS if hb else 0)
+    idx = zv.Index(m=m, metric=zv.METRIC_DOT if dot else zv.METRIC_L2SQ, flags=zv.FLAG_BF16_ROWS if hb else 0)
     idx.add(V)
     idx.upload_graph(adj, deg)
-    Q = rng.random((16, d), dtype=np.float32)
+    Q = rng.random((16, d), dtype=np.float32) - np.float32(0.5 if dot else 0.0)
     if ties: Q = np.floor(Q * 4).astype(np.float32)
     ok = True
     for _ in range(3):
-        k = int(rng.choice([1, 5, 10, 25, 60]))
+        k = int(rng.choice([1, 5, 10, 25, 60, 100]))
         ef = int(max(k, rng.choice([1, 10, 33, 64, 100, 128, 129, 200, 256, 300, 512, 600])))
         try:
             ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
@@ -63,16 +67,16 @@ for c in range(cases):
             print(f"case {c}: the two beam kernels differ: ids {np.array_equal(ids, ids2)} dist {np.array_equal(dist, dist2)} cnt {np.array_equal(cnt, cnt2)} "
                   f"stats reg {(ev, pp)} lds {(ev2, pp2)}", flush=True)
             ref.reset_counters()
-            r = [ref.search_ef(q, k, ef) for q in Q]
+            r = [ref.search_ef(q, k, ef, om) for q in Q]
             cs = ref.counters()
             print("   oracle stats", (cs.search_dist_evals, cs.search_pops), "reg rows equal:", [bool(np.array_equal(ids[i, :len(r[i][0])], r[i][0])) for i in range(len(Q))],
                   "lds rows equal:", [bool(np.array_equal(ids2[i, :len(r[i][0])], r[i][0])) for i in range(len(Q))], flush=True)
         ref.reset_counters()
         for qi, q in enumerate(Q):
-            ri, rd = ref.search_ef(q, k, ef)
+            ri, rd = ref.search_ef(q, k, ef, om)
             if not (cnt[qi] == len(ri) and np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)): ok = False
         cs = ref.counters()
         if (ev, pp) != (cs.search_dist_evals, cs.search_pops): ok = False
-        if not ok: print(f"MISMATCH case {c}: n={n} d={d} m={m} ties={ties} bf16_rows={hb} k={k} ef={ef}", flush=True); break
+        if not ok: print(f"MISMATCH case {c}: n={n} d={d} m={m} ties={ties} bf16_rows={hb} dot={dot} k={k} ef={ef}", flush=True); break
     bad += 0 if ok else 1
 print("done:", cases, "cases,", bad, "mismatches")

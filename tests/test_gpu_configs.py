@@ -262,21 +262,43 @@ def test_c5_cosine_1536d_bf16_rows_k100_ef256(zv, oracle):
         assert np.array_equal(ids, ri), mode
     a4, _, _ = idx.search_bruteforce(Q, k, zv.BF_FP4)
     assert np.mean([len(set(a4[i]) & set(ri[i])) / k for i in range(nq)]) >= 0.95
-    # graph route: exact 32-NN lists under the index's metric, ef = 256 beam search, recall@100 against the brute force
+    # graph route: exact 32-NN lists under the index's metric, ef = 256 beam search -- ids, distances, counts and the E / P counters
+    # against the oracle's spec (orc_hnsw_search_ef_ex, inner product, entry 0) bit for bit; recall@100 against the brute force
     idx.build_knn_graph(M, zv.BF_BF16)
     ref = oracle.HNSW(M, 200)
     for row in S:
         ref.insert(row, 0)
     for i in range(n):
         ref.set_neighbors(i, 0, [int(x) for x in idx.get_neighbors(i)])
-    gi, gd, gc = idx.search_graph(Q, k, ef=ef)
-    qn = Q / np.linalg.norm(Q.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+    gi, gd, gc, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
+    ref.reset_counters()
     hits = 0
     for qi in range(nq):
+        oi, od = ref.search_ef(Q[qi], k, ef, metric=1, entry=0)
+        assert gc[qi] == len(oi), qi
+        assert np.array_equal(gi[qi, :len(oi)], oi) and np.array_equal(gd[qi, :len(oi)], od), qi
         hits += len(set(int(x) for x in gi[qi, :gc[qi]]) & set(int(x) for x in ri[qi]))
         assert np.all(np.diff(gd[qi, :gc[qi]]) >= 0)
+    c = ref.counters()
+    assert (ev, pp) == (c.search_dist_evals, c.search_pops)
     assert hits / (nq * k) >= 0.5  # (a 32-regular exact-kNN graph entered at node 0: measured ~0.8; the bar guards regressions)
-    del qn
+    # ... and once more as configs[4] would run it: the bulk HNSW graph (M = 16 -> 32 links at layer 0) entered by descent
+    # (half the rows: the oracle builds this graph on the CPU)
+    n2 = n // 2
+    idx2 = zv.Index(metric=zv.METRIC_COSINE, m=M, graph_stride=M, flags=zv.FLAG_BF16_MIRROR | zv.FLAG_BF16_ROWS)
+    idx2.add(Vraw[:n2])
+    idx2.build_graph(M // 2, 64, zv.BF_BF16, 0xC5)
+    ref2, levels, top = oracle.build_bulk_graph(S[:n2], M // 2, 64, 0xC5, metric=1)
+    assert idx2.graph_info() == (top, int(levels.max()))
+    gi, gd, gc, (ev, pp) = idx2.search_graph(Q, k, ef=ef, entry=zv.ENTRY_DESCEND, with_stats=True)
+    ref2.reset_counters()
+    for qi in range(nq):
+        ent = ref2.descend(Q[qi], 1, top)
+        oi, od = ref2.search_ef(Q[qi], k, ef, 1, ent)
+        assert gc[qi] == len(oi), qi
+        assert np.array_equal(gi[qi, :len(oi)], oi) and np.array_equal(gd[qi, :len(oi)], od), qi
+    c = ref2.counters()
+    assert (ev, pp) == (c.search_dist_evals, c.search_pops)
 
 
 def test_bf16_row_storage_halves_the_footprint_and_keeps_every_route_exact(zv, oracle):

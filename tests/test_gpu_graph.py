@@ -258,7 +258,7 @@ def test_load_rejects_corrupt_and_hostile_files(zv, oracle, tmp_path):
     refused(with_word("off_slot", top, int(hd["up_count"][2])), "upper-layer slot past up_count")
 
 
-def test_descend_is_refused_once_the_bulk_graph_is_stale(zv, oracle):
+def test_descend_is_refused_once_the_bulk_graph_is_stale(zv, oracle, tmp_path):
     """The bulk graph's upper layers describe the index only as the build left it: after rows are added, or layer 0 is replaced
     (upload_graph / set_neighbors / build_knn_graph), ZVDB_ENTRY_DESCEND is an error instead of a descent through stale layers,
     and graph_info stops reporting the old entry; a rebuild restores it."""
@@ -275,7 +275,17 @@ def test_descend_is_refused_once_the_bulk_graph_is_stale(zv, oracle):
         idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
     assert idx.graph_info()[0] == 0
     idx.search_graph(Q, 5, ef=32, entry=0)                    # a plain entry still works
-    idx.build_graph(8, 32, zv.BF_I8, 3)
+    path = str(tmp_path / "stale.zvdb")                       # a save / load round trip does not launder the stale graph
+    idx.save(path)
+    got = zv.Index.load(path)
+    assert got.count() == n + 100 and got.graph_info()[0] == 0
+    with pytest.raises(zv.ZvdbError):
+        got.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
+    a = idx.search_graph(Q, 5, ef=32, entry=0)
+    b = got.search_graph(Q, 5, ef=32, entry=0)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(zv.ZvdbError):                          # a REJECTED list replacement changes nothing -- not the graph's validity either
+        idx.build_graph(8, 32, zv.BF_I8, 3) or idx.set_neighbors(7, [n + 5000])
     idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
     idx.build_knn_graph(8)                                    # layer 0 replaced under the upper layers
     with pytest.raises(zv.ZvdbError):
@@ -284,6 +294,46 @@ def test_descend_is_refused_once_the_bulk_graph_is_stale(zv, oracle):
     idx.set_neighbors(7, [1, 2, 3])
     with pytest.raises(zv.ZvdbError):
         idx.search_graph(Q, 5, ef=32, entry=zv.ENTRY_DESCEND)
+
+
+@pytest.mark.parametrize("bf16rows", [False, True])
+def test_load_does_not_trust_the_rows_padding_or_the_stored_norms(zv, oracle, tmp_path, bf16rows):
+    """Rows sit in the file padded to ld elements and the exact kernels walk whole chunks up to ld: a file whose padding holds
+    NaN / garbage, or whose norm section lies, loads into an index that answers exactly like the one that was saved."""
+    import struct
+    n, d = 4000, 100  # ld = 128 (fp32) / ldh = 128 (bf16): 28 padding elements per row
+    V = oracle.uniform_rows(55, 0, n, d)
+    Q = oracle.uniform_rows(56, 0, 16, d)
+    idx = zv.Index(m=8, graph_stride=8, flags=zv.FLAG_BF16_ROWS if bf16rows else zv.FLAG_BF16_MIRROR)
+    idx.add(V)
+    idx.build_knn_graph(8)
+    path = str(tmp_path / "pad.zvdb")
+    idx.save(path)
+    raw = bytearray(open(path, "rb").read())
+    hd = _file_header(bytes(raw))
+    esz, ld = (2, hd["ldh"][2]) if bf16rows else (4, hd["ld"][2])
+    assert ld == 128
+    rows_off = hd["off_rows"][2]
+    for r in range(n):
+        for c in range(d, ld):
+            if bf16rows:
+                struct.pack_into("<H", raw, rows_off + (r * ld + c) * esz, 0x7FC0 if (r + c) % 3 else 0x4120)  # NaN / 10.0
+            else:
+                struct.pack_into("<f", raw, rows_off + (r * ld + c) * esz, float("nan") if (r + c) % 3 else 10.0)
+    for r in range(0, n, 7):
+        struct.pack_into("<f", raw, hd["off_norm"][2] + 4 * r, 1.0e9)  # lying norms
+    with open(path, "wb") as f:
+        f.write(bytes(raw))
+    got = zv.Index.load(path)
+    for m in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+        a = idx.search_bruteforce(Q, 10, m)
+        b = got.search_bruteforce(Q, 10, m)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), m
+    for ef in (0, 32):
+        a = idx.search_graph(Q, 10, ef=ef)
+        b = got.search_graph(Q, 10, ef=ef)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), ef
+    assert np.array_equal(got.get_vector(17), idx.get_vector(17))
 
 
 def test_load_accepts_every_index_create_accepts(zv, oracle, tmp_path):

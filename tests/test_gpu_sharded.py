@@ -161,7 +161,27 @@ def _hip_rank(rank, world, port, n, d, nq, k, ret):
     torch.cuda.synchronize()
     a = ids.cpu().numpy().astype(np.uint64)
     rec = np.mean([len(set(a[i]) & set(ri[i])) / k for i in range(nq)])
-    ret[rank] = bool(ok) and rec >= 0.95
+    # the graph route, sharded: each rank builds the bulk HNSW graph of ITS id range on the device, searches it by descent + beam,
+    # and the merged result equals the oracle's merge of the per-shard oracle searches (the per-shard graph and search are
+    # bit-exact against the oracle: tests/test_gpu_graph.py) -- on a prefix of the corpus small enough for the CPU build
+    ng, M, efc, ef = 3001, 8, 32, 48
+    gshard = HipShard(ng, d, rank, world, 0, m=2 * M, graph_stride=2 * M)
+    gshard.add(V[gshard.lo:gshard.hi])
+    gshard.build_graph(M, efc, zv.BF_I8, 5)
+    gids, gdd, gcnt = Gloo(gshard).search(q_t, k, route="graph", ef=ef)
+    torch.cuda.synchronize()
+    from zvdb_amd.sharded import shard_range
+    per_i = np.zeros((world, nq, k), dtype=np.uint64); per_d = np.full((world, nq, k), np.inf, dtype=np.float32); per_c = np.zeros((world, nq), dtype=np.uint32)
+    for r in range(world):
+        lo, hi = shard_range(ng, world, r)
+        ref, levels, top = oracle.build_bulk_graph(V[lo:hi], M, efc, 5)
+        for qi in range(nq):
+            oi, od = ref.search_ef(Q[qi], k, ef, 0, ref.descend(Q[qi], 0, top))
+            per_i[r, qi, :len(oi)] = oi + np.uint64(lo); per_d[r, qi, :len(oi)] = od; per_c[r, qi] = len(oi)
+    mi, md, mc = oracle.merge_topk(per_i, per_d, per_c, k)
+    gok = (np.array_equal(gids.cpu().numpy().astype(np.uint64), mi) and np.array_equal(gdd.cpu().numpy(), md)
+           and np.array_equal(gcnt.cpu().numpy().astype(np.uint32), mc))
+    ret[rank] = bool(ok) and rec >= 0.95 and bool(gok)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -176,6 +196,54 @@ def test_two_rank_processes_on_the_hip_backend(oracle):
     ret = mgr.dict()
     mp.spawn(_hip_rank, args=(2, port, 20_001, 64, 33, 10, ret), nprocs=2, join=True)
     assert all(ret.get(r, False) for r in range(2)), dict(ret)
+
+
+def test_rccl_behind_the_c_abi_world_size_1(oracle):
+    """zvdb_hip_comm_* + zvdb_hip_search_{bruteforce,graph}_sharded_dev through ctypes at the one world size a one-GPU box allows:
+    unique id -> communicator -> local search + ncclAllGather + merge inside libzvdb_hip, on the caller's stream; results equal
+    the unsharded calls' (and therefore the oracle's), ids carry the shard's offset."""
+    import torch
+    import zvdb_amd as zv
+    from zvdb_amd.sharded import Comm, HipShard
+    n, d, nq, k, M = 30_001, 48, 65, 10, 8
+    comm = Comm(0, 1, Comm.unique_id(), 0)
+    assert (comm.rank, comm.world) == (0, 1)
+    shard = HipShard(n, d, 0, 1, 0, m=2 * M, graph_stride=2 * M, comm=comm)
+    shard.add_synthetic(0x5EED)
+    shard.lo = 1000  # (a shard in the middle of the id space: results carry the offset)
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    q_t = torch.from_numpy(Q).to(shard.device)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
+    for mode in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+        ids, dd, cnt = shard.search(q_t, k, mode)
+        torch.cuda.synchronize()
+        assert np.array_equal(ids.cpu().numpy().astype(np.uint64), ri + np.uint64(1000)) and np.array_equal(dd.cpu().numpy(), rd), mode
+        assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), rc)
+    shard.build_graph(M, 32, zv.BF_I8, 9)
+    ids, dd, cnt = shard.search(q_t, k, route="graph", ef=64)
+    li, ld, lc = shard.local_search(q_t, k, route="graph", ef=64)
+    torch.cuda.synchronize()
+    assert torch.equal(ids, li) and torch.equal(dd, ld) and torch.equal(cnt, lc)
+    assert int(ids.min()) >= 1000
+    comm.close()
+
+
+def test_bench_graph_route_sharded_rehearsal(oracle):
+    """`bench.py --route graph --row-dtype bf16` (BASELINE configs[3]'s route: bf16 rows, HNSW M = 16, sharded) launched as the driver
+    launches N > 1 runs, at world size 1 with the RCCL step forced on, on a small shard: one JSON line with the graph route's
+    recall against the sharded brute-force route and its HBM roofline object."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZVDB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(root, "bench.py"), "--gpus", "1", "--rows", "200000", "--dim", "128", "--steps", "3", "--warmup", "1",
+           "--route", "graph", "--row-dtype", "bf16", "--ef", "64", "--no-cpu-baseline", "--no-paths"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["route"] == "graph" and out["config"]["row_dtype"] == "bf16" and out["n_gpus"] == 1
+    assert out["value"] > 0 and 0.0 < out["recall_at_10"] <= 1.0 and out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] > 0
 
 
 def test_bench_under_torchrun_with_the_rccl_backend_world_size_1(oracle):

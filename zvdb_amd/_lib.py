@@ -16,6 +16,8 @@ FLAG_BF16_MIRROR = 1
 FLAG_BF16_ROWS = 2
 ENTRY_DESCEND = 0xFFFFFFFFFFFFFFFF  # search_graph entry: hierarchical descent from the bulk graph's top node
 ABI_VERSION = 1
+COMM_ID_BYTES = 128
+SHARDED_GRAPH = 0xFFFFFFFF
 
 
 class Config(C.Structure):
@@ -26,6 +28,14 @@ class Config(C.Structure):
 
 class SearchStats(C.Structure):
     _fields_ = [("dist_evals", C.c_uint64), ("pops", C.c_uint64)]
+
+
+class CertInfo(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("batches", C.c_uint64), ("repaired", C.c_uint64),
+                ("level", C.c_uint32), ("enabled", C.c_uint32)]
+
+
+OPT_CERTIFY, OPT_CERT_MIN_LEVEL, OPT_CERT_FORCE_REPAIR = 1, 2, 3
 
 
 # every symbol include/zvdb_hip.h declares: (name, restype, argtypes)
@@ -73,6 +83,15 @@ HIP_SYMBOLS = [
     ("zvdb_hip_merge_topk_packed_dev", _i32, [_vp, _u64, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_index_set_shard_count", _i32, [_vp, _u32]),
     ("zvdb_hip_index_set_screen_survivors", _i32, [_vp, _u32]),
+    ("zvdb_hip_index_set_option", _i32, [_vp, _u32, _u64]),
+    ("zvdb_hip_bruteforce_cert_info", _i32, [_vp, C.POINTER(CertInfo)]),
+    ("zvdb_hip_comm_unique_id", _i32, [_vp]),
+    ("zvdb_hip_comm_create", _i32, [_u32, _u32, _vp, C.c_int32, C.POINTER(_vp)]),
+    ("zvdb_hip_comm_destroy", None, [_vp]),
+    ("zvdb_hip_comm_info", _i32, [_vp, _u32p, _u32p]),
+    ("zvdb_hip_sharded_workspace", _i32, [_vp, _vp, _u32, _u32, _u32, _u64p]),
+    ("zvdb_hip_search_bruteforce_sharded_dev", _i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u64, _vp, _u64, _vp, _vp, _vp, _vp]),
+    ("zvdb_hip_search_graph_sharded_dev", _i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u64, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_timing_enable", _i32, [_vp, _i32]),
     ("zvdb_hip_timing_read", _i32, [_vp, C.POINTER(C.c_double), _u32p]),
 ]

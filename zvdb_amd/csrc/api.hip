@@ -322,6 +322,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->rows_p);
     (void)hipFree(h->norm_p);
     if (h->guess_flag_host) (void)hipHostFree(h->guess_flag_host);
+    if (h->cert_host) (void)hipHostFree(h->cert_host);
+    if (h->cert_dev) (void)hipFree(h->cert_dev);
     if (h->bal_host) (void)hipHostFree(h->bal_host);
     if (h->ef_hint_host) (void)hipHostFree(h->ef_hint_host);
     (void)hipFree(h->ef_hint_dev);
@@ -472,7 +474,6 @@ int zvdb_hip_set_neighbors(zvdb_hip_index *h, uint64_t node, const uint64_t *ids
         set_error("NodeNotFound: node %llu", (unsigned long long)node);
         return ZVDB_ERR_NODE_NOT_FOUND;
     }
-    h->bulk_graph = false;
     if (n > h->gstride) {
         set_error("neighbour list of %u exceeds the device stride %u", n, h->gstride);
         return ZVDB_ERR_INVALID;
@@ -487,6 +488,7 @@ int zvdb_hip_set_neighbors(zvdb_hip_index *h, uint64_t node, const uint64_t *ids
         p[i] = (uint32_t)ids[i];
     }
     p[h->gstride] = n;
+    h->bulk_graph = false;  // (only now: a rejected call changes nothing, so it must not cost the index its descent either)
     if (n)
         ZV_HIP(hipMemcpyAsync(h->adj + node * h->gstride, p, n * sizeof(uint32_t), hipMemcpyHostToDevice,
                               h->stream));
@@ -502,8 +504,6 @@ int zvdb_hip_upload_graph(zvdb_hip_index *h, const uint32_t *adj, const uint32_t
     ZV_CHECK(use_device(h));
     ZV_ARG(n <= h->count, "graph has more nodes than the index has rows");
     ZV_ARG(stride <= h->gstride, "graph stride exceeds the device stride");
-    h->bulk_graph = false;
-    ef_hint_reset(h, h->stream);
     for (uint64_t i = 0; i < n; ++i) {
         ZV_ARG(deg[i] <= stride, "degree exceeds stride");
         for (uint32_t j = 0; j < deg[i]; ++j)
@@ -513,6 +513,8 @@ int zvdb_hip_upload_graph(zvdb_hip_index *h, const uint32_t *adj, const uint32_t
                 return ZVDB_ERR_NODE_NOT_FOUND;
             }
     }
+    h->bulk_graph = false;  // (after the validation: a rejected call leaves the index as it was)
+    ef_hint_reset(h, h->stream);
     ZV_HIP(hipMemcpy2D(h->adj, h->gstride * sizeof(uint32_t), adj, stride * sizeof(uint32_t),
                        stride * sizeof(uint32_t), n, hipMemcpyHostToDevice));
     ZV_HIP(hipMemcpy(h->deg, deg, n * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1380,7 +1382,7 @@ int zvdb_hip_save(zvdb_hip_index *h, const char *path) {
     std::memcpy(hd.magic, "ZVDBHIP1", 8);
     hd.version = 1; hd.dim = h->dim; hd.ld = h->ld; hd.ldh = h->ldh; hd.metric = h->metric; hd.m = h->m;
     hd.ef_construction = h->ef_construction; hd.gstride = h->gstride; hd.flags = h->flags; hd.max_level = h->max_level;
-    hd.bulk_graph = h->bulk_graph ? 1u : 0u; hd.bulk_top = h->bulk_top; hd.count = h->count; hd.up_count = h->up_count;
+    hd.bulk_graph = bulk_graph_valid(h) ? 1u : 0u;  /* (a bulk graph that no longer covers every row is saved as what it is: lists without a descent) */ hd.bulk_top = h->bulk_top; hd.count = h->count; hd.up_count = h->up_count;
     const uint64_t n = h->count, rowb = hb ? (uint64_t)h->ldh * 2 : (uint64_t)h->ld * 4;
     uint64_t off = 256;
     auto place = [&](uint64_t bytes) { const uint64_t o = off; off = round_up64(off + bytes, 256); return o; };
@@ -1468,13 +1470,10 @@ int zvdb_hip_load(const char *path, int32_t device, zvdb_hip_index **out) {
             if (rc == ZVDB_OK) rc = copy_section_in(h, f, h->slot, n * 4, hd.off_slot);
             if (rc == ZVDB_OK && hd.up_count) rc = copy_section_in(h, f, h->adj_up, hd.up_count * h->gstride * 4, hd.off_adj_up);
             if (rc == ZVDB_OK && hd.up_count) rc = copy_section_in(h, f, h->deg_up, hd.up_count * 4, hd.off_deg_up);
-            if (rc == ZVDB_OK) {
-                if (hb) {  // the stored norms are those of the bf16 rows
-                    if (hipMemcpyAsync(h->norm_h, h->norm, n * 4, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) rc = ZVDB_ERR_HIP;
-                } else {
-                    rc = launch_finalize_rows(h, 0, n, h->stream);  // norms + the optional row-major bf16 mirror, from the rows
-                }
-            }
+            // the rows' padding [dim, ld) is zeroed (the exact kernels walk whole chunks and rely on it) and every norm is recomputed
+            // from the rows: neither is taken from the file on trust
+            if (rc == ZVDB_OK) rc = launch_sanitize_loaded_rows(h, n, h->stream);
+            if (rc == ZVDB_OK && !hb) rc = launch_finalize_rows(h, 0, n, h->stream);  // norms + the optional row-major bf16 mirror, from the rows
             if (rc == ZVDB_OK) {  // (3) the graph's indices
                 uint32_t *d_bad = nullptr, bad = 0;
                 if (hipMalloc(reinterpret_cast<void **>(&d_bad), 4) != hipSuccess) rc = ZVDB_ERR_OOM;
@@ -1587,6 +1586,40 @@ int zvdb_hip_index_set_screen_survivors(zvdb_hip_index *h, uint32_t survivors) {
     ZV_ARG(survivors == 0 || survivors == 64 || survivors == 128 || survivors == 256, "survivors must be 0, 64, 128 or 256");
     std::lock_guard<std::mutex> g(h->mu);
     h->screen_survivors = survivors;
+    return ZVDB_OK;
+}
+
+int zvdb_hip_index_set_option(zvdb_hip_index *h, uint32_t option, uint64_t value) {
+    ZV_ARG(h, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    switch (option) {
+    case ZVDB_OPT_CERTIFY:
+        ZV_ARG(value <= 1, "ZVDB_OPT_CERTIFY takes 0 or 1");
+        h->cert_on = value != 0;
+        return ZVDB_OK;
+    case ZVDB_OPT_CERT_MIN_LEVEL:
+        ZV_ARG(value <= 3, "ZVDB_OPT_CERT_MIN_LEVEL takes 0 .. 3");
+        h->cert_level_min = (uint32_t)value;
+        return ZVDB_OK;
+    case ZVDB_OPT_CERT_FORCE_REPAIR:
+        ZV_ARG(value <= 1, "ZVDB_OPT_CERT_FORCE_REPAIR takes 0 or 1");
+        h->cert_force = value != 0;
+        return ZVDB_OK;
+    default:
+        break;
+    }
+    set_error("unknown option %u", option);
+    return ZVDB_ERR_INVALID;
+}
+
+int zvdb_hip_bruteforce_cert_info(zvdb_hip_index *h, zvdb_hip_cert_info *out) {
+    ZV_ARG(h && out, "null argument");
+    std::lock_guard<std::mutex> g(h->mu);
+    out->queries = h->cert_queries;
+    out->batches = h->cert_batches;
+    out->repaired = h->cert_host ? (uint64_t)__atomic_load_n(h->cert_host + 1, __ATOMIC_RELAXED) : 0;
+    out->level = std::max(h->cert_level, h->cert_level_min);
+    out->enabled = h->cert_on ? 1u : 0u;
     return ZVDB_OK;
 }
 

@@ -670,7 +670,7 @@ int ensure_bf16_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     // whole units (NG groups) and whole 256-row tiles: 1536 = lcm(192, 256)
     const uint64_t rows_pad = round_up64(h->count, 1536);
     if (h->cap_hf < rows_pad) {
-        if (h->rows_hf) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_hf)); ZV_HIP(hipFree(h->norm_hf)); }
+        if (h->rows_hf) { ZV_HIP(hipDeviceSynchronize()); /* searches of this index may be in flight on OTHER streams: the mutex covers the host side only */ ZV_HIP(hipFree(h->rows_hf)); ZV_HIP(hipFree(h->norm_hf)); }
         h->rows_hf = nullptr;
         h->norm_hf = nullptr;
         const uint64_t ncap = round_up64(std::max<uint64_t>(h->count, h->cap), 1536);

@@ -649,7 +649,7 @@ int ensure_fp4_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     const uint32_t KS = fp4s_ksteps(h->dim);
     const uint64_t rows_pad = round_up64(h->count, 256);
     if (h->cap_pf < rows_pad) {
-        if (h->rows_pf) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_pf)); ZV_HIP(hipFree(h->norm_pf)); }
+        if (h->rows_pf) { ZV_HIP(hipDeviceSynchronize()); /* searches of this index may be in flight on OTHER streams: the mutex covers the host side only */ ZV_HIP(hipFree(h->rows_pf)); ZV_HIP(hipFree(h->norm_pf)); }
         h->rows_pf = nullptr;
         h->norm_pf = nullptr;
         const uint64_t ncap = round_up64(std::max<uint64_t>(h->count, h->cap), 256);

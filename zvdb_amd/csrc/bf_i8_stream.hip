@@ -531,7 +531,7 @@ int ensure_i8_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     const uint32_t KS = i8s_ksteps(h->dim);
     const uint64_t rows_pad = round_up64(h->count, 256);
     if (h->cap_qf < rows_pad) {
-        if (h->rows_qf) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_qf)); ZV_HIP(hipFree(h->norm_qf)); }
+        if (h->rows_qf) { ZV_HIP(hipDeviceSynchronize()); /* searches of this index may be in flight on OTHER streams: the mutex covers the host side only */ ZV_HIP(hipFree(h->rows_qf)); ZV_HIP(hipFree(h->norm_qf)); }
         h->rows_qf = nullptr;
         h->norm_qf = nullptr;
         const uint64_t ncap = round_up64(std::max<uint64_t>(h->count, h->cap), 256);
@@ -612,7 +612,7 @@ int ensure_f32_frag_mirror(zvdb_hip_index *h, hipStream_t s) {
     const uint32_t KS = f32s_ksteps(h->dim);
     const uint64_t rows_pad = round_up64(h->count, 256);
     if (h->cap_ff < rows_pad) {
-        if (h->rows_ff) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_ff)); ZV_HIP(hipFree(h->norm_ff)); }
+        if (h->rows_ff) { ZV_HIP(hipDeviceSynchronize()); /* searches of this index may be in flight on OTHER streams: the mutex covers the host side only */ ZV_HIP(hipFree(h->rows_ff)); ZV_HIP(hipFree(h->norm_ff)); }
         h->rows_ff = nullptr;
         h->norm_ff = nullptr;
         const uint64_t ncap = round_up64(std::max<uint64_t>(h->count, h->cap), 256);

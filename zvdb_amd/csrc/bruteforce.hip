@@ -16,6 +16,7 @@
 #include "wave_select.h"
 #include "bf_select.h"
 #include "row_types.h"
+#include "bf_cert.h"
 
 namespace zvdb {
 
@@ -559,7 +560,11 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
                                                      uint32_t kp, uint32_t cap, uint32_t l0 = 0, int vmode = 0,
                                                      uint32_t *__restrict__ flag = nullptr, uint32_t *__restrict__ defq = nullptr,
                                                      uint32_t *__restrict__ host_flag = nullptr /* mapped host memory */,
-                                                     uint32_t lkp = KP /* width (stride) of the lists and of cand_ids: 64, 128 or 256 */) {
+                                                     uint32_t lkp = KP /* width (stride) of the lists and of cand_ids: 64, 128 or 256 */,
+                                                     uint32_t *__restrict__ cand_keys = nullptr /* certificate (bf_cert.h): the candidates leave SORTED by (key, id), their keys here */,
+                                                     uint32_t *__restrict__ kth_out = nullptr /* ... and the k'-th key per query (0xFFFFFFFF: fewer than k' rows exist) */,
+                                                     uint32_t *__restrict__ cert_nflag = nullptr /* the repair list's counter: reset here, ahead of the re-rank that fills it */) {
+    if (cert_nflag && vmode != 2 && blockIdx.x == 0 && threadIdx.x == 0) *cert_nflag = 0;
     if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
@@ -603,7 +608,29 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
         __syncthreads();
     }
     reduce_pool();
-    if (cand_ids) {
+    if (cand_ids && cand_keys) {  // sorted by (key, id): rank by counting (n <= 256 keys in LDS)
+        for (uint32_t i = lane; i < lkp; i += kWave) {
+            if (i < n) {
+                const uint64_t k = pool[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint64_t o = pool[j];
+                    rank += (o < k || (o == k && j < i)) ? 1u : 0u;
+                }
+                cand_ids[(size_t)q * lkp + rank] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
+                cand_keys[(size_t)q * lkp + rank] = (uint32_t)(k >> 32);
+            } else {
+                cand_ids[(size_t)q * lkp + i] = 0xFFFFFFFFu;
+                cand_keys[(size_t)q * lkp + i] = 0xFFFFFFFFu;
+            }
+        }
+        if (kth_out) {
+            uint64_t mxl = 0;
+            for (uint32_t i = lane; i < n; i += kWave) mxl = umax64(mxl, pool[i]);
+            const uint64_t mx = wave_max64(mxl);
+            if (lane == 0) kth_out[q] = n >= kp ? (uint32_t)(mx >> 32) : 0xFFFFFFFFu;
+        }
+    } else if (cand_ids) {
         for (uint32_t i = lane; i < lkp; i += kWave) {
             const uint64_t k = i < n ? pool[i] : ~0ull;
             cand_ids[(size_t)q * lkp + i] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
@@ -706,7 +733,7 @@ __global__ __launch_bounds__(64) void k_rescale_queries(const float *__restrict_
 
 struct BfPlan {
     uint32_t tile, cap, nq_pad, QT, S, NT, KT, row_bytes, row_elems;
-    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_verify, off_pcnt, off_qs, total;
+    uint64_t off_q, off_cand, off_partial, off_ids, off_taug, off_verify, off_pcnt, off_qs, off_ckeys, off_kth, off_cert, cand_bytes, total;
     uint32_t QT8, S8;  // int8 stream kernel: tiles of 128 queries, streams
 };
 
@@ -728,7 +755,7 @@ static uint32_t effective_mode(const zvdb_hip_index *h, uint32_t mode) {
     return h->dim <= 4 ? (uint32_t)ZVDB_BF_F32 : mode;
 }
 
-BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
+BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode, uint32_t k) {
     mode = effective_mode(h, mode);
     BfPlan p{};
     p.tile = T2;
@@ -758,8 +785,11 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
                                          : mode == ZVDB_BF_F32 && f32s_eligible(h) ? f32s_query_bytes(h, p.nq_pad)
                                          : mode == ZVDB_BF_BF16 && bf16s_eligible(h) ? bf16s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
-    off += std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap,
-                              (uint64_t)std::max(p.QT * p.S, p.QT8 * p.S8) * BLKV_ENTRIES) * 8;
+    // (after the scan the region is free: the exact scan behind the certificate keeps its partial lists here)
+    p.cand_bytes = std::max<uint64_t>(std::max<uint64_t>((uint64_t)p.QT * p.S * p.tile * p.cap,
+                                                         (uint64_t)std::max(p.QT * p.S, p.QT8 * p.S8) * BLKV_ENTRIES) * 8,
+                                      round_up64(exact_scan_scratch_bytes(std::max(nq, 1u), std::max(k, 1u)), 256));
+    off += p.cand_bytes;
     p.off_partial = off;
     off += (uint64_t)p.nq_pad * 3 * p.S * KPMAX * 8;  // lists of up to three passes (widest list)
     p.off_ids = off;
@@ -772,6 +802,13 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode) {
     off += round_up64((uint64_t)p.nq_pad * 3 * p.S * 4, 256);  // valid-entry count of every list
     p.off_qs = off;  // rescaled fp32 queries (dot / cosine with a quantised screen)
     if (h->metric != ZVDB_METRIC_L2SQ && (mode == ZVDB_BF_I8 || mode == ZVDB_BF_FP4)) off += round_up64((uint64_t)p.nq_pad * h->dim * 4, 256);
+    // certificate (bf_cert.h): the candidates' screen keys, the k'-th key per query, the repair list [count 256 B][nq_pad ids]
+    p.off_ckeys = off;
+    off += (uint64_t)p.nq_pad * KPMAX * 4;
+    p.off_kth = off;
+    off += round_up64((uint64_t)p.nq_pad * 4, 256);
+    p.off_cert = off;
+    off += 256 + round_up64((uint64_t)p.nq_pad * 4, 256);
     p.total = off;
     return p;
 }
@@ -924,9 +961,8 @@ int launch_scan5(const BfPlan &p, const unsigned char *q_op, const unsigned char
 }  // namespace
 
 uint64_t bruteforce_workspace_bytes(const zvdb_hip_index *h, uint32_t nq, uint32_t k, uint32_t mode) {
-    (void)k;
     if (h->dim == 0) return 256;
-    return make_plan(h, nq, mode).total;
+    return make_plan(h, nq, mode, std::min(k, 256u)).total;
 }
 
 int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
@@ -945,7 +981,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         set_error("shard too large");
         return ZVDB_ERR_UNSUPPORTED;
     }
-    const BfPlan p = make_plan(h, nq, mode);
+    const BfPlan p = make_plan(h, nq, mode, std::min(k, 256u));
     static const int guess_off = [] { const char *e = getenv("ZVDB_BF_GUESS"); return e && e[0] == '0'; }();
     // fp4: barrier-free stream kernel over the fragment-order mirror when the query tile fits LDS, else the staged scan
     const bool f7 = mode == ZVDB_BF_FP4 && fp4s_eligible(h);
@@ -957,7 +993,34 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // A handful of dimensions and many rows put more rows inside the screen's rounding band of the k-th neighbour than 64
     // survivors hold (the screens evaluate |v|^2 - 2 q.v; 70k points on a line are ~1e-5 apart): keep 128 there.
     const bool dense_low_dim = h->dim <= 8 && h->count > 4096;
-    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32) || want > (uint32_t)KP || dense_low_dim;
+    // Certificate (bf_cert.h): the exact screens' results are PROVEN to be the top-k, query by query, or recomputed by the exact
+    // scan.  How many survivors the proof needs depends on the data (the k'-th screen key must clear the k-th exact distance by
+    // the screen's error bound): the index starts with as few as the route allows and keeps more (64, 128, 256) once a batch had
+    // to be repaired -- the flag is raised by the re-rank in host-mapped memory and read here without synchronisation.
+    const bool cert = h->cert_on && mode != ZVDB_BF_FP4;
+    if (cert) {
+        if (!h->cert_host) {
+            ZV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->cert_host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+            if (!h->cert_host) { set_error("hipHostMalloc returned no block"); return ZVDB_ERR_OOM; }
+            h->cert_host[0] = 0;
+            h->cert_host[1] = 0;
+            ZV_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->cert_hdev), h->cert_host, 0));
+        }
+        if (h->cert_force) {
+            __atomic_store_n(h->cert_host, 0u, __ATOMIC_RELAXED);  // (forced repairs say nothing about the survivors needed)
+        } else if (__atomic_load_n(h->cert_host, __ATOMIC_RELAXED) != 0) {
+            __atomic_store_n(h->cert_host, 0u, __ATOMIC_RELAXED);
+            if (h->cert_level < 3) ++h->cert_level;
+            h->cert_clean = 0;
+        } else if (++h->cert_clean >= 8192 && h->cert_level > 0) {  // a long clean run: try fewer survivors again
+            --h->cert_level;
+            h->cert_clean = 0;
+        }
+        h->cert_queries += nq;
+        h->cert_batches += 1;
+    }
+    const uint32_t cert_lvl = cert ? std::max(h->cert_level, h->cert_level_min) : 0u;
+    const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32) || want > (uint32_t)KP || dense_low_dim || cert_lvl >= 2;
     const bool big8 = !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);
     // fp4, 768 < dim <= 1536: the 128-query stream kernel (same conditions as the int8 one), else the staged scan
@@ -1028,7 +1091,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // (the staged kernel has the same two list widths; the v1 kernel kept for A/B has only k' = 64)
     // The stream kernels go on to k' = 256 (four entries per lane): k <= 240, and the fp4 screen uses it from k > 64
     // (recall@100: 0.84 with 128 survivors).
-    const bool widest = stream_route && (k > (uint32_t)KPW - 16 || (mode == ZVDB_BF_FP4 && k > 64) || want > (uint32_t)KPW);
+    const bool widest = stream_route && (k > (uint32_t)KPW - 16 || (mode == ZVDB_BF_FP4 && k > 64) || want > (uint32_t)KPW || cert_lvl >= 3);
     const uint32_t kpv = !wide_k ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
     if (k > (kpv != (uint32_t)KP ? kpv - 16 : kmax)) {
         set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d on the stream routes: "
@@ -1044,6 +1107,32 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                               (size_t)SG_Q * std::max(h->ld, h->ldh) * 4 <= 128 * 1024;  // (k_sample_guess keeps 4 padded queries in LDS)
     if (!guess_pipe && !staged_guess) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
+    uint32_t kp_used = (uint32_t)KP;
+    // certificate plumbing: the last merge of every route leaves the candidates sorted by screen key, with their keys and the
+    // k'-th key; the re-rank proves or lists the query; the exact scan recomputes the listed ones (a no-op launch otherwise)
+    uint32_t *ckeys = cert ? reinterpret_cast<uint32_t *>(ws + p.off_ckeys) : nullptr;
+    uint32_t *kth = cert ? reinterpret_cast<uint32_t *>(ws + p.off_kth) : nullptr;
+    uint32_t *nflag = cert ? reinterpret_cast<uint32_t *>(ws + p.off_cert) : nullptr;
+    uint32_t *flist = cert ? reinterpret_cast<uint32_t *>(ws + p.off_cert + 256) : nullptr;
+    if (cert) ZV_CHECK(ensure_cert_stats(h, mode, s));
+    auto finish = [&](uint32_t kp_valid) -> int {
+        if (!cert) return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid);
+        CertArgs ca;
+        ca.kth = kth;
+        ca.keys = ckeys;
+        ca.stats = reinterpret_cast<const float *>(h->cert_dev + 2 * mode);
+        ca.nflag = nflag;
+        ca.flist = flist;
+        ca.host_flag = h->cert_hdev;
+        ca.mode = (int)mode;
+        ca.q_lo = h->q_lo;
+        ca.q_inv = h->q_inv;
+        ca.affine = l2 ? 1 : 0;
+        ca.rescale_target = mode == ZVDB_BF_I8 ? 127.0f / h->q_inv : 0.0f;
+        ca.force = h->cert_force ? 1 : 0;
+        ZV_CHECK(launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid, &ca));
+        return launch_exact_scan(h, d_queries_exact, nq, k, id_offset, nflag, flist, cand, p.cand_bytes, d_ids, d_dist, d_count, h->cert_hdev + 1, s);
+    };
     timing_begin(h, s);
     {
         // The passes share one exact threshold: each pass but the last is followed by a merge of all lists;
@@ -1064,7 +1153,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         }
         const uint32_t kp = kpv != (uint32_t)KP ? kpv
                             : mode == ZVDB_BF_FP4 ? std::min<uint32_t>(h->shard_count > 1 ? fp4_share : std::max<uint32_t>(fp4_kp, k + 16), KP)
-                                                : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+                                                : (k <= 16 && !(debug_flags() & 8) && cert_lvl == 0) ? 32u : (uint32_t)KP;
+        kp_used = kp;
         const unsigned char *rows = mode == ZVDB_BF_BF16 ? reinterpret_cast<const unsigned char *>(h->rows_h)
                                     : mode == ZVDB_BF_I8 ? reinterpret_cast<const unsigned char *>(h->rows_q)
                                     : mode == ZVDB_BF_FP4 ? reinterpret_cast<const unsigned char *>(h->rows_p)
@@ -1139,17 +1229,17 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
-                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv);
+                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag);
             if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (sf) ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, kpv, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids,
-                               (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv);
+                               (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp);
+            return finish(kp);
         }
         if (staged_guess) {
             uint32_t *vflag = reinterpret_cast<uint32_t *>(ws + p.off_verify);
@@ -1197,13 +1287,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 1, vflag, defq,
-                               h->guess_flag_dev, kpv);
+                               h->guess_flag_dev, kpv, ckeys, kth, nflag);
             ZV_CHECK(scan1(tau_rep, p.S, vflag));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, (uint32_t *)nullptr, kp, cap, p.S, 2, vflag,
-                               defq, (uint32_t *)nullptr, kpv);
+                               defq, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp);
+            return finish(kp);
         }
         if (kpv != (uint32_t)KP && stream_route) {  // (small shard, k > 48) one flooding scan of the stream kernel with 128-wide lists
             const bool t128 = s8 || s4 || sf;
@@ -1217,10 +1307,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, (uint32_t *)nullptr, kp, cap,
-                               0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
+                               0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
-            return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp);
+            return finish(kp);
         }
         if (p.NT >= 4 * p.S && !(debug_flags() & 64)) {
             // pass A streams: every workgroup of pass A floods one tile (256 candidates per query, 8-byte
@@ -1296,17 +1386,18 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     }
     {
         const uint32_t kpf = kpv != (uint32_t)KP ? kpv
-                             : mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8)) ? 32u : (uint32_t)KP;
+                             : mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8) && cert_lvl == 0) ? 32u : (uint32_t)KP;
         const uint32_t cap = kpf + 64 * kpv;
         const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
         if (mlds > 64 * 1024)
             ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial,
                            reinterpret_cast<const uint32_t *>(ws + p.off_pcnt), nlists, stot_lists, cand_ids,
-                           (uint32_t *)nullptr, kpf, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
+                           (uint32_t *)nullptr, kpf, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
     }
     ZV_HIP(hipGetLastError());
-    return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s);
+    (void)kp_used;
+    return finish(0);
 }
 
 }  // namespace zvdb

@@ -186,6 +186,17 @@ struct zvdb_hip_index {
     bool own_stream_busy = false;  // a fused insert left its finalize kernel running on h->stream (see settle_own_stream)
     uint32_t screen_survivors = 0;  // zvdb_hip_index_set_screen_survivors: minimum k' of the fp4 screen (0 = from k)
     uint32_t shard_count = 1;  // zvdb_hip_index_set_shard_count: the approximate screen keeps its share of the survivors
+    // exactness certificate of the brute-force screens (bf_cert.h): per screen mode {largest residual |x' - x|, largest |x'|} of the
+    // mirror (device words; data_kernels.hip: ensure_cert_stats), valid while cert_count[mode] == count
+    uint32_t *cert_dev = nullptr;  // [4][2] float bit patterns
+    uint64_t cert_count[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    bool cert_on = true;           // ZVDB_OPT_CERTIFY
+    uint32_t cert_level = 0;       // survivors kept per query: 0 = as few as the route allows, 1: 64, 2: 128, 3: 256 -- raised when a batch needed the exact scan
+    uint32_t cert_level_min = 0;   // ZVDB_OPT_CERT_MIN_LEVEL
+    bool cert_force = false;       // ZVDB_OPT_CERT_FORCE_REPAIR
+    uint32_t cert_clean = 0;       // batches since the last repair at this level (lowers the level again after a long clean run)
+    uint32_t *cert_host = nullptr, *cert_hdev = nullptr;  // host-mapped {flag raised by a failing query, repaired queries (cumulative)}
+    uint64_t cert_queries = 0, cert_batches = 0;          // queries / batches that went through the certificate
     float *stage_f32 = nullptr;  // ZVDB_FLAG_BF16_ROWS: bounded fp32 staging chunk of the add paths (rows are stored as bf16 only)
     uint64_t stage_rows = 0;
     float *qrow_f32 = nullptr;   // ZVDB_FLAG_BF16_ROWS: one row widened to fp32 (a row of the index used as a query)
@@ -255,10 +266,18 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
 int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
                    unsigned long long *d_stats, hipStream_t s);
 // exact re-rank of candidate lists: cand[nq][kc] u32 (0xFFFFFFFF = empty) -> top-k by (dist,id)
+struct CertArgs;  // bf_cert.h
 int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, const uint32_t *d_cand,
                   uint32_t kc, uint32_t k, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
                   uint32_t *d_count, hipStream_t s,
-                  uint32_t kp_valid = 0 /* > 0: the lists hold at most this many candidates (compacted to the front) */);
+                  uint32_t kp_valid = 0 /* > 0: the lists hold at most this many candidates (compacted to the front) */,
+                  const CertArgs *cert = nullptr /* lists sorted by screen key + certificate (bf_cert.h) */);
+// exact_scan.hip: for every query on the list (*nflag entries) the exact top-k over ALL rows in the reference's arithmetic,
+// written over the query's results; scratch: >= exact_scan_scratch_bytes(nq, k); a no-op launch when the list is empty
+uint64_t exact_scan_scratch_bytes(uint32_t nq, uint32_t k);
+int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k, uint64_t id_offset, const uint32_t *nflag,
+                      const uint32_t *flist, void *scratch, uint64_t scratch_bytes, uint64_t *d_ids, float *d_dist, uint32_t *d_count,
+                      uint32_t *host_repaired, hipStream_t s);
 
 // ---- data_kernels.hip -------------------------------------------------------
 int launch_fill_synthetic(float *d_out, uint64_t nrows, uint32_t dim, uint32_t ld, uint64_t seed,
@@ -267,10 +286,12 @@ int launch_pack_rows(const float *d_src, uint32_t dim, float *d_dst, uint32_t ld
                      hipStream_t s);
 int launch_normalize_rows(float *d_rows, uint32_t dim, uint32_t ld, uint64_t n, hipStream_t s);
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s);
+int launch_sanitize_loaded_rows(const zvdb_hip_index *h, uint64_t n, hipStream_t s);  // zvdb_hip_load: zero padding, bf16 rows' norms from the rows
 int launch_store_rows_bf16(const zvdb_hip_index *h, const float *d_stage, uint64_t first, uint64_t n, hipStream_t s);  // ZVDB_FLAG_BF16_ROWS
 int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s);
 int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s);
 int fp4_range(zvdb_hip_index *h, hipStream_t s);  // sets p_mid / p_scale from the rows' value range
+int ensure_cert_stats(zvdb_hip_index *h, uint32_t mode, hipStream_t s);
 int launch_results_to_adj(const zvdb_hip_index *h, const uint64_t *d_ids, const uint32_t *d_cnt, uint32_t k,
                           uint64_t r0, uint32_t n, uint32_t degree, hipStream_t s);
 int launch_validate_graph(const zvdb_hip_index *h, uint64_t n, uint64_t up_count, uint32_t max_level, uint32_t *d_bad, hipStream_t s);

@@ -178,6 +178,49 @@ int launch_store_rows_bf16(const zvdb_hip_index *h, const float *d_stage, uint64
     return ZVDB_OK;
 }
 
+// Rows that did not come through the add paths (zvdb_hip_load copies them out of a file): elements [dim, ld) are zeroed -- the
+// exact kernels walk whole chunks up to ld and rely on the padding adding +0.0 (exact_kernels.hip: k_rerank_staged) -- and, for
+// bf16 row storage, the norms are recomputed from the rows the way k_store_rows_bf16 sums them instead of being taken on trust.
+__global__ __launch_bounds__(256) void k_sanitize_rows_f32(float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n) {
+    const uint32_t pad = ld - dim;
+    const uint64_t total = n * pad;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
+        rows[(t / pad) * ld + dim + (uint32_t)(t % pad)] = 0.0f;
+}
+__global__ __launch_bounds__(256) void k_sanitize_rows_bf16(uint16_t *__restrict__ rows_h, uint32_t dim, uint32_t ldh, float *__restrict__ norm,
+                                                            float *__restrict__ norm_h, uint64_t n) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    uint16_t *o = rows_h + r * ldh;
+    float sh = 0.0f;
+    for (uint32_t c = lane * 4; c < ldh; c += 256) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c + j >= dim) o[c + j] = 0;
+            const float f = c + j < dim ? __uint_as_float((uint32_t)o[c + j] << 16) : 0.0f;
+            sh += f * f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sh += __shfl_xor(sh, off);
+    if (lane == 0) {
+        norm[r] = sh;
+        norm_h[r] = sh;
+    }
+}
+int launch_sanitize_loaded_rows(const zvdb_hip_index *h, uint64_t n, hipStream_t s) {
+    if (n == 0) return ZVDB_OK;
+    if (h->flags & ZVDB_FLAG_BF16_ROWS) {
+        hipLaunchKernelGGL(k_sanitize_rows_bf16, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, s, h->rows_h, h->dim, h->ldh, h->norm, h->norm_h, n);
+    } else if (h->ld > h->dim) {
+        const uint64_t total = n * (h->ld - h->dim);
+        hipLaunchKernelGGL(k_sanitize_rows_f32, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 256 * 16)), dim3(256), 0, s, h->rows, h->dim, h->ld, n);
+    }
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 int launch_finalize_rows(const zvdb_hip_index *h, uint64_t first, uint64_t n, hipStream_t s) {
     if (n == 0) return ZVDB_OK;
     hipLaunchKernelGGL(k_finalize_rows, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, s, h->rows, h->dim,
@@ -279,7 +322,7 @@ int ensure_i8_mirror(zvdb_hip_index *h, hipStream_t s) {
     if (h->count == 0) return ZVDB_OK;
     h->ldq = round_up(h->dim, 128);
     if (h->cap_q < h->count) {
-        if (h->rows_q) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_q)); ZV_HIP(hipFree(h->norm_q)); }
+        if (h->rows_q) { ZV_HIP(hipDeviceSynchronize()); /* searches of this index may be in flight on OTHER streams: the mutex covers the host side only */ ZV_HIP(hipFree(h->rows_q)); ZV_HIP(hipFree(h->norm_q)); }
         h->rows_q = nullptr;
         h->norm_q = nullptr;
         const uint64_t ncap = std::max<uint64_t>(h->count, h->cap);
@@ -336,7 +379,7 @@ int ensure_fp4_mirror(zvdb_hip_index *h, hipStream_t s) {
     if (h->count == 0) return ZVDB_OK;
     h->ldp = round_up(h->dim, 256) / 2;
     if (h->cap_p < h->count) {
-        if (h->rows_p) { ZV_HIP(hipStreamSynchronize(s)); ZV_HIP(hipFree(h->rows_p)); ZV_HIP(hipFree(h->norm_p)); }
+        if (h->rows_p) { ZV_HIP(hipDeviceSynchronize()); /* searches of this index may be in flight on OTHER streams: the mutex covers the host side only */ ZV_HIP(hipFree(h->rows_p)); ZV_HIP(hipFree(h->norm_p)); }
         h->rows_p = nullptr;
         h->norm_p = nullptr;
         const uint64_t ncap = std::max<uint64_t>(h->count, h->cap);
@@ -556,6 +599,70 @@ int launch_merge_topk_strided(const uint64_t *d_ids, uint64_t rs_ids, const floa
     hipLaunchKernelGGL(k_merge_topk, dim3(nq), dim3(64), lds, s, d_ids, d_dist, d_count, rs_ids, rs_dist, rs_cnt,
                        G, nq, k, o_ids, o_dist, o_count);
     ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+// ---- certificate statistics of a screen's mirror (bf_cert.h) ------------------------------------
+// Per row the residual |x' - x| between the stored row x and what the screen multiplies (x' = the row rounded to bf16, or
+// reconstructed from its int8 code) and the norm |x'|; out[0] / out[1] <- the largest of each over the shard (atomicMax on the
+// bit patterns of non-negative floats, rounded up).  fp64 sums, one wave per row.  mode: enum zvdb_bf_mode (F32: x' = x).
+template <typename RT>
+__global__ __launch_bounds__(256) void k_cert_stats(const RT *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n, int mode, float q_lo,
+                                                    float q_inv, int affine, uint32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    double mr = 0.0, mu = 0.0;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (uint64_t)gridDim.x * 4) {
+        const RT *v = rows + r * ld;
+        double sr = 0.0, su = 0.0;
+        for (uint32_t c = lane; c < dim; c += 64) {
+            const float x = row_elem(v, c);
+            double rec = (double)x;
+            if (mode == ZVDB_BF_BF16) rec = (double)__uint_as_float((uint32_t)f32_to_bf16_rne(x) << 16);
+            else if (mode == ZVDB_BF_I8) {
+                const float f = affine ? __builtin_rintf((x - q_lo) * q_inv) - 128.0f : __builtin_rintf(x * q_inv);
+                const double code = (double)fminf(fmaxf(f, -128.0f), 127.0f);
+                rec = affine ? (double)q_lo + (code + 128.0) / (double)q_inv : code / (double)q_inv;
+            }
+            sr += (rec - (double)x) * (rec - (double)x);
+            su += rec * rec;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sr += __shfl_xor(sr, off);
+            su += __shfl_xor(su, off);
+        }
+        mr = fmax(mr, sr);
+        mu = fmax(mu, su);
+    }
+    if (lane == 0) {
+        auto up = [](double sq) {  // sqrt, rounded up to a float
+            const double d = sqrt(sq) * (1.0 + 1e-12);
+            float f = (float)d;
+            if ((double)f < d) f = __uint_as_float(__float_as_uint(f) + 1u);
+            return __float_as_uint(f);
+        };
+        atomicMax(out + 0, up(mr));
+        atomicMax(out + 1, up(mu));
+    }
+}
+
+int ensure_cert_stats(zvdb_hip_index *h, uint32_t mode, hipStream_t s) {
+    if (mode > ZVDB_BF_I8) return ZVDB_OK;
+    if (!h->cert_dev) {
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cert_dev), 8 * sizeof(uint32_t)));
+        ZV_HIP(hipMemsetAsync(h->cert_dev, 0, 8 * sizeof(uint32_t), s));
+    }
+    if (h->cert_count[mode] == h->count) return ZVDB_OK;
+    ZV_HIP(hipMemsetAsync(h->cert_dev + 2 * mode, 0, 2 * sizeof(uint32_t), s));
+    if (h->count > 0)
+        ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((h->count + 3) / 4, 256 * 16);
+            hipLaunchKernelGGL(k_cert_stats<row_elem_t<decltype(rows)>>, dim3(grid), dim3(256), 0, s, rows, h->dim, ld, h->count, (int)mode, h->q_lo,
+                               h->q_inv, h->metric == ZVDB_METRIC_L2SQ ? 1 : 0, h->cert_dev + 2 * mode);
+            ZV_HIP(hipGetLastError());
+            return ZVDB_OK;
+        }));
+    h->cert_count[mode] = h->count;
     return ZVDB_OK;
 }
 

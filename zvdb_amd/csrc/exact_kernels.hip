@@ -18,6 +18,7 @@
 #include "common.h"
 #include "wave_select.h"
 #include "exact_dist.h"
+#include "bf_cert.h"
 
 #pragma clang fp contract(off)
 
@@ -2231,7 +2232,7 @@ static int ef_reserve_visit(const zvdb_hip_index *h, size_t bytes) {
 }
 // table of the net: >= 16 ef stride slots (a straggler that filled the safe LDS table of 1.5 ef stride)
 static uint32_t ef_net_bits(const zvdb_hip_index *h, uint32_t ef) {
-    const uint64_t N = h->count;
+    const uint64_t N = std::max(h->count, h->cap);  // (from the capacity: rows added later must not make a reserved search reallocate)
     return bits_for(std::min<uint64_t>(std::max<uint64_t>(N, 1), std::max<uint64_t>((uint64_t)ef * h->gstride * 16, 65536)));
 }
 // the net's buffer: [list: 2 + nq words, padded to 256 B][kEfNetBlocks tables of 4 << bits bytes] -- 4 MiB at ef <= 256 / stride
@@ -2397,7 +2398,8 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         // (ef_scratch_end) -- the chain tie_buf has (api.hip).  h->mu serialises the host-side enqueue only.
         auto go = [&](auto kern, uint32_t wparam) -> int {
             if (safe_global) {
-                const size_t tb = 4ull << gbits;
+                // (sized from the CAPACITY: rows added after zvdb_hip_search_graph_reserve must not make a search reallocate)
+                const size_t tb = 4ull << bits_for(std::min<uint64_t>(std::max<uint64_t>(std::max<uint64_t>(N, h->cap), 1), (uint64_t)ef * h->gstride * 4 + 64));
                 ZV_CHECK(ef_reserve_visit(h, std::max<uint64_t>(1, std::min<uint64_t>(nq, (2ull << 30) / tb)) * tb));
             } else {
                 ZV_CHECK(ef_reserve_net(h, nq, ef));
@@ -2458,6 +2460,36 @@ void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s) {
 // cand[q][kc] (u32 local ids, 0xFFFFFFFF = empty).  One wave per query: every lane takes
 // candidates lane, lane+64, ... and computes the reference-exact distance; the final order
 // is (exact dist, id) ascending, duplicates dropped.
+// With a certificate (cert.kth != null; bf_cert.h) the lists arrive sorted by screen key and are evaluated 64 at a time: after
+// each round the k-th exact distance so far gives the largest screen key a row of the top-k can carry, candidates above it are
+// not evaluated, and the query is certified when that key lies below the k'-th survivor's -- else it goes on the repair list.
+__device__ __forceinline__ void cert_verdict(const CertArgs &cert, uint32_t qi, uint32_t ks, int lane) {
+    if (lane != 0) return;
+    const uint32_t kth = cert.kth[qi];
+    if (!cert.force && (kth == 0xFFFFFFFFu || ks < kth)) return;  // every row is a survivor / no row left out can reach the top-k
+    const uint32_t slot = atomicAdd(cert.nflag, 1u);
+    cert.flist[slot] = qi;
+    if (cert.host_flag) __hip_atomic_store(cert.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// k-th smallest (dist, id) among the valid entries [0, n) of the LDS lists (wave-collective; +inf if fewer than k are valid)
+__device__ __forceinline__ float cert_kth_dist(const float *cd, const uint32_t *ci, uint32_t n, uint32_t k, float *slot, int lane) {
+    if (lane == 0) *slot = __builtin_inff();
+    __syncthreads();
+    for (uint32_t i = lane; i < n; i += kWave) {
+        const uint32_t ii = ci[i];
+        if (ii == 0xFFFFFFFFu) continue;
+        const float di = cd[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t ij = ci[j];
+            if (ij != 0xFFFFFFFFu && lex_less(cd[j], ij, di, ii)) ++rank;
+        }
+        if (rank == k - 1) *slot = di;
+    }
+    __syncthreads();
+    return *slot;
+}
+
 template <typename RT>
 __global__ __launch_bounds__(64) void k_rerank(const RT *__restrict__ rows, uint32_t ld,
                                                uint32_t dim, int metric,
@@ -2466,17 +2498,22 @@ __global__ __launch_bounds__(64) void k_rerank(const RT *__restrict__ rows, uint
                                                uint32_t k, uint64_t id_offset,
                                                uint64_t *__restrict__ out_ids,
                                                float *__restrict__ out_dist,
-                                               uint32_t *__restrict__ out_count, uint32_t dim_pad) {
+                                               uint32_t *__restrict__ out_count, uint32_t dim_pad, CertArgs cert) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *q = reinterpret_cast<float *>(smem);
     float *cd = q + dim_pad;
     uint32_t *ci = reinterpret_cast<uint32_t *>(cd + kc);
+    uint32_t *ck = ci + kc;  // [kc] screen keys (certificate only)
+    float *dk_slot = reinterpret_cast<float *>(ck + kc);
     const int lane = threadIdx.x;
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
     __syncthreads();
-    for (uint32_t i = lane; i < kc; i += kWave) ci[i] = cand[(size_t)qi * kc + i];
+    for (uint32_t i = lane; i < kc; i += kWave) {
+        ci[i] = cand[(size_t)qi * kc + i];
+        if (cert.kth) ck[i] = cert.keys[(size_t)qi * kc + i];
+    }
     __syncthreads();
     // drop duplicate ids (keep the first copy), then evaluate the survivors exactly
     for (uint32_t base = 0; base < kc; base += kWave) {
@@ -2492,10 +2529,32 @@ __global__ __launch_bounds__(64) void k_rerank(const RT *__restrict__ rows, uint
         if (dup) ci[i] = 0xFFFFFFFFu;  // only later entries are cleared: earlier tests stay valid
         __syncthreads();
     }
-    for (uint32_t i = lane; i < kc; i += kWave) {
-        const uint32_t id = ci[i];
-        cd[i] = id == 0xFFFFFFFFu ? __builtin_inff()
-                                  : exact_dist_rt(metric, q, rows + (size_t)id * ld, dim);
+    if (cert.kth) {
+        const CertQ cq = cert_query_consts(cert, q, dim, metric, lane);
+        uint32_t ks = 0xFFFFFFFEu;
+        for (uint32_t base = 0; base < kc; base += kWave) {
+            const uint32_t i = base + lane;
+            const uint32_t id = i < kc ? ci[i] : 0xFFFFFFFFu;
+            const bool need = id != 0xFFFFFFFFu && (base == 0 || ck[i] <= ks);
+            if (i < kc) {
+                cd[i] = need ? exact_dist_rt(metric, q, rows + (size_t)id * ld, dim) : __builtin_inff();
+                if (!need) ci[i] = 0xFFFFFFFFu;  // provably outside the top-k: not evaluated, not ranked
+            }
+            if (__ballot(need) == 0) {  // (sorted lists: nothing further can be needed)
+                for (uint32_t j = base + kWave + lane; j < kc; j += kWave) { ci[j] = 0xFFFFFFFFu; cd[j] = __builtin_inff(); }
+                break;
+            }
+            const float dk = cert_kth_dist(cd, ci, min(base + kWave, kc), k, dk_slot, lane);
+            ks = cert_safe_key(cert, cq, dk, dim, metric);
+        }
+        __syncthreads();
+        cert_verdict(cert, qi, ks, lane);
+    } else {
+        for (uint32_t i = lane; i < kc; i += kWave) {
+            const uint32_t id = ci[i];
+            cd[i] = id == 0xFFFFFFFFu ? __builtin_inff()
+                                      : exact_dist_rt(metric, q, rows + (size_t)id * ld, dim);
+        }
     }
     __syncthreads();
     uint32_t total = 0;
@@ -2542,11 +2601,13 @@ typedef __attribute__((address_space(3))) void *rr_lptr_t;
 __device__ __forceinline__ void rr_dma16(const unsigned char *src, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
 }
-// KC = 64 / 128 / 256 candidates per query (KC / 64 batches of 64 rows through the same two stage buffers).  RT = stored row
+// KC = 64 / 128 / 256 candidates per query, evaluated in batches of SR rows through the same two stage buffers.  RT = stored row
 // element.  CHB = bytes of a row fetched per step (256 / 512 / 1024): one LDS-DMA instruction moves 1 KiB = 1024 / CHB rows x CHB
 // contiguous bytes, so a larger CHB reads longer runs of a row at once (a 16-byte piece holds 4 fp32 / 8 bf16 elements).  SR =
-// rows staged per batch: 64, or 32 when the lists hold at most 32 candidates (the brute-force routes at k <= 16: the host knows) --
-// then CHB = 512 fits the same 32 KiB of LDS (4 workgroups per CU) as 64 rows of 256 bytes.  Measured in the headline step (1,024
+// rows staged per batch: 64, or 32 with CHB = 512 (the same 32 KiB of LDS, 4 workgroups per CU) when the lists hold at most 32
+// candidates or arrive sorted by screen key with a certificate (bf_cert.h) -- then a batch is evaluated only as far as the bound
+// of the batches before it leaves candidates that could still enter the top-k (on the benchmark's data: the first 32 of 128).
+// Measured in the headline step (1,024
 // queries x 32 candidates x 3 KiB rows; rocprofv3 stats of `bench.py --mode bf16`): round 2's kernel 71.6 us; with the waits and the walk fixed (below) 41.7 us
 // (256 B x 64 rows), 40.3 us (512 B x 32 rows), 61.5 us (1 KiB x 32 rows: half the workgroups per CU); four stage buffers with three
 // chunks in flight 43.3 us -- what is left is the rate of 100 MB of scattered 256 .. 512-byte pieces (~3 TB/s), not round trips.
@@ -2555,32 +2616,39 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
                                                       const float *__restrict__ queries, const uint32_t *__restrict__ cand,
                                                       uint32_t k, uint64_t id_offset, uint64_t *__restrict__ out_ids,
                                                       float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
-                                                      uint32_t dim_pad /* multiple of a chunk's elements */) {
+                                                      uint32_t dim_pad /* multiple of a chunk's elements */, CertArgs cert) {
     constexpr uint32_t kc = KC;
-    constexpr int NB = KC / 64;
+    constexpr int NE = KC / 64;                   // list entries per lane
+    constexpr int NB = KC / SR;                   // batches
     constexpr int LPR = CHB / 16;                 // lanes per row of a DMA instruction = 16-byte pieces per chunk
     constexpr int RPI = 64 / LPR;                 // rows per DMA instruction
     constexpr int NINS = SR / RPI;                // DMA instructions per chunk
     constexpr int RR_CH = CHB / (int)sizeof(RT);  // elements per chunk
     constexpr int EPP = 16 / (int)sizeof(RT);     // elements per 16-byte piece
     constexpr uint32_t BUF = (uint32_t)SR * CHB;  // bytes of one stage buffer
-    static_assert(SR == 64 || (SR == 32 && KC == 64), "32 staged rows: single batch only");
+    static_assert(SR == 64 || SR == 32, "staged rows per batch");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *stage = smem;                                              // [2][SR rows][CHB]
     float *q = reinterpret_cast<float *>(smem + 2 * BUF);                     // [dim_pad], zero padded
     float *cd = q + dim_pad;
     uint32_t *ci = reinterpret_cast<uint32_t *>(cd + kc);
+    uint32_t *ck = ci + kc;  // [kc] screen keys (certificate only)
+    float *dk_slot = reinterpret_cast<float *>(ck + kc);
     const int lane = threadIdx.x;
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
 #pragma unroll
-    for (int bt = 0; bt < NB; ++bt) ci[lane + 64 * bt] = (SR == 64 || lane < SR) ? cand[(size_t)qi * kc + lane + 64 * bt] : 0xFFFFFFFFu;
+    for (int bt = 0; bt < NE; ++bt) {
+        ci[lane + 64 * bt] = cand[(size_t)qi * kc + lane + 64 * bt];
+        cd[lane + 64 * bt] = __builtin_inff();
+        if (cert.kth) ck[lane + 64 * bt] = cert.keys[(size_t)qi * kc + lane + 64 * bt];
+    }
     __syncthreads();
     {   // drop duplicate ids (keep the first copy)
-        bool dup[NB];
+        bool dup[NE];
 #pragma unroll
-        for (int bt = 0; bt < NB; ++bt) {
+        for (int bt = 0; bt < NE; ++bt) {
             dup[bt] = false;
             const int me = lane + 64 * bt;
             const uint32_t ii = ci[me];
@@ -2590,10 +2658,13 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
         }
         __syncthreads();
 #pragma unroll
-        for (int bt = 0; bt < NB; ++bt)
+        for (int bt = 0; bt < NE; ++bt)
             if (dup[bt]) ci[lane + 64 * bt] = 0xFFFFFFFFu;
         __syncthreads();
     }
+    CertQ cq{};
+    uint32_t ks = 0xFFFFFFFEu;  // largest screen key a row of the top-k can carry, by what has been evaluated so far
+    if (cert.kth) cq = cert_query_consts(cert, q, dim, metric, lane);
     const uint32_t nch = (ld * (uint32_t)sizeof(RT) + CHB - 1) / CHB;
     const uint32_t row_bytes = ld * (uint32_t)sizeof(RT);
     const uint32_t stage_lds = (uint32_t)(size_t)(rr_lptr_t)stage;
@@ -2601,24 +2672,36 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
     for (int bt = 0; bt < NB; ++bt) {
         // DMA side: instruction t fills rows RPI t .. RPI t + RPI - 1 of this batch; this lane serves row RPI t + lane / LPR, piece
         // lane % LPR -- of the SOURCE piece (lane % LPR) ^ (row % LPR): the swizzle that makes the walk's reads conflict-free
-        // slots past the last valid candidate of the batch (lists are compacted to the front: a shard that keeps fewer than
-        // 64 survivors leaves a ~0 tail) are not fetched at all: whole DMA instructions drop out, wave-uniformly
-        const unsigned long long vmask = __ballot(ci[64 * bt + lane] != 0xFFFFFFFFu);
-        const int nvalid = vmask ? 64 - __builtin_clzll(vmask) : 0;
+        // slots past the last candidate of the batch that is needed (lists are compacted to the front: a shard that keeps fewer than
+        // 64 survivors leaves a ~0 tail; with a certificate: candidates above the bound) are not fetched at all: whole DMA
+        // instructions drop out, wave-uniformly
+        uint32_t my_id = lane < SR ? ci[SR * bt + lane] : 0xFFFFFFFFu;
+        if (cert.kth && bt > 0 && my_id != 0xFFFFFFFFu && ck[SR * bt + lane] > ks) {  // provably outside the top-k
+            my_id = 0xFFFFFFFFu;
+            ci[SR * bt + lane] = 0xFFFFFFFFu;
+        }
+        const unsigned long long vmask = __ballot(my_id != 0xFFFFFFFFu);
+        if (vmask == 0) {
+            if (!cert.kth) continue;
+            // sorted lists: nothing further can be needed
+            for (uint32_t j = (uint32_t)SR * (bt + 1) + lane; j < kc; j += kWave) ci[j] = 0xFFFFFFFFu;
+            break;
+        }
+        __syncthreads();  // (the cleared entries are seen by the DMA lanes below)
+        const int nvalid = 64 - __builtin_clzll(vmask);
         const int nt_used = min((nvalid + RPI - 1) / RPI, NINS);
         auto issue = [&](uint32_t c, uint32_t buf) {
 #pragma unroll 8
             for (int t = 0; t < NINS; ++t) {
                 if (t >= nt_used) break;
                 const uint32_t r = (uint32_t)RPI * t + ((uint32_t)lane / LPR);
-                const uint32_t id = ci[64 * bt + r];
+                const uint32_t id = ci[SR * bt + r];
                 const unsigned char *src_row = reinterpret_cast<const unsigned char *>(rows + (size_t)(id == 0xFFFFFFFFu ? 0u : id) * ld);
                 // the row's last chunk may be short (ld is a multiple of 32 floats): stay inside the row
                 const uint32_t off = min(c * (uint32_t)CHB + ((((uint32_t)lane % LPR) ^ (r % LPR)) << 4), row_bytes - 16);
                 rr_dma16(src_row + off, (uint32_t)__builtin_amdgcn_readfirstlane((int)(stage_lds + buf * BUF + t * 1024)));
             }
         };
-        const uint32_t my_id = lane < SR ? ci[64 * bt + lane] : 0xFFFFFFFFu;
         float sum = 0.0f;
         issue(0, 0);
         for (uint32_t c = 0; c < nch; ++c) {
@@ -2667,13 +2750,22 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
             if (metric == ZVDB_METRIC_L2SQ) { if (full) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{}); }
             else { if (full) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{}); }
         }
-        cd[64 * bt + lane] = my_id == 0xFFFFFFFFu ? __builtin_inff() : (metric == ZVDB_METRIC_L2SQ ? sum : -sum);  // (lanes >= SR: no row, +inf)
+        if (lane < SR) cd[SR * bt + lane] = my_id == 0xFFFFFFFFu ? __builtin_inff() : (metric == ZVDB_METRIC_L2SQ ? sum : -sum);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads of the stage are done before the next batch refills it
+        if (cert.kth && bt + 1 < NB) {
+            const float dk = cert_kth_dist(cd, ci, (uint32_t)SR * (bt + 1), k, dk_slot, lane);
+            ks = cert_safe_key(cert, cq, dk, dim, metric);
+        }
     }
     __syncthreads();
+    if (cert.kth) {
+        const float dk = cert_kth_dist(cd, ci, kc, k, dk_slot, lane);
+        ks = cert_safe_key(cert, cq, dk, dim, metric);
+        cert_verdict(cert, qi, ks, lane);
+    }
     uint32_t total = 0;
 #pragma unroll
-    for (int bt = 0; bt < NB; ++bt) {
+    for (int bt = 0; bt < NE; ++bt) {
         const uint32_t my_id = ci[64 * bt + lane];
         const bool valid = my_id != 0xFFFFFFFFu;
         if (valid) {
@@ -2700,34 +2792,39 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
 
 int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, const uint32_t *d_cand,
                   uint32_t kc, uint32_t k, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
-                  uint32_t *d_count, hipStream_t s, uint32_t kp_valid) {
+                  uint32_t *d_count, hipStream_t s, uint32_t kp_valid, const CertArgs *cert_in) {
     if (nq == 0) return ZVDB_OK;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     static const bool staged_off = [] { const char *e = getenv("ZVDB_RERANK"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const CertArgs cert = cert_in ? *cert_in : CertArgs{};
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
         if ((kc == 64 || kc == 128 || kc == 256) && ld * sizeof(RT) >= 256 && !staged_off) {  // rows gathered through LDS-DMA (see k_rerank_staged)
             auto go_geo = [&](auto kern, uint32_t chb, uint32_t sr) -> int {
                 const uint32_t dp = round_up(h->dim, chb / (uint32_t)sizeof(RT));  // q is read a whole chunk at a time
-                const size_t lds2 = 2ull * sr * chb + 4ull * (dp + 2ull * kc);
+                const size_t lds2 = 2ull * sr * chb + 4ull * (dp + 3ull * kc) + 16;
                 ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds2));
                 hipLaunchKernelGGL(kern, dim3(nq), dim3(64), lds2, s, rows, ld, h->dim, metric, d_queries, d_cand, k, id_offset, d_ids, d_dist,
-                                   d_count, dp);
+                                   d_count, dp, cert);
                 ZV_HIP(hipGetLastError());
                 return ZVDB_OK;
             };
             auto go = [&](auto kern) -> int { return go_geo(kern, 256, 64); };
-            // lists of at most 32 candidates (the caller says so: k <= 16 on the exact screens): 32 staged rows, longer runs per row
-            if (kc == 64 && kp_valid && kp_valid <= 32 && ld * sizeof(RT) >= 1024) return go_geo(k_rerank_staged<64, RT, 512, 32>, 512, 32);
+            // lists of at most 32 candidates (the caller says so: k <= 16 on the exact screens), or sorted lists with a certificate
+            // (evaluated only as far as the bound requires): 32 staged rows, longer runs per row
+            const bool sr32 = ld * sizeof(RT) >= 1024 && ((kc == 64 && kp_valid && kp_valid <= 32) || (cert.kth && k <= 24));
+            if (sr32 && kc == 64) return go_geo(k_rerank_staged<64, RT, 512, 32>, 512, 32);
+            if (sr32 && kc == 128) return go_geo(k_rerank_staged<128, RT, 512, 32>, 512, 32);
+            if (sr32 && kc == 256) return go_geo(k_rerank_staged<256, RT, 512, 32>, 512, 32);
             if (kc == 64) return go(k_rerank_staged<64, RT>);
             if (kc == 128) return go(k_rerank_staged<128, RT>);
             return go(k_rerank_staged<256, RT>);
         }
         const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
-        const size_t lds = 4ull * (dim_pad + 2ull * kc);
+        const size_t lds = 4ull * (dim_pad + 3ull * kc) + 16;
         ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_rerank<RT>), lds));
         hipLaunchKernelGGL(k_rerank<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric, d_queries, d_cand, kc, k, id_offset, d_ids, d_dist,
-                           d_count, dim_pad);
+                           d_count, dim_pad, cert);
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
     });

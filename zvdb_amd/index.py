@@ -217,6 +217,18 @@ class Index:
         share of the survivor budget."""
         check(self._L.zvdb_hip_index_set_shard_count(self._h, int(shards)))
 
+    def set_option(self, option: int, value: int) -> None:
+        """zvdb_hip_index_set_option (OPT_CERTIFY, OPT_CERT_MIN_LEVEL, ...)."""
+        check(self._L.zvdb_hip_index_set_option(self._h, int(option), int(value)))
+
+    def cert_info(self) -> dict:
+        """Certificate counters of the exact brute-force screens: queries, batches, repaired (exact-scan recomputations), level."""
+        from ._lib import CertInfo
+        ci = CertInfo()
+        check(self._L.zvdb_hip_bruteforce_cert_info(self._h, C.byref(ci)))
+        return {"queries": ci.queries, "batches": ci.batches, "repaired": ci.repaired, "level": ci.level,
+                "enabled": bool(ci.enabled)}
+
     def set_screen_survivors(self, survivors: int) -> None:
         """Minimum number of fp4-screen survivors re-ranked exactly per query (0 = from k; 64, 128 or 256)."""
         check(self._L.zvdb_hip_index_set_screen_survivors(self._h, int(survivors)))
