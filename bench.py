@@ -51,6 +51,18 @@ def parse_args():
                          "auto = bf16 headline (recall@10 must measure 1.0, else fp32) + short legs of the fp32 / int8 / fp4 screens "
                          "reported under 'paths'")
     ap.add_argument("--no-paths", action="store_true", help="auto mode: skip the secondary bf16 / f32 legs")
+    ap.add_argument("--no-certify", action="store_true", help="(A/B) ZVDB_OPT_CERTIFY = 0: the exact screens run unchecked, as in rounds 1-3")
+    ap.add_argument("--cert-level", type=int, default=0, help="(A/B) ZVDB_OPT_CERT_MIN_LEVEL: survivors kept from the first batch on (1: 64, 2: 128, 3: 256)")
+    ap.add_argument("--route", choices=["bruteforce", "graph"], default="bruteforce",
+                    help="graph = BASELINE configs[2]-[4]'s route: per-shard bulk HNSW graph (M = --graph-m, layer 0 capped at 2 M) built on the "
+                         "device, ef-mode beam search entered by descent; recall is measured against the (sharded) brute-force route")
+    ap.add_argument("--row-dtype", choices=["f32", "bf16"], default="f32", help="row STORAGE of the index (bf16 = ZVDB_FLAG_BF16_ROWS: configs[3]-[4])")
+    ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--graph-m", type=int, default=16)
+    ap.add_argument("--graph-efc", type=int, default=64)
+    ap.add_argument("--data", choices=["uniform", "rank12"], default="uniform",
+                    help="uniform = the benchmark's generator (i.i.d. U[0,1), shared_benchmarks.zig:53-59); rank12 = rows of intrinsic rank 12 + 1 %% "
+                         "noise (data with neighbourhood structure: where a graph can reach the recall bar) -- NOT the benchmark's generator")
     ap.add_argument("--extras", action="store_true",
                     help="also measure BASELINE configs[1] (1M x 128 fp32 brute force, batch 256) and the reference's own "
                          "benchmark shape (compat-mode HNSW search, 128-d, k = 10) on GPU and CPU; adds ~1-2 min")
@@ -205,25 +217,29 @@ def reference_harness(zv):
     }
 
 
-def make_rows(zv, torch, g, n, dim, structured, dev, stream, nq):
-    """Fills index g with n rows and returns nq queries of the same distribution (device tensor).  structured = rows of intrinsic
-    rank 12 + 1 % noise (data that HAS neighbourhoods; seeded, generated on the device); else the benchmark's own generator,
-    i.i.d. U[0,1) coordinates (shared_benchmarks.zig:53-59)."""
+def make_rows(zv, torch, g, n, dim, structured, dev, stream, nq, lo=0, hi=None):
+    """Fills index g with rows [lo, hi) of an n-row corpus and returns nq queries of the same distribution (device tensor).
+    structured = rows of intrinsic rank 12 + 1 % noise (data that HAS neighbourhoods; generated on the device, seeded per 200k-row
+    chunk of the GLOBAL id space so that every sharding sees the same corpus); else the benchmark's own generator, i.i.d. U[0,1)
+    coordinates (shared_benchmarks.zig:53-59)."""
+    hi = n if hi is None else hi
     q = torch.empty((nq, dim), dtype=torch.float32, device=dev)
     if structured:
         gen = torch.Generator(device=dev)
         gen.manual_seed(5)
         A = torch.rand((12, dim), generator=gen, device=dev) - 0.5
-        for r0 in range(0, n, 200_000):
-            c = min(200_000, n - r0)
-            rows = (torch.rand((c, 12), generator=gen, device=dev) @ A + 0.01 * torch.randn((c, dim), generator=gen, device=dev)).contiguous()
-            torch.cuda.synchronize()
-            g.add_dev(rows.data_ptr(), c, dim, stream)
-            torch.cuda.synchronize()
         q.copy_(torch.rand((nq, 12), generator=gen, device=dev) @ A + 0.01 * torch.randn((nq, dim), generator=gen, device=dev))
-        torch.cuda.synchronize()
+        CH = 200_000
+        for ci in range(lo // CH, (hi + CH - 1) // CH):
+            gen.manual_seed(1000 + ci)
+            c0, c1 = ci * CH, min((ci + 1) * CH, n)
+            rows = torch.rand((c1 - c0, 12), generator=gen, device=dev) @ A + 0.01 * torch.randn((c1 - c0, dim), generator=gen, device=dev)
+            rows = rows[max(lo, c0) - c0:min(hi, c1) - c0].contiguous()
+            torch.cuda.synchronize()
+            g.add_dev(rows.data_ptr(), rows.shape[0], dim, stream)
+            torch.cuda.synchronize()
     else:
-        g.add_synthetic(n, dim, CORPUS_SEED)
+        g.add_synthetic(hi - lo, dim, CORPUS_SEED, first_row=lo)
         zv.fill_synthetic_dev(q.data_ptr(), nq, dim, QUERY_SEED, 0, stream)
     return q
 
@@ -498,17 +514,49 @@ def main():
     mode = MODES[args.mode]
 
     # ---- resident inputs -------------------------------------------------------------------
-    idx = zv.Index(dim=D, capacity=n_local, device=local_rank, flags=zv.FLAG_BF16_MIRROR)
-    idx.add_synthetic(n_local, D, CORPUS_SEED, first_row=lo)  # rows [lo, hi) of the global stream
+    graph = args.route == "graph"
+    bf16_rows = args.row_dtype == "bf16"
+    stream = torch.cuda.current_stream().cuda_stream
+    GM = args.graph_m
+    idx = zv.Index(dim=D, capacity=n_local, device=local_rank, m=2 * GM if graph else 16, graph_stride=2 * GM if graph else 0,
+                   flags=zv.FLAG_BF16_MIRROR | (zv.FLAG_BF16_ROWS if bf16_rows else 0))
+    if args.no_certify:
+        idx.set_option(zv.OPT_CERTIFY, 0)
+    if args.cert_level:
+        idx.set_option(zv.OPT_CERT_MIN_LEVEL, args.cert_level)
+    total_steps = args.warmup + args.steps
+    if args.data == "rank12":
+        q1 = make_rows(zv, torch, idx, N, D, True, dev, stream, (total_steps + 1) * B, lo, hi)
+        queries = q1.view(total_steps + 1, B, D)
+    else:
+        idx.add_synthetic(n_local, D, CORPUS_SEED, first_row=lo)  # rows [lo, hi) of the global stream
+        queries = torch.empty((total_steps + 1, B, D), dtype=torch.float32, device=dev)
+        zv.fill_synthetic_dev(queries.data_ptr(), (total_steps + 1) * B, D, QUERY_SEED, 0, stream)
     if world > 1 or args.rehearse_shard_of > 1:
         idx.set_shard_count(world if world > 1 else args.rehearse_shard_of)  # the approximate screen keeps this shard's share of the survivor budget
-    total_steps = args.warmup + args.steps
-    queries = torch.empty((total_steps + 1, B, D), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    zv.fill_synthetic_dev(queries.data_ptr(), (total_steps + 1) * B, D, QUERY_SEED, 0, stream)
+    t_build = 0.0
+    if graph:  # this rank's own graph over its id range (no cross-shard edges: SURVEY 8e)
+        t0 = time.perf_counter()
+        idx.build_graph(GM, args.graph_efc, zv.BF_I8, 7)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        idx.search_graph_reserve(B, K, args.ef)
+    # the collective: by default the C ABI's own RCCL communicator (zvdb_hip_comm: local search -> ncclAllGather -> merge in ONE library
+    # call on this stream); ZVDB_BENCH_COLLECTIVE=torch keeps the all-gather in torch.distributed; the gloo rehearsal always does
+    comm = None
+    if dist_on and not cpu_coll and os.environ.get("ZVDB_BENCH_COLLECTIVE", "abi") == "abi":
+        from zvdb_amd.sharded import Comm
+        comm = Comm.from_torch_distributed(local_rank)
 
     ws_bytes = max(idx.bruteforce_workspace(B, K, m) for m in (zv.BF_BF16, zv.BF_F32, zv.BF_I8, zv.BF_FP4))
+    if comm is not None:
+        import ctypes as C
+        nb = C.c_uint64(0)
+        for m in (zv.BF_BF16, zv.BF_F32, zv.BF_I8, zv.BF_FP4, _lib.SHARDED_GRAPH):
+            _lib.check(_lib.hip().zvdb_hip_sharded_workspace(idx._h, comm._h, B, K, m, C.byref(nb)))
+            ws_bytes = max(ws_bytes, nb.value)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    g_stats = torch.zeros(4, dtype=torch.int64, device=dev)
     # one packed send buffer per rank (ids u64 | dist f32 | count u32): ONE all-gather per batch
     pk_bytes = zv.packed_result_bytes(B, K)
     l_pack = torch.empty(pk_bytes, dtype=torch.uint8, device=dev)
@@ -521,9 +569,24 @@ def main():
     o_dist = torch.empty((B, K), dtype=torch.float32, device=dev)
     o_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
 
-    def step(q, m):
-        idx.search_bruteforce_dev(q.data_ptr(), B, D, K, m, lo, ws.data_ptr(), ws_bytes, l_ids.data_ptr(),
-                                  l_dist.data_ptr(), l_cnt.data_ptr(), stream)
+    GRAPH = "graph"  # `m` of a step: a brute-force screen mode, or the graph route
+
+    def step(q, m, stats=0):
+        if comm is not None:  # the whole sharded step inside libzvdb_hip (include/zvdb_hip.h: *_sharded_dev)
+            L = _lib.hip()
+            if m == GRAPH:
+                _lib.check(L.zvdb_hip_search_graph_sharded_dev(idx._h, comm._h, q.data_ptr(), B, D, K, args.ef, zv.ENTRY_DESCEND, lo, ws.data_ptr(),
+                                                               ws_bytes, o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), stats or None, stream))
+            else:
+                _lib.check(L.zvdb_hip_search_bruteforce_sharded_dev(idx._h, comm._h, q.data_ptr(), B, D, K, m, lo, ws.data_ptr(), ws_bytes,
+                                                                    o_ids.data_ptr(), o_dist.data_ptr(), o_cnt.data_ptr(), stream))
+            return o_ids, o_dist
+        if m == GRAPH:
+            idx.search_graph_dev(q.data_ptr(), B, D, K, args.ef, zv.ENTRY_DESCEND, lo, l_ids.data_ptr(), l_dist.data_ptr(), l_cnt.data_ptr(),
+                                 stats, stream)
+        else:
+            idx.search_bruteforce_dev(q.data_ptr(), B, D, K, m, lo, ws.data_ptr(), ws_bytes, l_ids.data_ptr(),
+                                      l_dist.data_ptr(), l_cnt.data_ptr(), stream)
         if dist_on:
             if cpu_coll:  # (gloo rehearsal: host-memory collective)
                 torch.cuda.synchronize()
@@ -545,7 +608,9 @@ def main():
     # ---- ground truth for recall: fp32-MFMA route on the last query batch (untimed) ------------
     # (k > 56: the staged fp32 route stops at k' = 64 survivors; the int8 stream route -- k' = 128, exact top-k tested
     # against the oracle up to k = 112 -- is the ground truth then)
-    gt_mode = zv.BF_F32 if K <= 56 else zv.BF_I8
+    gt_mode = (zv.BF_F32 if K <= 56 else zv.BF_I8) if not graph else zv.BF_I8
+    for _ in range(2 if graph else 0):  # (the certificate's survivor level settles)
+        step(queries[total_steps], gt_mode)
     gt_ids, _ = step(queries[total_steps], gt_mode)
     gt_ids = gt_ids.clone()
     b = gt_ids.cpu().numpy()
@@ -556,6 +621,10 @@ def main():
         an = gi.cpu().numpy()
         return float(np.mean([len(set(an[i]) & set(b[i])) / K for i in range(B)])), an, gd.cpu().numpy().copy()
 
+    if graph:
+        auto = False
+        args.mode = "bf16" if bf16_rows else "f32"  # (dtype of the line: the arithmetic type of the rows the beam search gathers)
+        mode = GRAPH
     recall, a, got_dist_h = recall_of(mode)
     fp4_survivors = 0  # 0 = chosen from k (64 for k <= 32)
     headline_note = None
@@ -612,6 +681,12 @@ def main():
                                         "achieved": ach2, "peak": PEAK_TFLOPS[name], "unit": "TFLOP/s" if name != "i8" else "TOP/s",
                                         "frac": ach2 / PEAK_TFLOPS[name]}}
 
+    g_ev = g_pp = 0
+    if graph:  # one counted launch: E (distance evaluations) and P (pops) of this rank's shard for the roofline's algorithmic bytes
+        g_stats.zero_()
+        step(queries[total_steps], GRAPH, g_stats.data_ptr())
+        torch.cuda.synchronize()
+        g_ev, g_pp = int(g_stats[0].item()), int(g_stats[1].item())
     cert = idx.cert_info()  # certificate counters of the headline index (all legs so far)
     if auto and not args.no_paths and world == 1 and not args.rehearse_shard_of and rank == 0:
         # the routes BASELINE configs[1]-[2] name, bounded (1M rows), each with its own roofline object: the graph route on the
@@ -695,6 +770,25 @@ def main():
                 "algorithmic_bytes_per_launch": float(n_local) * D * ELT_BYTES[args.mode],
             },
         }
+        out["config"]["route"] = args.route
+        out["config"]["row_dtype"] = args.row_dtype
+        out["config"]["data"] = args.data
+        out["config"]["collective"] = ("zvdb_hip_search_*_sharded_dev (ncclAllGather inside libzvdb_hip)" if comm is not None else
+                                       "torch.distributed all_gather_into_tensor" if dist_on else None)
+        if graph:
+            elt = 2 if bf16_rows else 4
+            nbytes = g_ev * D * elt + g_pp * 2 * GM * 4
+            out["config"].update({"ef": args.ef, "M": GM, "ef_construction": args.graph_efc, "layer0_cap": 2 * GM, "entry": "hierarchical descent",
+                                  "graph_build_s": t_build, "graph_build_rows_per_s": n_local / t_build if t_build > 0 else None,
+                                  "workload": (f"{N}x{D} {args.row_dtype} rows ({args.data}), batch={B}, k={K}: per-shard bulk HNSW graph (M={GM}, "
+                                               f"layer 0 <= {2 * GM} links), ef={args.ef} beam search entered by descent; recall vs the sharded brute-force route"),
+                                  "recall_ground_truth": "int8 brute-force route over the same shards (certified exact), merged"})
+            out["roofline"] = {"bound": "hbm", "kernel": "k_search_ef_reg (exact_kernels.hip)", "kernel_ms_avg": kavg * 1e3, "timed_regions": kern_n,
+                               "achieved": nbytes / kavg / 1e9 if kavg > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                               "frac": nbytes / kavg / 8e12 if kavg > 0 else 0.0, "traffic": None,
+                               "algorithmic_bytes_per_launch": nbytes, "dist_evals_per_query": g_ev / B, "pops_per_query": g_pp / B,
+                               "bytes_rule": "E d sizeof(elt) + P M0 4 per query (SURVEY 8d), E / P counted in-kernel on this rank's shard"}
+            out["metric"] = "QPS at recall@10>=0.95, 10Mx768 fp32, batch=1024 (graph route: recall as measured, see recall_at_10)"
         out["certificate"] = {**cert, "survivors_kept": {0: "32 (k <= 16) / 64", 1: 64, 2: 128, 3: 256}[cert["level"]],
                               "note": "queries = all that went through the certificate on the headline index (every leg); repaired = recomputed by the "
                                       "exact scan (expected only while the survivor level settles in the warm-up)"}
@@ -704,7 +798,9 @@ def main():
             out["paths"] = paths
         if args.extras and world == 1:
             out["extras"] = extras(args, zv, torch)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and (graph or bf16_rows or args.data != "uniform"):
+            out["cpu_baseline"] = None  # (the CPU leg checks and times the default workload: fp32 rows of the benchmark's generator, brute force)
+        elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, chk_ids, chk_dist, chk_q)
             del ws
             out["cpu_baseline"]["reference_harness"] = reference_harness(zv)

@@ -336,12 +336,24 @@ enum zvdb_option {
 };
 int zvdb_hip_index_set_option(zvdb_hip_index *h, uint32_t option, uint64_t value);
 
+/* Tuning switches: the A/B and test knobs of the launch code (kernel variants, forced thresholds, visited-table sizes, ...: the
+ * table "Runtime switches" in DESIGN.md lists them) are named string values in a process-wide table that the CALLER fills.
+ * They select between implementations with IDENTICAL results (tests hold them to that) -- none is needed for normal use.
+ * The library never reads the process environment (a diagnostic build with -DZVDB_TUNING_FROM_ENV falls back to getenv for
+ * names that were never set).  value NULL removes the entry.  Switches are read when a call is made. */
+int zvdb_hip_set_tuning(const char *name, const char *value);
+const char *zvdb_hip_get_tuning(const char *name); /* NULL if unset; valid until a few further calls on this thread */
+
 typedef struct zvdb_hip_cert_info {
     uint64_t queries;  /* queries that went through the certificate */
     uint64_t batches;
     uint64_t repaired; /* of them: recomputed by the exact scan (read without synchronising: launches still running are not counted) */
     uint32_t level;    /* survivors currently kept: 0 = the route's minimum (32 for k <= 16, else 64), 1 = 64, 2 = 128, 3 = 256 */
     uint32_t enabled;
+    uint64_t rerank_rows; /* diagnostic (tuning ZVDB_CERT_DEBUG): candidate rows the re-rank evaluated exactly, modulo 2^32 */
+    uint32_t rerank_cycles[5]; /* diagnostic: 100-MHz ticks of every 64th query's re-rank, summed per phase: query constants, first
+                                  (staged) batch, further candidates, final bound, ranking + output */
+    uint32_t reserved_;
 } zvdb_hip_cert_info;
 int zvdb_hip_bruteforce_cert_info(zvdb_hip_index *h, zvdb_hip_cert_info *out);
 

@@ -34,3 +34,26 @@ def oracle():
     import oracle as orc
     orc.build()
     return orc
+
+
+def tuning_prelude(switches: dict) -> str:
+    """Python source that sets tuning switches through the ABI (zvdb_hip_set_tuning) at the top of a child process's code:
+    the library takes its A/B switches from its caller, not from the environment."""
+    if not switches:
+        return ""
+    return "import zvdb_amd as _zv_t\n" + "".join(f"_zv_t.set_tuning({k!r}, {v!r})\n" for k, v in switches.items())
+
+
+@pytest.fixture
+def tuning():
+    """set(name, value) a tuning switch for the duration of the test (value None removes it)."""
+    import zvdb_amd
+    touched = set()
+
+    def set_(name, value):
+        touched.add(name)
+        zvdb_amd.set_tuning(name, value)
+
+    yield set_
+    for name in touched:
+        zvdb_amd.set_tuning(name, None)

@@ -21,10 +21,10 @@ for c in range(cases):
     for i in range(min(split, 50)): got.insert(V[i], _level=int(lv[i]))
     s0 = min(split, 50)
     form = ("", "rounds", "0")[c % 3]  # ZVDB_INSERT_SPEC: default = cooperative round loop
-    if form: os.environ["ZVDB_INSERT_SPEC"] = form
-    else: os.environ.pop("ZVDB_INSERT_SPEC", None)
+    if form: zv.set_tuning("ZVDB_INSERT_SPEC", form)
+    else: zv.set_tuning("ZVDB_INSERT_SPEC", None)
     if s0 < n: got.insert_many(V[s0:], lv[s0:])
-    os.environ.pop("ZVDB_INSERT_SPEC", None)
+    zv.set_tuning("ZVDB_INSERT_SPEC", None)
     ok = got.count() == n and got.max_level == ref.max_level
     for i in range(n):
         for layer in range(ref.node_level(i) + 1):

@@ -41,27 +41,27 @@ for c in range(cases):
         ef = int(max(k, rng.choice([1, 10, 33, 64, 100, 128, 129, 200, 256, 300, 512, 600])))
         try:
             ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
-            os.environ["ZVDB_EF_BEAM"] = "lds"
+            zv.set_tuning("ZVDB_EF_BEAM", "lds")
             ids2, dist2, cnt2, (ev2, pp2) = idx.search_graph(Q, k, ef=ef, with_stats=True)
             # the visited set sized in two passes: from the fills the calls above recorded, and forced tiny (2^8 slots: most
             # queries stop in the tight pass and are served by the safe retry launch) -- both beam kernels
             # ... and the safe pass with the visited sets in global memory (gv = "1": after a tight LDS pass, and on its own)
             for beam, tp, wpq, gv in (("reg", "", "1", ""), ("lds", "t8", "1", ""), ("reg", "t8", "2", ""), ("reg", "t9", "4", ""), ("reg", "", "2", ""),
                                       ("reg", "", "4", ""), ("reg", "t8", "2", "1"), ("reg", "0", "4", "1"), ("lds", "t9", "1", "1"), ("reg", "0", "2", "net"), ("lds", "t8", "1", "net")):
-                os.environ["ZVDB_EF_BEAM"] = beam; os.environ["ZVDB_EF_TWO_PASS"] = tp; os.environ["ZVDB_EF_WPQ"] = wpq  # waves per query
-                if gv: os.environ["ZVDB_EF_GLOBAL_VISITED"] = gv
-                else: os.environ.pop("ZVDB_EF_GLOBAL_VISITED", None)
+                zv.set_tuning("ZVDB_EF_BEAM", beam); zv.set_tuning("ZVDB_EF_TWO_PASS", tp); zv.set_tuning("ZVDB_EF_WPQ", wpq)  # waves per query
+                if gv: zv.set_tuning("ZVDB_EF_GLOBAL_VISITED", gv)
+                else: zv.set_tuning("ZVDB_EF_GLOBAL_VISITED", None)
                 # (gv = "net": the SAFE LDS table forced to 2^8 slots too -- the queries that fill it go through the net pass,
                 # visited set in a global table handed out on demand)
-                if gv == "net": os.environ.pop("ZVDB_EF_GLOBAL_VISITED", None); os.environ["ZVDB_EF_HASH_BITS"] = "8"
-                else: os.environ.pop("ZVDB_EF_HASH_BITS", None)
+                if gv == "net": zv.set_tuning("ZVDB_EF_GLOBAL_VISITED", None); zv.set_tuning("ZVDB_EF_HASH_BITS", "8")
+                else: zv.set_tuning("ZVDB_EF_HASH_BITS", None)
                 ids3, dist3, cnt3, (ev3, pp3) = idx.search_graph(Q, k, ef=ef, with_stats=True)
                 if not (np.array_equal(ids, ids3) and np.array_equal(dist, dist3) and np.array_equal(cnt, cnt3) and (ev, pp) == (ev3, pp3)):
                     ok = False; print(f"case {c}: two-pass visited sizing differs (beam {beam}, ZVDB_EF_TWO_PASS={tp!r}, ZVDB_EF_WPQ={wpq}, ZVDB_EF_GLOBAL_VISITED={gv!r}) stats {(ev3, pp3)} vs {(ev, pp)}", flush=True)
         except zv.ZvdbError as e:
             print(f"case {c}: n={n} d={d} m={m} k={k} ef={ef}: {e}"); continue
         finally:
-            os.environ.pop("ZVDB_EF_BEAM", None); os.environ.pop("ZVDB_EF_TWO_PASS", None); os.environ.pop("ZVDB_EF_WPQ", None); os.environ.pop("ZVDB_EF_GLOBAL_VISITED", None); os.environ.pop("ZVDB_EF_HASH_BITS", None)
+            zv.set_tuning("ZVDB_EF_BEAM", None); zv.set_tuning("ZVDB_EF_TWO_PASS", None); zv.set_tuning("ZVDB_EF_WPQ", None); zv.set_tuning("ZVDB_EF_GLOBAL_VISITED", None); zv.set_tuning("ZVDB_EF_HASH_BITS", None)
         if not (np.array_equal(ids, ids2) and np.array_equal(dist, dist2) and np.array_equal(cnt, cnt2) and (ev, pp) == (ev2, pp2)):
             ok = False
             print(f"case {c}: the two beam kernels differ: ids {np.array_equal(ids, ids2)} dist {np.array_equal(dist, dist2)} cnt {np.array_equal(cnt, cnt2)} "

@@ -13,8 +13,8 @@ levels = np.random.default_rng(2).geometric(0.5, N).astype(np.int32) - 1
 levels = np.minimum(levels, 31)
 graphs = {}
 for tag, env in (("speculative rounds", None), ("one wave, in order", "0")):
-    if env is None: os.environ.pop("ZVDB_INSERT_SPEC", None)
-    else: os.environ["ZVDB_INSERT_SPEC"] = env
+    if env is None: zv.set_tuning("ZVDB_INSERT_SPEC", None)
+    else: zv.set_tuning("ZVDB_INSERT_SPEC", env)
     h = zv.HNSW(m, 200)
     t0 = time.perf_counter()
     h.insert_many(V, levels)
@@ -27,6 +27,6 @@ for tag, env in (("speculative rounds", None), ("one wave, in order", "0")):
         for L in range(0, min(int(levels[i]), ml) + 1):
             g.append((i, L, tuple(int(x) for x in h.index.get_neighbors_layer(i, L))))
     graphs[tag] = g
-os.environ.pop("ZVDB_INSERT_SPEC", None)
+zv.set_tuning("ZVDB_INSERT_SPEC", None)
 a, b = graphs["speculative rounds"], graphs["one wave, in order"]
 print("graphs equal on the sampled nodes, every layer:", a == b, f"({len(a)} lists compared)")

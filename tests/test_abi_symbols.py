@@ -51,3 +51,14 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")) or fn == "Makefile":
                 txt = open(os.path.join(dp, fn), errors="replace").read()
                 assert not bad.search(txt), os.path.join(dp, fn)
+
+
+def test_header_is_c99_and_a_c_program_links_against_the_library(tmp_path):
+    """include/zvdb_hip.h is what Zig's @cImport parses: it must be C (not C++), and a C translation unit must link against
+    libzvdb_hip.so.  tests/c/abi_smoke.c is compiled with gcc -std=c99 -pedantic -Wall -Wextra -Werror; without a GPU it exits 77."""
+    import subprocess
+    import zvdb_amd as zv
+    from zvdb_amd import _build
+    exe = _build.build_c_smoke(force=True)
+    out = subprocess.run([exe, str(tmp_path / "x.zvdb")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == (0 if zv.device_count() > 0 else 77), out.stdout + out.stderr

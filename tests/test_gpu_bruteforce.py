@@ -3,6 +3,7 @@ exact (distance, id) top-k): MFMA screen (fp32 / bf16) + fused threshold top-k' 
 Bit-exact ids AND distances (the re-rank recomputes the reference arithmetic)."""
 import numpy as np
 import pytest
+from conftest import tuning_prelude
 
 pytestmark = pytest.mark.gpu
 
@@ -154,7 +155,7 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
                       "i8staged": {"ZVDB_BF_I8_KERNEL": "v6"},
                       "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2"}}.items():
         out = tmp_path / (name + ".npz")
-        r = subprocess.run([sys.executable, "-c", code, str(out), metric], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", tuning_prelude(env) + code, str(out), metric], cwd=root, capture_output=True, text=True)
         assert r.returncode == 0, name + ": " + r.stdout + r.stderr
         res[name] = np.load(out)
     base = res["cascade"]
@@ -313,7 +314,7 @@ def test_bruteforce_fp4_wide_rows_stream_equals_staged(zv, oracle, tmp_path, d):
     res = {}
     for name, env in {"stream": {}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"}, "repair": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}}.items():
         out = tmp_path / (name + ".npz")
-        r = subprocess.run([sys.executable, "-c", code, str(out), str(d)], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", tuning_prelude(env) + code, str(out), str(d)], cwd=root, capture_output=True, text=True)
         assert r.returncode == 0, name + ": " + r.stdout + r.stderr
         res[name] = np.load(out)
     base = res["staged"]

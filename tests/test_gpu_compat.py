@@ -5,6 +5,7 @@ import threading
 
 import numpy as np
 import pytest
+from conftest import tuning_prelude
 
 pytestmark = pytest.mark.gpu
 
@@ -189,7 +190,7 @@ def test_exact_ties_follow_oracle_heap_order(zv, oracle):
         assert np.array_equal(ids[qi, :cnt[qi]], ri) and np.array_equal(dist[qi, :cnt[qi]], rd)
 
 
-def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle, monkeypatch):
+def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle, tuning):
     n, d, m = 4000, 48, 12
     V = oracle.uniform_rows(31, 0, n, d)
     nn, _, _ = oracle.bruteforce_topk(V, V, m + 1)
@@ -212,8 +213,7 @@ def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle, monkeypatch):
         # first call left (exact_kernels.hip: launch_search_ef); 3rd / 4th: tight tables forced so small that most queries fill
         # them and are served again by the safe pass -- a power-of-two one and one of 300 slots.  Same results, same counters.
         for env in (None, None, "t8", "s300"):
-            if env: monkeypatch.setenv("ZVDB_EF_TWO_PASS", env)
-            else: monkeypatch.delenv("ZVDB_EF_TWO_PASS", raising=False)
+            tuning("ZVDB_EF_TWO_PASS", env)
             ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
             ref.reset_counters()
             for qi, q in enumerate(Q):
@@ -222,7 +222,7 @@ def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle, monkeypatch):
                 assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)
             c = ref.counters()
             assert (ev, pp) == (c.search_dist_evals, c.search_pops), env
-        monkeypatch.delenv("ZVDB_EF_TWO_PASS", raising=False)
+        tuning("ZVDB_EF_TWO_PASS", None)
 
 
 def test_greedy_layer0_seam(zv, oracle):
@@ -301,16 +301,13 @@ def test_fused_insert_under_exact_ties(zv, oracle, n, d, m):
 
 @pytest.mark.parametrize("form", ["", "rounds", "0"])
 @pytest.mark.parametrize("n,d,m,ties", [(3000, 32, 16, False), (700, 2, 3, True), (9000, 8, 4, False)])
-def test_insert_many_equals_sequential_inserts(zv, oracle, monkeypatch, n, d, m, ties, form):
+def test_insert_many_equals_sequential_inserts(zv, oracle, tuning, n, d, m, ties, form):
     """HNSW.insert_many (zvdb_hip_insert_batch: a chunk of inserts, each seeing the lists its predecessors left) builds the
     graph of n insert() calls: identical to the oracle's on every layer, device mirror included; also when the index already
     holds points and when a chunk boundary (8192) falls inside the batch.  In all three forms of the bulk insert
     (ZVDB_INSERT_SPEC): speculative parallel rounds in one cooperative launch (default), round by round from the host, and
     one wave in order -- on tie-heavy data with tiny m too, where nearly every point of a round ends on the same few nodes."""
-    if form:
-        monkeypatch.setenv("ZVDB_INSERT_SPEC", form)
-    else:
-        monkeypatch.delenv("ZVDB_INSERT_SPEC", raising=False)
+    tuning("ZVDB_INSERT_SPEC", form or None)
     rng = np.random.default_rng(n)
     V = rng.random((n, d), dtype=np.float32)
     if ties:
@@ -368,7 +365,7 @@ def test_step_by_step_binding_still_bit_exact(oracle):
         "    assert np.array_equal(ri, gi) and np.array_equal(rd, gd)\n"
         "print('steps ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZVDB_HOST_INSERT="steps"), cwd=root,
+    out = subprocess.run([sys.executable, "-c", tuning_prelude({"ZVDB_HOST_INSERT": "steps"}) + code], cwd=root,
                          capture_output=True, text=True)
     assert out.returncode == 0 and "steps ok" in out.stdout, out.stdout + out.stderr
 
@@ -389,12 +386,12 @@ def test_heap_emulation_alone_equals_the_two_kernel_search(zv, oracle):
         "    Q = V[:200] + np.float32(0.0 if ties else 0.01)\n"
         "    ids, dist, cnt, (ev, pp) = h.index.search_graph(Q, 12, with_stats=True)\n"
         "    out.append((ids, dist, cnt, ev, pp))\n"
-        "np.save('/tmp/zvdb_compat_' + ('heap' if __import__('os').environ.get('ZVDB_COMPAT_SEARCH') else 'fast') + '.npy',\n"
+        "np.save('/tmp/zvdb_compat_' + ('heap' if zv._lib.hip().zvdb_hip_get_tuning(b'ZVDB_COMPAT_SEARCH') else 'fast') + '.npy',\n"
         "        np.array([np.concatenate([o[0].ravel().astype(np.float64), o[1].ravel().astype(np.float64), o[2].ravel().astype(np.float64), [o[3], o[4]]]) for o in out]))\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for env in ({}, {"ZVDB_COMPAT_SEARCH": "heap"}):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", tuning_prelude(env) + code], cwd=root, capture_output=True, text=True)
         assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
     a, b = np.load("/tmp/zvdb_compat_fast.npy"), np.load("/tmp/zvdb_compat_heap.npy")
     assert np.array_equal(a, b)

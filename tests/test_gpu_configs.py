@@ -10,6 +10,7 @@ import threading
 
 import numpy as np
 import pytest
+from conftest import tuning_prelude
 
 pytestmark = pytest.mark.gpu
 
@@ -95,7 +96,7 @@ def test_bf16_stream_guess_verified_repaired_and_staged_agree(zv, oracle, tmp_pa
     for name, env in {"guess": {}, "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2.5"},
                       "staged": {"ZVDB_BF_BF16_KERNEL": "v6"}}.items():
         out = tmp_path / (name + ".npz")
-        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", tuning_prelude(env) + code, str(out)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, name + ": " + r.stdout + r.stderr
         res[name] = np.load(out)
     V = oracle.uniform_rows(0x5EED, 0, 650_001, 160)

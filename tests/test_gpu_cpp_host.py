@@ -18,3 +18,13 @@ def test_cpp_host_mirror_passes_reference_tests():
     for name in ("basic_functionality", "empty_index", "single_point", "edge_cases", "large_dataset",
                  "consistency", "concurrent_access", "stress", "memory_leaks"):
         assert f"ok {name}" in out.stdout
+
+
+def test_pure_c99_caller_of_the_abi(tmp_path):
+    """tests/c/abi_smoke.c (gcc -std=c99 -pedantic -Werror): create -> insert_batch -> search_graph -> brute force on two certified
+    screens -> options -> save / load -> destroy, linked against libzvdb_hip.so -- the stand-in for Zig's @cImport of the header."""
+    from zvdb_amd import _build
+    exe = _build.build_c_smoke()
+    out = subprocess.run([exe, str(tmp_path / "abi_smoke.zvdb")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi_smoke ok" in out.stdout

@@ -129,7 +129,7 @@ def test_on_disk_format_round_trip(zv, oracle, tmp_path, kind):
     {"ZVDB_EF_HASH_BITS": "8", "ZVDB_EF_TWO_PASS": "0"},  # safe LDS table forced tiny: most queries are served by the net (work list + table pool)
     {},
 ])
-def test_ef_search_from_two_streams_shares_the_index_scratch(zv, oracle, env, monkeypatch):
+def test_ef_search_from_two_streams_shares_the_index_scratch(zv, oracle, env, tuning):
     """ef searches launched on two streams of ONE index share its scratch (global visited tables, the net's work list and table
     pool): each search waits for the previous user's marker (exact_kernels.hip: ef_scratch_begin / _end).  Results, launched
     back to back on two streams, equal the single-stream results and the oracle's -- in every mode that uses that scratch."""
@@ -144,7 +144,7 @@ def test_ef_search_from_two_streams_shares_the_index_scratch(zv, oracle, env, mo
     Qb = oracle.uniform_rows(0xC0FFEE, nq, nq, d)
     qa, qb = torch.from_numpy(Qa).to(dev), torch.from_numpy(Qb).to(dev)
     for key, val in env.items():
-        monkeypatch.setenv(key, val)
+        tuning(key, val)
     idx.search_graph_reserve(nq, k, ef)
 
     def run(q, stream):

@@ -103,8 +103,7 @@ def test_hip_path_reproduces_the_hand_derived_fixture(name, binding, tmp_path):
         "for i in range(len(f['points'])):\n"
         "    assert [int(x) for x in h.index.get_neighbors(i)] == f['adj'][str(i)]['0']\n"
         "print('fixture ok')\n") % root
-    env = dict(os.environ)
-    if binding == "steps":
-        env["ZVDB_HOST_INSERT"] = "steps"
-    r = subprocess.run([sys.executable, "-c", code, name, binding], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    from conftest import tuning_prelude
+    pre = tuning_prelude({"ZVDB_HOST_INSERT": "steps"} if binding == "steps" else {})
+    r = subprocess.run([sys.executable, "-c", pre + code, name, binding], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fixture ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -28,10 +28,10 @@ for flags, tag in ((zv.FLAG_BF16_MIRROR, "fp32 rows"), (zv.FLAG_BF16_ROWS, "bf16
         i1, d1, c1 = ids.cpu().numpy().copy(), dd.cpu().numpy().copy(), cnt.cpu().numpy().copy()
         ok = bool(np.all(c1 == K) and np.all(np.diff(d1, axis=1) >= 0) and int(st[2].item()) == 0)
         if b % 20 == 0:
-            os.environ["ZVDB_EF_BEAM"] = "lds"
+            zv.set_tuning("ZVDB_EF_BEAM", "lds")
             idx.search_graph_dev(q.data_ptr(), B, D, K, ef, entry, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, s)
             torch.cuda.synchronize()
-            os.environ.pop("ZVDB_EF_BEAM")
+            zv.set_tuning("ZVDB_EF_BEAM", None)
             ok = ok and np.array_equal(i1, ids.cpu().numpy()) and np.array_equal(d1, dd.cpu().numpy())
         if not ok:
             bad += 1

@@ -3,6 +3,7 @@
   libzvdb_hip.so   hipcc, HIP kernels + C ABI (include/zvdb_hip.h)        -- the drop-in boundary
   libzvdb_host.so  g++,  C wrappers over host/hnsw.hpp (C++ HNSW(T) mirror) -- for ctypes callers
   tests/cpp/test_hnsw_host  g++, C++ restatement of the reference's test_hnsw.zig over hnsw.hpp
+  tests/c/abi_smoke         gcc -std=c99 -pedantic, a pure C caller of include/zvdb_hip.h (what @cImport sees)
 """
 from __future__ import annotations
 
@@ -16,6 +17,8 @@ LIB_HIP = os.path.join(PKG, "libzvdb_hip.so")
 LIB_HOST = os.path.join(PKG, "libzvdb_host.so")
 CPP_TEST_SRC = os.path.join(ROOT, "tests", "cpp", "test_hnsw_host.cpp")
 CPP_TEST_BIN = os.path.join(ROOT, "tests", "cpp", "test_hnsw_host")
+C_TEST_SRC = os.path.join(ROOT, "tests", "c", "abi_smoke.c")
+C_TEST_BIN = os.path.join(ROOT, "tests", "c", "abi_smoke")
 
 
 def _newer(srcs, out) -> bool:
@@ -50,7 +53,17 @@ def build_cpp_tests(force: bool = False) -> str:
     return CPP_TEST_BIN
 
 
+def build_c_smoke(force: bool = False) -> str:
+    """The pure-C99 caller of include/zvdb_hip.h (stand-in for Zig's @cImport: no zig toolchain in this image)."""
+    srcs = [C_TEST_SRC, os.path.join(ROOT, "include", "zvdb_hip.h"), LIB_HIP]
+    if os.path.exists(C_TEST_SRC) and (force or _newer(srcs, C_TEST_BIN)):
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
+                               "-o", C_TEST_BIN, C_TEST_SRC, "-L" + PKG, "-lzvdb_hip", "-lm", "-Wl,-rpath," + PKG])
+    return C_TEST_BIN
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_host(force)
     build_cpp_tests(force)
+    build_c_smoke(force)

@@ -32,7 +32,8 @@ class SearchStats(C.Structure):
 
 class CertInfo(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("batches", C.c_uint64), ("repaired", C.c_uint64),
-                ("level", C.c_uint32), ("enabled", C.c_uint32)]
+                ("level", C.c_uint32), ("enabled", C.c_uint32), ("rerank_rows", C.c_uint64),
+                ("rerank_cycles", C.c_uint32 * 5), ("reserved_", C.c_uint32)]
 
 
 OPT_CERTIFY, OPT_CERT_MIN_LEVEL, OPT_CERT_FORCE_REPAIR = 1, 2, 3
@@ -84,6 +85,8 @@ HIP_SYMBOLS = [
     ("zvdb_hip_index_set_shard_count", _i32, [_vp, _u32]),
     ("zvdb_hip_index_set_screen_survivors", _i32, [_vp, _u32]),
     ("zvdb_hip_index_set_option", _i32, [_vp, _u32, _u64]),
+    ("zvdb_hip_set_tuning", _i32, [C.c_char_p, C.c_char_p]),
+    ("zvdb_hip_get_tuning", C.c_char_p, [C.c_char_p]),
     ("zvdb_hip_bruteforce_cert_info", _i32, [_vp, C.POINTER(CertInfo)]),
     ("zvdb_hip_comm_unique_id", _i32, [_vp]),
     ("zvdb_hip_comm_create", _i32, [_u32, _u32, _vp, C.c_int32, C.POINTER(_vp)]),
@@ -165,6 +168,28 @@ def check(rc: int) -> None:
     if rc == ERR_DIM_MISMATCH:
         raise ZvdbPanic(msg)
     raise ZvdbError(rc, msg)
+
+
+def set_tuning(name: str, value=None) -> None:
+    """zvdb_hip_set_tuning: an A/B / test switch of the launch code (DESIGN.md "Runtime switches"); value None removes it."""
+    check(hip().zvdb_hip_set_tuning(name.encode(), None if value is None else str(value).encode()))
+
+
+class tuned:
+    """with tuned(ZVDB_EF_BEAM="lds", ...): the switches are set inside the block and removed after it."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            set_tuning(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            set_tuning(k, None)
+        return False
 
 
 def device_count() -> int:

@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 
 #include <sys/types.h>
+#include <map>
 #include <unistd.h>
 
 namespace zvdb {
@@ -20,6 +21,36 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// Tuning table: the A/B and test switches of the kernels' launch code (DESIGN.md "Runtime switches") are entries of a
+// process-wide name -> value table that the CALLER fills (zvdb_hip_set_tuning); an embedded library does not read its
+// configuration from the process environment.  Only a diagnostic build (-DZVDB_TUNING_FROM_ENV) falls back to getenv for a name
+// that was never set.  Every switch is read when a call is made (no value is latched at first use).
+namespace {
+std::mutex g_tune_mu;
+std::map<std::string, std::string> &tune_map() {
+    static std::map<std::string, std::string> m;
+    return m;
+}
+}  // namespace
+const char *tuning(const char *name) {
+    static thread_local std::string hold[8];
+    static thread_local unsigned slot = 0;
+    {
+        std::lock_guard<std::mutex> g(g_tune_mu);
+        auto it = tune_map().find(name);
+        if (it != tune_map().end()) {
+            std::string &h = hold[slot++ & 7];
+            h = it->second;
+            return h.c_str();
+        }
+    }
+#ifdef ZVDB_TUNING_FROM_ENV
+    return getenv(name);
+#else
+    return nullptr;
+#endif
 }
 
 int ensure_pin(zvdb_hip_index *h, size_t bytes) {
@@ -808,7 +839,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
     const uint32_t m = h->m, rw = 4 + h->gstride, ow = 4 + m;
     uint64_t done = 0, rec_out = 0;
     // chunks of more than 4 points run as speculative parallel rounds (exact_kernels.hip: k_insert_spec); ZVDB_INSERT_SPEC=0: one wave, in order
-    const char *spec_env = getenv("ZVDB_INSERT_SPEC");
+    const char *spec_env = tuning("ZVDB_INSERT_SPEC");
     // (list ids carry two flag bits: shards beyond 2^30 rows or upper-layer slots fall back to the in-order kernel)
     const bool spec = !(spec_env && spec_env[0] == '0') && m >= 1 && h->count + n < (1ull << 30) && h->up_count + 32ull * n < (1ull << 30);
     const uint32_t spec_bmax = 1024;
@@ -940,7 +971,7 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                 bool looped = false;
                 if (!(spec_env && spec_env[0] == 'r')) {
                     uint32_t lb = 48;  // (measured 200k x 128: 32 -> 204k, 48 -> 257k, 64 -> 252k, 96 -> 219k inserts/s)
-                    if (const char *be = getenv("ZVDB_INSERT_SPEC_B")) lb = (uint32_t)std::max(1, std::min((int)spec_bmax, atoi(be)));
+                    if (const char *be = tuning("ZVDB_INSERT_SPEC_B")) lb = (uint32_t)std::max(1, std::min((int)spec_bmax, atoi(be)));
                     const int rc = launch_insert_spec_loop(h, (uint32_t)id0, (uint32_t)nc, lb, reinterpret_cast<const float *>(scr),
                                                            reinterpret_cast<const InsertParam *>(scr + pb), reinterpret_cast<uint32_t *>(scr + pb + qb),
                                                            h->spec_wpos0, h->spec_wposU, d_rset, d_rcnt, d_cmin, h->spec_epoch + 1, h->stream);
@@ -984,11 +1015,11 @@ int zvdb_hip_insert_batch(zvdb_hip_index *h, const float *points, uint32_t dim, 
                 h->spec_epoch += rounds;
                 spec_dbg_rounds = rounds;
                 spec_dbg_launched = spec_dbg_launched * rounds;
-                if (getenv("ZVDB_INSERT_SPEC_DEBUG"))
+                if (tuning("ZVDB_INSERT_SPEC_DEBUG"))
                     fprintf(stderr, "[zvdb insert spec] rounds stopped by: a scanned list with two earlier writers %u, re-scanned list leads elsewhere %u, appended point closer %u, read set overflow %u; deferred connects redone %u\n",
                             ctl_h[8], ctl_h[9], ctl_h[10], ctl_h[11], ctl_h[12]);
             }
-            if (spec && getenv("ZVDB_INSERT_SPEC_DEBUG"))
+            if (spec && tuning("ZVDB_INSERT_SPEC_DEBUG"))
                 fprintf(stderr, "[zvdb insert spec] chunk of %llu points at id %llu: %llu rounds%s, %llu point-slots launched (%.1f committed per round)\n",
                         (unsigned long long)nc, (unsigned long long)id0, (unsigned long long)spec_dbg_rounds, spec_looped ? " in one cooperative launch" : "",
                         (unsigned long long)spec_dbg_launched, (double)nc / (double)std::max<uint64_t>(spec_dbg_rounds, 1));
@@ -1274,6 +1305,7 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode) 
     ef_hint_reset(h, h->stream);
     const uint32_t k = degree + 1;  // the row itself is (one of) its own nearest
     const uint32_t B = 1024;        // rows per search batch
+    CertPause no_cert(h);           // (common.h: the builders' kNN passes run uncertified)
     const size_t ib = round_up64((size_t)B * k * 8, 256), db = round_up64((size_t)B * k * 4, 256);
     const size_t cb = round_up64((size_t)B * 4, 256), qb = round_up64((size_t)B * h->dim * 4, 256);
     const uint64_t wsb = bruteforce_workspace_bytes(h, B, k, mode);
@@ -1589,6 +1621,16 @@ int zvdb_hip_index_set_screen_survivors(zvdb_hip_index *h, uint32_t survivors) {
     return ZVDB_OK;
 }
 
+int zvdb_hip_set_tuning(const char *name, const char *value) {
+    if (!name || strncmp(name, "ZVDB_", 5) != 0) { set_error("tuning names start with ZVDB_"); return ZVDB_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(g_tune_mu);
+    if (value) tune_map()[name] = value;
+    else tune_map().erase(name);
+    return ZVDB_OK;
+}
+
+const char *zvdb_hip_get_tuning(const char *name) { return name ? tuning(name) : nullptr; }
+
 int zvdb_hip_index_set_option(zvdb_hip_index *h, uint32_t option, uint64_t value) {
     ZV_ARG(h, "null argument");
     std::lock_guard<std::mutex> g(h->mu);
@@ -1620,6 +1662,8 @@ int zvdb_hip_bruteforce_cert_info(zvdb_hip_index *h, zvdb_hip_cert_info *out) {
     out->repaired = h->cert_host ? (uint64_t)__atomic_load_n(h->cert_host + 1, __ATOMIC_RELAXED) : 0;
     out->level = std::max(h->cert_level, h->cert_level_min);
     out->enabled = h->cert_on ? 1u : 0u;
+    out->rerank_rows = h->cert_host ? (uint64_t)__atomic_load_n(h->cert_host + 2, __ATOMIC_RELAXED) : 0;
+    for (int i = 0; i < 5; ++i) out->rerank_cycles[i] = h->cert_host ? __atomic_load_n(h->cert_host + 3 + i, __ATOMIC_RELAXED) : 0;
     return ZVDB_OK;
 }
 

@@ -656,7 +656,7 @@ uint32_t bf16s_ksteps(uint32_t dim) { return dim <= 128 ? 8u : dim <= 256 ? 16u 
 static uint32_t bf16s_groups_per_unit(uint32_t KS) { return KS == 8 ? 6u : KS == 16 ? 3u : 1u; }
 
 bool bf16s_eligible(const zvdb_hip_index *h) {
-    static const bool off = [] { const char *e = getenv("ZVDB_BF_BF16_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    const bool off = [] { const char *e = tuning("ZVDB_BF_BF16_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 4 && h->dim <= 768;
 }
 
@@ -709,8 +709,8 @@ int launch_bf16s_prep_queries(const zvdb_hip_index *h, const float *d_queries, u
 // follow them with damping 1/2, and the next launch runs with the new split.  Results do not depend on the split (every row is
 // scanned once; the merged lists hold the exact k' best keys either way).  ZVDB_BF16S_BALANCE=0: even split.
 static int bh_balance(const zvdb_hip_index *h, uint32_t QT, uint32_t S, BhSplit *split, uint32_t **dur_out) {
-    static const bool off = [] { const char *e = getenv("ZVDB_BF16S_BALANCE"); return e && e[0] == '0'; }();
-    static const bool dbg = [] { const char *e = getenv("ZVDB_BF16S_BALANCE"); return e && e[0] == 'v'; }();
+    const bool off = [] { const char *e = tuning("ZVDB_BF16S_BALANCE"); return e && e[0] == '0'; }();
+    const bool dbg = [] { const char *e = tuning("ZVDB_BF16S_BALANCE"); return e && e[0] == 'v'; }();
     const uint32_t nb = QT * S, G = (uint32_t)((h->count + 31) / 32);
     const uint32_t NG = bf16s_groups_per_unit(bf16s_ksteps(h->dim)), U = (G + NG - 1) / NG;
     if (off || S % 8 != 0 || nb > 4096 || U < 64 * S) return ZVDB_OK;  // (short streams: nothing to balance)

@@ -43,6 +43,7 @@ struct CertArgs {
     int affine = 0;
     float rescale_target = 0.0f;     // int8, dot / cosine: queries are scaled to this largest magnitude before they are quantised
     int force = 0;                   // ZVDB_OPT_CERT_FORCE_REPAIR (tests): every query is listed for the exact scan
+    uint32_t *dbg_rows = nullptr;    // tuning ZVDB_CERT_DEBUG: mapped host counter of the candidate rows the re-rank evaluated
 };
 
 struct CertQ {  // per-query constants (wave-uniform)

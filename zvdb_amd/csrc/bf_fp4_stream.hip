@@ -632,12 +632,12 @@ uint32_t fp4s_ksteps(uint32_t dim) {
 // 16-cycle MFMA holds the SIMD's vector issue for half of its cycles, which starves the partner wave's selection
 // epilogue and LDS reads.  Kept as a tested A/B variant.
 int fp4s_shape() {
-    static const int v = [] { const char *e = getenv("ZVDB_BF_FP4_SHAPE"); return (e && e[0] == '1') ? 16 : 32; }();
+    const int v = [] { const char *e = tuning("ZVDB_BF_FP4_SHAPE"); return (e && e[0] == '1') ? 16 : 32; }();
     return v;
 }
 
 bool fp4s_eligible(const zvdb_hip_index *h) {
-    static const bool off = [] { const char *e = getenv("ZVDB_BF_FP4_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    const bool off = [] { const char *e = tuning("ZVDB_BF_FP4_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 0 && fp4s_ksteps(h->dim) <= 12;  // instantiated: KS = 6 (dim <= 384), 12 (dim <= 768)
 }
 
@@ -721,7 +721,7 @@ int launch_fp4s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
         return launch_stream<0, KPMAX>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     if (kpv == (uint32_t)KPW)
         return launch_stream<0, KPW>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, nullptr, s);
-    static const uint32_t dbg = [] { const char *e = getenv("ZVDB_BF_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t dbg = [] { const char *e = tuning("ZVDB_BF_DEBUG"); return e ? (uint32_t)atoi(e) : 0u; }();
 #define ZV_F7_ARGS h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, t_first, list_base, Stot, pcnt, 0u, gate, (float *)nullptr, s
     if (dbg == 1) return launch_stream<1>(ZV_F7_ARGS);
     if (dbg == 3) return launch_stream<3>(ZV_F7_ARGS);

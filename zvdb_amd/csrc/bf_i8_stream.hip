@@ -518,7 +518,7 @@ uint32_t i8s_ksteps(uint32_t dim) {
 }
 
 bool i8s_eligible(const zvdb_hip_index *h) {
-    static const bool off = [] { const char *e = getenv("ZVDB_BF_I8_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    const bool off = [] { const char *e = tuning("ZVDB_BF_I8_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 0 && h->dim <= 768;
 }
 
@@ -587,7 +587,7 @@ int launch_i8s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
 // ---- the same 128-query kernel on the fp4 fragment-order mirror: 768 < dim <= 1536 (KS = 18, 24) -------------------------
 uint32_t fp4s128_ksteps(uint32_t dim) { return (dim + 63) / 64 <= 18 ? 18 : 24; }
 bool fp4s128_eligible(const zvdb_hip_index *h) {
-    static const bool off = [] { const char *e = getenv("ZVDB_BF_FP4_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    const bool off = [] { const char *e = tuning("ZVDB_BF_FP4_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 768 && h->dim <= 1536;
 }
 int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
@@ -602,7 +602,7 @@ int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint
 // ---- the same 128-query kernel with fp32 MFMAs on a fragment-order fp32 mirror: dim <= 128 (KS = 8, 16) -------------------------
 uint32_t f32s_ksteps(uint32_t dim) { return dim <= 64 ? 8u : 16u; }
 bool f32s_eligible(const zvdb_hip_index *h) {
-    static const bool off = [] { const char *e = getenv("ZVDB_BF_F32_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
+    const bool off = [] { const char *e = tuning("ZVDB_BF_F32_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 4 && h->dim <= 128;
 }
 uint64_t f32s_query_bytes(const zvdb_hip_index *h, uint32_t nq_pad) { return (uint64_t)nq_pad * f32s_ksteps(h->dim) * 32; }

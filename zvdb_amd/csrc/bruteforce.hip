@@ -613,10 +613,14 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
             if (i < n) {
                 const uint64_t k = pool[i];
                 uint32_t rank = 0;
-                for (uint32_t j = 0; j < n; ++j) {
-                    const uint64_t o = pool[j];
-                    rank += (o < k || (o == k && j < i)) ? 1u : 0u;
+                const uint32_t n2 = n & ~1u;  // (two keys per 16-byte LDS read, four reads in flight: the one-key loop is a chain of LDS round trips)
+#pragma unroll 4
+                for (uint32_t j = 0; j < n2; j += 2) {
+                    const ulonglong2 o = *reinterpret_cast<const ulonglong2 *>(pool + j);
+                    rank += (o.x < k || (o.x == k && j < i)) ? 1u : 0u;
+                    rank += (o.y < k || (o.y == k && j + 1 < i)) ? 1u : 0u;
                 }
+                if (n2 < n) rank += (pool[n2] < k || (pool[n2] == k && n2 < i)) ? 1u : 0u;
                 cand_ids[(size_t)q * lkp + rank] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
                 cand_keys[(size_t)q * lkp + rank] = (uint32_t)(k >> 32);
             } else {
@@ -738,11 +742,8 @@ struct BfPlan {
 };
 
 uint32_t debug_flags() {
-    static const uint32_t f = [] {
-        const char *e = getenv("ZVDB_BF_DEBUG");
-        return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    return f;
+    const char *e = tuning("ZVDB_BF_DEBUG");
+    return e ? (uint32_t)atoi(e) : 0u;
 }
 
 // Up to 4 dimensions a reduced-precision screen cannot tell rows apart (an 8-bit code has 256 values per dimension; 200k
@@ -815,7 +816,7 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode, uint32_t k
 
 // k-slice rotation per query tile (nibble qt&7), each < KT.  ZVDB_BF_ROT=<hex> overrides (A/B).
 uint32_t rot_table(uint32_t KT) {
-    static const uint32_t env = [] { const char *e = getenv("ZVDB_BF_ROT"); return e ? (uint32_t)strtoul(e, nullptr, 16) : 0x53145420u; }();
+    const uint32_t env = [] { const char *e = tuning("ZVDB_BF_ROT"); return e ? (uint32_t)strtoul(e, nullptr, 16) : 0x53145420u; }();
     uint32_t t = 0;
     for (int i = 0; i < 8; ++i) t |= (((env >> (4 * i)) & 15u) % KT) << (4 * i);
     return t;
@@ -982,7 +983,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         return ZVDB_ERR_UNSUPPORTED;
     }
     const BfPlan p = make_plan(h, nq, mode, std::min(k, 256u));
-    static const int guess_off = [] { const char *e = getenv("ZVDB_BF_GUESS"); return e && e[0] == '0'; }();
+    const int guess_off = [] { const char *e = tuning("ZVDB_BF_GUESS"); return e && e[0] == '0'; }();
     // fp4: barrier-free stream kernel over the fragment-order mirror when the query tile fits LDS, else the staged scan
     const bool f7 = mode == ZVDB_BF_FP4 && fp4s_eligible(h);
     // int8: the stream kernel serves large shards (one scan against guessed + verified thresholds); small ones stay on the
@@ -1004,6 +1005,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             if (!h->cert_host) { set_error("hipHostMalloc returned no block"); return ZVDB_ERR_OOM; }
             h->cert_host[0] = 0;
             h->cert_host[1] = 0;
+            for (int i = 2; i < 16; ++i) h->cert_host[i] = 0;
             ZV_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->cert_hdev), h->cert_host, 0));
         }
         if (h->cert_force) {
@@ -1029,7 +1031,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // staged kernel streams both operands through LDS and reaches 0.68 of the fp32-MFMA peak at BASELINE configs[1]
     // -- measured: +13 % at 64 dimensions, +0 .. 5 % at 128 (both designs sit at ~0.68 there: DESIGN 3, K4), for a mirror as large as
     // the rows; so: by default up to 64 dimensions, and wherever k > 112 needs its wider lists; ZVDB_BF_F32_KERNEL=stream: up to 128
-    static const bool sf_wide = [] { const char *e = getenv("ZVDB_BF_F32_KERNEL"); return e && e[0] == 's'; }();
+    const bool sf_wide = [] { const char *e = tuning("ZVDB_BF_F32_KERNEL"); return e && e[0] == 's'; }();
     const bool sf = mode == ZVDB_BF_F32 && f32s_eligible(h) && ((big8 && (h->dim <= 64 || sf_wide)) || k > (uint32_t)KPW - 16);
     // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
     // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
@@ -1130,6 +1132,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         ca.affine = l2 ? 1 : 0;
         ca.rescale_target = mode == ZVDB_BF_I8 ? 127.0f / h->q_inv : 0.0f;
         ca.force = h->cert_force ? 1 : 0;
+        ca.dbg_rows = tuning("ZVDB_CERT_DEBUG") ? h->cert_hdev + 2 : nullptr;
         ZV_CHECK(launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid, &ca));
         return launch_exact_scan(h, d_queries_exact, nq, k, id_offset, nflag, flist, cand, p.cand_bytes, d_ids, d_dist, d_count, h->cert_hdev + 1, s);
     };
@@ -1143,7 +1146,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         uint32_t *tau_g = reinterpret_cast<uint32_t *>(ws + p.off_taug);
         uint32_t *pcnt = reinterpret_cast<uint32_t *>(ws + p.off_pcnt);
         // survivors per query: 32 suffice for k <= 16 with the (near-)exact screens; the 4-bit screen keeps 64
-        static const uint32_t fp4_kp = [] { const char *e = getenv("ZVDB_BF_FP4_KP"); return e ? (uint32_t)atoi(e) : (uint32_t)KP; }();  // tuning
+        const uint32_t fp4_kp = [] { const char *e = tuning("ZVDB_BF_FP4_KP"); return e ? (uint32_t)atoi(e) : (uint32_t)KP; }();  // tuning
         // one of G id-range shards: its share of the global 64 best screen keys is Binomial(64, 1/G) -> mean + 6 sigma
         // (zvdb_hip_index_set_shard_count; G = 8: 24 survivors instead of 64)
         uint32_t fp4_share = fp4_kp;
@@ -1183,8 +1186,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         // is too loose is self-correcting (the append buffers fill and the prune rounds tighten the bound).
         float z = 0.0f;
         if (guess_pipe || staged_guess) {
-            static const double target = [] { const char *e = getenv("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
-            static const double zshift = [] { const char *e = getenv("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
+            const double target = [] { const char *e = tuning("ZVDB_BF_GUESS_TARGET"); return e ? atof(e) : 384.0; }();
+            const double zshift = [] { const char *e = tuning("ZVDB_BF_GUESS_ZSHIFT"); return e ? atof(e) : 0.0; }();  // tests: < 0 forces repairs
             // candidates admitted per query: 6 per survivor wanted (384 for the usual 64; fewer survivors, fewer appends)
             const double tail = std::min(0.25, std::max(std::min(target, target * kp / 64.0), 4.0 * kp) / (double)N);
             // adaptive part: a batch that needed a repair (keys not Gaussian enough, e.g. low dimensions) loosens the guess of
@@ -1246,7 +1249,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             uint32_t *defq = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256);
             uint32_t *tau_rep = reinterpret_cast<uint32_t *>(ws + p.off_verify + 256 + round_up64((uint64_t)p.nq_pad * 4, 256));
             unsigned long long *dbg_area = reinterpret_cast<unsigned long long *>(tau_g + p.nq_pad);  // (never written in production builds)
-            static const uint32_t nsamp_env = [] { const char *e = getenv("ZVDB_BF_SAMPLE"); return e ? (uint32_t)atoi(e) : 0u; }();  // (tuning)
+            const uint32_t nsamp_env = [] { const char *e = tuning("ZVDB_BF_SAMPLE"); return e ? (uint32_t)atoi(e) : 0u; }();  // (tuning)
             const uint32_t nsamp = nsamp_env ? nsamp_env : 4096;
             ZV_CHECK(rows_dispatch(h, [&](auto rws, uint32_t ld) -> int {
                 using RT = row_elem_t<decltype(rws)>;
@@ -1266,7 +1269,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 // one query tile: no other workgroup shares a stream's L2 lines, every slice is an HBM round trip -- the 64-byte slices'
                 // 4-stage ring (three in flight) covers it better than two 128-byte stages: +3 % at 1M x 128, +2 % at 256-d
                 // (ZVDB_BF_F32_KBV=128 / 64 forces either)
-                static const int kbv_env = [] { const char *e = getenv("ZVDB_BF_F32_KBV"); return e ? atoi(e) : 0; }();
+                const int kbv_env = [] { const char *e = tuning("ZVDB_BF_F32_KBV"); return e ? atoi(e) : 0; }();
                 const bool kbv64 = kbv_env ? kbv_env == 64 : p.QT == 1;
                 if (kbv64) return launch_scan5<0, 2, 64>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
                 return launch_scan5<0, 2, 128>(p, q_op, rows, vn, N, nq, alpha_i, cand, partial, tau, kp, 0, p.NT, list_base, Stot, pcnt, s, gate, dbg_area);
@@ -1316,7 +1319,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             // pass A streams: every workgroup of pass A floods one tile (256 candidates per query, 8-byte
             // scattered stores) -- the fewer the cheaper, as long as pass B's candidates (rows_B * k' /
             // rows_A per query) stay far below the sub-buffer capacity.  ZVDB_BF_SA overrides (tuning).
-            static const uint32_t sa_env = [] { const char *e = getenv("ZVDB_BF_SA"); return e ? (uint32_t)atoi(e) : 0u; }();
+            const uint32_t sa_env = [] { const char *e = tuning("ZVDB_BF_SA"); return e ? (uint32_t)atoi(e) : 0u; }();
             const uint32_t SA = sa_env ? std::min(p.S, std::max(8u, sa_env / 8 * 8)) : std::min(p.S, 16u);
             uint32_t t0 = SA;
             passes[np++] = {0, SA, SA};

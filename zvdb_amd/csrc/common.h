@@ -17,6 +17,8 @@ namespace zvdb {
 constexpr int kWave = 64;
 
 void set_error(const char *fmt, ...);
+// value of a tuning switch (zvdb_hip_set_tuning; DESIGN.md "Runtime switches"), or nullptr; the pointer stays valid for a few further calls on this thread
+const char *tuning(const char *name);
 
 #define ZV_HIP(expr)                                                                  \
     do {                                                                              \
@@ -212,6 +214,17 @@ struct zvdb_hip_index {
 };
 
 namespace zvdb {
+
+// The graph builders' self-kNN passes (k = degree + 1 up to 97 of <= 256 survivors: too few for the certificate's bound on
+// high-dimensional rows, so nearly every row would take the exact scan) run the screens UNCERTIFIED, as in rounds 1-3: what such a
+// pass can get wrong is a candidate at the tail of a node's list, i.e. an edge of the graph -- never a search result, and the
+// certificate exists for those.
+struct CertPause {
+    zvdb_hip_index *h;
+    bool was;
+    explicit CertPause(zvdb_hip_index *hh) : h(hh), was(hh->cert_on) { h->cert_on = false; }
+    ~CertPause() { h->cert_on = was; }
+};
 
 int ensure_pin(zvdb_hip_index *h, size_t bytes);
 int ensure_scratch(zvdb_hip_index *h, size_t bytes);

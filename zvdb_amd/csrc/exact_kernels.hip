@@ -1331,7 +1331,7 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
     const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
     const size_t lds = 4ull * (dim_pad + 2ull * heap_cap + (1ull << hash_bits) + 2ull * rcap + 2 * kWave);
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    static const bool fast_off = [] { const char *e = getenv("ZVDB_COMPAT_SEARCH"); return e && e[0] == 'h'; }();  // "heap": emulation only
+    const bool fast_off = [] { const char *e = tuning("ZVDB_COMPAT_SEARCH"); return e && e[0] == 'h'; }();  // "heap": emulation only
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
         ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat<RT>), lds));
@@ -2264,10 +2264,10 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // A query that still exhausts it is flagged in stats[2] (the host entry point reports it).
     uint64_t want = std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride * 3 / 2 + 64);
     uint32_t hash_bits = bits_for(want);  // the SAFE table
-    if (const char *hb_env = getenv("ZVDB_EF_HASH_BITS")) hash_bits = (uint32_t)std::max(8, std::min(15, atoi(hb_env)));  // (experiment)
+    if (const char *hb_env = tuning("ZVDB_EF_HASH_BITS")) hash_bits = (uint32_t)std::max(8, std::min(15, atoi(hb_env)));  // (experiment)
     const uint32_t efp = round_up(ef, kWave), kpad = round_up(std::max(k, 1u), kWave);
     // beam in registers up to ef = 1024 (k_search_ef_reg), in LDS beyond (k_search_ef); ZVDB_EF_BEAM=lds forces the LDS kernel
-    const char *beam_env = getenv("ZVDB_EF_BEAM");  // (read per call: the parity test switches it)
+    const char *beam_env = tuning("ZVDB_EF_BEAM");  // (read per call: the parity test switches it)
     const bool beam_lds = beam_env && beam_env[0] == 'l';
     const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : ef <= 1024 ? 16 : 0;
     auto lds_slots = [&](uint64_t slots) -> size_t {  // LDS of a query with a visited table of `slots` entries
@@ -2280,7 +2280,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // an index-owned buffer, the batch in chunks of <= 2 GiB) -- slower per pop, but it serves only what the tight LDS pass
     // handed back (or the first batch of an ef bucket, which establishes the fill), and nothing overflows: before, such searches
     // ran one wave per CU on a table clamped to the LDS and failed with "visited set exhausted" beyond it.
-    const char *gv_env = getenv("ZVDB_EF_GLOBAL_VISITED");  // "1" / "0": force / forbid the global safe pass (tests; read per call)
+    const char *gv_env = tuning("ZVDB_EF_GLOBAL_VISITED");  // "1" / "0": force / forbid the global safe pass (tests; read per call)
     uint32_t lds_cap_bits = 15;
     while (lds_bytes(lds_cap_bits) > 160 * 1024 && lds_cap_bits > 8) --lds_cap_bits;
     const bool safe_global = gv_env ? gv_env[0] == '1' : lds_bytes(hash_bits) > 80 * 1024;
@@ -2296,7 +2296,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     uint32_t bucket = 0;
     while ((1u << bucket) < ef && bucket < 15) ++bucket;
     const uint32_t seen = __atomic_load_n(&h->ef_hint_host[bucket], __ATOMIC_RELAXED);
-    const char *tp_env = getenv("ZVDB_EF_TWO_PASS");  // "0": always the safe table; "t<bits>": force the tight table (tests; read per call)
+    const char *tp_env = tuning("ZVDB_EF_TWO_PASS");  // "0": always the safe table; "t<bits>": force the tight table (tests; read per call)
     const uint32_t safe_rank = safe_global ? 32u : hash_bits;  // (a global safe table is "larger" than any LDS one)
     uint32_t tight_bits = safe_rank;
     if (tp_env && tp_env[0] == 't') {
@@ -2322,7 +2322,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         // instead of running whole on the safe table; a query that visits more is served by the safe pass like any other overflow)
         const uint32_t seen_eff = seen ? seen : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride / 2);
         uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
-        if (const char *we = getenv("ZVDB_EF_WPQ")) wq = (uint32_t)atoi(we);
+        if (const char *we = tuning("ZVDB_EF_WPQ")) wq = (uint32_t)atoi(we);
         if (epl >= 8 && wq == 4) wq = 2;
         // workgroups per CU the kernels' registers allow: 2 waves x <= 160 VGPRs (EPL <= 4): 6; 2 x 172 .. 200 (EPL 8, 16), 4 x 128, 1 x 256+: 4
         const uint32_t vlim = (wq == 2 && epl <= 4) ? 6u : 4u;
@@ -2348,7 +2348,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     }
     const bool two_pass = tight_slots ? true : tight_bits < safe_rank;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    static const bool prof = [] { const char *e = getenv("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
+    const bool prof = [] { const char *e = tuning("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
         uint32_t wpq_launch = 1;
@@ -2436,7 +2436,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         // 993k, 2 waves 863k / 982k / 1.09M, 4 waves 894k / 1.03M / 1.11M; bf16 rows 1.00M / 1.19M / 1.30M, 2 waves 1.23M / 1.54M /
         // 1.67M, 4 waves 0.69M (8 rows per wave step: half the waves idle on 16-entry lists; with the 16-lane walk 0.94M / 1.20M / 1.29M)
         uint32_t wpq = sizeof(RT) == 2 ? 2 : 4;
-        if (const char *we = getenv("ZVDB_EF_WPQ")) wpq = (uint32_t)atoi(we);  // (1, 2, 4: experiment / tests; read per call)
+        if (const char *we = tuning("ZVDB_EF_WPQ")) wpq = (uint32_t)atoi(we);  // (1, 2, 4: experiment / tests; read per call)
         if (epl >= 8 && wpq == 4) wpq = 2;
         if (epl == 0 || (wpq != 2 && wpq != 4)) wpq = 1;
         wpq_launch = wpq;
@@ -2463,13 +2463,31 @@ void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s) {
 // With a certificate (cert.kth != null; bf_cert.h) the lists arrive sorted by screen key and are evaluated 64 at a time: after
 // each round the k-th exact distance so far gives the largest screen key a row of the top-k can carry, candidates above it are
 // not evaluated, and the query is certified when that key lies below the k'-th survivor's -- else it goes on the repair list.
-__device__ __forceinline__ void cert_verdict(const CertArgs &cert, uint32_t qi, uint32_t ks, int lane) {
+__device__ __forceinline__ void cert_verdict(const CertArgs &cert, uint32_t qi, uint32_t ks, int lane, uint32_t rows_evaluated = 0) {
     if (lane != 0) return;
+    if (cert.dbg_rows) __hip_atomic_fetch_add(cert.dbg_rows, rows_evaluated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t kth = cert.kth[qi];
     if (!cert.force && (kth == 0xFFFFFFFFu || ks < kth)) return;  // every row is a survivor / no row left out can reach the top-k
     const uint32_t slot = atomicAdd(cert.nflag, 1u);
     cert.flist[slot] = qi;
     if (cert.host_flag) __hip_atomic_store(cert.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// number of valid entries of the LDS lists [0, n) (n a multiple of 4, the arrays 16-byte aligned) that precede (di, ii) in
+// (distance, id) order.  Four entries per 16-byte LDS read, four reads in flight: the plain one-entry loop is a chain of dependent
+// LDS round trips (~120 cycles each) -- at 128 candidates the ranking loops of a re-rank cost more than its row fetches
+// (profiles/r4/: 140 us against 33 us).  Entries without a candidate carry id ~0 (and distance +inf).
+__device__ __forceinline__ uint32_t lex_rank4(const float *cd, const uint32_t *ci, uint32_t n, float di, uint32_t ii) {
+    uint32_t rank = 0;
+#pragma unroll 4
+    for (uint32_t j = 0; j < n; j += 4) {
+        const float4 d = *reinterpret_cast<const float4 *>(cd + j);
+        const uint4 c = *reinterpret_cast<const uint4 *>(ci + j);
+        rank += (c.x != 0xFFFFFFFFu && lex_less(d.x, c.x, di, ii)) ? 1u : 0u;
+        rank += (c.y != 0xFFFFFFFFu && lex_less(d.y, c.y, di, ii)) ? 1u : 0u;
+        rank += (c.z != 0xFFFFFFFFu && lex_less(d.z, c.z, di, ii)) ? 1u : 0u;
+        rank += (c.w != 0xFFFFFFFFu && lex_less(d.w, c.w, di, ii)) ? 1u : 0u;
+    }
+    return rank;
 }
 // k-th smallest (dist, id) among the valid entries [0, n) of the LDS lists (wave-collective; +inf if fewer than k are valid)
 __device__ __forceinline__ float cert_kth_dist(const float *cd, const uint32_t *ci, uint32_t n, uint32_t k, float *slot, int lane) {
@@ -2479,12 +2497,7 @@ __device__ __forceinline__ float cert_kth_dist(const float *cd, const uint32_t *
         const uint32_t ii = ci[i];
         if (ii == 0xFFFFFFFFu) continue;
         const float di = cd[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t ij = ci[j];
-            if (ij != 0xFFFFFFFFu && lex_less(cd[j], ij, di, ii)) ++rank;
-        }
-        if (rank == k - 1) *slot = di;
+        if (lex_rank4(cd, ci, n, di, ii) == k - 1) *slot = di;
     }
     __syncthreads();
     return *slot;
@@ -2561,13 +2574,17 @@ __global__ __launch_bounds__(64) void k_rerank(const RT *__restrict__ rows, uint
     for (uint32_t base = 0; base < kc; base += kWave) {
         const uint32_t i = base + lane;
         const bool valid = i < kc && ci[i] != 0xFFFFFFFFu;
-        uint32_t rank = 0;
         if (valid) {
             const float di = cd[i];
             const uint32_t ii = ci[i];
-            for (uint32_t j = 0; j < kc; ++j) {
-                const uint32_t ij = ci[j];
-                if (ij != 0xFFFFFFFFu && lex_less(cd[j], ij, di, ii)) ++rank;
+            uint32_t rank = 0;
+            if ((kc & 3u) == 0 && (dim_pad & 3u) == 0) {
+                rank = lex_rank4(cd, ci, kc, di, ii);
+            } else {
+                for (uint32_t j = 0; j < kc; ++j) {
+                    const uint32_t ij = ci[j];
+                    if (ij != 0xFFFFFFFFu && lex_less(cd[j], ij, di, ii)) ++rank;
+                }
             }
             if (rank < k) {
                 out_ids[(size_t)qi * k + rank] = (uint64_t)ii + id_offset;
@@ -2645,16 +2662,19 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
         if (cert.kth) ck[lane + 64 * bt] = cert.keys[(size_t)qi * kc + lane + 64 * bt];
     }
     __syncthreads();
-    {   // drop duplicate ids (keep the first copy)
+    {   // drop duplicate ids (keep the first copy); lists sorted by (key, id) -- the certificate's -- hold the copies of a row side by side
         bool dup[NE];
 #pragma unroll
         for (int bt = 0; bt < NE; ++bt) {
             dup[bt] = false;
             const int me = lane + 64 * bt;
             const uint32_t ii = ci[me];
-            if (ii != 0xFFFFFFFFu)
-                for (int j = 0; j < me; ++j)
-                    if (ci[j] == ii) { dup[bt] = true; break; }
+            if (ii != 0xFFFFFFFFu) {
+                if (cert.kth) dup[bt] = me > 0 && ci[me - 1] == ii;
+                else
+                    for (int j = 0; j < me; ++j)
+                        if (ci[j] == ii) { dup[bt] = true; break; }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -2664,12 +2684,21 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
     }
     CertQ cq{};
     uint32_t ks = 0xFFFFFFFEu;  // largest screen key a row of the top-k can carry, by what has been evaluated so far
+    unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
+    const bool prof = cert.dbg_rows && (qi & 63u) == 0;  // (tuning ZVDB_CERT_DEBUG: cycle stamps of every 64th query)
+    if (prof) tstamp[0] = __builtin_amdgcn_s_memtime();
     if (cert.kth) cq = cert_query_consts(cert, q, dim, metric, lane);
+    if (prof) tstamp[1] = __builtin_amdgcn_s_memtime();
     const uint32_t nch = (ld * (uint32_t)sizeof(RT) + CHB - 1) / CHB;
     const uint32_t row_bytes = ld * (uint32_t)sizeof(RT);
     const uint32_t stage_lds = (uint32_t)(size_t)(rr_lptr_t)stage;
+    // With a certificate only the FIRST batch is staged: what the bound leaves of the other candidates (on the benchmark's data ~3 of
+    // 96 on average, up to ~70 for the densest neighbourhoods of a batch) is walked straight from global memory, one lane per row,
+    // 64 rows at a time (below) -- a staged batch is a chain of dependent chunk fetches whatever it holds, and a 1,024-query launch
+    // is ONE round of workgroups, so its time is the slowest query's: three staged batches made it 140 us, profiles/r4/.
+    const int nb_staged = cert.kth ? 1 : NB;
 #pragma unroll 1
-    for (int bt = 0; bt < NB; ++bt) {
+    for (int bt = 0; bt < nb_staged; ++bt) {
         // DMA side: instruction t fills rows RPI t .. RPI t + RPI - 1 of this batch; this lane serves row RPI t + lane / LPR, piece
         // lane % LPR -- of the SOURCE piece (lane % LPR) ^ (row % LPR): the swizzle that makes the walk's reads conflict-free
         // slots past the last candidate of the batch that is needed (lists are compacted to the front: a shard that keeps fewer than
@@ -2752,16 +2781,35 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
         }
         if (lane < SR) cd[SR * bt + lane] = my_id == 0xFFFFFFFFu ? __builtin_inff() : (metric == ZVDB_METRIC_L2SQ ? sum : -sum);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my LDS reads of the stage are done before the next batch refills it
-        if (cert.kth && bt + 1 < NB) {
-            const float dk = cert_kth_dist(cd, ci, (uint32_t)SR * (bt + 1), k, dk_slot, lane);
-            ks = cert_safe_key(cert, cq, dk, dim, metric);
-        }
     }
     __syncthreads();
+    if (prof) tstamp[2] = __builtin_amdgcn_s_memtime();
     if (cert.kth) {
+        for (uint32_t base = SR; base < kc; base += kWave) {
+            const float dk0 = cert_kth_dist(cd, ci, base, k, dk_slot, lane);
+            ks = cert_safe_key(cert, cq, dk0, dim, metric);
+            const uint32_t i = base + lane;
+            const uint32_t id = i < kc ? ci[i] : 0xFFFFFFFFu;
+            const bool need = id != 0xFFFFFFFFu && ck[i] <= ks;
+            if (i < kc && !need) ci[i] = 0xFFFFFFFFu;  // provably outside the top-k: not evaluated, not ranked
+            if (__ballot(need) == 0) {  // sorted lists: nothing further can be needed
+                for (uint32_t j = base + kWave + lane; j < kc; j += kWave) ci[j] = 0xFFFFFFFFu;
+                break;
+            }
+            if (need) cd[i] = exact_dist_rt(metric, q, rows + (size_t)id * ld, dim);
+            __syncthreads();
+        }
+        __syncthreads();
+        if (prof) tstamp[3] = __builtin_amdgcn_s_memtime();
         const float dk = cert_kth_dist(cd, ci, kc, k, dk_slot, lane);
         ks = cert_safe_key(cert, cq, dk, dim, metric);
-        cert_verdict(cert, qi, ks, lane);
+        if (prof) tstamp[4] = __builtin_amdgcn_s_memtime();
+        uint32_t nev = 0;
+        if (cert.dbg_rows) {
+#pragma unroll
+            for (int bt = 0; bt < NE; ++bt) nev += (uint32_t)__popcll(__ballot(ci[64 * bt + lane] != 0xFFFFFFFFu));
+        }
+        cert_verdict(cert, qi, ks, lane, nev);
     }
     uint32_t total = 0;
 #pragma unroll
@@ -2770,11 +2818,7 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
         const bool valid = my_id != 0xFFFFFFFFu;
         if (valid) {
             const float di = cd[64 * bt + lane];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < kc; ++j) {
-                const uint32_t ij = ci[j];
-                if (ij != 0xFFFFFFFFu && lex_less(cd[j], ij, di, my_id)) ++rank;
-            }
+            const uint32_t rank = lex_rank4(cd, ci, kc, di, my_id);
             if (rank < k) {
                 out_ids[(size_t)qi * k + rank] = (uint64_t)my_id + id_offset;
                 out_dist[(size_t)qi * k + rank] = di;
@@ -2788,6 +2832,11 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
         out_dist[(size_t)qi * k + i] = __builtin_inff();
     }
     if (lane == 0) out_count[qi] = nres;
+    if (prof && lane == 0) {
+        tstamp[5] = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 5; ++i)
+            __hip_atomic_fetch_add(cert.dbg_rows + 1 + i, (uint32_t)(tstamp[i + 1] - tstamp[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, const uint32_t *d_cand,
@@ -2795,7 +2844,7 @@ int launch_rerank(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, 
                   uint32_t *d_count, hipStream_t s, uint32_t kp_valid, const CertArgs *cert_in) {
     if (nq == 0) return ZVDB_OK;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    static const bool staged_off = [] { const char *e = getenv("ZVDB_RERANK"); return e && e[0] == 'v' && e[1] == '1'; }();
+    const bool staged_off = [] { const char *e = tuning("ZVDB_RERANK"); return e && e[0] == 'v' && e[1] == '1'; }();
     const CertArgs cert = cert_in ? *cert_in : CertArgs{};
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;

@@ -251,6 +251,7 @@ size_t gb_lds_bytes(uint32_t dim) {
 template <class F>
 int gb_self_knn(zvdb_hip_index *src, uint32_t k, uint32_t mode, F consume) {
     const uint32_t B = 1024;
+    CertPause no_cert(src);  // (common.h: the builders' kNN passes run uncertified)
     const size_t ib = round_up64((size_t)B * k * 8, 256), db = round_up64((size_t)B * k * 4, 256);
     const size_t cb = round_up64((size_t)B * 4, 256), qb = round_up64((size_t)B * src->dim * 4, 256);
     const uint64_t wsb = bruteforce_workspace_bytes(src, B, k, mode);

@@ -371,7 +371,7 @@ class HNSW<float> {
     std::vector<std::vector<std::vector<size_t>>> conns_;    // Node.connections
     std::vector<uint64_t> ids_, out_ids_, l0_, b_ep_, b_lists_;
     std::vector<uint32_t> b_epn_, b_on_, lv_, nrec_, recs_;
-    bool device_layers_ = [] { const char *e = std::getenv("ZVDB_HOST_INSERT"); return !(e && e[0] == 's'); }();
+    bool device_layers_ = [] { const char *e = zvdb_hip_get_tuning("ZVDB_HOST_INSERT"); return !(e && e[0] == 's'); }();
     std::vector<float> b_dist_;
     std::vector<float> dist_, out_dist_, last_dist_;
     zvdb_hip_search_stats last_stats_{};
