@@ -332,7 +332,15 @@ enum zvdb_option {
     ZVDB_OPT_CERT_MIN_LEVEL = 2,
     /* 1: every query is sent through the exact scan whatever the certificate says (tests of the repair path; results are the
      * same by definition, only slower) */
-    ZVDB_OPT_CERT_FORCE_REPAIR = 3
+    ZVDB_OPT_CERT_FORCE_REPAIR = 3,
+    /* 1 (default) .. 4: SEARCH WIDTH of the ef-mode beam search -- the number of unexpanded beam entries taken per step: all of them
+     * are marked expanded, then their neighbour lists are read TOGETHER (width lists' worth of row fetches per dependent step
+     * instead of one list's: the search is a chain of dependent steps, so on a GPU its rate is bytes in flight per step).
+     * Specification: orc_hnsw_search_ef_w in oracle/zvdb_oracle.h, matched bit for bit (ids, distances, E / P counters); width 1
+     * is the plain beam search.  Recall at equal ef is the same to within noise; E grows by a few per cent (nodes that a
+     * step's own insertions would have pushed past position ef are expanded anyway).  No reference counterpart (hnsw.zig:211-224
+     * pops one node at a time); ef = 0 (reference-compat search) ignores it. */
+    ZVDB_OPT_EF_SEARCH_WIDTH = 4
 };
 int zvdb_hip_index_set_option(zvdb_hip_index *h, uint32_t option, uint64_t value);
 

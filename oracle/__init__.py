@@ -75,6 +75,8 @@ def lib():
     L.orc_hnsw_search_many.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p, u64p]
     L.orc_hnsw_search_ef_ex.restype = C.c_size_t
     L.orc_hnsw_search_ef_ex.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, u64p, f32p]
+    L.orc_hnsw_search_ef_w.restype = C.c_size_t
+    L.orc_hnsw_search_ef_w.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, u64p, f32p]
     L.orc_hnsw_search_ef.restype = C.c_size_t
     L.orc_hnsw_search_ef.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, u64p, f32p]
     L.orc_hnsw_count.restype = C.c_size_t
@@ -215,13 +217,14 @@ class HNSW:
             x.join()
         return ids, dist, n
 
-    def search_ef(self, query, k: int, ef: int, metric: int = 0, entry: int = 0) -> Tuple[np.ndarray, np.ndarray]:
-        """ef-mode beam search (extension; the spec of k_search_ef): metric 0 = squared L2, 1 = inner product."""
+    def search_ef(self, query, k: int, ef: int, metric: int = 0, entry: int = 0, width: int = 1) -> Tuple[np.ndarray, np.ndarray]:
+        """ef-mode beam search (extension; the spec of k_search_ef): metric 0 = squared L2, 1 = inner product; width = nodes
+        expanded per step (orc_hnsw_search_ef_w; 1 = the plain search)."""
         q = _f32(query)
         ids = np.zeros(max(k, 1), dtype=np.uint64)
         dist = np.zeros(max(k, 1), dtype=np.float32)
-        n = self._L.orc_hnsw_search_ef_ex(self._h, _p(q, C.c_float), q.size, k, ef, metric, entry,
-                                          _p(ids, C.c_uint64), _p(dist, C.c_float))
+        n = self._L.orc_hnsw_search_ef_w(self._h, _p(q, C.c_float), q.size, k, ef, metric, entry, width,
+                                         _p(ids, C.c_uint64), _p(dist, C.c_float))
         return ids[:n].copy(), dist[:n].copy()
 
     def descend(self, query, metric: int = 0, top: int = 0) -> int:

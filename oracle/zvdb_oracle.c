@@ -432,6 +432,16 @@ static int lex_less(float da, uint64_t ia, float db, uint64_t ib) {
 
 size_t orc_hnsw_search_ef_ex(orc_hnsw *h, const float *query, size_t d, size_t k, size_t ef, int metric, size_t entry,
                              uint64_t *out_ids, float *out_dist) {
+    return orc_hnsw_search_ef_w(h, query, d, k, ef, metric, entry, 1, out_ids, out_dist);
+}
+
+/* The same beam search with a SEARCH WIDTH (extension of the extension; zvdb_oracle.h): every iteration takes the first `width`
+ * unexpanded entries of W (in W's order) at once -- all marked expanded, each counted as a pop -- and only then walks their lists,
+ * one after the other in that order.  width = 1 is orc_hnsw_search_ef_ex. */
+size_t orc_hnsw_search_ef_w(orc_hnsw *h, const float *query, size_t d, size_t k, size_t ef, int metric, size_t entry, size_t width,
+                            uint64_t *out_ids, float *out_dist) {
+    if (width == 0) width = 1;
+    if (width > 8) width = 8;
     if (!h->has_entry || k == 0 || ef == 0 || d != h->dim || entry >= h->count) return 0;
     if (ef < k) ef = k;
     float *wd = (float *)malloc(ef * sizeof(float));
@@ -447,12 +457,13 @@ size_t orc_hnsw_search_ef_ex(orc_hnsw *h, const float *query, size_t d, size_t k
     visited[entry] = 1;
 
     for (;;) {
-        size_t c = 0;
-        while (c < wn && wx[c]) ++c;
-        if (c == wn) break;
-        wx[c] = 1;
-        h->ctr.search_pops += 1;
-        const idlist *lst = &h->nodes[wi[c]].conn[0];
+        size_t sel[8], ns = 0;
+        for (size_t c = 0; c < wn && ns < width; ++c)
+            if (!wx[c]) { wx[c] = 1; sel[ns++] = (size_t)wi[c]; }
+        if (ns == 0) break;
+        h->ctr.search_pops += ns;
+        for (size_t s = 0; s < ns; ++s) {
+        const idlist *lst = &h->nodes[sel[s]].conn[0];
         for (size_t i = 0; i < lst->len; ++i) {
             const size_t nb = (size_t)lst->items[i];
             if (visited[nb]) continue;
@@ -467,6 +478,7 @@ size_t orc_hnsw_search_ef_ex(orc_hnsw *h, const float *query, size_t d, size_t k
                 --pos;
             }
             wd[pos] = dn; wi[pos] = nb; wx[pos] = 0;
+        }
         }
     }
     const size_t nres = wn < k ? wn : k;

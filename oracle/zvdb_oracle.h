@@ -98,6 +98,14 @@ size_t orc_hnsw_search_ef(orc_hnsw *h, const float *query, size_t d, size_t k,
 float orc_neg_dot_blocked16_f32(const float *a, const float *b, size_t d);
 size_t orc_hnsw_search_ef_ex(orc_hnsw *h, const float *query, size_t d, size_t k, size_t ef, int metric, size_t entry,
                              uint64_t *out_ids, float *out_dist);
+/* ... with a SEARCH WIDTH w (1 .. 8; the specification of ZVDB_OPT_EF_SEARCH_WIDTH): the step "c = first entry of W not yet
+ * expanded" becomes "c_1 .. c_j = the first j <= w entries of W not yet expanded (none -> stop); mark ALL of them expanded
+ * (j pops)", then the neighbour lists of c_1, ..., c_j are walked one after the other exactly as above (visited test, distance,
+ * insertion into W).  A node picked in a step stays picked whatever its step's insertions do to W.  w = 1 is the search above;
+ * w > 1 gives a GPU w lists' worth of row fetches per dependent step (the reference has no counterpart: hnsw.zig:211-224 pops
+ * one node at a time). */
+size_t orc_hnsw_search_ef_w(orc_hnsw *h, const float *query, size_t d, size_t k, size_t ef, int metric, size_t entry, size_t width,
+                            uint64_t *out_ids, float *out_dist);
 
 size_t orc_hnsw_count(const orc_hnsw *h);
 size_t orc_hnsw_dim(const orc_hnsw *h);

@@ -84,7 +84,8 @@ int main(int argc, char **argv) {
         CHECK(zvdb_hip_count(h, &count));
         CHECK(zvdb_hip_dim(h, &got_dim));
         EXPECT(count == n && got_dim == dim);
-        for (i = 0; i < n; ++i) EXPECT(nrec[i] >= 1 && nrec[i] <= levels[i] + 1);
+        EXPECT(nrec[0] == 0); /* the first node links to nothing (hnsw.zig:110-112) */
+        for (i = 1; i < n; ++i) EXPECT(nrec[i] >= 1 && nrec[i] <= levels[i] + 1);
         /* search (hnsw.zig:194-236), reference-compat mode, queries = rows of the index: each finds itself first at distance 0 */
         CHECK(zvdb_hip_search_graph(h, rows, nq, dim, k, 0, 0, ids, dist, cnt, &st));
         EXPECT(st.dist_evals > 0 && st.pops > 0);

@@ -2,6 +2,8 @@
 # kNN graphs: ids, distances, counts and evaluation / pop counters bit for bit, on fp32 and on bf16 rows, through BOTH beam
 # kernels (registers for ef <= 512, LDS beyond or with ZVDB_EF_BEAM=lds); both metrics of the spec (squared L2 and inner product,
 # orc_hnsw_search_ef_ex's `metric`), k up to 100, rows up to 1536 dimensions (BASELINE configs[4]: 1536-d, k = 100, ef = 256).
+# Search widths 1 .. 4 (ZVDB_OPT_EF_SEARCH_WIDTH) against orc_hnsw_search_ef_w: the side-by-side window of the register-beam kernel
+# (width x stride <= 64) and the list-by-list form (wider strides, the LDS-beam kernel, the retry / net passes).
 # usage: python tests/manual/fuzz_ef.py [cases] [seed]
 import sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -38,6 +40,8 @@ for c in range(cases):
     ok = True
     for _ in range(3):
         k = int(rng.choice([1, 5, 10, 25, 60, 100]))
+        width = int(rng.choice([1, 1, 2, 3, 4]))  # search width (ZVDB_OPT_EF_SEARCH_WIDTH; spec: orc_hnsw_search_ef_w)
+        idx.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
         ef = int(max(k, rng.choice([1, 10, 33, 64, 100, 128, 129, 200, 256, 300, 512, 600])))
         try:
             ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
@@ -67,16 +71,16 @@ for c in range(cases):
             print(f"case {c}: the two beam kernels differ: ids {np.array_equal(ids, ids2)} dist {np.array_equal(dist, dist2)} cnt {np.array_equal(cnt, cnt2)} "
                   f"stats reg {(ev, pp)} lds {(ev2, pp2)}", flush=True)
             ref.reset_counters()
-            r = [ref.search_ef(q, k, ef, om) for q in Q]
+            r = [ref.search_ef(q, k, ef, om, 0, width) for q in Q]
             cs = ref.counters()
             print("   oracle stats", (cs.search_dist_evals, cs.search_pops), "reg rows equal:", [bool(np.array_equal(ids[i, :len(r[i][0])], r[i][0])) for i in range(len(Q))],
                   "lds rows equal:", [bool(np.array_equal(ids2[i, :len(r[i][0])], r[i][0])) for i in range(len(Q))], flush=True)
         ref.reset_counters()
         for qi, q in enumerate(Q):
-            ri, rd = ref.search_ef(q, k, ef, om)
+            ri, rd = ref.search_ef(q, k, ef, om, 0, width)
             if not (cnt[qi] == len(ri) and np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd)): ok = False
         cs = ref.counters()
         if (ev, pp) != (cs.search_dist_evals, cs.search_pops): ok = False
-        if not ok: print(f"MISMATCH case {c}: n={n} d={d} m={m} ties={ties} bf16_rows={hb} dot={dot} k={k} ef={ef}", flush=True); break
+        if not ok: print(f"MISMATCH case {c}: n={n} d={d} m={m} ties={ties} bf16_rows={hb} dot={dot} k={k} ef={ef} width={width}", flush=True); break
     bad += 0 if ok else 1
 print("done:", cases, "cases,", bad, "mismatches")

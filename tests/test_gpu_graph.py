@@ -58,6 +58,40 @@ def test_bulk_graph_equals_the_oracle_spec(zv, oracle, n, d, M, efc, metric, tie
         assert (ev, pp) == (c.search_dist_evals, c.search_pops), (k, ef)
 
 
+@pytest.mark.parametrize("width", [2, 3, 4])
+@pytest.mark.parametrize("M,bf16rows,metric", [(8, False, "l2"), (16, True, "l2"), (8, False, "dot")])
+def test_search_width_equals_the_oracle_spec(zv, oracle, width, M, bf16rows, metric):
+    """ZVDB_OPT_EF_SEARCH_WIDTH = w: the beam search takes the first w unexpanded entries per step (spec: orc_hnsw_search_ef_w) --
+    ids, distances, counts and the E / P counters bit for bit, entered by descent on the bulk graph: layer-0 stride 16 (w lists side
+    by side in one window) and 32 (w = 3, 4 fall back to list by list), fp32 and bf16 rows, both metrics, small and large ef (the
+    LDS-beam kernel beyond 1,024), and with the visited table forced tiny (retry + net passes)."""
+    n, d, efc = 4000, 40, 48
+    m = {"l2": zv.METRIC_L2SQ, "dot": zv.METRIC_DOT}[metric]
+    om = 0 if metric == "l2" else 1
+    rng = np.random.default_rng(100 * width + M)
+    V = rng.random((n, d), dtype=np.float32) - np.float32(0.0 if metric == "l2" else 0.5)
+    if bf16rows:
+        V = oracle.bf16_round(V)
+    idx = zv.Index(metric=m, m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_ROWS if bf16rows else zv.FLAG_BF16_MIRROR)
+    idx.add(V)
+    idx.build_graph(M, efc, zv.BF_I8, 21)
+    ref, levels, top = oracle.build_bulk_graph(V, M, efc, 21, metric=om)
+    idx.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
+    Q = rng.random((48, d), dtype=np.float32) - np.float32(0.0 if metric == "l2" else 0.5)
+    for k, ef, tune in ((10, 16, {}), (10, 128, {}), (50, 300, {}), (10, 1100, {}), (10, 96, {"ZVDB_EF_TWO_PASS": "t8"}),
+                        (10, 96, {"ZVDB_EF_HASH_BITS": "8", "ZVDB_EF_TWO_PASS": "0"}), (10, 64, {"ZVDB_EF_BEAM": "lds"})):
+        with zv.tuned(**tune):
+            ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, entry=zv.ENTRY_DESCEND, with_stats=True)
+        ref.reset_counters()
+        for qi, q in enumerate(Q):
+            ent = ref.descend(q, om, top)
+            ri, rd = ref.search_ef(q, k, ef, om, ent, width)
+            assert cnt[qi] == len(ri), (k, ef, tune, qi)
+            assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd), (k, ef, tune, qi)
+        c = ref.counters()
+        assert (ev, pp) == (c.search_dist_evals, c.search_pops), (k, ef, tune)
+
+
 def test_bulk_graph_recall_beats_the_knn_graph(zv, oracle):
     """What the builder is for: with the SAME parameter M and at the same ef, the heuristic + reverse-link graph entered by
     descent out-recalls the directed exact M-NN lists entered at node 0 (measured 0.79 vs 0.62 at ef = 128 on 20k x 128

@@ -36,7 +36,7 @@ class CertInfo(C.Structure):
                 ("rerank_cycles", C.c_uint32 * 5), ("reserved_", C.c_uint32)]
 
 
-OPT_CERTIFY, OPT_CERT_MIN_LEVEL, OPT_CERT_FORCE_REPAIR = 1, 2, 3
+OPT_CERTIFY, OPT_CERT_MIN_LEVEL, OPT_CERT_FORCE_REPAIR, OPT_EF_SEARCH_WIDTH = 1, 2, 3, 4
 
 
 # every symbol include/zvdb_hip.h declares: (name, restype, argtypes)

@@ -1643,6 +1643,11 @@ int zvdb_hip_index_set_option(zvdb_hip_index *h, uint32_t option, uint64_t value
         ZV_ARG(value <= 3, "ZVDB_OPT_CERT_MIN_LEVEL takes 0 .. 3");
         h->cert_level_min = (uint32_t)value;
         return ZVDB_OK;
+    case ZVDB_OPT_EF_SEARCH_WIDTH:
+        ZV_ARG(value >= 1 && value <= 4, "ZVDB_OPT_EF_SEARCH_WIDTH takes 1 .. 4");
+        h->ef_width = (uint32_t)value;
+        ef_hint_reset(h, h->stream);  // (the visited-set fills recorded so far belong to the other width)
+        return ZVDB_OK;
     case ZVDB_OPT_CERT_FORCE_REPAIR:
         ZV_ARG(value <= 1, "ZVDB_OPT_CERT_FORCE_REPAIR takes 0 or 1");
         h->cert_force = value != 0;

@@ -187,6 +187,7 @@ struct zvdb_hip_index {
     uint32_t ins_seq = 0;
     bool own_stream_busy = false;  // a fused insert left its finalize kernel running on h->stream (see settle_own_stream)
     uint32_t screen_survivors = 0;  // zvdb_hip_index_set_screen_survivors: minimum k' of the fp4 screen (0 = from k)
+    uint32_t ef_width = 1;     // ZVDB_OPT_EF_SEARCH_WIDTH: nodes the ef-mode beam search expands per step (1 .. 4)
     uint32_t shard_count = 1;  // zvdb_hip_index_set_shard_count: the approximate screen keeps its share of the survivors
     // exactness certificate of the brute-force screens (bf_cert.h): per screen mode {largest residual |x' - x|, largest |x'|} of the
     // mirror (device words; data_kernels.hip: ensure_cert_stats), valid while cert_count[mode] == count

@@ -1548,7 +1548,7 @@ __device__ __forceinline__ void ef_search_one(
     uint64_t id_offset, uint64_t *__restrict__ out_ids, float *__restrict__ out_dist,
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries, uint32_t pass, uint32_t *__restrict__ fill_hint,
-    uint32_t *hash_g, uint32_t qi, uint32_t *net_list, unsigned char *smem) {
+    uint32_t *hash_g, uint32_t qi, uint32_t *net_list, unsigned char *smem, uint32_t width) {
     if ((pass == kEfRetry || pass == kEfRetryMark) && out_count[qi] != kEfAgain) return;  // served by an earlier pass
     if (entries) entry = entries[qi];
     float *q = reinterpret_cast<float *>(smem);
@@ -1594,17 +1594,26 @@ __device__ __forceinline__ void ef_search_one(
         for (;;) {
             uint64_t *W = wk + cur * efp;
             uint32_t *X = wx + cur * efp;
-            // next to expand: the smallest unexpanded key
-            uint64_t lm = ~0ull;
-            uint32_t li = 0;  // slot of this lane's smallest unexpanded key
-            for (uint32_t i = lane; i < wn; i += kWave)
-                if (X[i] == 0 && W[i] < lm) { lm = W[i]; li = i; }
-            const uint64_t kbest = wave_min64(lm);
-            if (kbest == ~0ull) break;
-            if (lm == kbest) X[li] = 1;  // (keys are distinct: one lane)
-            const uint32_t cid = (uint32_t)kbest;
-            pops += 1;
+            // next to expand: the smallest unexpanded key -- with a search width (orc_hnsw_search_ef_w) the `width` smallest, all marked
+            // expanded before any list is read; their lists are then walked one after the other (the spec's own order)
+            uint32_t cids[4] = {0, 0, 0, 0}, nsel = 0;
+            for (uint32_t w = 0; w < width && w < 4; ++w) {
+                uint64_t lm = ~0ull;
+                uint32_t li = 0;  // slot of this lane's smallest unexpanded key
+                for (uint32_t i = lane; i < wn; i += kWave)
+                    if (X[i] == 0 && W[i] < lm) { lm = W[i]; li = i; }
+                const uint64_t kbest = wave_min64(lm);
+                if (kbest == ~0ull) break;
+                if (lm == kbest) X[li] = 1;  // (keys are distinct: one lane)
+                cids[w] = (uint32_t)kbest;
+                nsel = w + 1;
+                __syncthreads();
+            }
+            if (nsel == 0) break;
+            pops += nsel;
             stamp(0);  // next-to-expand scan
+            for (uint32_t sidx = 0; sidx < nsel; ++sidx) {
+            const uint32_t cid = cids[sidx];
             // the degree and the first 64 list slots are requested TOGETHER (both depend on cid only): one memory round trip per
             // pop instead of two (slots past the degree hold stale or zero ids and are masked below)
             const uint32_t nb_first = (uint32_t)lane < gstride ? adj[(size_t)cid * gstride + lane] : 0u;
@@ -1716,6 +1725,7 @@ __device__ __forceinline__ void ef_search_one(
                 }
                 stamp(3);  // beam update (append / radix select)
             }
+            }
         }
         __syncthreads();
     }
@@ -1789,7 +1799,7 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
     uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t *ghash, uint32_t qoff,
-    uint32_t *net_list /* LDS passes: marks are appended here (may be null); GH: non-null = the net launch */, uint32_t /* unused */) {
+    uint32_t *net_list /* LDS passes: marks are appended here (may be null); GH: non-null = the net launch */, uint32_t width /* nodes expanded per step */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (GH) {
         uint32_t *table = ghash + ((size_t)blockIdx.x << hash_bits);
@@ -1805,15 +1815,15 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 __threadfence();
                 __syncthreads();
                 ef_search_one<RT, PROF, true>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, ef, entry, id_offset, out_ids, out_dist, out_count,
-                                              stats, dim_pad, hash_bits, efp, entries, pass, fill_hint, table, qi, nullptr, smem);
+                                              stats, dim_pad, hash_bits, efp, entries, pass, fill_hint, table, qi, nullptr, smem, width);
                 __syncthreads();
             }
         }
         ef_search_one<RT, PROF, true>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, ef, entry, id_offset, out_ids, out_dist, out_count, stats,
-                                      dim_pad, hash_bits, efp, entries, pass, fill_hint, table, blockIdx.x + qoff, nullptr, smem);
+                                      dim_pad, hash_bits, efp, entries, pass, fill_hint, table, blockIdx.x + qoff, nullptr, smem, width);
     } else {
         ef_search_one<RT, PROF, false>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, ef, entry, id_offset, out_ids, out_dist, out_count, stats,
-                                       dim_pad, hash_bits, efp, entries, pass, fill_hint, nullptr, blockIdx.x + qoff, net_list, smem);
+                                       dim_pad, hash_bits, efp, entries, pass, fill_hint, nullptr, blockIdx.x + qoff, net_list, smem, width);
     }
 }
 
@@ -1854,7 +1864,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_size /* slots of the visited table: any count >= 256 */, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
     uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */,
-    uint32_t *net_list /* marks are appended here (the last LDS pass of a call; else null) */, uint32_t /* unused */) {
+    uint32_t *net_list /* marks are appended here (the last LDS pass of a call; else null) */, uint32_t width /* nodes expanded per step: 1 .. 4 */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if ((pass == kEfRetry || pass == kEfRetryMark) && out_count[blockIdx.x] != kEfAgain) return;  // served by an earlier pass
     if (entries) entry = entries[blockIdx.x];
@@ -1956,47 +1966,40 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
         hash_used = 1;
         sync_w();
         for (;;) {
-            // next to expand: the first unexpanded slot
-            uint32_t slot = kWave * EPL;
+            // next to expand: the first unexpanded slots of W -- one (the search of orc_hnsw_search_ef_ex) or, with a search width
+            // (ZVDB_OPT_EF_SEARCH_WIDTH; spec: orc_hnsw_search_ef_w), up to `width` of them, ALL marked expanded before any of
+            // their lists is read
+            uint32_t cids[4] = {0, 0, 0, 0}, nsel = 0;
 #pragma unroll
-            for (int e = EPL - 1; e >= 0; --e)
-                if (~xm[e] != 0ull) slot = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
-            if (slot >= wn) break;
-            uint64_t kbest = 0;
+            for (uint32_t w = 0; w < 4; ++w) {
+                if (w >= width) break;
+                uint32_t slot = kWave * EPL;
 #pragma unroll
-            for (int e = 0; e < EPL; ++e)
-                if (slot >> 6 == (uint32_t)e) { kbest = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
-            const uint32_t cid = (uint32_t)kbest;
-            pops += 1;
-            stamp(0);  // next-to-expand
-            // one vector load brings the first list slots AND the degree (lane 63 reads deg[cid] when the stride leaves it free) --
-            // or brought them already: the list of the NEXT unexpanded slot is requested speculatively a whole distance phase
-            // ahead (below); it is this pop's node unless a candidate of the previous pop went in before it
-            uint32_t nb_first, dg_all;  // lists longer than 64 are walked 64 entries at a time
-            if (cid == pre_id) {
-                nb_first = pre_list;
-                if constexpr (PROF) pre_hits += 1;
-            } else {
-                nb_first = *((uint32_t)lane < gstride ? adj + (size_t)cid * gstride + lane : deg + cid);
+                for (int e = EPL - 1; e >= 0; --e)
+                    if (~xm[e] != 0ull) slot = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
+                if (slot >= wn) break;
+                uint64_t kb = 0;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e)
+                    if (slot >> 6 == (uint32_t)e) { kb = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
+                cids[w] = (uint32_t)kb;
+                nsel = w + 1;
             }
-            dg_all = gstride < kWave ? (uint32_t)__builtin_amdgcn_readlane((int)nb_first, kWave - 1) : deg[cid];
-            pre_id = 0xFFFFFFFFu;
-            if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); list_wait += n - pt + (dg_all & 0u); }
-            for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
-                const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
+            if (nsel == 0) break;
+            pops += nsel;
+            stamp(0);  // next-to-expand
+            // one window: <= 64 list entries (one lane each) -> visited test-and-set, the fresh ones compacted, their distances (shared
+            // with the helper waves), the beam update.  false: the visited table is full and a later launch serves the query.
+            auto window = [&](bool valid, uint32_t nbl, uint32_t cnt, bool prefetch_ok) -> bool {
                 sync_w();
                 if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
                 if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
                     if (lane == 0) ef_mark_again(out_count, qi, net_list);
                     release_helpers();
-                    return;
+                    return false;
                 }
-                uint32_t nbl = 0;
                 bool fresh1 = false;
-                if ((uint32_t)lane < cnt && !overflow) {
-                    nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
-                    fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
-                }
+                if (valid && !overflow) fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
                 // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
                 // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
                 const unsigned long long fb0 = __ballot(fresh1);
@@ -2009,7 +2012,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                 } else {
                     sync_w();
                 }
-                if (lbase == 0 && gstride < kWave) {  // speculative list request for the next pop, in flight during the distance phase (47 % of
+                if (prefetch_ok && gstride < kWave) {  // speculative list request for the next pop, in flight during the distance phase (47 % of
                                                       // pops use it at 1M x 768, ef = 128: +1.7 % QPS on bf16 rows, +0.7 % on fp32, A/B on one box)
                     uint32_t slot2 = kWave * EPL;
 #pragma unroll
@@ -2023,7 +2026,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                     }
                 }
                 stamp(1);  // degree + list load + visited test-and-set
-                if (nf == 0) continue;
+                if (nf == 0) return true;
                 ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, nf, nb_i, nb_d, lane, 0);
                 hash_used += nf;
                 evals += nf;
@@ -2080,6 +2083,43 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                     }
                 }
                 stamp(3);  // beam update
+                return true;
+            };
+            if (nsel > 1 && nsel * gstride <= (uint32_t)kWave) {
+                // the lists of all picked nodes side by side in ONE window (lane = list w, entry j): w lists' worth of row fetches per
+                // dependent step.  The beam is a set, so merging the candidates together equals the spec's list-by-list insertion.
+                const uint32_t w = (uint32_t)lane / gstride, j = (uint32_t)lane - w * gstride;
+                const bool live = w < nsel;
+                const uint32_t cw = w == 0 ? cids[0] : w == 1 ? cids[1] : w == 2 ? cids[2] : cids[3];
+                uint32_t nbl = 0, dgw = 0;
+                if (live) { nbl = adj[(size_t)cw * gstride + j]; dgw = min(deg[cw], gstride); }
+                pre_id = 0xFFFFFFFFu;
+                const bool valid = live && j < dgw;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+                if (cnt != 0 && !window(valid, nbl, cnt, false)) return;
+            } else {
+                for (uint32_t s = 0; s < nsel; ++s) {
+                    const uint32_t cid = cids[s];
+                    // one vector load brings the first list slots AND the degree (lane 63 reads deg[cid] when the stride leaves it free) --
+                    // or brought them already: the list of the NEXT unexpanded slot is requested speculatively a whole distance phase
+                    // ahead (in `window`); it is this pop's node unless a candidate of the previous pop went in before it
+                    uint32_t nb_first, dg_all;  // lists longer than 64 are walked 64 entries at a time
+                    if (cid == pre_id) {
+                        nb_first = pre_list;
+                        if constexpr (PROF) pre_hits += 1;
+                    } else {
+                        nb_first = *((uint32_t)lane < gstride ? adj + (size_t)cid * gstride + lane : deg + cid);
+                    }
+                    dg_all = gstride < kWave ? (uint32_t)__builtin_amdgcn_readlane((int)nb_first, kWave - 1) : deg[cid];
+                    pre_id = 0xFFFFFFFFu;
+                    if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); list_wait += n - pt + (dg_all & 0u); }
+                    for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
+                        const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
+                        const bool valid = (uint32_t)lane < cnt;
+                        const uint32_t nbl = !valid ? 0u : lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
+                        if (!window(valid, nbl, cnt, lbase == 0 && width == 1)) return;
+                    }
+                }
             }
         }
         sync_w();
@@ -2254,6 +2294,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                      float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, const uint32_t *d_entries,
                      bool reserve_only) {
     if (nq == 0) return ZVDB_OK;
+    const uint32_t width = std::max(1u, std::min(4u, h->ef_width));  // ZVDB_OPT_EF_SEARCH_WIDTH (spec: orc_hnsw_search_ef_w)
     if (ef < k) ef = k;
     const uint64_t N = h->count;
     // q in LDS: zero padded to the rows' padded length for bf16 rows (the unmasked 8-lane walk reads whole 128-byte lines)
@@ -2360,7 +2401,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
-                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, net_list, 0u);
+                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, net_list, width);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
@@ -2375,7 +2416,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                 ZV_HIP(hipMemsetAsync(h->ef_visit_buf, 0, (size_t)nc * tb, s));
                 hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(nc), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                    d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, gbits, efp, d_entries,
-                                   pass, h->ef_hint_dev + bucket, h->ef_visit_buf, (uint32_t)q0, static_cast<uint32_t *>(nullptr), 0u);
+                                   pass, h->ef_hint_dev + bucket, h->ef_visit_buf, (uint32_t)q0, static_cast<uint32_t *>(nullptr), width);
                 ZV_HIP(hipGetLastError());
             }
             return ZVDB_OK;
@@ -2389,7 +2430,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 0, true>), lds));
             hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(kEfNetBlocks), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride,
                                (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, ef_net_bits(h, ef), efp, d_entries,
-                               (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_net_buf + h->ef_net_list_words, 0u, h->ef_net_buf, 0u);
+                               (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_net_buf + h->ef_net_list_words, 0u, h->ef_net_buf, width);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
