@@ -58,6 +58,7 @@ def parse_args():
                          "device, ef-mode beam search entered by descent; recall is measured against the (sharded) brute-force route")
     ap.add_argument("--row-dtype", choices=["f32", "bf16"], default="f32", help="row STORAGE of the index (bf16 = ZVDB_FLAG_BF16_ROWS: configs[3]-[4])")
     ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--search-width", type=int, default=4, help="graph route: ZVDB_OPT_EF_SEARCH_WIDTH (nodes expanded per step; 1 = plain beam search)")
     ap.add_argument("--graph-m", type=int, default=16)
     ap.add_argument("--graph-efc", type=int, default=64)
     ap.add_argument("--data", choices=["uniform", "rank12"], default="uniform",
@@ -244,7 +245,7 @@ def make_rows(zv, torch, g, n, dim, structured, dev, stream, nq, lo=0, hi=None):
     return q
 
 
-def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16_rows=False, M=16, efc=64, reps=5):
+def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16_rows=False, M=16, efc=64, reps=5, widths=(4, 1)):
     """The graph route (BASELINE configs[2]-[4]: HNSW M = 16, efSearch) on one GPU: bulk HNSW graph built on the device (M = 16:
     heuristic forward links over the `efc` exact nearest + reverse links, cut to 2 M; upper layers), ef-mode beam search entered by
     hierarchical descent (spec = the oracle, bit-exact: tests/test_gpu_graph.py), recall@k against the exact brute-force route of the
@@ -275,7 +276,10 @@ def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16
                     else "i.i.d. U[0,1) coordinates (the benchmark's generator, shared_benchmarks.zig:53-59)"),
            "recall_ground_truth": "int8 brute-force route of the same index (certified exact)", "ef": {}}
     g.search_graph_reserve(batch, k, max(efs))
-    for ef in efs:
+    # search width (ZVDB_OPT_EF_SEARCH_WIDTH; spec: orc_hnsw_search_ef_w): the first width is the leg's number, the others are reported
+    # beside it under "width<w>" (width 1 = the plain beam search, one node per step)
+    for ef, width in [(e, w) for e in efs for w in widths]:
+        g.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
         for _ in range(2):
             g.search_graph_dev(qg.data_ptr(), batch, dim, k, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
         st.zero_()
@@ -294,12 +298,18 @@ def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16
         g.timing_enable(False)
         kavg = kms / max(kn, 1) * 1e-3
         nbytes = ev * dim * elt + pp * 2 * M * 4
-        out["ef"][str(ef)] = {
+        rec_obj = {
+            "search_width": width,
             "qps": batch / el, "ms_per_batch": el * 1e3, f"recall_at_{k}": rec, "dist_evals_per_query": ev / batch, "pops_per_query": pp / batch,
             "roofline": {"bound": "hbm", "kernel": "k_search_ef_reg (exact_kernels.hip; + k_descend ahead of it, outside the timed kernel)",
                          "kernel_ms_avg": kavg * 1e3, "timed_launches": kn, "achieved": nbytes / kavg / 1e9 if kavg > 0 else 0.0, "peak": 8000.0,
                          "unit": "GB/s", "frac": nbytes / kavg / 8e12 if kavg > 0 else 0.0,
                          "algorithmic_bytes_per_launch": nbytes, "bytes_rule": "E d sizeof(elt) + P M0 4 (SURVEY 8d), E / P counted in-kernel"}}
+        if width == widths[0]:
+            out["ef"][str(ef)] = rec_obj
+        else:
+            out["ef"][str(ef)][f"width{width}"] = {kk: rec_obj[kk] for kk in ("qps", "ms_per_batch", f"recall_at_{k}", "dist_evals_per_query", "pops_per_query")}
+            out["ef"][str(ef)][f"width{width}"]["hbm_frac"] = rec_obj["roofline"]["frac"]
     return out
 
 
@@ -540,6 +550,7 @@ def main():
         idx.build_graph(GM, args.graph_efc, zv.BF_I8, 7)
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t0
+        idx.set_option(zv.OPT_EF_SEARCH_WIDTH, args.search_width)
         idx.search_graph_reserve(B, K, args.ef)
     # the collective: by default the C ABI's own RCCL communicator (zvdb_hip_comm: local search -> ncclAllGather -> merge in ONE library
     # call on this stream); ZVDB_BENCH_COLLECTIVE=torch keeps the all-gather in torch.distributed; the gloo rehearsal always does
@@ -778,7 +789,7 @@ def main():
         if graph:
             elt = 2 if bf16_rows else 4
             nbytes = g_ev * D * elt + g_pp * 2 * GM * 4
-            out["config"].update({"ef": args.ef, "M": GM, "ef_construction": args.graph_efc, "layer0_cap": 2 * GM, "entry": "hierarchical descent",
+            out["config"].update({"ef": args.ef, "search_width": args.search_width, "M": GM, "ef_construction": args.graph_efc, "layer0_cap": 2 * GM, "entry": "hierarchical descent",
                                   "graph_build_s": t_build, "graph_build_rows_per_s": n_local / t_build if t_build > 0 else None,
                                   "workload": (f"{N}x{D} {args.row_dtype} rows ({args.data}), batch={B}, k={K}: per-shard bulk HNSW graph (M={GM}, "
                                                f"layer 0 <= {2 * GM} links), ef={args.ef} beam search entered by descent; recall vs the sharded brute-force route"),

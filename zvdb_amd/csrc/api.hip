@@ -1159,15 +1159,13 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
             const uint32_t seq = ++h->ins_seq ? h->ins_seq : ++h->ins_seq;
             volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(hb + total);
             *flag = 0;
-            ZV_HIP(hipMemsetAsync(h->scratch, 0, 64, h->stream));
-            ZV_CHECK(launch_search_compat(h, reinterpret_cast<const float *>(dbs), 1, k, (uint32_t)entry, 0,
-                                          reinterpret_cast<uint64_t *>(dbs + qb), reinterpret_cast<float *>(dbs + qb + ib),
-                                          reinterpret_cast<uint32_t *>(dbs + qb + ib + db),
-                                          static_cast<unsigned long long *>(h->scratch), h->stream, h->tie_buf));
+            // ONE launch (exact_kernels.hip: k_search_compat_single): counters cleared, search, counters and the sequence word published
+            ZV_CHECK(launch_search_compat_single(h, reinterpret_cast<const float *>(dbs), k, (uint32_t)entry, reinterpret_cast<uint64_t *>(dbs + qb),
+                                                 reinterpret_cast<float *>(dbs + qb + ib), reinterpret_cast<uint32_t *>(dbs + qb + ib + db),
+                                                 static_cast<unsigned long long *>(h->scratch), h->tie_buf,
+                                                 reinterpret_cast<unsigned long long *>(dbs + qb + ib + db + cb), reinterpret_cast<uint32_t *>(dbs + total), seq,
+                                                 h->stream));
             ZV_CHECK(tie_end(h, h->stream));
-            ZV_CHECK(launch_publish(reinterpret_cast<unsigned long long *>(dbs + qb + ib + db + cb),
-                                    static_cast<const unsigned long long *>(h->scratch), 8,
-                                    reinterpret_cast<uint32_t *>(dbs + total), seq, h->stream));
             for (int spin = 0; spin < 40000 && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq; ++spin) __builtin_ia32_pause();
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) ZV_HIP(hipStreamSynchronize(h->stream));
             std::memcpy(out_ids, hb + qb, (size_t)k * 8);

@@ -271,6 +271,10 @@ int launch_greedy_layer0(const zvdb_hip_index *h, uint32_t owner, uint32_t *d_ep
 int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                          uint32_t entry, uint64_t id_offset, uint64_t *d_ids, float *d_dist,
                          uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, uint32_t *d_tie = nullptr /* [nq] scratch: enables the unordered-frontier kernel */);
+// one query, one launch: counters cleared, search (unordered frontier, heap emulation on ties), counters + sequence word published to host-mapped memory
+int launch_search_compat_single(const zvdb_hip_index *h, const float *d_query, uint32_t k, uint32_t entry, uint64_t *d_ids, float *d_dist,
+                                uint32_t *d_count, unsigned long long *d_stats, uint32_t *d_tie, unsigned long long *host_stats, uint32_t *seq_dst,
+                                uint32_t seq, hipStream_t s);
 void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s);
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,

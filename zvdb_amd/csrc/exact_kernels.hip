@@ -1087,15 +1087,13 @@ __device__ __forceinline__ void heap_remove(LdsHeap &hp, uint32_t &id, float &di
 
 // ---- a5/a6: reference-compat search (hnsw.zig:194-236) -------------------------
 template <typename RT>
-__global__ __launch_bounds__(64) void k_search_compat(
+__device__ __forceinline__ void compat_heap_body(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
     uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
     unsigned long long *__restrict__ stats, uint32_t dim_pad, uint32_t heap_cap, uint32_t hash_bits,
-    uint32_t rcap, const uint32_t *__restrict__ gate /* optional: run only the queries the fast kernel gave up on */) {
-    if (gate && gate[blockIdx.x] == 0) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t rcap, uint32_t qi_arg, unsigned char *smem) {
     float *q = reinterpret_cast<float *>(smem);
     float *heap_d = q + dim_pad;
     uint32_t *heap_i = reinterpret_cast<uint32_t *>(heap_d + heap_cap);
@@ -1106,7 +1104,7 @@ __global__ __launch_bounds__(64) void k_search_compat(
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
 
     const int lane = threadIdx.x;
-    const uint32_t qi = blockIdx.x;
+    const uint32_t qi = qi_arg;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
     for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
@@ -1187,14 +1185,13 @@ __global__ __launch_bounds__(64) void k_search_compat(
 // emulation runs it instead (gated launch right behind this one): identical results either way, ~10x fewer dependent LDS
 // round trips in the common case.
 template <typename RT>
-__global__ __launch_bounds__(64) void k_search_compat_fast(
+__device__ __forceinline__ bool compat_fast_body(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
     uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
     unsigned long long *__restrict__ stats, uint32_t dim_pad, uint32_t heap_cap, uint32_t hash_bits,
-    uint32_t rcap, uint32_t *__restrict__ tie) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t rcap, uint32_t *__restrict__ tie, uint32_t qi_arg, unsigned char *smem) {
     float *q = reinterpret_cast<float *>(smem);
     float *fr_d = q + dim_pad;
     uint32_t *fr_i = reinterpret_cast<uint32_t *>(fr_d + heap_cap);
@@ -1203,7 +1200,7 @@ __global__ __launch_bounds__(64) void k_search_compat_fast(
     uint32_t *res_i = reinterpret_cast<uint32_t *>(res_d + rcap);
 
     const int lane = threadIdx.x;
-    const uint32_t qi = blockIdx.x;
+    const uint32_t qi = qi_arg;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
     for (uint32_t i = lane; i < (1u << hash_bits); i += kWave) hash[i] = 0;
@@ -1283,7 +1280,7 @@ __global__ __launch_bounds__(64) void k_search_compat_fast(
     }
     if (gave_up) {
         if (lane == 0) tie[qi] = 1;
-        return;
+        return false;
     }
     if (lane == 0) tie[qi] = 0;
     __syncthreads();
@@ -1310,8 +1307,73 @@ __global__ __launch_bounds__(64) void k_search_compat_fast(
             atomicAdd(&stats[1], pops);
         }
     }
+    return true;
 }
 
+
+template <typename RT>
+__global__ __launch_bounds__(64) void k_search_compat(
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
+    uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
+    uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
+    unsigned long long *__restrict__ stats, uint32_t dim_pad, uint32_t heap_cap, uint32_t hash_bits,
+    uint32_t rcap, const uint32_t *__restrict__ gate /* optional: run only the queries the fast kernel gave up on */) {
+    if (gate && gate[blockIdx.x] == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    compat_heap_body<RT>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, entry, id_offset, out_ids, out_dist, out_count, stats, dim_pad,
+                         heap_cap, hash_bits, rcap, blockIdx.x, smem);
+}
+template <typename RT>
+__global__ __launch_bounds__(64) void k_search_compat_fast(
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
+    uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry, uint64_t id_offset,
+    uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
+    unsigned long long *__restrict__ stats, uint32_t dim_pad, uint32_t heap_cap, uint32_t hash_bits,
+    uint32_t rcap, uint32_t *__restrict__ tie) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    compat_fast_body<RT>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, entry, id_offset, out_ids, out_dist, out_count, stats, dim_pad,
+                         heap_cap, hash_bits, rcap, tie, blockIdx.x, smem);
+}
+// ONE query per call (the reference's calling pattern, hnsw.zig:194 / shared_benchmarks.zig:104-109), ONE launch: what the batched
+// route does with a memset, the unordered-frontier kernel, the gated heap emulation and a publish kernel -- four launches and an
+// event pair, ~15 us of a 57-us call (profiles/r4/per_call_*) -- in one wave: clear the counters, run the unordered-frontier search,
+// fall back to the PriorityQueue emulation if a pop's minimum was not unique, copy the counters next to the results (host-mapped
+// memory) and release the sequence word the host polls.
+template <typename RT>
+__global__ __launch_bounds__(64) void k_search_compat_single(
+    const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+    const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
+    uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry,
+    uint64_t *__restrict__ out_ids, float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
+    unsigned long long *__restrict__ stats /* device: 2 words */, uint32_t dim_pad, uint32_t heap_cap, uint32_t hash_bits,
+    uint32_t rcap, uint32_t *__restrict__ tie /* device: 1 word */, int fast_ok, unsigned long long *__restrict__ host_stats,
+    uint32_t *__restrict__ seq_dst, uint32_t seq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&stats[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&stats[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tie, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (one wave: its stores and atomics reach the L2 in program order, and a barrier waits for them -- no device-scope fence, which
+    // on this part writes the XCD's L2 back: three of them cost this kernel 11 us)
+    __syncthreads();
+    bool done = false;  // (wave-uniform)
+    if (fast_ok)
+        done = compat_fast_body<RT>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, entry, 0ull, out_ids, out_dist, out_count, stats, dim_pad,
+                                    heap_cap, hash_bits, rcap, tie, 0u, smem);
+    __syncthreads();
+    if (!done) {
+        compat_heap_body<RT>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, entry, 0ull, out_ids, out_dist, out_count, stats, dim_pad,
+                             heap_cap, hash_bits, rcap, 0u, smem);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) host_stats[threadIdx.x] = __hip_atomic_load(&stats[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seq_dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 static uint32_t bits_for(uint64_t entries) {  // table with >= 2x entries, at least 64 slots
     uint32_t b = 6;
@@ -1347,6 +1409,29 @@ int launch_search_compat(const zvdb_hip_index *h, const float *d_queries, uint32
         hipLaunchKernelGGL(k_search_compat<RT>, dim3(nq), dim3(64), lds, s, rows, ld, h->dim, metric,
                            h->adj, h->deg, h->gstride, (uint32_t)N, d_queries, k, entry, id_offset, d_ids,
                            d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, tie);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    });
+}
+
+int launch_search_compat_single(const zvdb_hip_index *h, const float *d_query, uint32_t k, uint32_t entry, uint64_t *d_ids, float *d_dist,
+                                uint32_t *d_count, unsigned long long *d_stats, uint32_t *d_tie, unsigned long long *host_stats, uint32_t *seq_dst,
+                                uint32_t seq, hipStream_t s) {
+    const uint64_t N = h->count;
+    const uint32_t rcap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(k, N));
+    const uint64_t bound = std::max<uint64_t>(1, std::min<uint64_t>(N, 1 + (uint64_t)rcap * h->gstride));
+    const uint32_t heap_cap = (uint32_t)bound;
+    const uint32_t hash_bits = bits_for(bound);
+    const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
+    const size_t lds = 4ull * (dim_pad + 2ull * heap_cap + (1ull << hash_bits) + 2ull * rcap + 2 * kWave);
+    const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
+    const bool fast_off = [] { const char *e = tuning("ZVDB_COMPAT_SEARCH"); return e && e[0] == 'h'; }();
+    return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
+        ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_compat_single<RT>), lds));
+        hipLaunchKernelGGL(k_search_compat_single<RT>, dim3(1), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
+                           d_query, k, entry, d_ids, d_dist, d_count, d_stats, dim_pad, heap_cap, hash_bits, rcap, d_tie, fast_off ? 0 : 1, host_stats,
+                           seq_dst, seq);
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
     });
@@ -1886,7 +1971,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     for (uint32_t i = threadIdx.x; i < hash_size; i += kWave * WPQ) hash[i] = 0;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
-    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : 4 / WPQ;  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32)
+    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : 4 / WPQ;  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32; two rows per group at WPQ = 2 measured 24 % SLOWER with a search width, r4)
     if constexpr (WPQ > 1) {
         if (wave != 0) {  // helper waves: their share of every published window's distances
             for (;;) {
@@ -2085,18 +2170,24 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                 stamp(3);  // beam update
                 return true;
             };
-            if (nsel > 1 && nsel * gstride <= (uint32_t)kWave) {
-                // the lists of all picked nodes side by side in ONE window (lane = list w, entry j): w lists' worth of row fetches per
-                // dependent step.  The beam is a set, so merging the candidates together equals the spec's list-by-list insertion.
-                const uint32_t w = (uint32_t)lane / gstride, j = (uint32_t)lane - w * gstride;
-                const bool live = w < nsel;
-                const uint32_t cw = w == 0 ? cids[0] : w == 1 ? cids[1] : w == 2 ? cids[2] : cids[3];
-                uint32_t nbl = 0, dgw = 0;
-                if (live) { nbl = adj[(size_t)cw * gstride + j]; dgw = min(deg[cw], gstride); }
+            const uint32_t per = (uint32_t)kWave / max(gstride, 1u);  // whole lists that fit one window
+            if (nsel > 1 && per > 1) {
+                // the lists of the picked nodes side by side in a window (lane = list w, entry j), `per` lists per window: that many
+                // lists' worth of row fetches per dependent step.  The beam is a set, so merging the candidates of several lists
+                // together equals the spec's list-by-list insertion.
                 pre_id = 0xFFFFFFFFu;
-                const bool valid = live && j < dgw;
-                const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
-                if (cnt != 0 && !window(valid, nbl, cnt, false)) return;
+                for (uint32_t s0 = 0; s0 < nsel; s0 += per) {
+                    const uint32_t nl = min(per, nsel - s0);
+                    const uint32_t w = (uint32_t)lane / gstride, j = (uint32_t)lane - w * gstride;
+                    const bool live = w < nl;
+                    const uint32_t iw = s0 + w;
+                    const uint32_t cw = iw == 0 ? cids[0] : iw == 1 ? cids[1] : iw == 2 ? cids[2] : cids[3];
+                    uint32_t nbl = 0, dgw = 0;
+                    if (live) { nbl = adj[(size_t)cw * gstride + j]; dgw = min(deg[cw], gstride); }
+                    const bool valid = live && j < dgw;
+                    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+                    if (cnt != 0 && !window(valid, nbl, cnt, false)) return;
+                }
             } else {
                 for (uint32_t s = 0; s < nsel; ++s) {
                     const uint32_t cid = cids[s];
