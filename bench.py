@@ -720,7 +720,7 @@ def main():
         achieved = flops / kavg / 1e12 if kavg > 0 else 0.0
         peak = PEAK_TFLOPS[args.mode]
         traffic, traffic_src = None, None
-        for rnd in ("r3", "r2", "r1"):
+        for rnd in ("r4", "r3", "r2", "r1"):
             tf = os.path.join(ROOT, "profiles", rnd, "traffic_10Mx768.json")
             if world == 1 and traffic is None and os.path.exists(tf):
                 tj = json.load(open(tf)).get(args.mode)
@@ -767,14 +767,14 @@ def main():
                 "timed_regions": kern_n,
                 "region": ("per step: sample-moments launch + threshold guess + ONE scan of the whole shard (stream kernel) + verifying merge "
                            "+ gated repair scan/merge (no-ops when the guess held); the scan is ~99 % of the region "
-                           "(profiles/r3/: rocprofv3 kernel stats of this command)" if args.mode in ("fp4", "i8", "bf16") else
+                           "(profiles/r4/: rocprofv3 kernel stats of this command)" if args.mode in ("fp4", "i8", "bf16") else
                            "per step: row-sample moments (k_sample_guess) + thresholds + ONE scan of the whole shard (staged 256 x 256 kernel) + verifying "
                            "merge + gated repair scan/merge (no-ops when the guess held)"),
                 "peak_note": ("spec dense fp4 MFMA peak; tools/mfma_peak_bench.hip measures 6.7 PFLOP/s for back-to-back "
                               "v_mfma_scale_f32_32x32x64_f8f6f4 on random operands (the chip lowers its clock under load)" if args.mode == "fp4" else
                               "spec dense bf16 MFMA peak (2.4 GHz); on random bf16 operands the chip is power-limited: the bare "
                               "v_mfma_f32_32x32x16_bf16 loop holds 1.99 PFLOP/s (profiles/r1/mfma_peak_bench.txt) and this kernel's loop "
-                              "holds ~1.85 GHz with the MFMA pipes busy 0.82 of the cycles (rocprofv3 SQ counters: profiles/r3/pmc_mfma_utilisation_bf16_stream.txt)" if args.mode == "bf16" else None),
+                              "holds ~1.85 GHz with the MFMA pipes busy 0.82 of the cycles (rocprofv3 SQ counters: profiles/r3/pmc_mfma_utilisation_bf16_stream.txt; the scan loop is unchanged in r4)" if args.mode == "bf16" else None),
                 "hbm_achieved_GBps": float(n_local) * D * ELT_BYTES[args.mode] / kavg / 1e9 if kavg > 0 else 0.0,
                 "hbm_peak_GBps": 8000.0,
                 "algorithmic_flops_per_launch": flops,

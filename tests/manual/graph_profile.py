@@ -15,6 +15,8 @@ def ef_leg(tag, flags, N=int(os.environ.get("ZVDB_PROFILE_ROWS", "1000000")), d=
     idx = zv.Index(dim=d, capacity=N, m=M, flags=flags)
     idx.add_synthetic(N, d, 0x5EED)
     idx.build_knn_graph(M, zv.BF_I8)
+    width = int(os.environ.get("ZVDB_PROFILE_WIDTH", "1"))  # (a variable of THIS script: the search width it sets through the ABI)
+    idx.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
     q = torch.empty((nq, d), dtype=torch.float32, device=dev)
     zv.fill_synthetic_dev(q.data_ptr(), nq, d, 0xC0FFEE, 0, stream)
     ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
@@ -32,7 +34,7 @@ def ef_leg(tag, flags, N=int(os.environ.get("ZVDB_PROFILE_ROWS", "1000000")), d=
     rb, _ = idx.storage_info()
     elt = rb // d
     alg = E * d * elt + P * M * 4
-    out[tag] = {"rows": N, "dim": d, "M": M, "ef": ef, "batch": nq, "row_bytes": rb, "E": E, "P": P, "algorithmic_bytes_per_launch": alg,
+    out[tag] = {"rows": N, "dim": d, "M": M, "ef": ef, "search_width": width, "batch": nq, "row_bytes": rb, "E": E, "P": P, "algorithmic_bytes_per_launch": alg,
                 "ms_per_launch_wall": el * 1e3, "algorithmic_TBps_wall": alg / el / 1e12, "qps": nq / el}
     print(tag, json.dumps(out[tag]), flush=True)
 
@@ -74,4 +76,4 @@ if "batch" in legs:  # the same search at larger batches (more waves per CU): wh
         ef_leg(f"ef128_1Mx768_bf16_rows_batch{nq}", zv.FLAG_BF16_ROWS, nq=nq)
 if "compat" in legs:
     compat_leg()
-json.dump(out, open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "graph_profile_counters_%s.json" % "_".join(legs)), "w"), indent=1)
+json.dump(out, open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "graph_profile_counters_%s_w%s.json" % ("_".join(legs), os.environ.get("ZVDB_PROFILE_WIDTH", "1"))), "w"), indent=1)

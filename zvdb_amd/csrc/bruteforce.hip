@@ -1012,7 +1012,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             __atomic_store_n(h->cert_host, 0u, __ATOMIC_RELAXED);  // (forced repairs say nothing about the survivors needed)
         } else if (__atomic_load_n(h->cert_host, __ATOMIC_RELAXED) != 0) {
             __atomic_store_n(h->cert_host, 0u, __ATOMIC_RELAXED);
-            if (h->cert_level < 3) ++h->cert_level;
+            // one level above what the failing batch ran with (large shards start at 1: see cert_lvl below)
+            h->cert_level = std::min(3u, std::max(std::max(h->cert_level, h->cert_level_min), h->count >= (1ull << 20) ? 1u : 0u) + 1u);
             h->cert_clean = 0;
         } else if (++h->cert_clean >= 8192 && h->cert_level > 0) {  // a long clean run: try fewer survivors again
             --h->cert_level;
@@ -1021,7 +1022,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         h->cert_queries += nq;
         h->cert_batches += 1;
     }
-    const uint32_t cert_lvl = cert ? std::max(h->cert_level, h->cert_level_min) : 0u;
+    // (a shard of a million rows or more starts at 64 survivors: with 32 the bound fails for a large share of the queries of the first
+    // batch on high-dimensional rows -- 40 % at 10M x 768 -- and every one of them is an exact scan)
+    const uint32_t cert_lvl = cert ? std::max(std::max(h->cert_level, h->cert_level_min), h->count >= (1ull << 20) ? 1u : 0u) : 0u;
     const bool wide_k = k > kmax || (mode == ZVDB_BF_FP4 && k > 32) || want > (uint32_t)KP || dense_low_dim || cert_lvl >= 2;
     const bool big8 = !guess_off && p.NT >= 16 * p.S8 && !(debug_flags() & 64);
     const bool s8 = mode == ZVDB_BF_I8 && i8s_eligible(h) && (big8 || wide_k);

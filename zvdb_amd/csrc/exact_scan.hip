@@ -20,7 +20,8 @@ namespace zvdb {
 
 namespace {
 
-constexpr int XS_QB = 4;      // queries per pass over a row range
+// XS_QB (template): queries per pass over a row range -- the rows are read once per XS_QB listed queries; 8, or 2 for rows so wide that 8
+// queries do not fit the LDS
 constexpr int XS_CAP = 512;   // buffered (dist, id) words per query and block
 constexpr int XS_T = 256;     // rows per tile = threads per block
 constexpr uint32_t XS_POOL = 8192;  // B k <= this many words in the merge
@@ -44,7 +45,7 @@ __device__ __forceinline__ uint64_t xs_prune(uint64_t *buf, uint32_t n, uint32_t
     return T;
 }
 
-template <typename RT>
+template <typename RT, int XS_QB>
 __global__ __launch_bounds__(XS_T) void k_exact_scan(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric, uint32_t N,
                                                      const float *__restrict__ queries, const uint32_t *__restrict__ nflag,
                                                      const uint32_t *__restrict__ flist, uint32_t k, uint64_t id_offset,
@@ -129,17 +130,19 @@ __global__ __launch_bounds__(XS_T) void k_exact_scan(const RT *__restrict__ rows
                 }
             }
             __syncthreads();
-            if ((uint32_t)wave < nqg && cnt[wave] > (uint32_t)(XS_CAP - XS_T)) {  // wave j prunes query j
-                const uint64_t T = xs_prune(buf + (size_t)wave * XS_CAP, cnt[wave], k, hist + wave * 256, tmp + wave * 256, lane);
-                if (lane == 0) { cnt[wave] = k; thr[wave] = T; }
+            for (uint32_t j = (uint32_t)wave; j < nqg; j += XS_T / kWave) {  // wave w prunes queries w, w + 4, ...
+                if (cnt[j] > (uint32_t)(XS_CAP - XS_T)) {
+                    const uint64_t T = xs_prune(buf + (size_t)j * XS_CAP, cnt[j], k, hist + wave * 256, tmp + wave * 256, lane);
+                    if (lane == 0) { cnt[j] = k; thr[j] = T; }
+                }
             }
             __syncthreads();
         }
-        if ((uint32_t)wave < nqg) {
-            uint32_t n = cnt[wave];
-            if (n > k) { xs_prune(buf + (size_t)wave * XS_CAP, n, k, hist + wave * 256, tmp + wave * 256, lane); n = k; }
-            uint64_t *out = partial + ((size_t)(g0 + wave) * B + b) * k;
-            for (uint32_t i = lane; i < k; i += kWave) out[i] = i < n ? buf[(size_t)wave * XS_CAP + i] : ~0ull;
+        for (uint32_t j = (uint32_t)wave; j < nqg; j += XS_T / kWave) {
+            uint32_t n = cnt[j];
+            if (n > k) { xs_prune(buf + (size_t)j * XS_CAP, n, k, hist + wave * 256, tmp + wave * 256, lane); n = k; }
+            uint64_t *out = partial + ((size_t)(g0 + j) * B + b) * k;
+            for (uint32_t i = lane; i < k; i += kWave) out[i] = i < n ? buf[(size_t)j * XS_CAP + i] : ~0ull;
         }
     }
 }
@@ -217,18 +220,23 @@ int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t 
     if (scratch_bytes < (uint64_t)nq * B * k * 8) { set_error("exact scan: scratch too small"); return ZVDB_ERR_INVALID; }
     const uint32_t rpb = round_up((N + B - 1) / B, XS_T);
     B = (N + rpb - 1) / rpb;
-    const uint32_t Y = std::max(1u, std::min((nq + XS_QB - 1) / XS_QB, std::max(1u, 2048u / B)));
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
-    const size_t lds = (size_t)XS_QB * dim_pad * 4 + (size_t)XS_QB * XS_CAP * 8 + 4 * 256 * 8 + XS_QB * 8 + XS_QB * 4 + 4 * 256 * 4 + 16;
+    auto lds_for = [&](size_t qb) { return qb * dim_pad * 4 + qb * XS_CAP * 8 + 4 * 256 * 8 + qb * 8 + qb * 4 + 4 * 256 * 4 + 16; };
+    const uint32_t QB = lds_for(8) <= 128 * 1024 ? 8u : 2u;
+    const size_t lds = lds_for(QB);
     if (lds > 160 * 1024) { set_error("exact scan: dimension too large for the query tile"); return ZVDB_ERR_UNSUPPORTED; }
+    const uint32_t Y = std::max(1u, std::min((nq + QB - 1) / QB, std::max(1u, 2048u / B)));
     ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = row_elem_t<decltype(rows)>;
-        if (lds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scan<RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_exact_scan<RT>, dim3(B, Y), dim3(XS_T), lds, s, rows, ld, h->dim, metric, N, d_queries, nflag, flist, k, id_offset, d_ids,
-                           d_dist, d_count, reinterpret_cast<uint64_t *>(scratch), rpb, dim_pad);
-        ZV_HIP(hipGetLastError());
-        return ZVDB_OK;
+        auto go = [&](auto kern) -> int {
+            if (lds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(B, Y), dim3(XS_T), lds, s, rows, ld, h->dim, metric, N, d_queries, nflag, flist, k, id_offset, d_ids,
+                               d_dist, d_count, reinterpret_cast<uint64_t *>(scratch), rpb, dim_pad);
+            ZV_HIP(hipGetLastError());
+            return ZVDB_OK;
+        };
+        return QB == 8 ? go(k_exact_scan<RT, 8>) : go(k_exact_scan<RT, 2>);
     }));
     const size_t mlds = SEL_HIST_BYTES + 256 * 8 + (size_t)B * k * 8;
     if (mlds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scan_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
