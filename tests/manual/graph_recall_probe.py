@@ -82,4 +82,8 @@ deg = np.array([len(idx.get_neighbors(i)) for i in range(0, N, max(1, N // 2000)
 e, ml = idx.graph_info()
 print(f" bulk graph M={M} (cap {2 * M}), build {t1 - t0:.2f} s = {N / (t1 - t0):.0f} rows/s, mean layer-0 degree {deg.mean():.1f}, max level {ml}, entry {e}")
 sweep("bulk/desc", zv.ENTRY_DESCEND)
-sweep("bulk/top ", e)
+if only != "bulk":
+    sweep("bulk/top ", e)
+for w in [int(x) for x in os.environ.get("ZVDB_PROBE_WIDTHS", "").split(",") if x]:  # search widths (ZVDB_OPT_EF_SEARCH_WIDTH) on the bulk graph
+    idx.set_option(zv.OPT_EF_SEARCH_WIDTH, w)
+    sweep(f"bulk/desc width {w}", zv.ENTRY_DESCEND)

@@ -43,7 +43,8 @@ struct CertArgs {
     int affine = 0;
     float rescale_target = 0.0f;     // int8, dot / cosine: queries are scaled to this largest magnitude before they are quantised
     int force = 0;                   // ZVDB_OPT_CERT_FORCE_REPAIR (tests): every query is listed for the exact scan
-    uint32_t *dbg_rows = nullptr;    // tuning ZVDB_CERT_DEBUG: mapped host counter of the candidate rows the re-rank evaluated
+    uint32_t *dbg_rows = nullptr;    // tuning ZVDB_CERT_DEBUG: mapped host counters -- 1: candidate rows the re-rank evaluated; 2: cycle stamps of its phases
+    int dbg_mode = 0;
 };
 
 struct CertQ {  // per-query constants (wave-uniform)

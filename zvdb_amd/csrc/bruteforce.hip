@@ -563,7 +563,9 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
                                                      uint32_t lkp = KP /* width (stride) of the lists and of cand_ids: 64, 128 or 256 */,
                                                      uint32_t *__restrict__ cand_keys = nullptr /* certificate (bf_cert.h): the candidates leave SORTED by (key, id), their keys here */,
                                                      uint32_t *__restrict__ kth_out = nullptr /* ... and the k'-th key per query (0xFFFFFFFF: fewer than k' rows exist) */,
-                                                     uint32_t *__restrict__ cert_nflag = nullptr /* the repair list's counter: reset here, ahead of the re-rank that fills it */) {
+                                                     uint32_t *__restrict__ cert_nflag = nullptr /* the repair list's counter: reset here, ahead of the re-rank that fills it */,
+                                                     uint32_t lw = kWave /* lists taken per round (one lane each): cap >= kp + lw * lkp -- 16 for the wide lists keeps the pool at
+                                                                            17 - 35 KB instead of 67 - 133 KB, i.e. 4+ workgroups per CU instead of 1 - 2 */) {
     if (cert_nflag && vmode != 2 && blockIdx.x == 0 && threadIdx.x == 0) *cert_nflag = 0;
     if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -594,11 +596,11 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
         n = kp;
         __syncthreads();
     };
-    for (uint32_t s0 = 0; s0 < S; s0 += kWave) {
+    for (uint32_t s0 = 0; s0 < S; s0 += lw) {
         // one lane per list; its valid-entry count was written by the scan
         const uint32_t li = s0 + lane;
         const uint64_t *lp = p + (size_t)li * lkp;
-        const uint32_t cnt = li < S ? min(pcnt[(size_t)q * Stot + l0 + li], lkp) : 0u;
+        const uint32_t cnt = ((uint32_t)lane < lw && li < S) ? min(pcnt[(size_t)q * Stot + l0 + li], lkp) : 0u;
         const uint32_t inc = wave_incl_scan(cnt, lane);
         const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (n + tot > cap) reduce_pool();  // make room (cap >= kp + 64 * lkp)
@@ -1135,7 +1137,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         ca.affine = l2 ? 1 : 0;
         ca.rescale_target = mode == ZVDB_BF_I8 ? 127.0f / h->q_inv : 0.0f;
         ca.force = h->cert_force ? 1 : 0;
-        ca.dbg_rows = tuning("ZVDB_CERT_DEBUG") ? h->cert_hdev + 2 : nullptr;
+        if (const char *dbg = tuning("ZVDB_CERT_DEBUG")) { ca.dbg_rows = h->cert_hdev + 2; ca.dbg_mode = dbg[0] == '2' ? 2 : 1; }
         ZV_CHECK(launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid, &ca));
         return launch_exact_scan(h, d_queries_exact, nq, k, id_offset, nflag, flist, cand, p.cand_bytes, d_ids, d_dist, d_count, h->cert_hdev + 1, s);
     };
@@ -1230,19 +1232,19 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 ZV_CHECK(launch_fp4s_guess(h, q_op, nq, p.QT, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
             }
-            const uint32_t cap = kp + 64 * kpv;
+            const uint32_t mlw = kpv == (uint32_t)KP ? 64u : 16u, cap = kp + mlw * kpv;
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
-                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag);
+                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (sf) ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_rep, kp, 0, SS, Stot, pcnt, vflag, kpv, s));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids,
-                               (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
+                               (uint32_t *)nullptr, kp, cap, SS, 2, vflag, defq, (uint32_t *)nullptr, kpv, ckeys, kth, nflag, mlw);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
             return finish(kp);
@@ -1288,15 +1290,15 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                         p.NT, p.S, c[0], c[1], c[2], c[3], c[4] / nb, c[6] / nb, c[7] / nb, c[9] / nb, c[10] / nb, c[11] / nb);
                 ZV_HIP(hipMemsetAsync(dbg_area, 0, 128, s));
             }
-            const uint32_t cap = kp + 64 * kpv;
+            const uint32_t mlw = kpv == (uint32_t)KP ? 64u : 16u, cap = kp + mlw * kpv;
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 1, vflag, defq,
-                               h->guess_flag_dev, kpv, ckeys, kth, nflag);
+                               h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             ZV_CHECK(scan1(tau_rep, p.S, vflag));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, (uint32_t *)nullptr, kp, cap, p.S, 2, vflag,
-                               defq, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
+                               defq, (uint32_t *)nullptr, kpv, ckeys, kth, nflag, mlw);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
             return finish(kp);
@@ -1309,11 +1311,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
-            const uint32_t cap = kp + 64 * kpv;
+            const uint32_t mlw = kpv == (uint32_t)KP ? 64u : 16u, cap = kp + mlw * kpv;
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, (uint32_t *)nullptr, kp, cap,
-                               0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
+                               0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv, ckeys, kth, nflag, mlw);
             timing_end(h, s);
             ZV_HIP(hipGetLastError());
             return finish(kp);
@@ -1368,12 +1370,12 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             }
             if (i + 1 < np)
                 {
-                    const uint32_t cap = kp + 64 * kpv;
+                    const uint32_t mlw = kpv == (uint32_t)KP ? 64u : 16u, cap = kp + mlw * kpv;
                     const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
                     if (mlds > 64 * 1024)
                         ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
                     hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, lists, Stot,
-                                       (uint32_t *)nullptr, tau_g, kp, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv);
+                                       (uint32_t *)nullptr, tau_g, kp, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, mlw);
                 }
         }
         nlists = lists;
@@ -1393,13 +1395,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     {
         const uint32_t kpf = kpv != (uint32_t)KP ? kpv
                              : mode == ZVDB_BF_FP4 ? (uint32_t)KP : (k <= 16 && !(debug_flags() & 8) && cert_lvl == 0) ? 32u : (uint32_t)KP;
-        const uint32_t cap = kpf + 64 * kpv;
+        const uint32_t mlw = kpv == (uint32_t)KP ? 64u : 16u, cap = kpf + mlw * kpv;
         const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
         if (mlds > 64 * 1024)
             ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
         hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial,
                            reinterpret_cast<const uint32_t *>(ws + p.off_pcnt), nlists, stot_lists, cand_ids,
-                           (uint32_t *)nullptr, kpf, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv, ckeys, kth, nflag);
+                           (uint32_t *)nullptr, kpf, cap, 0u, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, kpv, ckeys, kth, nflag, mlw);
     }
     ZV_HIP(hipGetLastError());
     (void)kp_used;

@@ -2597,7 +2597,7 @@ void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s) {
 // not evaluated, and the query is certified when that key lies below the k'-th survivor's -- else it goes on the repair list.
 __device__ __forceinline__ void cert_verdict(const CertArgs &cert, uint32_t qi, uint32_t ks, int lane, uint32_t rows_evaluated = 0) {
     if (lane != 0) return;
-    if (cert.dbg_rows) __hip_atomic_fetch_add(cert.dbg_rows, rows_evaluated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (cert.dbg_rows && cert.dbg_mode == 1) __hip_atomic_fetch_add(cert.dbg_rows, rows_evaluated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t kth = cert.kth[qi];
     if (!cert.force && (kth == 0xFFFFFFFFu || ks < kth)) return;  // every row is a survivor / no row left out can reach the top-k
     const uint32_t slot = atomicAdd(cert.nflag, 1u);
@@ -2817,7 +2817,7 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
     CertQ cq{};
     uint32_t ks = 0xFFFFFFFEu;  // largest screen key a row of the top-k can carry, by what has been evaluated so far
     unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
-    const bool prof = cert.dbg_rows && (qi & 63u) == 0;  // (tuning ZVDB_CERT_DEBUG: cycle stamps of every 64th query)
+    const bool prof = cert.dbg_rows && cert.dbg_mode == 2 && (qi & 255u) == 0;  // (tuning ZVDB_CERT_DEBUG=2: cycle stamps of every 256th query)
     if (prof) tstamp[0] = __builtin_amdgcn_s_memtime();
     if (cert.kth) cq = cert_query_consts(cert, q, dim, metric, lane);
     if (prof) tstamp[1] = __builtin_amdgcn_s_memtime();
@@ -2916,9 +2916,11 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
     }
     __syncthreads();
     if (prof) tstamp[2] = __builtin_amdgcn_s_memtime();
+    uint32_t n_hi = kc;  // entries [n_hi, kc) hold no evaluated candidate (sorted lists: what is evaluated is, but for holes, a prefix)
     if (cert.kth) {
+        n_hi = SR;
         for (uint32_t base = SR; base < kc; base += kWave) {
-            const float dk0 = cert_kth_dist(cd, ci, base, k, dk_slot, lane);
+            const float dk0 = cert_kth_dist(cd, ci, n_hi, k, dk_slot, lane);
             ks = cert_safe_key(cert, cq, dk0, dim, metric);
             const uint32_t i = base + lane;
             const uint32_t id = i < kc ? ci[i] : 0xFFFFFFFFu;
@@ -2929,15 +2931,17 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
                 break;
             }
             if (need) cd[i] = exact_dist_rt(metric, q, rows + (size_t)id * ld, dim);
+            const unsigned long long nm = __ballot(need);
+            n_hi = min(kc, (base + 64u - (uint32_t)__builtin_clzll(nm) + 3u) & ~3u);
             __syncthreads();
         }
         __syncthreads();
         if (prof) tstamp[3] = __builtin_amdgcn_s_memtime();
-        const float dk = cert_kth_dist(cd, ci, kc, k, dk_slot, lane);
+        const float dk = cert_kth_dist(cd, ci, n_hi, k, dk_slot, lane);
         ks = cert_safe_key(cert, cq, dk, dim, metric);
         if (prof) tstamp[4] = __builtin_amdgcn_s_memtime();
         uint32_t nev = 0;
-        if (cert.dbg_rows) {
+        if (cert.dbg_rows && cert.dbg_mode == 1) {
 #pragma unroll
             for (int bt = 0; bt < NE; ++bt) nev += (uint32_t)__popcll(__ballot(ci[64 * bt + lane] != 0xFFFFFFFFu));
         }
@@ -2950,7 +2954,7 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
         const bool valid = my_id != 0xFFFFFFFFu;
         if (valid) {
             const float di = cd[64 * bt + lane];
-            const uint32_t rank = lex_rank4(cd, ci, kc, di, my_id);
+            const uint32_t rank = lex_rank4(cd, ci, n_hi, di, my_id);
             if (rank < k) {
                 out_ids[(size_t)qi * k + rank] = (uint64_t)my_id + id_offset;
                 out_dist[(size_t)qi * k + rank] = di;

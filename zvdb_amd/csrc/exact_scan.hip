@@ -203,11 +203,18 @@ __global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restr
     }
 }
 
-uint32_t xs_blocks(uint32_t k) { return std::max(1u, std::min(1024u, XS_POOL / std::max(k, 1u))); }
+// row ranges (= partial lists per listed query): B k <= XS_POOL words in the merge, and nq B k words of scratch kept under 64 MiB for large
+// batches (down to 16 ranges: the grid's second dimension -- query groups -- carries the parallelism then)
+uint32_t xs_blocks(uint32_t nq, uint32_t k) {
+    k = std::max(k, 1u);
+    const uint32_t by_pool = std::max(1u, std::min(1024u, XS_POOL / k));
+    const uint64_t by_mem = (64ull << 20) / (8ull * k * std::max(nq, 1u));
+    return std::max<uint32_t>(std::min<uint32_t>(by_pool, 16u), (uint32_t)std::min<uint64_t>(by_pool, by_mem));
+}
 
 }  // namespace
 
-uint64_t exact_scan_scratch_bytes(uint32_t nq, uint32_t k) { return (uint64_t)nq * xs_blocks(k) * k * 8; }
+uint64_t exact_scan_scratch_bytes(uint32_t nq, uint32_t k) { return (uint64_t)nq * xs_blocks(nq, k) * k * 8; }
 
 int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k, uint64_t id_offset, const uint32_t *nflag,
                       const uint32_t *flist, void *scratch, uint64_t scratch_bytes, uint64_t *d_ids, float *d_dist, uint32_t *d_count,
@@ -215,7 +222,7 @@ int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t 
     if (nq == 0 || k == 0 || h->count == 0) return ZVDB_OK;
     if (k > 256) { set_error("exact scan: k <= 256"); return ZVDB_ERR_UNSUPPORTED; }
     const uint32_t N = (uint32_t)h->count;
-    uint32_t B = xs_blocks(k);
+    uint32_t B = xs_blocks(nq, k);
     B = std::min<uint32_t>(B, (N + XS_T - 1) / XS_T);
     if (scratch_bytes < (uint64_t)nq * B * k * 8) { set_error("exact scan: scratch too small"); return ZVDB_ERR_INVALID; }
     const uint32_t rpb = round_up((N + B - 1) / B, XS_T);
