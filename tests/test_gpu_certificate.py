@@ -53,6 +53,28 @@ def test_tight_clusters_every_exact_route_returns_the_oracles_top_k(zv, oracle, 
         assert info["repaired"] > 0, info  # the bound cannot certify these queries from 32 .. 256 survivors: the exact scan ran
 
 
+@pytest.mark.parametrize("metric", ["dot", "cosine"])
+@pytest.mark.parametrize("mode", ["bf16", "i8", "f32"])
+def test_tight_clusters_inner_product_metrics(zv, oracle, mode, metric):
+    """The same hard data under the inner-product metrics (their bound has no distance term to lean on: it uses the mirror's largest row
+    norm, and the int8 screen ranks by a RESCALED query): 32 tight clusters around centred directions, 120k x 256 -- the oracle's
+    ids and distances on every query of every batch, for every exact screen."""
+    n, d, nq, k = 120_000, 256, 64, 10
+    rng = np.random.default_rng(21)
+    C = rng.random((32, d), dtype=np.float32) - np.float32(0.5)
+    V = (C[rng.integers(0, 32, size=n)] * (1.0 + 0.2 * rng.random((n, 1), dtype=np.float32)) + 0.004 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    Q = (C[rng.integers(0, 32, size=nq)] + 0.01 * rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+    mt = zv.METRIC_DOT if metric == "dot" else zv.METRIC_COSINE
+    idx = zv.Index(dim=d, capacity=n, metric=mt, flags=zv.FLAG_BF16_MIRROR)
+    idx.add(V)
+    S = np.stack([idx.get_vector(i) for i in range(0, n)]) if metric == "cosine" else V  # rows as stored (normalised under cosine)
+    ri, rd, rc = oracle.bruteforce_topk(S, Q, k, 1)
+    m = {"f32": zv.BF_F32, "bf16": zv.BF_BF16, "i8": zv.BF_I8}[mode]
+    for _ in range(3):
+        _check(*idx.search_bruteforce(Q, k, m), ri, rd, rc)
+    assert idx.cert_info()["queries"] == 3 * nq
+
+
 def test_without_the_certificate_the_same_data_is_not_guaranteed(zv, oracle):
     """The switch exists and the unchecked route still returns exact DISTANCES for the ids it returns (documented behaviour)."""
     n, d, nq, k = 100_000, 256, 64, 10

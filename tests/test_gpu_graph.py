@@ -92,6 +92,26 @@ def test_search_width_equals_the_oracle_spec(zv, oracle, width, M, bf16rows, met
         assert (ev, pp) == (c.search_dist_evals, c.search_pops), (k, ef, tune)
 
 
+def test_search_width_hand_derived_on_the_device(zv, oracle):
+    """The paper example of tests/test_oracle_graph_spec.py::test_search_width_hand_derived through the ABI: six points on a line,
+    query 4.6, ef = 2 -- width 1 ends on [4, 2] after 3 pops / 4 evaluations, width 2 reaches [5, 4] after 6 / 6."""
+    idx = zv.Index(m=2)
+    idx.add(np.arange(6, dtype=np.float32).reshape(6, 1))
+    adj = np.zeros((6, 2), dtype=np.uint32); deg = np.zeros(6, dtype=np.uint32)
+    for i, lst in {0: [1, 2], 1: [0, 3], 2: [0, 4], 3: [1, 5], 4: [2], 5: [3]}.items():
+        adj[i, :len(lst)] = lst; deg[i] = len(lst)
+    idx.upload_graph(adj, deg)
+    q = np.array([[4.6]], dtype=np.float32)
+    d = lambda i: oracle.distance(q[0], np.array([i], dtype=np.float32))
+    for width, want, pops, evals in ((1, [4, 2], 3, 4), (2, [5, 4], 6, 6), (4, [5, 4], 6, 6)):
+        idx.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
+        for tune in ({}, {"ZVDB_EF_BEAM": "lds"}):
+            with zv.tuned(**tune):
+                ids, dist, cnt, (ev, pp) = idx.search_graph(q, 2, ef=2, with_stats=True)
+            assert cnt[0] == 2 and [int(x) for x in ids[0]] == want and list(dist[0]) == [d(want[0]), d(want[1])], (width, tune)
+            assert (pp, ev) == (pops, evals), (width, tune)
+
+
 def test_bulk_graph_recall_beats_the_knn_graph(zv, oracle):
     """What the builder is for: with the SAME parameter M and at the same ef, the heuristic + reverse-link graph entered by
     descent out-recalls the directed exact M-NN lists entered at node 0 (measured 0.79 vs 0.62 at ef = 128 on 20k x 128

@@ -104,3 +104,63 @@ def test_ef_spec_metric_and_entry(oracle):
         for entry in (0, 17, n - 1):
             ids, dist = h.search_ef(q, 10, n, metric, entry)
             assert np.array_equal(ids, gt[0]) and np.array_equal(dist, gd[0]), (metric, entry)
+
+
+def _line_graph(oracle):
+    """Six points on a line (x = 0 .. 5), layer-0 lists 0:[1,2] 1:[0,3] 2:[0,4] 3:[1,5] 4:[2] 5:[3]."""
+    h = oracle.HNSW(2, 200)
+    for x in range(6):
+        h.insert(np.array([x], dtype=np.float32), 0)
+    for i, lst in {0: [1, 2], 1: [0, 3], 2: [0, 4], 3: [1, 5], 4: [2], 5: [3]}.items():
+        h.set_neighbors(i, 0, lst)
+    return h
+
+
+def test_search_width_hand_derived(oracle):
+    """orc_hnsw_search_ef_w on a graph small enough to run on paper (query x = 4.6, entry 0, ef = 2, k = 2):
+    width 1: W = [0]; pop 0 -> 1, 2 evaluated, W = [2, 1]; pop 2 -> 4 in, W = [4, 2] (1 falls off unexpanded); pop 4 -> nothing new;
+             stop: 3 pops, 4 evaluations, result [4, 2].
+    width 2: pop 0 -> W = [2, 1]; pops 2 AND 1 together (both marked before either list is read): 2's list brings 4, W = [4, 2];
+             1's list brings 3 (2.56 < 6.76), W = [4, 3]; pops 4 and 3: 3's list brings 5, W = [5, 4]; pop 5: nothing;
+             stop: 6 pops, 6 evaluations, result [5, 4] -- the node the plain search never reaches."""
+    h = _line_graph(oracle)
+    q = np.array([4.6], dtype=np.float32)
+    d = lambda i: oracle.distance(q, np.array([i], dtype=np.float32))
+    h.reset_counters()
+    ids, dist = h.search_ef(q, 2, 2, 0, 0, 1)
+    c = h.counters()
+    assert [int(x) for x in ids] == [4, 2] and list(dist) == [d(4), d(2)]
+    assert (c.search_pops, c.search_dist_evals) == (3, 4)
+    h.reset_counters()
+    ids, dist = h.search_ef(q, 2, 2, 0, 0, 2)
+    c = h.counters()
+    assert [int(x) for x in ids] == [5, 4] and list(dist) == [d(5), d(4)]
+    assert (c.search_pops, c.search_dist_evals) == (6, 6)
+    # a width beyond the beam's unexpanded entries takes what there is; width 0 means 1
+    assert [int(x) for x in h.search_ef(q, 2, 2, 0, 0, 8)[0]] == [5, 4]
+    assert [int(x) for x in h.search_ef(q, 2, 2, 0, 0, 0)[0]] == [4, 2]
+
+
+def test_search_width_one_is_the_plain_beam_search(oracle):
+    """width = 1 of orc_hnsw_search_ef_w is orc_hnsw_search_ef_ex (which now calls it), on a random bulk graph, counters included;
+    larger widths return beams of the same quality on data with neighbourhoods (recall within a point of width 1)."""
+    rng = np.random.default_rng(9)
+    V = (rng.random((1500, 3), dtype=np.float32) @ rng.random((3, 24), dtype=np.float32)).astype(np.float32)
+    ref, levels, top = oracle.build_bulk_graph(V, 8, 32, 5)
+    Q = (rng.random((30, 3), dtype=np.float32) @ rng.random((3, 24), dtype=np.float32)).astype(np.float32)
+    gt, _, _ = oracle.bruteforce_topk(V, Q, 10)
+    rec = {}
+    for w in (1, 2, 4):
+        hits = 0
+        for qi, q in enumerate(Q):
+            ids, _ = ref.search_ef(q, 10, 48, 0, ref.descend(q, 0, top), w)
+            hits += len(set(int(x) for x in ids) & set(int(x) for x in gt[qi]))
+            if w == 1:
+                a = ref._L.orc_hnsw_search_ef_ex  # the un-widthed entry point returns the same list
+                import ctypes as C
+                oi = np.zeros(10, dtype=np.uint64); od = np.zeros(10, dtype=np.float32)
+                n = a(ref._h, q.ctypes.data_as(C.POINTER(C.c_float)), q.size, 10, 48, 0, ref.descend(q, 0, top),
+                      oi.ctypes.data_as(C.POINTER(C.c_uint64)), od.ctypes.data_as(C.POINTER(C.c_float)))
+                assert np.array_equal(oi[:n], ids)
+        rec[w] = hits / (len(Q) * 10)
+    assert rec[1] >= 0.9 and abs(rec[2] - rec[1]) <= 0.02 and abs(rec[4] - rec[1]) <= 0.02, rec
