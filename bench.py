@@ -709,9 +709,13 @@ def main():
             gl = graph_leg(zv, torch, dev, stream, 1_000_000, 768, 1024, K, (128,), structured, bf16_rows=hb)
             e = gl.pop("ef")["128"]
             paths[nm] = {"value": e["qps"], "unit": "QPS", "ef": 128, **{kk: vv for kk, vv in e.items() if kk != "qps"}, **gl}
-        c2 = c2_leg(zv, torch, dev, stream, K, modes=("f32",))[0]
+        c2 = c2_leg(zv, torch, dev, stream, K, modes=("f32", "bf16"))[0]
         paths["c2_1Mx128_b256_f32"] = {"value": c2["f32"]["qps"], "unit": "QPS", "rows": c2["rows"], "dim": c2["dim"], "batch": c2["batch"],
                                        "ms_per_batch": c2["f32"]["ms_per_batch"], "roofline": c2["f32"]["roofline"], "certificate": c2["certificate"]}
+        # the same shape on the bf16 screen: since r4 its results are CERTIFIED to be the fp32 route's (proof per query or exact scan)
+        paths["c2_1Mx128_b256_bf16_certified"] = {"value": c2["bf16"]["qps"], "unit": "QPS", "rows": c2["rows"], "dim": c2["dim"], "batch": c2["batch"],
+                                                  "ms_per_batch": c2["bf16"]["ms_per_batch"], "roofline": c2["bf16"]["roofline"],
+                                                  "note": "bf16 MFMA screen + certificate: ids proven equal to the exact top-k (certificate counters under c2_1Mx128_b256_f32)"}
 
     if rank == 0:
         qps = B * args.steps / elapsed

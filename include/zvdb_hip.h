@@ -382,7 +382,9 @@ int zvdb_hip_merge_topk_packed_dev(const void *d_packed, uint64_t rank_stride_by
  * (nq k 12 + nq 4 bytes per rank) and the k-way merge by (distance, id) -- everything enqueued on the caller's stream, no host
  * round trip; every rank ends with the same global top-k in d_ids / d_dist / d_count (layouts of the unsharded *_dev calls).
  * Exactness: the union of exact per-shard top-k lists contains the exact global top-k, so the brute-force routes stay exact
- * (and certified) when sharded; the graph route's recall is the per-shard recall. */
+ * (and certified) when sharded; the graph route's recall is the per-shard recall.
+ * A communicator serves one call at a time (RCCL's rule for a rank): callers that search from several threads use one
+ * communicator per thread or serialise the sharded calls themselves. */
 typedef struct zvdb_hip_comm zvdb_hip_comm; /* opaque */
 #define ZVDB_COMM_ID_BYTES 128
 #define ZVDB_SHARDED_GRAPH 0xFFFFFFFFu /* `mode` of zvdb_hip_sharded_workspace for the graph route */

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, zvdb_amd as zv, numpy as np
 N2, D2, B2, K = (int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000), int(sys.argv[1]) if len(sys.argv) > 1 else 128, 256, 10
 dev = torch.device("cuda", 0)

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, zvdb_amd as zv
 N2, D2, B2, K = 1_000_000, 128, 256, 10
 dev = torch.device("cuda", 0)
