@@ -1940,7 +1940,7 @@ __device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v) {  // lane i <- lan
 // workgroup barriers per window (window published in ctl[0] / distances done).  Same results, same counters; what it buys is
 // latency: a 1,024-query batch is one round of resident workgroups either way, its time is the slowest query's chain of pops.
 constexpr uint32_t kEfDone = 0xFFFFFFFFu;  // ctl[0]: no further window (a window has 1 .. 64 rows)
-template <typename RT, int EPL, int WPQ = 1, int PROF = 0>
+template <typename RT, int EPL, int WPQ = 1, int PROF = 0, bool WIDE = false>
 __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_search_ef_reg(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
@@ -2050,169 +2050,300 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
         hashn_insert_uniform(hash, hash_size, entry);
         hash_used = 1;
         sync_w();
+        if constexpr (!WIDE) {  // width 1: the loop of rounds 2-3, untouched -- every restructuring that also served a search width
+                                // (a shared lambda with two call sites: +17 % time on bf16 rows; a window state machine: +21 %) cost it
         for (;;) {
-            // next to expand: the first unexpanded slots of W -- one (the search of orc_hnsw_search_ef_ex) or, with a search width
-            // (ZVDB_OPT_EF_SEARCH_WIDTH; spec: orc_hnsw_search_ef_w), up to `width` of them, ALL marked expanded before any of
-            // their lists is read
-            uint32_t cids[4] = {0, 0, 0, 0}, nsel = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < 4; ++w) {
-                if (w >= width) break;
+                // next to expand: the first unexpanded slot
                 uint32_t slot = kWave * EPL;
-#pragma unroll
+    #pragma unroll
                 for (int e = EPL - 1; e >= 0; --e)
                     if (~xm[e] != 0ull) slot = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
                 if (slot >= wn) break;
-                uint64_t kb = 0;
-#pragma unroll
+                uint64_t kbest = 0;
+    #pragma unroll
                 for (int e = 0; e < EPL; ++e)
-                    if (slot >> 6 == (uint32_t)e) { kb = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
-                cids[w] = (uint32_t)kb;
-                nsel = w + 1;
-            }
-            if (nsel == 0) break;
-            pops += nsel;
-            stamp(0);  // next-to-expand
-            // one window: <= 64 list entries (one lane each) -> visited test-and-set, the fresh ones compacted, their distances (shared
-            // with the helper waves), the beam update.  false: the visited table is full and a later launch serves the query.
-            auto window = [&](bool valid, uint32_t nbl, uint32_t cnt, bool prefetch_ok) -> bool {
-                sync_w();
-                if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
-                if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
-                    if (lane == 0) ef_mark_again(out_count, qi, net_list);
-                    release_helpers();
-                    return false;
-                }
-                bool fresh1 = false;
-                if (valid && !overflow) fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
-                // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
-                // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
-                const unsigned long long fb0 = __ballot(fresh1);
-                if (fresh1) nb_i[__popcll(fb0 & ((1ull << lane) - 1ull))] = nbl;
-                const uint32_t nf = (uint32_t)__popcll(fb0);
-                const unsigned long long fb = nf == kWave ? ~0ull : (1ull << nf) - 1ull;
-                if (WPQ > 1 && nf != 0) {
-                    if (lane == 0) ctl[0] = nf;
-                    __syncthreads();  // (A) window published to the helper waves
+                    if (slot >> 6 == (uint32_t)e) { kbest = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
+                const uint32_t cid = (uint32_t)kbest;
+                pops += 1;
+                stamp(0);  // next-to-expand
+                // one vector load brings the first list slots AND the degree (lane 63 reads deg[cid] when the stride leaves it free) --
+                // or brought them already: the list of the NEXT unexpanded slot is requested speculatively a whole distance phase
+                // ahead (below); it is this pop's node unless a candidate of the previous pop went in before it
+                uint32_t nb_first, dg_all;  // lists longer than 64 are walked 64 entries at a time
+                if (cid == pre_id) {
+                    nb_first = pre_list;
+                    if constexpr (PROF) pre_hits += 1;
                 } else {
-                    sync_w();
+                    nb_first = *((uint32_t)lane < gstride ? adj + (size_t)cid * gstride + lane : deg + cid);
                 }
-                if (prefetch_ok && gstride < kWave) {  // speculative list request for the next pop, in flight during the distance phase (47 % of
-                                                      // pops use it at 1M x 768, ef = 128: +1.7 % QPS on bf16 rows, +0.7 % on fp32, A/B on one box)
-                    uint32_t slot2 = kWave * EPL;
-#pragma unroll
-                    for (int e = EPL - 1; e >= 0; --e)
-                        if (~xm[e] != 0ull) slot2 = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
-                    if (slot2 < wn) {
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e)
-                            if (slot2 >> 6 == (uint32_t)e) pre_id = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wkr[e], (int)(slot2 & 63));
-                        pre_list = *((uint32_t)lane < gstride ? adj + (size_t)pre_id * gstride + lane : deg + pre_id);
-                    }
-                }
-                stamp(1);  // degree + list load + visited test-and-set
-                if (nf == 0) return true;
-                ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, nf, nb_i, nb_d, lane, 0);
-                hash_used += nf;
-                evals += nf;
-                __syncthreads();  // (B) distances done
-                stamp(2);  // blocked distances of the fresh neighbours
-                uint64_t ck = ~0ull;
-                if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
-                const bool pass = ck != ~0ull && (wn < ef || ck < worst);
-                unsigned long long todo = __ballot(pass);
-                const uint32_t na = (uint32_t)__popcll(todo);
-                if (na == 1) {
-                    insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
-                } else if (na > 1) {
-                    // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
-                    // below it); new slot of a candidate = #(W entries below it) + #(candidates below it) -- per candidate two readlanes,
-                    // a compare + add per block and per candidate lane, and a ballot/popcount per block, ~16 instructions against ~70
-                    // for an insertion; then one scatter through LDS (slots >= ef fall off: the best ef of the union stay).
-                    uint32_t shift[EPL], crank = 0, wless = 0;
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) shift[e] = 0;
-                    while (todo) {
-                        const int l = __builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        const uint64_t ckl = readlane64(ck, l);
-                        uint32_t below = 0;
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) {
-                            const bool valid = (uint32_t)(e * kWave + lane) < wn;
-                            shift[e] += (valid && ckl < wkr[e]) ? 1u : 0u;
-                            below += (uint32_t)__popcll(__ballot(valid && wkr[e] < ckl));
-                        }
-                        crank += ckl < ck ? 1u : 0u;
-                        if (lane == l) wless = below;
-                    }
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) {
-                        const uint32_t slot = (uint32_t)(e * kWave + lane), np = slot + shift[e];
-                        if (slot < wn && np < ef) { Wt[np] = wkr[e]; Ft[np] = (uint32_t)(xm[e] >> lane) & 1u; }
-                    }
-                    if (pass && wless + crank < ef) { Wt[wless + crank] = ck; Ft[wless + crank] = 0; }
-                    wn = min(wn + na, ef);
-                    sync_w();
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) {
-                        const uint32_t slot = (uint32_t)(e * kWave + lane);
-                        const bool live = slot < wn;
-                        if (live) wkr[e] = Wt[slot];
-                        xm[e] = __ballot(live && Ft[slot] != 0);
-                    }
-                    if (wn == ef) {
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e)
-                            if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
-                    }
-                }
-                stamp(3);  // beam update
-                return true;
-            };
-            const uint32_t per = (uint32_t)kWave / max(gstride, 1u);  // whole lists that fit one window
-            if (nsel > 1 && per > 1) {
-                // the lists of the picked nodes side by side in a window (lane = list w, entry j), `per` lists per window: that many
-                // lists' worth of row fetches per dependent step.  The beam is a set, so merging the candidates of several lists
-                // together equals the spec's list-by-list insertion.
+                dg_all = gstride < kWave ? (uint32_t)__builtin_amdgcn_readlane((int)nb_first, kWave - 1) : deg[cid];
                 pre_id = 0xFFFFFFFFu;
-                for (uint32_t s0 = 0; s0 < nsel; s0 += per) {
-                    const uint32_t nl = min(per, nsel - s0);
-                    const uint32_t w = (uint32_t)lane / gstride, j = (uint32_t)lane - w * gstride;
-                    const bool live = w < nl;
-                    const uint32_t iw = s0 + w;
-                    const uint32_t cw = iw == 0 ? cids[0] : iw == 1 ? cids[1] : iw == 2 ? cids[2] : cids[3];
-                    uint32_t nbl = 0, dgw = 0;
-                    if (live) { nbl = adj[(size_t)cw * gstride + j]; dgw = min(deg[cw], gstride); }
-                    const bool valid = live && j < dgw;
-                    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
-                    if (cnt != 0 && !window(valid, nbl, cnt, false)) return;
-                }
-            } else {
-                for (uint32_t s = 0; s < nsel; ++s) {
-                    const uint32_t cid = cids[s];
-                    // one vector load brings the first list slots AND the degree (lane 63 reads deg[cid] when the stride leaves it free) --
-                    // or brought them already: the list of the NEXT unexpanded slot is requested speculatively a whole distance phase
-                    // ahead (in `window`); it is this pop's node unless a candidate of the previous pop went in before it
-                    uint32_t nb_first, dg_all;  // lists longer than 64 are walked 64 entries at a time
-                    if (cid == pre_id) {
-                        nb_first = pre_list;
-                        if constexpr (PROF) pre_hits += 1;
-                    } else {
-                        nb_first = *((uint32_t)lane < gstride ? adj + (size_t)cid * gstride + lane : deg + cid);
+                if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); list_wait += n - pt + (dg_all & 0u); }
+                for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
+                    const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
+                    sync_w();
+                    if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
+                    if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
+                        if (lane == 0) ef_mark_again(out_count, qi, net_list);
+                        release_helpers();
+                        return;
                     }
-                    dg_all = gstride < kWave ? (uint32_t)__builtin_amdgcn_readlane((int)nb_first, kWave - 1) : deg[cid];
+                    uint32_t nbl = 0;
+                    bool fresh1 = false;
+                    if ((uint32_t)lane < cnt && !overflow) {
+                        nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
+                        fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
+                    }
+                    // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
+                    // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
+                    const unsigned long long fb0 = __ballot(fresh1);
+                    if (fresh1) nb_i[__popcll(fb0 & ((1ull << lane) - 1ull))] = nbl;
+                    const uint32_t nf = (uint32_t)__popcll(fb0);
+                    const unsigned long long fb = nf == kWave ? ~0ull : (1ull << nf) - 1ull;
+                    if (WPQ > 1 && nf != 0) {
+                        if (lane == 0) ctl[0] = nf;
+                        __syncthreads();  // (A) window published to the helper waves
+                    } else {
+                        sync_w();
+                    }
+                    if (lbase == 0 && gstride < kWave) {  // speculative list request for the next pop, in flight during the distance phase (47 % of
+                                                          // pops use it at 1M x 768, ef = 128: +1.7 % QPS on bf16 rows, +0.7 % on fp32, A/B on one box)
+                        uint32_t slot2 = kWave * EPL;
+    #pragma unroll
+                        for (int e = EPL - 1; e >= 0; --e)
+                            if (~xm[e] != 0ull) slot2 = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
+                        if (slot2 < wn) {
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e)
+                                if (slot2 >> 6 == (uint32_t)e) pre_id = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wkr[e], (int)(slot2 & 63));
+                            pre_list = *((uint32_t)lane < gstride ? adj + (size_t)pre_id * gstride + lane : deg + pre_id);
+                        }
+                    }
+                    stamp(1);  // degree + list load + visited test-and-set
+                    if (nf == 0) continue;
+                    ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, nf, nb_i, nb_d, lane, 0);
+                    hash_used += nf;
+                    evals += nf;
+                    __syncthreads();  // (B) distances done
+                    stamp(2);  // blocked distances of the fresh neighbours
+                    uint64_t ck = ~0ull;
+                    if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
+                    const bool pass = ck != ~0ull && (wn < ef || ck < worst);
+                    unsigned long long todo = __ballot(pass);
+                    const uint32_t na = (uint32_t)__popcll(todo);
+                    if (na == 1) {
+                        insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
+                    } else if (na > 1) {
+                        // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
+                        // below it); new slot of a candidate = #(W entries below it) + #(candidates below it) -- per candidate two readlanes,
+                        // a compare + add per block and per candidate lane, and a ballot/popcount per block, ~16 instructions against ~70
+                        // for an insertion; then one scatter through LDS (slots >= ef fall off: the best ef of the union stay).
+                        uint32_t shift[EPL], crank = 0, wless = 0;
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) shift[e] = 0;
+                        while (todo) {
+                            const int l = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            const uint64_t ckl = readlane64(ck, l);
+                            uint32_t below = 0;
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e) {
+                                const bool valid = (uint32_t)(e * kWave + lane) < wn;
+                                shift[e] += (valid && ckl < wkr[e]) ? 1u : 0u;
+                                below += (uint32_t)__popcll(__ballot(valid && wkr[e] < ckl));
+                            }
+                            crank += ckl < ck ? 1u : 0u;
+                            if (lane == l) wless = below;
+                        }
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const uint32_t slot = (uint32_t)(e * kWave + lane), np = slot + shift[e];
+                            if (slot < wn && np < ef) { Wt[np] = wkr[e]; Ft[np] = (uint32_t)(xm[e] >> lane) & 1u; }
+                        }
+                        if (pass && wless + crank < ef) { Wt[wless + crank] = ck; Ft[wless + crank] = 0; }
+                        wn = min(wn + na, ef);
+                        sync_w();
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const uint32_t slot = (uint32_t)(e * kWave + lane);
+                            const bool live = slot < wn;
+                            if (live) wkr[e] = Wt[slot];
+                            xm[e] = __ballot(live && Ft[slot] != 0);
+                        }
+                        if (wn == ef) {
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e)
+                                if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
+                        }
+                    }
+                    stamp(3);  // beam update
+                }
+            }
+} else {
+        for (;;) {
+                // next to expand: the first unexpanded slots of W -- one (the search of orc_hnsw_search_ef_ex) or, with a search width
+                // (ZVDB_OPT_EF_SEARCH_WIDTH; spec: orc_hnsw_search_ef_w), up to `width` of them, ALL marked expanded before any of
+                // their lists is read
+                uint32_t cids[4] = {0, 0, 0, 0}, nsel = 0;
+    #pragma unroll
+                for (uint32_t w = 0; w < 4; ++w) {
+                    if (w >= width) break;
+                    uint32_t slot = kWave * EPL;
+    #pragma unroll
+                    for (int e = EPL - 1; e >= 0; --e)
+                        if (~xm[e] != 0ull) slot = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
+                    if (slot >= wn) break;
+                    uint64_t kb = 0;
+    #pragma unroll
+                    for (int e = 0; e < EPL; ++e)
+                        if (slot >> 6 == (uint32_t)e) { kb = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
+                    cids[w] = (uint32_t)kb;
+                    nsel = w + 1;
+                }
+                if (nsel == 0) break;
+                pops += nsel;
+                stamp(0);  // next-to-expand
+                // one window: <= 64 list entries (one lane each) -> visited test-and-set, the fresh ones compacted, their distances (shared
+                // with the helper waves), the beam update.  false: the visited table is full and a later launch serves the query.
+                auto window = [&](bool valid, uint32_t nbl, uint32_t cnt, bool prefetch_ok) -> bool {
+                    sync_w();
+                    if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
+                    if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
+                        if (lane == 0) ef_mark_again(out_count, qi, net_list);
+                        release_helpers();
+                        return false;
+                    }
+                    bool fresh1 = false;
+                    if (valid && !overflow) fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
+                    // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
+                    // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
+                    const unsigned long long fb0 = __ballot(fresh1);
+                    if (fresh1) nb_i[__popcll(fb0 & ((1ull << lane) - 1ull))] = nbl;
+                    const uint32_t nf = (uint32_t)__popcll(fb0);
+                    const unsigned long long fb = nf == kWave ? ~0ull : (1ull << nf) - 1ull;
+                    if (WPQ > 1 && nf != 0) {
+                        if (lane == 0) ctl[0] = nf;
+                        __syncthreads();  // (A) window published to the helper waves
+                    } else {
+                        sync_w();
+                    }
+                    if (prefetch_ok && gstride < kWave) {  // speculative list request for the next pop, in flight during the distance phase (47 % of
+                                                          // pops use it at 1M x 768, ef = 128: +1.7 % QPS on bf16 rows, +0.7 % on fp32, A/B on one box)
+                        uint32_t slot2 = kWave * EPL;
+    #pragma unroll
+                        for (int e = EPL - 1; e >= 0; --e)
+                            if (~xm[e] != 0ull) slot2 = (uint32_t)e * kWave + (uint32_t)__builtin_ctzll(~xm[e]);
+                        if (slot2 < wn) {
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e)
+                                if (slot2 >> 6 == (uint32_t)e) pre_id = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wkr[e], (int)(slot2 & 63));
+                            pre_list = *((uint32_t)lane < gstride ? adj + (size_t)pre_id * gstride + lane : deg + pre_id);
+                        }
+                    }
+                    stamp(1);  // degree + list load + visited test-and-set
+                    if (nf == 0) return true;
+                    ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, nf, nb_i, nb_d, lane, 0);
+                    hash_used += nf;
+                    evals += nf;
+                    __syncthreads();  // (B) distances done
+                    stamp(2);  // blocked distances of the fresh neighbours
+                    uint64_t ck = ~0ull;
+                    if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
+                    const bool pass = ck != ~0ull && (wn < ef || ck < worst);
+                    unsigned long long todo = __ballot(pass);
+                    const uint32_t na = (uint32_t)__popcll(todo);
+                    if (na == 1) {
+                        insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
+                    } else if (na > 1) {
+                        // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
+                        // below it); new slot of a candidate = #(W entries below it) + #(candidates below it) -- per candidate two readlanes,
+                        // a compare + add per block and per candidate lane, and a ballot/popcount per block, ~16 instructions against ~70
+                        // for an insertion; then one scatter through LDS (slots >= ef fall off: the best ef of the union stay).
+                        uint32_t shift[EPL], crank = 0, wless = 0;
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) shift[e] = 0;
+                        while (todo) {
+                            const int l = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            const uint64_t ckl = readlane64(ck, l);
+                            uint32_t below = 0;
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e) {
+                                const bool valid = (uint32_t)(e * kWave + lane) < wn;
+                                shift[e] += (valid && ckl < wkr[e]) ? 1u : 0u;
+                                below += (uint32_t)__popcll(__ballot(valid && wkr[e] < ckl));
+                            }
+                            crank += ckl < ck ? 1u : 0u;
+                            if (lane == l) wless = below;
+                        }
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const uint32_t slot = (uint32_t)(e * kWave + lane), np = slot + shift[e];
+                            if (slot < wn && np < ef) { Wt[np] = wkr[e]; Ft[np] = (uint32_t)(xm[e] >> lane) & 1u; }
+                        }
+                        if (pass && wless + crank < ef) { Wt[wless + crank] = ck; Ft[wless + crank] = 0; }
+                        wn = min(wn + na, ef);
+                        sync_w();
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const uint32_t slot = (uint32_t)(e * kWave + lane);
+                            const bool live = slot < wn;
+                            if (live) wkr[e] = Wt[slot];
+                            xm[e] = __ballot(live && Ft[slot] != 0);
+                        }
+                        if (wn == ef) {
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e)
+                                if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
+                        }
+                    }
+                    stamp(3);  // beam update
+                    return true;
+                };
+                const uint32_t per = (uint32_t)kWave / max(gstride, 1u);  // whole lists that fit one window
+                if (nsel > 1 && per > 1) {
+                    // the lists of the picked nodes side by side in a window (lane = list w, entry j), `per` lists per window: that many
+                    // lists' worth of row fetches per dependent step.  The beam is a set, so merging the candidates of several lists
+                    // together equals the spec's list-by-list insertion.
                     pre_id = 0xFFFFFFFFu;
-                    if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); list_wait += n - pt + (dg_all & 0u); }
-                    for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
-                        const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
-                        const bool valid = (uint32_t)lane < cnt;
-                        const uint32_t nbl = !valid ? 0u : lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
-                        if (!window(valid, nbl, cnt, lbase == 0 && width == 1)) return;
+                    for (uint32_t s0 = 0; s0 < nsel; s0 += per) {
+                        const uint32_t nl = min(per, nsel - s0);
+                        const uint32_t w = (uint32_t)lane / gstride, j = (uint32_t)lane - w * gstride;
+                        const bool live = w < nl;
+                        const uint32_t iw = s0 + w;
+                        const uint32_t cw = iw == 0 ? cids[0] : iw == 1 ? cids[1] : iw == 2 ? cids[2] : cids[3];
+                        uint32_t nbl = 0, dgw = 0;
+                        if (live) { nbl = adj[(size_t)cw * gstride + j]; dgw = min(deg[cw], gstride); }
+                        const bool valid = live && j < dgw;
+                        const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+                        if (cnt != 0 && !window(valid, nbl, cnt, false)) return;
+                    }
+                } else {
+                    for (uint32_t s = 0; s < nsel; ++s) {
+                        const uint32_t cid = cids[s];
+                        // one vector load brings the first list slots AND the degree (lane 63 reads deg[cid] when the stride leaves it free) --
+                        // or brought them already: the list of the NEXT unexpanded slot is requested speculatively a whole distance phase
+                        // ahead (in `window`); it is this pop's node unless a candidate of the previous pop went in before it
+                        uint32_t nb_first, dg_all;  // lists longer than 64 are walked 64 entries at a time
+                        if (cid == pre_id) {
+                            nb_first = pre_list;
+                            if constexpr (PROF) pre_hits += 1;
+                        } else {
+                            nb_first = *((uint32_t)lane < gstride ? adj + (size_t)cid * gstride + lane : deg + cid);
+                        }
+                        dg_all = gstride < kWave ? (uint32_t)__builtin_amdgcn_readlane((int)nb_first, kWave - 1) : deg[cid];
+                        pre_id = 0xFFFFFFFFu;
+                        if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); list_wait += n - pt + (dg_all & 0u); }
+                        for (uint32_t lbase = 0; lbase < dg_all; lbase += kWave) {
+                            const uint32_t cnt = min(dg_all - lbase, (uint32_t)kWave);
+                            const bool valid = (uint32_t)lane < cnt;
+                            const uint32_t nbl = !valid ? 0u : lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
+                            if (!window(valid, nbl, cnt, lbase == 0 && width == 1)) return;
+                        }
                     }
                 }
             }
-        }
+}
         sync_w();
     }
     release_helpers();
@@ -2572,6 +2703,13 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         if (epl >= 8 && wpq == 4) wpq = 2;
         if (epl == 0 || (wpq != 2 && wpq != 4)) wpq = 1;
         wpq_launch = wpq;
+        if (width > 1) {  // the search-width form of the loop (its own instantiations: the width-1 loop stays as it was)
+            if (wpq == 4) return epl == 2 ? go(k_search_ef_reg<RT, 2, 4, 0, true>, kpad) : go(k_search_ef_reg<RT, 4, 4, 0, true>, kpad);
+            if (wpq == 2) return epl == 2 ? go(k_search_ef_reg<RT, 2, 2, 0, true>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 2, 0, true>, kpad)
+                                 : epl == 8 ? go(k_search_ef_reg<RT, 8, 2, 0, true>, kpad) : go(k_search_ef_reg<RT, 16, 2, 0, true>, kpad);
+            return epl == 2 ? go(k_search_ef_reg<RT, 2, 1, 0, true>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 1, 0, true>, kpad)
+                   : epl == 8 ? go(k_search_ef_reg<RT, 8, 1, 0, true>, kpad) : epl == 16 ? go(k_search_ef_reg<RT, 16, 1, 0, true>, kpad) : go(k_search_ef<RT>, efp);
+        }
         if (wpq == 4) return epl == 2 ? go(k_search_ef_reg<RT, 2, 4>, kpad) : go(k_search_ef_reg<RT, 4, 4>, kpad);
         if (wpq == 2) return epl == 2 ? go(k_search_ef_reg<RT, 2, 2>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 2>, kpad)
                              : epl == 8 ? go(k_search_ef_reg<RT, 8, 2>, kpad) : go(k_search_ef_reg<RT, 16, 2>, kpad);
