@@ -358,10 +358,12 @@ typedef struct zvdb_hip_cert_info {
     uint64_t repaired; /* of them: recomputed by the exact scan (read without synchronising: launches still running are not counted) */
     uint32_t level;    /* survivors currently kept: 0 = the route's minimum (32 for k <= 16, else 64), 1 = 64, 2 = 128, 3 = 256 */
     uint32_t enabled;
-    uint64_t rerank_rows; /* diagnostic (tuning ZVDB_CERT_DEBUG): candidate rows the re-rank evaluated exactly, modulo 2^32 */
+    uint64_t rerank_rows; /* diagnostic (tuning ZVDB_CERT_DEBUG=1): candidate rows the re-rank evaluated exactly, modulo 2^32 */
     uint32_t rerank_cycles[5]; /* diagnostic: 100-MHz ticks of every 64th query's re-rank, summed per phase: query constants, first
                                   (staged) batch, further candidates, final bound, ranking + output */
     uint32_t reserved_;
+    uint32_t bound_checked;    /* diagnostic (tuning ZVDB_CERT_DEBUG=3): evaluated candidates whose screen key was held against the bound of */
+    uint32_t bound_violations; /* their own exact distance, and how many exceeded it (must be 0: the inequality of bf_cert.h on real hardware) */
 } zvdb_hip_cert_info;
 int zvdb_hip_bruteforce_cert_info(zvdb_hip_index *h, zvdb_hip_cert_info *out);
 

@@ -148,3 +148,31 @@ def test_uniform_rows_are_certified_without_repairs_once_the_level_has_settled(z
             if b >= 6:
                 assert rep == last, (m, b, idx.cert_info())  # settled: no repairs in the last batches
             last = rep
+
+
+@pytest.mark.parametrize("metric", ["l2", "dot"])
+def test_the_bound_holds_on_every_row_the_rerank_evaluates(zv, oracle, metric):
+    """The certificate's inequality, checked on the hardware where it can be checked: for every candidate the re-rank evaluates, its
+    screen key must not exceed key_safe(its own exact distance) -- the statement the proof applies to the rows it does NOT evaluate
+    (tuning ZVDB_CERT_DEBUG=3 counts checks and violations on the device).  Uniform rows, tight clusters and a corpus with one huge
+    outlier row (which inflates the mirror's largest residual and norm), all three screens, level 0 .. 3."""
+    mt = zv.METRIC_L2SQ if metric == "l2" else zv.METRIC_DOT
+    rng = np.random.default_rng(33)
+    d, nq, k = 192, 128, 10
+    shift = np.float32(0.0 if metric == "l2" else 0.5)
+    sets = {"uniform": rng.random((150_000, d), dtype=np.float32) - shift,
+            "clusters": _clusters(150_000, d, 32, 0.01, 34)[0] - shift}
+    out = sets["uniform"][:60_000].copy()
+    out[777] *= np.float32(300.0)
+    sets["outlier"] = out
+    with zv.tuned(ZVDB_CERT_DEBUG="3"):
+        for name, V in sets.items():
+            idx = zv.Index(dim=d, metric=mt, capacity=len(V), flags=zv.FLAG_BF16_MIRROR)
+            idx.add(V)
+            Q = (V[rng.integers(0, len(V), size=nq)] + 0.05 * rng.standard_normal((nq, d), dtype=np.float32)).astype(np.float32)
+            for lvl in (0, 1, 2, 3):
+                idx.set_option(zv.OPT_CERT_MIN_LEVEL, lvl)
+                for m in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+                    idx.search_bruteforce(Q, k, m)
+            ci = idx.cert_info()
+            assert ci["bound_checked"] >= 12 * nq * k and ci["bound_violations"] == 0, (name, ci)

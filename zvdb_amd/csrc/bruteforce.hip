@@ -1137,7 +1137,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         ca.affine = l2 ? 1 : 0;
         ca.rescale_target = mode == ZVDB_BF_I8 ? 127.0f / h->q_inv : 0.0f;
         ca.force = h->cert_force ? 1 : 0;
-        if (const char *dbg = tuning("ZVDB_CERT_DEBUG")) { ca.dbg_rows = h->cert_hdev + 2; ca.dbg_mode = dbg[0] == '2' ? 2 : 1; }
+        if (const char *dbg = tuning("ZVDB_CERT_DEBUG")) { ca.dbg_rows = h->cert_hdev + 2; ca.dbg_mode = dbg[0] == '2' ? 2 : dbg[0] == '3' ? 3 : 1; }
         ZV_CHECK(launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid, &ca));
         return launch_exact_scan(h, d_queries_exact, nq, k, id_offset, nflag, flist, cand, p.cand_bytes, d_ids, d_dist, d_count, h->cert_hdev + 1, s);
     };

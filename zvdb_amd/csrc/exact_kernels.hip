@@ -3078,6 +3078,25 @@ __global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ row
         const float dk = cert_kth_dist(cd, ci, n_hi, k, dk_slot, lane);
         ks = cert_safe_key(cert, cq, dk, dim, metric);
         if (prof) tstamp[4] = __builtin_amdgcn_s_memtime();
+        if (cert.dbg_rows && cert.dbg_mode == 3) {
+            // self-check of the inequality on the rows this query DID evaluate: a row with exact distance d carries a screen key of at
+            // most key_safe(d) -- the statement the certificate applies to the rows it did not evaluate.  [6] += checked, [7] += violations
+            uint32_t chk = 0, bad = 0;
+#pragma unroll
+            for (int bt = 0; bt < NE; ++bt) {
+                const uint32_t i = 64 * bt + lane;
+                if (ci[i] != 0xFFFFFFFFu) {
+                    chk += 1;
+                    bad += ck[i] > cert_safe_key(cert, cq, cd[i], dim, metric) ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { chk += __shfl_xor(chk, off); bad += __shfl_xor(bad, off); }
+            if (lane == 0) {
+                __hip_atomic_fetch_add(cert.dbg_rows + 6, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_fetch_add(cert.dbg_rows + 7, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         uint32_t nev = 0;
         if (cert.dbg_rows && cert.dbg_mode == 1) {
 #pragma unroll
