@@ -42,7 +42,7 @@ for c in range(cases):
         k = int(rng.choice([1, 5, 10, 25, 60, 100]))
         width = int(rng.choice([1, 1, 2, 3, 4]))  # search width (ZVDB_OPT_EF_SEARCH_WIDTH; spec: orc_hnsw_search_ef_w)
         idx.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
-        ef = int(max(k, rng.choice([1, 10, 33, 64, 100, 128, 129, 200, 256, 300, 512, 600])))
+        ef = int(max(k, rng.choice([1, 10, 33, 64, 100, 128, 129, 200, 256, 300, 512, 600, 1000])))
         try:
             ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, with_stats=True)
             zv.set_tuning("ZVDB_EF_BEAM", "lds")
@@ -59,13 +59,18 @@ for c in range(cases):
                 # visited set in a global table handed out on demand)
                 if gv == "net": zv.set_tuning("ZVDB_EF_GLOBAL_VISITED", None); zv.set_tuning("ZVDB_EF_HASH_BITS", "8")
                 else: zv.set_tuning("ZVDB_EF_HASH_BITS", None)
+                # large beams (ef > 256): the packed visited table off / with more (small) regions than the ids need; 8 waves per query
+                pk = [None, "0", "r3", "r6"][int(rng.integers(0, 4))] if ef > 256 else None
+                zv.set_tuning("ZVDB_EF_PACKED_VISITED", "0" if pk == "0" else None); zv.set_tuning("ZVDB_EF_PACKED_R", pk[1:] if pk and pk[0] == "r" else None)
+                if ef > 256 and width > 1 and wpq == "4" and rng.random() < 0.5: zv.set_tuning("ZVDB_EF_WPQ", "8")
                 ids3, dist3, cnt3, (ev3, pp3) = idx.search_graph(Q, k, ef=ef, with_stats=True)
                 if not (np.array_equal(ids, ids3) and np.array_equal(dist, dist3) and np.array_equal(cnt, cnt3) and (ev, pp) == (ev3, pp3)):
-                    ok = False; print(f"case {c}: two-pass visited sizing differs (beam {beam}, ZVDB_EF_TWO_PASS={tp!r}, ZVDB_EF_WPQ={wpq}, ZVDB_EF_GLOBAL_VISITED={gv!r}) stats {(ev3, pp3)} vs {(ev, pp)}", flush=True)
+                    ok = False; print(f"case {c}: two-pass (packed visited {pk!r}) visited sizing differs (beam {beam}, ZVDB_EF_TWO_PASS={tp!r}, ZVDB_EF_WPQ={wpq}, ZVDB_EF_GLOBAL_VISITED={gv!r}) stats {(ev3, pp3)} vs {(ev, pp)}", flush=True)
         except zv.ZvdbError as e:
             print(f"case {c}: n={n} d={d} m={m} k={k} ef={ef}: {e}"); continue
         finally:
             zv.set_tuning("ZVDB_EF_BEAM", None); zv.set_tuning("ZVDB_EF_TWO_PASS", None); zv.set_tuning("ZVDB_EF_WPQ", None); zv.set_tuning("ZVDB_EF_GLOBAL_VISITED", None); zv.set_tuning("ZVDB_EF_HASH_BITS", None)
+            zv.set_tuning("ZVDB_EF_PACKED_VISITED", None); zv.set_tuning("ZVDB_EF_PACKED_R", None)
         if not (np.array_equal(ids, ids2) and np.array_equal(dist, dist2) and np.array_equal(cnt, cnt2) and (ev, pp) == (ev2, pp2)):
             ok = False
             print(f"case {c}: the two beam kernels differ: ids {np.array_equal(ids, ids2)} dist {np.array_equal(dist, dist2)} cnt {np.array_equal(cnt, cnt2)} "

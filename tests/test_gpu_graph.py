@@ -92,6 +92,47 @@ def test_search_width_equals_the_oracle_spec(zv, oracle, width, M, bf16rows, met
         assert (ev, pp) == (c.search_dist_evals, c.search_pops), (k, ef, tune)
 
 
+@pytest.mark.parametrize("width,M,bf16rows", [(1, 8, False), (4, 8, True), (4, 16, False)])
+def test_large_beams_packed_visited_table_gather_merge_wide_workgroups(zv, oracle, width, M, bf16rows):
+    """ef > 256 (register beam of 8 / 16 blocks): the visited set in 21-bit entries, three to a word, behind a bijection of the ids
+    (exact membership), the window's candidates merged by gather from the LDS copy of the beam, 2 / 4 / 8 waves per query -- ids,
+    distances and the E / P counters equal the oracle's search in every combination; also with the packed table switched off, with
+    MORE regions than the row count needs (ZVDB_EF_PACKED_R: 2^4 regions of a forced 768-unit table are 24 words each -- regions
+    fill up and the query is handed to the next pass) and with the table forced tiny (overflow -> retry -> net)."""
+    n, d, efc = 4000, 24, 48
+    rng = np.random.default_rng(7 * width + M)
+    V = rng.random((n, d), dtype=np.float32)
+    if bf16rows:
+        V = oracle.bf16_round(V)
+    idx = zv.Index(m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_ROWS if bf16rows else zv.FLAG_BF16_MIRROR)
+    idx.add(V)
+    idx.build_graph(M, efc, zv.BF_I8, 21)
+    ref, levels, top = oracle.build_bulk_graph(V, M, efc, 21)
+    idx.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
+    Q = rng.random((40, d), dtype=np.float32)
+    want = {}
+    for k, ef in ((10, 300), (100, 520), (10, 1000)):
+        ref.reset_counters()
+        res = []
+        for q in Q:
+            res.append(ref.search_ef(q, k, ef, 0, ref.descend(q, 0, top), width))
+        c = ref.counters()
+        want[(k, ef)] = (res, (c.search_dist_evals, c.search_pops))
+    tunes = [{}, {"ZVDB_EF_PACKED_VISITED": "0"}, {"ZVDB_EF_PACKED_R": "3"}, {"ZVDB_EF_PACKED_R": "4", "ZVDB_EF_TWO_PASS": "s768"},
+             {"ZVDB_EF_PACKED_R": "6", "ZVDB_EF_TWO_PASS": "s512"}, {"ZVDB_EF_TWO_PASS": "s320"}, {"ZVDB_EF_TWO_PASS": "t8"}]
+    if width > 1:
+        tunes += [{"ZVDB_EF_WPQ": "1"}, {"ZVDB_EF_WPQ": "2"}, {"ZVDB_EF_WPQ": "4"}, {"ZVDB_EF_WPQ": "8"}, {"ZVDB_EF_WPQ": "8", "ZVDB_EF_PACKED_R": "5", "ZVDB_EF_TWO_PASS": "s768"}]
+    for tune in tunes:
+        for (k, ef), (res, counters) in want.items():
+            for _ in range(2):  # (the second call runs on the table sized from the first one's fill)
+                with zv.tuned(**tune):
+                    ids, dist, cnt, (ev, pp) = idx.search_graph(Q, k, ef=ef, entry=zv.ENTRY_DESCEND, with_stats=True)
+                for qi, (ri, rd) in enumerate(res):
+                    assert cnt[qi] == len(ri), (k, ef, tune, qi)
+                    assert np.array_equal(ids[qi, :len(ri)], ri) and np.array_equal(dist[qi, :len(ri)], rd), (k, ef, tune, qi)
+                assert (ev, pp) == counters, (k, ef, tune)
+
+
 def test_search_width_hand_derived_on_the_device(zv, oracle):
     """The paper example of tests/test_oracle_graph_spec.py::test_search_width_hand_derived through the ABI: six points on a line,
     query 4.6, ef = 2 -- width 1 ends on [4, 2] after 3 pops / 4 evaluations, width 2 reaches [5, 4] after 6 / 6."""

@@ -1037,6 +1037,45 @@ __device__ __forceinline__ bool hashn_insert_atomic(uint32_t *tab, uint32_t size
     }
 }
 
+// Visited set of the LARGE beams (k_search_ef_reg with 8 / 16 beam blocks: ef > 256), r4: 21-bit entries, three to a 64-bit word.
+// The table's LDS decides how many queries a CU holds (a third of HBM at ef = 512 with two, an eighth at ef = 1,024 with one), and a
+// 32-bit slot spends a third of its bits on what the slot's position already says.  A node id is first sent through a BIJECTION
+// of [0, 2^b) (b = bits of the row count: multiply by an odd constant, xor with the own right shift, twice); the low r = max(0, b -
+// 20) bits of the image pick one of 2^r regions of the table, the remaining <= 20 bits (+ 1; 0 = empty) are what is stored, and an
+// entry never leaves its region (bucketised linear probing over the region's words, wrapping inside it).  (region, stored bits)
+// give the image and the image gives the id, so membership is EXACT -- no fingerprint collisions -- at 21.3 bits per entry.  A region
+// that fills up (cw words, all three fields taken) reports 2: the caller hands the query to the next pass like any full table.
+// Fields of a word fill in the order 0, 1, 2 and are never cleared; lanes of the wave meet in one 64-bit compare-and-swap.
+__device__ __forceinline__ uint32_t hp_mix(uint32_t id, uint32_t bmask, uint32_t half) {
+    uint32_t h = (id * 0x9E3779B1u) & bmask;
+    h ^= h >> half;
+    h = (h * 0x85EBCA6Bu) & bmask;
+    h ^= h >> half;
+    return h;
+}
+// 0: the id was there; 1: THIS lane put it in; 2: its region is full
+__device__ __forceinline__ uint32_t hp_insert_atomic(unsigned long long *tab, uint32_t cw, uint32_t r, uint32_t bmask, uint32_t half, uint32_t id) {
+    const uint32_t h = hp_mix(id, bmask, half);
+    const uint32_t quo = h >> r;  // < 2^20
+    const unsigned long long tag = (unsigned long long)quo + 1ull;
+    unsigned long long *reg = tab + (size_t)(h & ((1u << r) - 1u)) * cw;
+    uint32_t w = __umulhi(quo << 12, cw);  // home word: quo cw / 2^20
+    for (uint32_t n = 0; n < cw; ++n) {
+        unsigned long long v = reg[w];
+        for (;;) {
+            const uint32_t f0 = (uint32_t)v & 0x1FFFFFu, f1 = (uint32_t)(v >> 21) & 0x1FFFFFu, f2 = (uint32_t)(v >> 42) & 0x1FFFFFu;
+            if (f0 == (uint32_t)tag || f1 == (uint32_t)tag || f2 == (uint32_t)tag) return 0;
+            const int sh = f0 == 0 ? 0 : f1 == 0 ? 21 : f2 == 0 ? 42 : -1;
+            if (sh < 0) break;  // the word is full: on to the next
+            const unsigned long long old = atomicCAS(&reg[w], v, v | (tag << sh));
+            if (old == v) return 1;
+            v = old;  // another lane's entry went into this word meanwhile: look again
+        }
+        w = w + 1 == cw ? 0 : w + 1;
+    }
+    return 2;
+}
+
 // Frontier: Zig std.PriorityQueue (std/priority_queue.zig, Zig >= 0.13) restated on two LDS
 // arrays; executed wave-uniformly (every lane performs the same reads and writes) so the
 // pop order -- including the order of exactly equal distances -- is the oracle's.
@@ -1941,7 +1980,7 @@ __device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v) {  // lane i <- lan
 // latency: a 1,024-query batch is one round of resident workgroups either way, its time is the slowest query's chain of pops.
 constexpr uint32_t kEfDone = 0xFFFFFFFFu;  // ctl[0]: no further window (a window has 1 .. 64 rows)
 template <typename RT, int EPL, int WPQ = 1, int PROF = 0, bool WIDE = false>
-__global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_search_ef_reg(
+__global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 : 4) : WPQ == 2 ? 2 : 1) void k_search_ef_reg(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
@@ -1949,8 +1988,14 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_size /* slots of the visited table: any count >= 256 */, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
     uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */,
-    uint32_t *net_list /* marks are appended here (the last LDS pass of a call; else null) */, uint32_t width /* nodes expanded per step: 1 .. 4 */) {
+    uint32_t *net_list /* marks are appended here (the last LDS pass of a call; else null) */,
+    uint32_t width_mode /* nodes expanded per step: 1 .. 4; large beams (EPL >= 8) also: r << 8 | b << 16 | packed visited table << 24 (hp_insert_atomic) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t width = EPL >= 8 ? (width_mode & 0xFFu) : width_mode;
+    const bool hp_on = EPL >= 8 && ((width_mode >> 24) & 1u) != 0;
+    const uint32_t hp_r = (width_mode >> 8) & 0xFFu, hp_b = (width_mode >> 16) & 0xFFu;
+    const uint32_t hp_bmask = hp_b >= 32 ? ~0u : (1u << hp_b) - 1u, hp_half = hp_b / 2 > 1 ? hp_b / 2 : 1u;
+    const uint32_t hp_cw = (hash_size / 2) >> hp_r;  // 64-bit words per region
     if ((pass == kEfRetry || pass == kEfRetryMark) && out_count[blockIdx.x] != kEfAgain) return;  // served by an earlier pass
     if (entries) entry = entries[blockIdx.x];
     float *q = reinterpret_cast<float *>(smem);
@@ -1962,6 +2007,9 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     uint32_t *R = nb_i + kWave;                          // [kpad] result ids
     float *RD = reinterpret_cast<float *>(R + kpad);     // [kpad] their exact distances
     uint32_t *ctl = reinterpret_cast<uint32_t *>(RD + kpad);  // [4] window hand-over to the helper waves (WPQ > 1)
+    constexpr bool LMERGE = EPL >= 8;  // large beams: Wt / Ft always hold the beam and a window merges by gather (merge_lds below)
+    uint64_t *Cs = reinterpret_cast<uint64_t *>(ctl + 4);  // LMERGE: [64] the window's candidates in key order ...
+    uint32_t *Mb = reinterpret_cast<uint32_t *>(Cs + kWave);  // ... and [2 EPL] one bit per beam slot a candidate lands in
 
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int t = lane & 15;
@@ -1971,7 +2019,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     for (uint32_t i = threadIdx.x; i < hash_size; i += kWave * WPQ) hash[i] = 0;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
-    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : 4 / WPQ;  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32; two rows per group at WPQ = 2 measured 24 % SLOWER with a search width, r4)
+    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : (WPQ >= 4 ? 1 : 4 / WPQ);  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32; two rows per group at WPQ = 2 measured 24 % SLOWER with a search width, r4)
     if constexpr (WPQ > 1) {
         if (wave != 0) {  // helper waves: their share of every published window's distances
             for (;;) {
@@ -2005,9 +2053,23 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     unsigned long long pf[6] = {0, 0, 0, 0, 0, 0}, pt = 0;
     auto stamp = [&](int ph) { if constexpr (PROF) { const unsigned long long n = __builtin_amdgcn_s_memtime(); pf[ph] += n - pt; pt = n; } };
     if constexpr (PROF) pt = __builtin_amdgcn_s_memtime();
-    const uint32_t hash_limit = hash_size - hash_size / 8;  // 87.5 % load cap (the tight table is sized for <= 74 % at the largest fill seen)
+    uint32_t hash_limit = hash_size - hash_size / 8;  // 87.5 % load cap (the tight table is sized for <= 74 % at the largest fill seen)
+    if constexpr (EPL >= 8) {
+        if (hp_on) { const uint32_t cap = (3u * hp_cw) << hp_r; hash_limit = cap - cap / 8; }
+    }
     uint32_t hash_used = 0;
     bool overflow = false;
+    // visited test-and-set of one lane's neighbour: true = fresh.  Large beams on the packed table: `full` = its region is full
+    auto visit = [&](uint32_t id, bool &full) -> bool {
+        if constexpr (EPL >= 8) {
+            if (hp_on) {
+                const uint32_t v = hp_insert_atomic(reinterpret_cast<unsigned long long *>(hash), hp_cw, hp_r, hp_bmask, hp_half, id);
+                full = v == 2;
+                return v == 1;
+            }
+        }
+        return hashn_insert_atomic(hash, hash_size, id);
+    };
 
     uint32_t pre_id = 0xFFFFFFFFu, pre_list = 0;  // speculative list prefetch (ids are < N <= 2^32 - 1)
     unsigned long long pre_hits = 0, list_wait = 0;
@@ -2041,13 +2103,82 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
         }
     };
 
+    // Large beams (EPL >= 8: ef > 256).  The merge by ranks further down costs ~6 instructions per (candidate, block) pair -- at 16
+    // blocks and the 20-40 candidates a search-width window accepts, more than the window's row fetches (ZVDB_EF_PROF: the beam
+    // update is a sixth of a pop at ef = 128, a third at ef = 512).  Here the LDS copy of the beam is kept current (Wt: keys in slot
+    // order, Ft: expanded flags, also set when a slot is picked) and a window's candidates merge in O(blocks + candidates):
+    //   candidate lane: #beam entries below it by BINARY SEARCH in Wt (<= 11 dependent LDS reads, all candidates at once), + its
+    //   rank among the candidates = its slot in the merged beam; it sets that slot's bit in Mb and leaves its key in Cs[rank];
+    //   every beam slot p then GATHERS: with c = #candidate bits below p (a popcount prefix), p holds candidate Cs[c] if its own
+    //   bit is set, else the old entry p - c -- one LDS read per slot; the registers take the result, then refresh Wt / Ft.
+    // Same beam as the sorted insertion of each candidate in turn (keys are distinct), so results and counters do not change.
+    auto merge_lds = [&](uint64_t ck, bool cpass, unsigned long long todo, uint32_t na) {
+        if ((uint32_t)lane < 2u * EPL) Mb[lane] = 0;
+        uint32_t lo = 0, hi = cpass ? wn : 0u;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (Wt[mid] < ck) lo = mid + 1; else hi = mid;
+        }
+        uint32_t crank = 0;
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            crank += readlane64(ck, l) < ck ? 1u : 0u;
+        }
+        sync_w();  // (Mb cleared before the bits go in)
+        if (cpass) {
+            const uint32_t pos = lo + crank;
+            Cs[crank] = ck;
+            if (pos < ef) atomicOr(&Mb[pos >> 5], 1u << (pos & 31));
+        }
+        const uint32_t wn_new = min(wn + na, ef);
+        sync_w();
+        uint32_t cbase = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const uint64_t mw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)Mb[2 * e + 1]) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)Mb[2 * e]);
+            const uint32_t p = (uint32_t)(e * kWave + lane);
+            const uint32_t c = cbase + (uint32_t)__popcll(mw & ((1ull << lane) - 1ull));
+            const bool isc = (mw >> lane) & 1ull;
+            const bool live = p < wn_new;
+            uint32_t f = 0;
+            if (live) {
+                wkr[e] = isc ? Cs[c] : Wt[p - c];
+                f = isc ? 0u : Ft[p - c];
+            }
+            xm[e] = __ballot(live && f != 0);
+            cbase += (uint32_t)__popcll(mw);
+        }
+        wn = wn_new;
+        sync_w();  // (every gather done before the slots are overwritten)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const uint32_t p = (uint32_t)(e * kWave + lane);
+            if (p < wn) { Wt[p] = wkr[e]; Ft[p] = (uint32_t)(xm[e] >> lane) & 1u; }
+        }
+        if (wn == ef) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
+        }
+    };
+
     if (N > 0 && k > 0) {
         const RT *erow = rows + (size_t)entry * ld;
         const float d0 = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, erow, nchunks, t)
                                                     : blocked16_dist<ZVDB_METRIC_DOT>(q, erow, nchunks, t);
         insert_sorted(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)f32_key(d0)) << 32) | entry);
+        if constexpr (LMERGE) {
+            if (lane == 0) { Wt[0] = wkr[0]; Ft[0] = 0; }
+        }
         evals = 1;
-        hashn_insert_uniform(hash, hash_size, entry);
+        if constexpr (EPL >= 8) {
+            bool full0 = false;
+            (void)visit(entry, full0);  // (every lane the same id: one of them puts it in)
+        } else {
+            hashn_insert_uniform(hash, hash_size, entry);
+        }
         hash_used = 1;
         sync_w();
         if constexpr (!WIDE) {  // width 1: the loop of rounds 2-3, untouched -- every restructuring that also served a search width
@@ -2063,6 +2194,9 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     #pragma unroll
                 for (int e = 0; e < EPL; ++e)
                     if (slot >> 6 == (uint32_t)e) { kbest = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
+                if constexpr (LMERGE) {
+                    if (lane == 0) Ft[slot] = 1;
+                }
                 const uint32_t cid = (uint32_t)kbest;
                 pops += 1;
                 stamp(0);  // next-to-expand
@@ -2090,6 +2224,21 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                     }
                     uint32_t nbl = 0;
                     bool fresh1 = false;
+                    if constexpr (EPL >= 8) {
+                        bool full1 = false;
+                        if ((uint32_t)lane < cnt && !overflow) {
+                            nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
+                            fresh1 = visit(nbl, full1);
+                        }
+                        if (__ballot(full1)) {  // a region of the packed table is full: the launch behind this one serves the query
+                            if (pass == kEfTight || pass == kEfRetryMark) {
+                                if (lane == 0) ef_mark_again(out_count, qi, net_list);
+                                release_helpers();
+                                return;
+                            }
+                            overflow = true;
+                        }
+                    } else
                     if ((uint32_t)lane < cnt && !overflow) {
                         nbl = lbase == 0 ? nb_first : adj[(size_t)cid * gstride + lbase + lane];
                         fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
@@ -2131,7 +2280,9 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                     const bool pass = ck != ~0ull && (wn < ef || ck < worst);
                     unsigned long long todo = __ballot(pass);
                     const uint32_t na = (uint32_t)__popcll(todo);
-                    if (na == 1) {
+                    if constexpr (LMERGE) {
+                        if (na != 0) merge_lds(ck, pass, todo, na);
+                    } else if (na == 1) {
                         insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
                     } else if (na > 1) {
                         // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
@@ -2197,6 +2348,9 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
     #pragma unroll
                     for (int e = 0; e < EPL; ++e)
                         if (slot >> 6 == (uint32_t)e) { kb = readlane64(wkr[e], (int)(slot & 63)); xm[e] |= 1ull << (slot & 63); }
+                    if constexpr (LMERGE) {
+                        if (lane == 0) Ft[slot] = 1;
+                    }
                     cids[w] = (uint32_t)kb;
                     nsel = w + 1;
                 }
@@ -2213,8 +2367,18 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                         release_helpers();
                         return false;
                     }
-                    bool fresh1 = false;
-                    if (valid && !overflow) fresh1 = hashn_insert_atomic(hash, hash_size, nbl);
+                    bool fresh1 = false, full1 = false;
+                    if (valid && !overflow) fresh1 = visit(nbl, full1);
+                    if constexpr (EPL >= 8) {
+                        if (__ballot(full1)) {  // a region of the packed table is full: the launch behind this one serves the query
+                            if (pass == kEfTight || pass == kEfRetryMark) {
+                                if (lane == 0) ef_mark_again(out_count, qi, net_list);
+                                release_helpers();
+                                return false;
+                            }
+                            overflow = true;
+                        }
+                    }
                     // the fresh neighbours move to the front of nb_i (list order kept): the distance passes below take 16 rows each,
                     // and ~15 of a 32-entry list are fresh in the steady state -- one pass instead of two for most pops
                     const unsigned long long fb0 = __ballot(fresh1);
@@ -2252,7 +2416,9 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 4 ? 4 : WPQ == 2 ? 2 : 1) void k_s
                     const bool pass = ck != ~0ull && (wn < ef || ck < worst);
                     unsigned long long todo = __ballot(pass);
                     const uint32_t na = (uint32_t)__popcll(todo);
-                    if (na == 1) {
+                    if constexpr (LMERGE) {
+                        if (na != 0) merge_lds(ck, pass, todo, na);
+                    } else if (na == 1) {
                         insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
                     } else if (na > 1) {
                         // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
@@ -2511,6 +2677,25 @@ static int ef_reserve_net(const zvdb_hip_index *h, uint32_t nq, uint32_t ef) {
     return ZVDB_OK;
 }
 
+// waves per query of the register-beam kernel (epl: its beam blocks).  Measured at 1M x 768, M = 16, ef = 128, batch 1,024 / 4,096 /
+// 16,384 (QPS): fp32 rows 1 wave 775k / 901k / 993k, 2 waves 863k / 982k / 1.09M, 4 waves 894k / 1.03M / 1.11M; bf16 rows 1.00M /
+// 1.19M / 1.30M, 2 waves 1.23M / 1.54M / 1.67M, 4 waves 0.69M (8 rows per wave step: half the waves idle on 16-entry lists; with the
+// 16-lane walk 0.94M / 1.20M / 1.29M).  ZVDB_EF_WPQ = 1 / 2 / 4 / 8: experiment / tests, read per call.
+// Large beams (epl 8, 16: ef > 256) with a search width: the visited table leaves room for one or two queries per CU (lds_g: what the
+// LDS allows, 0 = unknown), so the idle wave slots join the query's distance phases instead -- 4 waves per query at two queries per
+// CU, 8 at one (1M x 768, M = 16, width 4, 2 / 4 / 8 waves: ef = 512 bf16 rows 234k / 290k / 189k QPS, fp32 rows 181k / 235k / 168k;
+// ef = 1,024 bf16 rows 57.5k / 70.3k / 77.3k, fp32 rows 48.3k / 58.6k / 71.4k; profiles/r4/ef_large_probe_*).
+static uint32_t ef_waves_per_query(const zvdb_hip_index *h, int epl, uint32_t width, uint32_t lds_g) {
+    uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
+    bool forced = false;
+    if (const char *we = tuning("ZVDB_EF_WPQ")) { wq = (uint32_t)atoi(we); forced = true; }
+    if (wq != 1 && wq != 2 && wq != 4 && wq != 8) wq = 1;
+    if (epl < 8 && wq == 8) wq = 4;                       // (not instantiated)
+    if (epl >= 8 && width <= 1 && wq >= 4) wq = 2;        // the wide workgroups exist for the search-width loop only
+    if (epl >= 8 && width > 1 && !forced) wq = lds_g == 1 ? 8u : lds_g == 2 ? 4u : 2u;  // (lds_g: queries per CU of the two-wave plan)
+    return wq;
+}
+
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
                      float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, const uint32_t *d_entries,
@@ -2534,7 +2719,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     const bool beam_lds = beam_env && beam_env[0] == 'l';
     const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : ef <= 1024 ? 16 : 0;
     auto lds_slots = [&](uint64_t slots) -> size_t {  // LDS of a query with a visited table of `slots` entries
-        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * slots + 8ull * kWave + 8ull * kpad + 16;
+        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * slots + 8ull * kWave + 8ull * kpad + 16 + (epl >= 8 ? 8ull * kWave + 8ull * epl : 0);  // (+ Cs, Mb of merge_lds)
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * slots + 8ull * kWave;
     };
     auto lds_bytes = [&](uint32_t hb) -> size_t { return lds_slots(1ull << hb); };
@@ -2576,6 +2761,18 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // full.  Rule: the MOST queries per CU (up to what the kernel's VGPRs allow) whose table still holds the largest fill seen at
     // <= 74 % load (cap 87.5 %: beyond it the safe pass serves the query, as before), never more slots than 2.5 x that fill.
     uint32_t tight_slots = 0;
+    uint32_t wq_sel = epl ? ef_waves_per_query(h, epl, width, 0) : 1u;  // waves per query of the launch
+    // large beams keep the visited set in 21-bit entries, three to a 64-bit word (hp_insert_atomic): 1.5 entries per 32-bit unit of LDS
+    // where the plain table has one.  hp_b: bits of an id; its low hp_r bits (after a bijection) pick the region.  Needs regions of >=
+    // 16 words (beyond ~10^8 rows at these table sizes they get too small: the plain table then); ZVDB_EF_PACKED_VISITED=0 / 1: tests
+    uint32_t hp_b = 1;
+    while (hp_b < 32 && (1ull << hp_b) < std::max<uint64_t>(N, 2)) ++hp_b;
+    uint32_t hp_r = hp_b > 20 ? hp_b - 20 : 0;
+    const char *pk_env = tuning("ZVDB_EF_PACKED_VISITED");
+    const char *pr_env = tuning("ZVDB_EF_PACKED_R");  // tests: MORE regions than the row count needs (small regions fill up: the retry path)
+    if (pr_env) hp_r = std::min(hp_b, std::max(hp_r, (uint32_t)atoi(pr_env)));
+    auto packed_fits = [&](uint64_t units) { return ((units / 2) >> hp_r) >= (pr_env ? 1u : 16u); };
+    bool packed = epl >= 8 && !(pk_env && pk_env[0] == '0') && (safe_global || packed_fits(1ull << hash_bits));
     if (epl && tp_env && tp_env[0] == 's') {  // "s<slots>": force a tight table of that many slots (tests: overflow + retry on a non-power-of-two table)
         tight_slots = (uint32_t)std::max(64, std::min(1 << 15, atoi(tp_env + 1)));
         if (lds_slots(tight_slots) > 160 * 1024) tight_slots = 0;
@@ -2584,32 +2781,40 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
         // (no fill seen yet for this ef on this index: the first batch assumes ef * stride / 2 -- about what searches visit --
         // instead of running whole on the safe table; a query that visits more is served by the safe pass like any other overflow)
         const uint32_t seen_eff = seen ? seen : (uint32_t)std::min<uint64_t>(std::max<uint64_t>(N, 1), (uint64_t)ef * h->gstride / 2);
-        uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
-        if (const char *we = tuning("ZVDB_EF_WPQ")) wq = (uint32_t)atoi(we);
-        if (epl >= 8 && wq == 4) wq = 2;
-        // workgroups per CU the kernels' registers allow: 2 waves x <= 160 VGPRs (EPL <= 4): 6; 2 x 172 .. 200 (EPL 8, 16), 4 x 128, 1 x 256+: 4
-        const uint32_t vlim = (wq == 2 && epl <= 4) ? 6u : 4u;
-        const uint64_t smin = (uint64_t)seen_eff * 27 / 20 + 64, spref = (uint64_t)seen_eff * 5 / 2 + 128;
-        static const uint32_t ncu = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(v, 1); }();
-        auto fit_of = [&](uint32_t g) -> uint64_t {  // slots a table may take with g queries per CU (0: the fill does not fit)
+        // (entries wanted: smin .. spref; in 32-bit units of LDS that is 2/3 of it on the packed table)
+        const uint64_t smin_e = (uint64_t)seen_eff * 27 / 20 + 64, spref_e = (uint64_t)seen_eff * 5 / 2 + 128;
+        packed = packed && packed_fits(smin_e * 2 / 3);
+        const uint64_t smin = packed ? (smin_e * 2 + 2) / 3 : smin_e, spref = packed ? round_up64((spref_e * 2 + 2) / 3, 64) : spref_e;
+        auto fit_of = [&](uint32_t g) -> uint64_t {  // 32-bit units a table may take with g queries per CU (0: the fill does not fit)
             const size_t per = (160u * 1024u) / g;
             if (per <= lds_slots(0) + 4 * smin) return 0;
             const uint64_t fit = ((per - lds_slots(0)) / 4) & ~63ull;
             return fit >= smin ? fit : 0;
         };
-        uint32_t gmax = 0;
-        for (uint32_t g = vlim; g >= 1 && !gmax; --g) if (fit_of(g)) gmax = g;
-        if (gmax) {
-            // ... and of those, the FEWEST queries per CU that take no more rounds for this batch (a larger table probes less)
+        static const uint32_t ncu = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(v, 1); }();
+        // queries per CU under a register limit of vlim workgroups: the MOST whose table holds the fill, and of those the FEWEST that
+        // take no more rounds for this batch (a larger table probes less); 0: the fill does not fit the LDS
+        auto plan = [&](uint32_t vlim) -> uint32_t {
+            uint32_t gmax = 0;
+            for (uint32_t g = vlim; g >= 1 && !gmax; --g) if (fit_of(g)) gmax = g;
+            if (!gmax) return 0;
             const uint32_t rounds = (nq + ncu * gmax - 1) / (ncu * gmax);
             uint32_t g = gmax;
             while (g > 1 && fit_of(g - 1) && (nq + ncu * (g - 1) - 1) / (ncu * (g - 1)) == rounds) --g;
-            tight_slots = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(fit_of(g), spref), 1ull << 15);
-        }
+            return g;
+        };
+        // workgroups per CU the kernels' registers allow: 2 waves x <= 160 VGPRs (EPL <= 4): 6; 2 x 172 .. 236 (EPL 8, 16), 4 x 128, 1 x 256+: 4;
+        // the wide workgroups of the large beams (EPL 8, 16 at 4 / 8 waves of <= 256 VGPRs): 2 / 1 -- taken (ef_waves_per_query) when
+        // the two-wave plan would leave the CU with two queries or one anyway
+        const uint32_t wq = wq_sel = ef_waves_per_query(h, epl, width, epl >= 8 ? plan(4) : 0);
+        const uint32_t vlim = wq == 8 ? 1u : (wq == 4 && epl >= 8) ? 2u : (wq == 2 && epl <= 4) ? 6u : 4u;
+        if (const uint32_t g = plan(vlim)) tight_slots = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(fit_of(g), spref), 1ull << 15);
         if (tight_slots && !safe_global && tight_slots >= (1u << hash_bits)) tight_slots = 0;  // (the safe table is no larger: one pass)
         if (tight_slots) tight_bits = 0;  // (marks "sized in slots" below)
     }
     const bool two_pass = tight_slots ? true : tight_bits < safe_rank;
+    if (packed && two_pass && !packed_fits(tight_slots ? tight_slots : 1ull << tight_bits)) packed = false;  // (forced tiny tables of the tests)
+    const uint32_t width_mode = epl >= 8 ? (width | hp_r << 8 | hp_b << 16 | (packed ? 1u << 24 : 0u)) : width;  // k_search_ef_reg's last argument
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
     const bool prof = [] { const char *e = tuning("ZVDB_EF_PROF"); return e && e[0] == '1'; }();
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
@@ -2623,7 +2828,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
-                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, net_list, width);
+                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, net_list, epl ? width_mode : width);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
@@ -2690,20 +2895,16 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_HIP(hipMemcpyFromSymbol(got, HIP_SYMBOL(g_ef_prof), sizeof(got)));
             const double nw = (double)std::max<unsigned long long>(got[7], 1), np = (double)std::max<unsigned long long>(got[6], 1);
             fprintf(stderr, "[zvdb ef prof] %llu queries, %.1f pops each; shader cycles per POP: next-scan %.0f, list+visited %.0f, distances %.0f, beam update %.0f; "
-                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop; visited table %u slots (safe 2^%u%s)\n", got[7], np / nw,
+                    "per QUERY: tail %.0f, final-k %.0f, total %.0f; list prefetch hits %.2f, list wait %.0f / pop; visited table %u units%s, %u waves per query (safe 2^%u%s)\n", got[7], np / nw,
                     got[0] / np, got[1] / np, got[2] / np, got[3] / np, got[4] / nw, got[5] / nw, (got[0] + got[1] + got[2] + got[3] + got[4] + got[5]) / nw,
-                    got[8] / np, got[9] / np, two_pass ? (tight_slots ? tight_slots : 1u << tight_bits) : 1u << (safe_global ? gbits : hash_bits), safe_global ? gbits : hash_bits, safe_global ? " global" : "");
+                    got[8] / np, got[9] / np, two_pass ? (tight_slots ? tight_slots : 1u << tight_bits) : 1u << (safe_global ? gbits : hash_bits), packed ? " of 1.5 packed entries" : "", wq_sel, safe_global ? gbits : hash_bits, safe_global ? " global" : "");
             return ZVDB_OK;
         }
-        // waves per query.  Measured at 1M x 768, M = 16, ef = 128, batch 1,024 / 4,096 / 16,384 (QPS): fp32 rows 1 wave 775k / 901k /
-        // 993k, 2 waves 863k / 982k / 1.09M, 4 waves 894k / 1.03M / 1.11M; bf16 rows 1.00M / 1.19M / 1.30M, 2 waves 1.23M / 1.54M /
-        // 1.67M, 4 waves 0.69M (8 rows per wave step: half the waves idle on 16-entry lists; with the 16-lane walk 0.94M / 1.20M / 1.29M)
-        uint32_t wpq = sizeof(RT) == 2 ? 2 : 4;
-        if (const char *we = tuning("ZVDB_EF_WPQ")) wpq = (uint32_t)atoi(we);  // (1, 2, 4: experiment / tests; read per call)
-        if (epl >= 8 && wpq == 4) wpq = 2;
-        if (epl == 0 || (wpq != 2 && wpq != 4)) wpq = 1;
+        const uint32_t wpq = wq_sel;
         wpq_launch = wpq;
         if (width > 1) {  // the search-width form of the loop (its own instantiations: the width-1 loop stays as it was)
+            if (wpq == 8) return epl == 8 ? go(k_search_ef_reg<RT, 8, 8, 0, true>, kpad) : go(k_search_ef_reg<RT, 16, 8, 0, true>, kpad);
+            if (wpq == 4 && epl >= 8) return epl == 8 ? go(k_search_ef_reg<RT, 8, 4, 0, true>, kpad) : go(k_search_ef_reg<RT, 16, 4, 0, true>, kpad);
             if (wpq == 4) return epl == 2 ? go(k_search_ef_reg<RT, 2, 4, 0, true>, kpad) : go(k_search_ef_reg<RT, 4, 4, 0, true>, kpad);
             if (wpq == 2) return epl == 2 ? go(k_search_ef_reg<RT, 2, 2, 0, true>, kpad) : epl == 4 ? go(k_search_ef_reg<RT, 4, 2, 0, true>, kpad)
                                  : epl == 8 ? go(k_search_ef_reg<RT, 8, 2, 0, true>, kpad) : go(k_search_ef_reg<RT, 16, 2, 0, true>, kpad);
