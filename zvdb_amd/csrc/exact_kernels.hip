@@ -2007,7 +2007,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
     uint32_t *R = nb_i + kWave;                          // [kpad] result ids
     float *RD = reinterpret_cast<float *>(R + kpad);     // [kpad] their exact distances
     uint32_t *ctl = reinterpret_cast<uint32_t *>(RD + kpad);  // [4] window hand-over to the helper waves (WPQ > 1)
-    constexpr bool LMERGE = EPL >= 8;  // large beams: Wt / Ft always hold the beam and a window merges by gather (merge_lds below)
+    constexpr bool LMERGE = EPL >= 8;  // (at 4 blocks -- ef = 256 -- the gather merge measured the same as the merge by ranks: A/B on one box) large beams: Wt / Ft always hold the beam and a window merges by gather (merge_lds below)
     uint64_t *Cs = reinterpret_cast<uint64_t *>(ctl + 4);  // LMERGE: [64] the window's candidates in key order ...
     uint32_t *Mb = reinterpret_cast<uint32_t *>(Cs + kWave);  // ... and [2 EPL] one bit per beam slot a candidate lands in
 
