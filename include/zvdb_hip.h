@@ -237,7 +237,9 @@ int zvdb_hip_greedy_layer0(zvdb_hip_index *h, uint64_t owner, uint64_t *ep, floa
  *             then stable sort (bit-exact ids/distances vs the oracle);
  *   ef  > 0 : ef-mode beam search (extension; spec in oracle/zvdb_oracle.h).  The per-query visited
  *             set lives in LDS, sized from the fills the index has seen for this ef (a query that
- *             outgrows it is re-run by a second launch with the safe size); when the safe size
+ *             outgrows it is re-run by a second launch with the safe size; beyond ef = 256 its
+ *             entries are 21 bits wide behind a bijection of the ids -- exact membership, three
+ *             to a 64-bit word: twice the queries per CU at ef = 512 / 1,024); when the safe size
  *             does not fit (ef * stride beyond ~12k) that launch keeps the visited sets in an
  *             index-owned device buffer of up to 2 GiB, allocated on first need; otherwise a last
  *             16-workgroup launch serves the rare query that fills even the safe LDS table from a
