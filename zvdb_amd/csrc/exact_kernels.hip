@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64) void k_insert_layer0(RT *rows, uint32_t ld, uin
 // computed by the host (level, first upper-layer slot, record offset, max_level before the insert).
 // `rows` is read AND written (Node.init's copy of the new row is read back by ep's shrink and by later inserts of the batch):
 // one plain pointer, no restrict / const, so the compiler may not treat the loads as invariant.
-__global__ __launch_bounds__(64) void k_insert_full(float *rows, uint32_t ld, uint32_t dim, int metric,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_insert_full(float *rows, uint32_t ld, uint32_t dim, int metric,
                                                     uint32_t *adj, uint32_t *deg, uint32_t *adj_up, uint32_t *deg_up,
                                                     uint32_t *lvl, uint32_t *slot, uint32_t gstride, uint32_t m,
                                                     uint32_t first_owner, uint32_t n_batch, const float *__restrict__ points,
@@ -1380,8 +1380,10 @@ __global__ __launch_bounds__(64) void k_search_compat_fast(
 // event pair, ~15 us of a 57-us call (profiles/r4/per_call_*) -- in one wave: clear the counters, run the unordered-frontier search,
 // fall back to the PriorityQueue emulation if a pop's minimum was not unique, copy the counters next to the results (host-mapped
 // memory) and release the sequence word the host polls.
+// (amdgpu_waves_per_eu(1, 1): ONE wave runs on the whole device -- without it hipcc schedules for occupancy, keeps the kernel at 75
+// VGPRs and serialises the 16 row loads a lane has in flight: 52 -> 42 us per call, r4)
 template <typename RT>
-__global__ __launch_bounds__(64) void k_search_compat_single(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_search_compat_single(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t entry,
