@@ -554,10 +554,20 @@ def main():
         idx.search_graph_reserve(B, K, args.ef)
     # the collective: by default the C ABI's own RCCL communicator (zvdb_hip_comm: local search -> ncclAllGather -> merge in ONE library
     # call on this stream); ZVDB_BENCH_COLLECTIVE=torch keeps the all-gather in torch.distributed; the gloo rehearsal always does
-    comm = None
+    comm, comm_note = None, None
     if dist_on and not cpu_coll and os.environ.get("ZVDB_BENCH_COLLECTIVE", "abi") == "abi":
         from zvdb_amd.sharded import Comm
-        comm = Comm.from_torch_distributed(local_rank)
+        try:
+            comm = Comm.from_torch_distributed(local_rank)
+        except Exception as e:  # the same RCCL collective through torch.distributed then (said in config.collective, never silent)
+            comm_note = f"{type(e).__name__}: {e}"
+        if world > 1:  # every rank takes the same path
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close(); comm = None; comm_note = "the communicator failed on another rank"
+        if comm is None:
+            print(f"[bench rank {rank}] zvdb_hip_comm_create failed ({comm_note}): all-gather through torch.distributed (RCCL) instead", file=sys.stderr, flush=True)
 
     ws_bytes = max(idx.bruteforce_workspace(B, K, m) for m in (zv.BF_BF16, zv.BF_F32, zv.BF_I8, zv.BF_FP4))
     if comm is not None:
@@ -797,7 +807,7 @@ def main():
         out["config"]["row_dtype"] = args.row_dtype
         out["config"]["data"] = args.data
         out["config"]["collective"] = ("zvdb_hip_search_*_sharded_dev (ncclAllGather inside libzvdb_hip)" if comm is not None else
-                                       "torch.distributed all_gather_into_tensor" if dist_on else None)
+                                       "torch.distributed all_gather_into_tensor" + (f" (zvdb_hip_comm_create failed: {comm_note})" if comm_note else "") if dist_on else None)
         if graph:
             elt = 2 if bf16_rows else 4
             nbytes = g_ev * D * elt + g_pp * 2 * GM * 4

@@ -53,9 +53,16 @@ class Comm:
         """Rank 0 draws the unique id; torch.distributed (any backend) carries its 128 bytes to the other ranks."""
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as e:  # (the other ranks wait in the broadcast below: tell them instead of leaving them there)
+                box[0] = e
         if world > 1:
             dist.broadcast_object_list(box, src=0, group=group)
+        if isinstance(box[0], Exception):
+            raise box[0]
         return cls(rank, world, box[0], device_index)
 
     def close(self) -> None:
