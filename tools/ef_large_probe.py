@@ -26,7 +26,9 @@ for tag, structured, hb, bulk in (("uniform_knn16_f32", False, False, False), ("
     elt = 2 if hb else 4
     for ef in EFS:
         ref = None
-        for width, wpq, packed in ((1, None, None), (4, None, None), (4, None, "0"), (4, "2", None), (4, "4", None), (4, "8", None)):
+        combos = ((1, None, None), (4, None, None), (4, None, "0"), (4, "2", None), (4, "4", None), (4, "8", None))
+        if os.environ.get("ZVDB_PROBE_COMBOS") == "auto": combos = ((4, None, None),)  # (the rocprofv3 pass: one kernel per ef)
+        for width, wpq, packed in combos:
             g.set_option(zv.OPT_EF_SEARCH_WIDTH, width); zv.set_tuning("ZVDB_EF_WPQ", wpq); zv.set_tuning("ZVDB_EF_PACKED_VISITED", packed)
             for _ in range(3): g.search_graph_dev(q.data_ptr(), B, D, K, ef, entry, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, s)
             st.zero_(); g.search_graph_dev(q.data_ptr(), B, D, K, ef, entry, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), s)
