@@ -210,7 +210,7 @@ def test_ef_mode_bit_exact_vs_oracle_spec(zv, oracle, tuning):
     Q = oracle.uniform_rows(32, 0, 64, d)
     for k, ef in ((10, 10), (10, 64), (25, 200)):
         # 1st call: the safe visited table (no fill seen yet for this ef); 2nd: the tight table sized IN SLOTS from the fill the
-        # first call left (exact_kernels.hip: launch_search_ef); 3rd / 4th: tight tables forced so small that most queries fill
+        # first call left (ef_search.hip: launch_search_ef); 3rd / 4th: tight tables forced so small that most queries fill
         # them and are served again by the safe pass -- a power-of-two one and one of 300 slots.  Same results, same counters.
         for env in (None, None, "t8", "s300"):
             tuning("ZVDB_EF_TWO_PASS", env)

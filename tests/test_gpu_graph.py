@@ -226,7 +226,7 @@ def test_on_disk_format_round_trip(zv, oracle, tmp_path, kind):
 ])
 def test_ef_search_from_two_streams_shares_the_index_scratch(zv, oracle, env, tuning):
     """ef searches launched on two streams of ONE index share its scratch (global visited tables, the net's work list and table
-    pool): each search waits for the previous user's marker (exact_kernels.hip: ef_scratch_begin / _end).  Results, launched
+    pool): each search waits for the previous user's marker (ef_search.hip: ef_scratch_begin / _end).  Results, launched
     back to back on two streams, equal the single-stream results and the oracle's -- in every mode that uses that scratch."""
     import torch
     n, d, m, k, ef, nq = 6000, 32, 8, 10, 48, 1500

@@ -1,7 +1,7 @@
 // bf_bf16_stream.hip -- the bf16 MFMA screen of the brute-force route (north_star: "MFMA bf16 ... for the
 // batched brute-force QxV^T contraction") for large shards: REGISTER-RESIDENT QUERIES, corpus streamed once per workgroup
 // through an LDS ring.  No reference symbol (hnsw.zig has no brute force); results are pinned by the oracle's exact top-k
-// through the exact fp32 re-rank that follows (exact_kernels.hip:k_rerank_staged, hnsw.zig:182-192 arithmetic).
+// through the exact fp32 re-rank that follows (rerank.hip:k_rerank_staged, hnsw.zig:182-192 arithmetic).
 //
 // Why not the resident-LDS-query design of the int8 / fp4 stream kernels: a bf16 row is 2 bytes per element, a 256-query tile
 // of 768-d rows is 384 KB -- it does not fit LDS (160 KB).  It does fit the REGISTER file (512 KB per CU): a wave keeps the

@@ -1,5 +1,5 @@
 // bruteforce.hip -- K4: batched brute-force Q x V^T on MFMA with a fused, never-materialised per-query top-k'
-// selection, followed by a merge of the per-stream lists and (in exact_kernels.hip) the exact fp32 re-rank.  No
+// selection, followed by a merge of the per-stream lists and (in rerank.hip) the exact fp32 re-rank.  No
 // reference symbol exists for this path (a10): north_star names it; it is the recall-guaranteed route.
 //
 //   screen key        |v'|^2 / 2 - q'.v'  (the |q|^2 term is constant per query; dot / cosine: -q'.v')

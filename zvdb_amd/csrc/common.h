@@ -161,7 +161,7 @@ struct zvdb_hip_index {
     // calls loosen the guess by guess_adapt standard deviations (no synchronisation: the flag is read whenever it has arrived)
     uint32_t *guess_flag_host = nullptr;  // hipHostMalloc'ed, mapped
     uint32_t *guess_flag_dev = nullptr;   // its device alias
-    mutable uint32_t *ef_hint_dev = nullptr;   // [16] largest visited-set fill seen per ef bucket (exact_kernels.hip: kEfTight)
+    mutable uint32_t *ef_hint_dev = nullptr;   // [16] largest visited-set fill seen per ef bucket (ef_search.hip: kEfTight)
     mutable uint32_t *ef_hint_host = nullptr;  // pinned copy, refreshed asynchronously after every ef launch
     unsigned long long *spec_wpos0 = nullptr, *spec_wposU = nullptr;  // speculative insert: per-list write stamps (layer 0 / upper slots)
     uint64_t spec_cap0 = 0, spec_capU = 0;
@@ -233,7 +233,7 @@ int ensure_capacity(zvdb_hip_index *h, uint64_t want);
 void timing_begin(zvdb_hip_index *h, hipStream_t s);
 void timing_end(zvdb_hip_index *h, hipStream_t s);
 
-// ---- exact_kernels.hip (compiled with -ffp-contract=off) -------------------
+// ---- exact_kernels.hip, ef_search.hip, rerank.hip (compiled with -ffp-contract=off) ---
 int launch_exact_distances(const zvdb_hip_index *h, const float *d_query, const uint32_t *d_ids,
                            uint32_t n, float *d_out, hipStream_t s);
 // result block of k_insert_layer0 (device scratch -> pinned host memory)

@@ -179,7 +179,7 @@ int launch_store_rows_bf16(const zvdb_hip_index *h, const float *d_stage, uint64
 }
 
 // Rows that did not come through the add paths (zvdb_hip_load copies them out of a file): elements [dim, ld) are zeroed -- the
-// exact kernels walk whole chunks up to ld and rely on the padding adding +0.0 (exact_kernels.hip: k_rerank_staged) -- and, for
+// exact kernels walk whole chunks up to ld and rely on the padding adding +0.0 (rerank.hip: k_rerank_staged) -- and, for
 // bf16 row storage, the norms are recomputed from the rows the way k_store_rows_bf16 sums them instead of being taken on trust.
 __global__ __launch_bounds__(256) void k_sanitize_rows_f32(float *__restrict__ rows, uint32_t dim, uint32_t ld, uint64_t n) {
     const uint32_t pad = ld - dim;

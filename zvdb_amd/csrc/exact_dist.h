@@ -1,5 +1,5 @@
 // exact_dist.h -- the reference's distance arithmetic (hnsw.zig:182-192) as device functions, shared by the translation units
-// that must reproduce it bit for bit (exact_kernels.hip, graph_build.hip).  Both are compiled with -ffp-contract=off; the
+// that must reproduce it bit for bit (exact_kernels.hip, ef_search.hip, rerank.hip, graph_build.hip).  Both are compiled with -ffp-contract=off; the
 // pragma below additionally pins it, so hipcc's default -ffp-contract=fast-honor-pragmas cannot fuse mul + add into v_fma.
 #pragma once
 #include "common.h"
