@@ -724,9 +724,15 @@ def main():
         ws = None  # (the headline's workspace is no longer needed)
         for nm, structured, hb in (("graph_ef128_1Mx768_uniform", False, False), ("graph_ef128_1Mx768_rank12", True, False),
                                    ("graph_ef128_1Mx768_rank12_bf16rows", True, True)):
-            gl = graph_leg(zv, torch, dev, stream, 1_000_000, 768, 1024, K, (128,), structured, bf16_rows=hb)
-            e = gl.pop("ef")["128"]
+            # (the bf16-row leg also at ef = 512: the large-beam path -- gather merge, packed exact visited set, wide workgroups, DESIGN 3 K2')
+            gl = graph_leg(zv, torch, dev, stream, 1_000_000, 768, 1024, K, (128, 512) if hb else (128,), structured, bf16_rows=hb)
+            efd = gl.pop("ef")
+            e = efd["128"]
             paths[nm] = {"value": e["qps"], "unit": "QPS", "ef": 128, **{kk: vv for kk, vv in e.items() if kk != "qps"}, **gl}
+            if "512" in efd:
+                e5 = efd["512"]
+                paths[nm.replace("ef128", "ef512")] = {"value": e5["qps"], "unit": "QPS", "ef": 512, **{kk: vv for kk, vv in e5.items() if kk != "qps"},
+                                                       **{kk: vv for kk, vv in gl.items() if kk not in ("build_s", "build_rows_per_s")}, "graph": "the index of " + nm}
         c2 = c2_leg(zv, torch, dev, stream, K, modes=("f32", "bf16"))[0]
         paths["c2_1Mx128_b256_f32"] = {"value": c2["f32"]["qps"], "unit": "QPS", "rows": c2["rows"], "dim": c2["dim"], "batch": c2["batch"],
                                        "ms_per_batch": c2["f32"]["ms_per_batch"], "roofline": c2["f32"]["roofline"], "certificate": c2["certificate"]}
