@@ -85,17 +85,9 @@ __global__ __launch_bounds__(64) void k_greedy_layer0(const RT *__restrict__ row
                 nb = adj[(size_t)ep * gstride + j];
                 d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
             }
-            // wave arg-min over (d, j) of active lanes that beat best_d strictly
-            float md = act ? d : __builtin_inff();
-            uint32_t mj = act ? j : 0xFFFFFFFFu;
-            uint32_t mid = nb;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float od = __shfl_xor(md, off);
-                const uint32_t oj = __shfl_xor(mj, off);
-                const uint32_t oid = __shfl_xor(mid, off);
-                if (od < md || (od == md && oj < mj)) { md = od; mj = oj; mid = oid; }
-            }
+            float md;  // wave arg-min over (d, j) of the active lanes
+            uint32_t mj, mid;
+            wave_argmin_dj(act, d, j, nb, md, mj, mid);
             if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
         }
         evals += dg;
@@ -178,14 +170,9 @@ __global__ __launch_bounds__(64) void k_insert_layer0(RT *rows, uint32_t ld, uin
                 nb = ld_u32(adj + (size_t)ep * gstride + j);
                 d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
             }
-            float md = act ? d : __builtin_inff();
-            uint32_t mj = act ? j : 0xFFFFFFFFu, mid = nb;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float od = __shfl_xor(md, off);
-                const uint32_t oj = __shfl_xor(mj, off), oid = __shfl_xor(mid, off);
-                if (od < md || (od == md && oj < mj)) { md = od; mj = oj; mid = oid; }
-            }
+            float md;  // wave arg-min over (d, j) of the active lanes
+            uint32_t mj, mid;
+            wave_argmin_dj(act, d, j, nb, md, mj, mid);
             if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
         }
         evals += dg;
@@ -331,14 +318,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         nb = base == 0 ? nb0 : ld_u32(al + j);
                         d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
                     }
-                    float md = act ? d : __builtin_inff();
-                    uint32_t mj = act ? j : 0xFFFFFFFFu, mid = nb;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const float od = __shfl_xor(md, off);
-                        const uint32_t oj = __shfl_xor(mj, off), oid = __shfl_xor(mid, off);
-                        if (od < md || (od == md && oj < mj)) { md = od; mj = oj; mid = oid; }
-                    }
+                    float md;  // wave arg-min over (d, j) of the active lanes
+                    uint32_t mj, mid;
+                    wave_argmin_dj(act, d, j, nb, md, mj, mid);
                     if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
                 }
                 if (best_j != 0xFFFFFFFFu) { ep = best_id; cur = best_d; changed = true; }
@@ -538,14 +520,9 @@ __device__ __forceinline__ void spec_body(const SpecArgs &A, uint32_t b, uint32_
                     nb = base == 0 ? nb0 : ldc<COH>(al + j);
                     d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);
                 }
-                float md = act ? d : __builtin_inff();
-                uint32_t mj = act ? j : 0xFFFFFFFFu, mid = nb;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const float od = __shfl_xor(md, off);
-                    const uint32_t oj = __shfl_xor(mj, off), oid = __shfl_xor(mid, off);
-                    if (od < md || (od == md && oj < mj)) { md = od; mj = oj; mid = oid; }
-                }
+                float md;  // wave arg-min over (d, j) of the active lanes
+                uint32_t mj, mid;
+                wave_argmin_dj(act, d, j, nb, md, mj, mid);
                 if (mj != 0xFFFFFFFFu && md < best_d) { best_d = md; best_j = mj; best_id = mid; }
             }
             note_read(lid, best_d, best_j != 0xFFFFFFFFu ? best_id : 0xFFFFFFFFu, layer);
@@ -1150,23 +1127,15 @@ __device__ __forceinline__ bool compat_fast_body(
         evals = 1;
         __syncthreads();
         while (n > 0 && nres < k) {                                         // :211
-            // pop: the minimum and how many entries hold it
-            float bd = __builtin_inff();
-            uint32_t bp = 0xFFFFFFFFu;
-            for (uint32_t i = lane; i < n; i += kWave) {
-                const float d = fr_d[i];
-                if (d < bd || bp == 0xFFFFFFFFu) { bd = d; bp = i; }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float od = __shfl_xor(bd, off);
-                const uint32_t op = __shfl_xor(bp, off);
-                if (op != 0xFFFFFFFFu && (bp == 0xFFFFFFFFu || od < bd || (od == bd && op < bp))) { bd = od; bp = op; }
-            }
+            // pop: the minimum and how many entries hold it -- a DPP reduction of (order key, position) and ballots (r4: the __shfl_xor
+            // butterflies that stood here were 18 dependent ds_bpermute round trips: 2,700 shader cycles of a pop, 1,270 now)
+            uint64_t bk = ~0ull;
+            for (uint32_t i = lane; i < n; i += kWave) bk = umin64(bk, ((uint64_t)dist_order_key(fr_d[i]) << 32) | i);
+            bk = wave_min64(bk);
+            const uint32_t bp = (uint32_t)bk;
+            const float bd = fr_d[bp];
             uint32_t same = 0;
-            for (uint32_t i = lane; i < n; i += kWave) same += fr_d[i] == bd ? 1u : 0u;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) same += __shfl_xor(same, off);
+            for (uint32_t b0 = 0; b0 < n; b0 += kWave) same += (uint32_t)__popcll(__ballot(b0 + lane < n && fr_d[b0 + lane] == bd));
             if (same != 1) { gave_up = true; break; }  // equal minima (or a NaN): the heap's layout decides -> exact emulation
             const uint32_t cid = fr_i[bp];
             __syncthreads();

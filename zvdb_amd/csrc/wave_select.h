@@ -110,4 +110,21 @@ __device__ __forceinline__ uint64_t wave_reduce64(uint64_t v) {
 __device__ __forceinline__ uint64_t wave_max64(uint64_t v) { return wave_reduce64<false>(v); }
 __device__ __forceinline__ uint64_t wave_min64(uint64_t v) { return wave_reduce64<true>(v); }
 
+// Order key of a distance for a wave arg-min over (distance, position) packed as key << 32 | position: ascending like the float
+// compare of the reference (hnsw.zig:96 `d < best`), -0 = +0 (so equal distances fall to the lower position), a NaN after everything.
+__device__ __forceinline__ uint32_t dist_order_key(float d) { return d != d ? 0xFFFFFFFFu : f32_key(d + 0.0f); }
+// Wave arg-min over (d, j) of the active lanes (j distinct per lane), ties to the lower j -- the reference's strict `<` walked in
+// list order.  mj = 0xFFFFFFFF when no lane is active; md / mid = the winning lane's own d and id.  One DPP reduction, a ballot and
+// two readlanes: the __shfl_xor butterfly over three values it replaces (r4) was 18 dependent ds_bpermute round trips.
+__device__ __forceinline__ void wave_argmin_dj(bool act, float d, uint32_t j, uint32_t id, float &md, uint32_t &mj, uint32_t &mid) {
+    const uint64_t best = wave_min64(act ? (((uint64_t)dist_order_key(d) << 32) | j) : ~0ull);
+    mj = (uint32_t)best;
+    md = __builtin_inff();
+    mid = id;
+    if (best == ~0ull) { mj = 0xFFFFFFFFu; return; }  // (wave-uniform)
+    const int wl = __builtin_ctzll(__ballot(act && j == mj));
+    md = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d), wl));
+    mid = (uint32_t)__builtin_amdgcn_readlane((int)id, wl);
+}
+
 }  // namespace zvdb
