@@ -99,9 +99,7 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
             else walk(integral_constant<int, 6>{}, std::true_type{});
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                float sl = slo[u], sh = shi[u];
-#pragma unroll
-                for (int off = 4; off > 0; off >>= 1) { sl = sl + __shfl_xor(sl, off); sh = sh + __shfl_xor(sh, off); }
+                const float sl = group_sum_lane0<8>(slo[u]), sh = group_sum_lane0<8>(shi[u]);  // (the butterfly 4, 2, 1 as the group's lane 0 sees it)
                 const float sv = sl + sh;
                 if (fr[u] && a8 == 0) nb_d[r0 + (uint32_t)(u * WPQ + wave) * G + g8] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
             }
@@ -156,9 +154,7 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                float sv = sacc[u];
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) sv = sv + __shfl_xor(sv, off);
+                const float sv = group_sum_lane0<16>(sacc[u]);  // (the butterfly 8, 4, 2, 1 as the group's lane 0 sees it)
                 if (fr[u] && t == 0) nb_d[r0 + (uint32_t)(u * WPQ + wave) * G + g] = metric == ZVDB_METRIC_L2SQ ? sv : -sv;
             }
         }
@@ -1126,7 +1122,6 @@ __global__ __launch_bounds__(64 * WPQ) void k_descend(const RT *__restrict__ row
     uint32_t cur = top;
     float dcur = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, rows + (size_t)cur * ld, nchunks, t)
                                             : blocked16_dist<ZVDB_METRIC_DOT>(q, rows + (size_t)cur * ld, nchunks, t);
-    dcur = __shfl(dcur, 0);
     unsigned long long evals = 1;
     for (uint32_t layer = lvl[top]; layer >= 1; --layer) {
         for (;;) {

@@ -2,6 +2,7 @@
 // that must reproduce it bit for bit (exact_kernels.hip, ef_search.hip, rerank.hip, graph_build.hip).  Both are compiled with -ffp-contract=off; the
 // pragma below additionally pins it, so hipcc's default -ffp-contract=fast-honor-pragmas cannot fuse mul + add into v_fma.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "row_types.h"
 
@@ -64,6 +65,22 @@ __device__ __forceinline__ bool lex_less(float da, uint32_t ia, float db, uint32
     return da < db || (da == db && ia < ib);
 }
 
+// Sum over a group of 8 / 16 consecutive lanes with the association of the xor butterfly (8,) 4, 2, 1 AS LANE 0 OF THE GROUP sees
+// it: ((s0 + s4) + (s2 + s6)) + ((s1 + s5) + (s3 + s7)) -- only that lane's value is the sum, the others hold partial terms.  DPP
+// row shifts inside the 16-lane row (lane i reads lane i + n) instead of __shfl_xor, which hipcc lowers to ds_bpermute: three or
+// four dependent LDS-crossbar round trips per row of a distance pass, and the pass is a link of every query's chain (r4).
+template <int GROUP>
+__device__ __forceinline__ float group_sum_lane0(float v) {
+    auto shl = [](float x, auto ctrl) {
+        return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    if constexpr (GROUP == 16) v = v + shl(v, std::integral_constant<int, 0x108>{});  // row_shl:8
+    v = v + shl(v, std::integral_constant<int, 0x104>{});                            // row_shl:4
+    v = v + shl(v, std::integral_constant<int, 0x102>{});                            // row_shl:2
+    v = v + shl(v, std::integral_constant<int, 0x101>{});                            // row_shl:1
+    return v;
+}
+
 // 16-way BLOCKED traversal distance of the ef-mode beam search and the entry descent (specification:
 // orc_distance_blocked16_f32 / orc_neg_dot_blocked16_f32): lane t of a 16-lane group takes the 4-element chunks t, t + 16, ...
 // of the row, accumulates them sequentially, un-contracted; the 16 partials are combined by the xor butterfly 8, 4, 2, 1.
@@ -76,8 +93,8 @@ __device__ __forceinline__ float blocked16_dist(const float *__restrict__ q /*LD
         const float4 a = *reinterpret_cast<const float4 *>(q + 4 * c);
         ZV_A1_STEP(a.x, v.x) ZV_A1_STEP(a.y, v.y) ZV_A1_STEP(a.z, v.z) ZV_A1_STEP(a.w, v.w)
     }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) sum = sum + __shfl_xor(sum, off);
+    sum = group_sum_lane0<16>(sum);
+    sum = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum)));  // (every group walked the same row: the wave's lane 0 speaks for all)
     return METRIC == ZVDB_METRIC_L2SQ ? sum : -sum;
 }
 
