@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void compat_heap_body(
 // among EQUAL minima.  When the minimum is not unique at a pop, this kernel gives the query up (tie[qi] = 1) and the exact
 // emulation runs it instead (gated launch right behind this one): identical results either way, ~10x fewer dependent LDS
 // round trips in the common case.
-template <typename RT>
+template <typename RT, bool LAT = false>
 __device__ __forceinline__ bool compat_fast_body(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
@@ -1127,15 +1127,34 @@ __device__ __forceinline__ bool compat_fast_body(
         evals = 1;
         __syncthreads();
         while (n > 0 && nres < k) {                                         // :211
-            // pop: the minimum and how many entries hold it -- a DPP reduction of (order key, position) and ballots (r4: the __shfl_xor
-            // butterflies that stood here were 18 dependent ds_bpermute round trips: 2,700 shader cycles of a pop, 1,270 now)
-            uint64_t bk = ~0ull;
-            for (uint32_t i = lane; i < n; i += kWave) bk = umin64(bk, ((uint64_t)dist_order_key(fr_d[i]) << 32) | i);
-            bk = wave_min64(bk);
-            const uint32_t bp = (uint32_t)bk;
-            const float bd = fr_d[bp];
-            uint32_t same = 0;
-            for (uint32_t b0 = 0; b0 < n; b0 += kWave) same += (uint32_t)__popcll(__ballot(b0 + lane < n && fr_d[b0 + lane] == bd));
+            // pop: the minimum and how many entries hold it.  LAT (the one-query-per-call kernel, one wave on the device): a DPP reduction
+            // of (order key, position) and ballots -- the __shfl_xor butterflies are 18 dependent ds_bpermute round trips, 2,700 shader
+            // cycles of a 10,000-cycle pop (1,270 on DPP).  The batched kernel keeps the butterflies: with thousands of waves the round
+            // trips are hidden and the DPP form's extra vector instructions cost it 4-7 % (A/B on one box, 100k x 128 / 768, r4)
+            float bd = __builtin_inff();
+            uint32_t bp = 0xFFFFFFFFu, same = 0;
+            if constexpr (LAT) {
+                uint64_t bk = ~0ull;
+                for (uint32_t i = lane; i < n; i += kWave) bk = umin64(bk, ((uint64_t)dist_order_key(fr_d[i]) << 32) | i);
+                bk = wave_min64(bk);
+                bp = (uint32_t)bk;
+                bd = fr_d[bp];
+                for (uint32_t b0 = 0; b0 < n; b0 += kWave) same += (uint32_t)__popcll(__ballot(b0 + lane < n && fr_d[b0 + lane] == bd));
+            } else {
+                for (uint32_t i = lane; i < n; i += kWave) {
+                    const float d = fr_d[i];
+                    if (d < bd || bp == 0xFFFFFFFFu) { bd = d; bp = i; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float od = __shfl_xor(bd, off);
+                    const uint32_t op = __shfl_xor(bp, off);
+                    if (op != 0xFFFFFFFFu && (bp == 0xFFFFFFFFu || od < bd || (od == bd && op < bp))) { bd = od; bp = op; }
+                }
+                for (uint32_t i = lane; i < n; i += kWave) same += fr_d[i] == bd ? 1u : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) same += __shfl_xor(same, off);
+            }
             if (same != 1) { gave_up = true; break; }  // equal minima (or a NaN): the heap's layout decides -> exact emulation
             const uint32_t cid = fr_i[bp];
             __syncthreads();
@@ -1159,10 +1178,10 @@ __device__ __forceinline__ bool compat_fast_body(
                 float d = 0.0f;
                 if (j < dg) {
                     nb = base == 0 ? nb0 : adj[(size_t)cid * gstride + j];
-                    if (!hash_contains(hash, hash_bits, nb)) {              // :217
-                        d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);  // :219
-                        fresh = hash_insert_atomic(hash, hash_bits, nb);    // :221 (one owner per id)
-                    }
+                    // :217 + :221 in one test-and-set (one owner per id; marking the node before its distance instead of after changes nothing
+                    // another lane could see: a second occurrence of the id in the list loses either way)
+                    fresh = hash_insert_atomic(hash, hash_bits, nb);
+                    if (fresh) d = exact_dist_rt(metric, q, rows + (size_t)nb * ld, dim);  // :219
                 }
                 const unsigned long long fm = __ballot(fresh);
                 if (fresh) {
@@ -1261,8 +1280,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     __syncthreads();
     bool done = false;  // (wave-uniform)
     if (fast_ok)
-        done = compat_fast_body<RT>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, entry, 0ull, out_ids, out_dist, out_count, stats, dim_pad,
-                                    heap_cap, hash_bits, rcap, tie, 0u, smem);
+        done = compat_fast_body<RT, true>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, entry, 0ull, out_ids, out_dist, out_count, stats, dim_pad,
+                                          heap_cap, hash_bits, rcap, tie, 0u, smem);
     __syncthreads();
     if (!done) {
         compat_heap_body<RT>(rows, ld, dim, metric, adj, deg, gstride, N, queries, k, entry, 0ull, out_ids, out_dist, out_count, stats, dim_pad,
