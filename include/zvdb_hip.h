@@ -162,7 +162,9 @@ int zvdb_hip_build_knn_graph(zvdb_hip_index *h, uint32_t degree, uint32_t mode);
  *   layer L  the M exact nearest among the nodes whose level reaches L;
  *   entry    the first node of the highest level (zvdb_hip_graph_info).
  * `mode` = enum zvdb_bf_mode of the screen behind the nearest-neighbour lists: the exact screens (ZVDB_BF_F32 / _BF16 / _I8)
- * give the oracle's graph; ZVDB_BF_FP4 (approximate candidates, exact re-rank) builds wide shards faster -- beyond 768
+ * give the oracle's graph (list for list at every tested size; the builder's passes run WITHOUT the exactness certificate
+ * -- k = 65 .. 97 leaves it too few survivors -- so on very large wide shards the _BF16 / _I8 lists can differ from the
+ * exact nearest neighbours in a few entries: DESIGN 3 C); ZVDB_BF_FP4 (approximate candidates, exact re-rank) builds wide shards faster -- beyond 768
  * dimensions the exact screens run on the staged kernels: 12.5M x 1536 bf16 rows build in 226 s instead of 335 and answer the
  * same recall (profiles/r3/).
  * Replaces every layer of the index's graph.  Search it with zvdb_hip_search_graph(ef > 0, entry = ZVDB_ENTRY_DESCEND):
