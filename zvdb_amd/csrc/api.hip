@@ -1098,13 +1098,10 @@ int zvdb_hip_search_graph_dev(zvdb_hip_index *h, const void *d_queries, uint32_t
                                   static_cast<uint32_t *>(d_count),
                                   static_cast<unsigned long long *>(d_stats), s, h->tie_buf);
     else {
-        rc = descend ? launch_descend(h, static_cast<const float *>(d_queries), nq, (uint32_t)entry, h->tie_buf,
-                                      static_cast<unsigned long long *>(d_stats), s) : ZVDB_OK;
-        if (rc == ZVDB_OK)
-            rc = launch_search_ef(h, static_cast<const float *>(d_queries), nq, k, ef, (uint32_t)entry,
-                                  id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
-                                  static_cast<uint32_t *>(d_count),
-                                  static_cast<unsigned long long *>(d_stats), s, descend ? h->tie_buf : nullptr);
+        rc = launch_search_ef(h, static_cast<const float *>(d_queries), nq, k, ef, (uint32_t)entry,
+                              id_offset, static_cast<uint64_t *>(d_ids), static_cast<float *>(d_dist),
+                              static_cast<uint32_t *>(d_count),
+                              static_cast<unsigned long long *>(d_stats), s, descend ? h->tie_buf : nullptr, false, descend);
     }
     timing_end(h, s);
     if ((ef == 0 || descend) && rc == ZVDB_OK) ZV_CHECK(tie_end(h, s));
@@ -1204,11 +1201,10 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
             ZV_CHECK(ensure_tie(h, nq));
             ZV_CHECK(tie_begin(h, h->stream));
         }
-        if (descend) ZV_CHECK(launch_descend(h, reinterpret_cast<float *>(scr), nq, (uint32_t)entry, h->tie_buf, d_st, h->stream));
         int rc = ef == 0 ? launch_search_compat(h, reinterpret_cast<float *>(scr), nq, k, (uint32_t)entry, 0,
                                                 d_ids, d_dist, d_cnt, d_st, h->stream, h->tie_buf)
                          : launch_search_ef(h, reinterpret_cast<float *>(scr), nq, k, ef, (uint32_t)entry,
-                                            0, d_ids, d_dist, d_cnt, d_st, h->stream, descend ? h->tie_buf : nullptr);
+                                            0, d_ids, d_dist, d_cnt, d_st, h->stream, descend ? h->tie_buf : nullptr, false, descend);
         ZV_CHECK(rc);
         if (ef == 0 || descend) ZV_CHECK(tie_end(h, h->stream));
         unsigned char *pin = static_cast<unsigned char *>(h->pin.ptr);

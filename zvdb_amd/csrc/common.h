@@ -279,8 +279,10 @@ void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s);
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
                      float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s,
-                     const uint32_t *d_entries = nullptr /* per-query entry nodes (launch_descend) */,
-                     bool reserve_only = false /* allocate what a launch of this shape needs, launch nothing */);
+                     uint32_t *d_entries = nullptr /* per-query entry nodes (buffer of nq words; with `descend` the call fills it) */,
+                     bool reserve_only = false /* allocate what a launch of this shape needs, launch nothing */,
+                     bool descend = false /* `entry` is the bulk graph's top node: descend through the upper layers first (in the first pass of
+                                             the register-beam kernel, or as launch_descend ahead of the search) */);
 int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
                    unsigned long long *d_stats, hipStream_t s);
 // exact re-rank of candidate lists: cand[nq][kc] u32 (0xFFFFFFFF = empty) -> top-k by (dist,id)

@@ -161,6 +161,70 @@ __device__ __forceinline__ void ef_window_distances(const RT *__restrict__ rows,
     }
 }
 
+// ---- hierarchical entry descent of the bulk graph: the per-query body (k_descend and the first pass of k_search_ef_reg) --------
+// (specification: orc_hnsw_descend; the kernel's comment further down describes the algorithm)
+// the descent of one query by the WPQ waves of its workgroup (every wave runs the same control flow on the same LDS / global values);
+// q is in LDS already; returns the layer-0 entry, adds the distance evaluations to `evals`
+template <typename RT, int WPQ, int U>
+__device__ __forceinline__ uint32_t descend_body(const RT *__restrict__ rows, uint32_t ld, int metric, const uint32_t *__restrict__ lvl,
+                                                 const uint32_t *__restrict__ slot, const uint32_t *__restrict__ adj_up,
+                                                 const uint32_t *__restrict__ deg_up, uint32_t gstride, uint32_t top, const float *q, uint32_t nchunks,
+                                                 float *nb_d, uint32_t *nb_i, int lane, int wave, unsigned long long &evals) {
+    const int t = lane & 15;
+    // every wave keeps the same (cur, dcur): all decisions below derive from LDS / global values the waves share
+    uint32_t cur = top;
+    float dcur = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, rows + (size_t)cur * ld, nchunks, t)
+                                            : blocked16_dist<ZVDB_METRIC_DOT>(q, rows + (size_t)cur * ld, nchunks, t);
+    evals += 1;
+    // A hop is a link of the query's chain.  The first version read lvl[cur] -> slot[cur] -> deg_up[row] -> the list -> the rows: five
+    // dependent memory round trips, 3.75 us per hop, 150 us per 1,024-query batch at 1M rows -- a fifth of an ef = 128 search (r4).
+    // Now the degree and the first 64 list entries are requested TOGETHER, and the level / slot of every neighbour travel with its
+    // row (the next hop starts from one of them): list -> rows, two round trips per hop.  Same hops, same evaluations, same entry.
+    uint32_t cur_lvl = lvl[top], cur_slot = slot[top];
+    for (uint32_t layer = cur_lvl; layer >= 1; --layer) {
+        for (;;) {
+            if (cur_lvl < layer) break;
+            const size_t row = (size_t)cur_slot + layer - 1;
+            const uint32_t first = (uint32_t)lane < gstride ? adj_up[row * gstride + lane] : 0u;  // (slots past the degree: stale or zero ids, not used)
+            const uint32_t dg = min(deg_up[row], gstride);
+            uint32_t best = cur, best_lvl = cur_lvl, best_slot = cur_slot;
+            float dbest = dcur;
+            for (uint32_t base = 0; base < dg; base += kWave) {
+                const uint32_t cnt = min(dg - base, (uint32_t)kWave);
+                __syncthreads();  // (the previous window's readers are done)
+                uint32_t nbv = 0, nl = 0, ns = 0;
+                if ((uint32_t)lane < cnt) {
+                    nbv = base == 0 ? first : adj_up[row * gstride + base + lane];
+                    nl = lvl[nbv];
+                    ns = slot[nbv];
+                    if (wave == 0) nb_i[lane] = nbv;
+                }
+                __syncthreads();
+                ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, cnt, nb_i, nb_d, lane, wave);
+                __syncthreads();
+                // list order: the smallest (distance, position); strict '<' against the running best keeps the earliest of equal minima
+                const uint64_t key = (uint32_t)lane < cnt ? ((uint64_t)f32_key(nb_d[lane]) << 32) | (uint32_t)lane : ~0ull;
+                const uint32_t jm = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_min64(key));
+                const float dm = nb_d[jm];
+                if (dm < dbest) {
+                    dbest = dm;
+                    best = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)jm);
+                    best_lvl = (uint32_t)__builtin_amdgcn_readlane((int)nl, (int)jm);
+                    best_slot = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)jm);
+                }
+            }
+            evals += dg;
+            if (best == cur) break;
+            cur = best;
+            dcur = dbest;
+            cur_lvl = best_lvl;
+            cur_slot = best_slot;
+        }
+    }
+    __syncthreads();  // (the last window's readers are done before the caller reuses nb_i / nb_d)
+    return cur;
+}
+
 // ---- ef-mode beam search (extension; specification: oracle/zvdb_oracle.h) --------
 // W = sorted (dist,id) list of <= ef entries with an "expanded" flag, LDS resident.
 //
@@ -193,6 +257,14 @@ __device__ unsigned long long g_ef_prof[10];
 // cursor of the net launch, [2 ...] = query indices.  The LAST LDS pass of a call appends every query it marks; the net launch is
 // kEfNetBlocks workgroups that pop queries until the list is empty, each on its own global visited table.
 constexpr uint32_t kEfNetBlocks = 16;
+// The entry descent fused into the first pass of the register-beam kernel (r4): as two launches a batch paid the slowest query's
+// descent plus the slowest query's search; in one kernel a query starts its search when ITS descent ends.  on = 0: the entry comes
+// from the kernel's `entry` / `entries` arguments as before (retry passes read what the first pass left in entries_out).
+struct EfDescend {
+    const uint32_t *lvl, *slot, *adj_up, *deg_up;
+    uint32_t *entries_out;
+    uint32_t top, on;
+};
 __device__ __forceinline__ void ef_mark_again(uint32_t *out_count, uint32_t qi, uint32_t *net_list) {  // (one lane)
     out_count[qi] = kEfAgain;
     if (net_list) net_list[2 + atomicAdd(net_list, 1u)] = qi;
@@ -458,7 +530,8 @@ __global__ __launch_bounds__(64) void k_search_ef(
     uint32_t *__restrict__ out_count, unsigned long long *__restrict__ stats, uint32_t dim_pad,
     uint32_t hash_bits, uint32_t efp, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
     uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t *ghash, uint32_t qoff,
-    uint32_t *net_list /* LDS passes: marks are appended here (may be null); GH: non-null = the net launch */, uint32_t width /* nodes expanded per step */) {
+    uint32_t *net_list /* LDS passes: marks are appended here (may be null); GH: non-null = the net launch */, uint32_t width /* nodes expanded per step */,
+    EfDescend /* (k_search_ef_reg's: this kernel always takes its entries from `entries`) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (GH) {
         uint32_t *table = ghash + ((size_t)blockIdx.x << hash_bits);
@@ -524,7 +597,8 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
     uint32_t hash_size /* slots of the visited table: any count >= 256 */, uint32_t kpad, const uint32_t *__restrict__ entries /* optional: per-query entry (k_descend) */,
     uint32_t pass, uint32_t *__restrict__ fill_hint, uint32_t * /* ghash: k_search_ef only */, uint32_t /* qoff */,
     uint32_t *net_list /* marks are appended here (the last LDS pass of a call; else null) */,
-    uint32_t width_mode /* nodes expanded per step: 1 .. 4; large beams (EPL >= 8) also: r << 8 | b << 16 | packed visited table << 24 (hp_insert_atomic) */) {
+    uint32_t width_mode /* nodes expanded per step: 1 .. 4; large beams (EPL >= 8) also: r << 8 | b << 16 | packed visited table << 24 (hp_insert_atomic) */,
+    EfDescend desc /* on: this (first) pass runs the entry descent itself */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t width = EPL >= 8 ? (width_mode & 0xFFu) : width_mode;
     const bool hp_on = EPL >= 8 && ((width_mode >> 24) & 1u) != 0;
@@ -555,6 +629,14 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
     constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : (WPQ >= 4 ? 1 : 4 / WPQ);  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32; two rows per group at WPQ = 2 measured 24 % SLOWER with a search width, r4)
+    if (desc.on) {  // the entry descent of this query, by all waves of the workgroup (wave-uniform branch); later passes find the entry in entries_out
+        unsigned long long dev = 0;
+        entry = descend_body<RT, WPQ, U>(rows, ld, metric, desc.lvl, desc.slot, desc.adj_up, desc.deg_up, gstride, desc.top, q, nchunks, nb_d, nb_i, lane, wave, dev);
+        if (threadIdx.x == 0) {
+            desc.entries_out[qi] = entry;
+            if (stats) atomicAdd(&stats[0], dev);
+        }
+    }
     if constexpr (WPQ > 1) {
         if (wave != 0) {  // helper waves: their share of every published window's distances
             for (;;) {
@@ -1111,63 +1193,14 @@ __global__ __launch_bounds__(64 * WPQ) void k_descend(const RT *__restrict__ row
     float *nb_d = q + dim_pad;                                  // [64]
     uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);  // [64]
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const int t = lane & 15;
     const uint32_t qi = blockIdx.x;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = threadIdx.x; i < dim_pad; i += kWave * WPQ) q[i] = i < dim ? qg[i] : 0.0f;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
     constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : 4 / WPQ;  // 16 rows per step
-    // every wave keeps the same (cur, dcur): all decisions below derive from LDS / global values the waves share
-    uint32_t cur = top;
-    float dcur = metric == ZVDB_METRIC_L2SQ ? blocked16_dist<ZVDB_METRIC_L2SQ>(q, rows + (size_t)cur * ld, nchunks, t)
-                                            : blocked16_dist<ZVDB_METRIC_DOT>(q, rows + (size_t)cur * ld, nchunks, t);
-    unsigned long long evals = 1;
-    // A hop is a link of the query's chain.  The first version read lvl[cur] -> slot[cur] -> deg_up[row] -> the list -> the rows: five
-    // dependent memory round trips, 3.75 us per hop, 150 us per 1,024-query batch at 1M rows -- a fifth of an ef = 128 search (r4).
-    // Now the degree and the first 64 list entries are requested TOGETHER, and the level / slot of every neighbour travel with its
-    // row (the next hop starts from one of them): list -> rows, two round trips per hop.  Same hops, same evaluations, same entry.
-    uint32_t cur_lvl = lvl[top], cur_slot = slot[top];
-    for (uint32_t layer = cur_lvl; layer >= 1; --layer) {
-        for (;;) {
-            if (cur_lvl < layer) break;
-            const size_t row = (size_t)cur_slot + layer - 1;
-            const uint32_t first = (uint32_t)lane < gstride ? adj_up[row * gstride + lane] : 0u;  // (slots past the degree: stale or zero ids, not used)
-            const uint32_t dg = min(deg_up[row], gstride);
-            uint32_t best = cur, best_lvl = cur_lvl, best_slot = cur_slot;
-            float dbest = dcur;
-            for (uint32_t base = 0; base < dg; base += kWave) {
-                const uint32_t cnt = min(dg - base, (uint32_t)kWave);
-                __syncthreads();  // (the previous window's readers are done)
-                uint32_t nbv = 0, nl = 0, ns = 0;
-                if ((uint32_t)lane < cnt) {
-                    nbv = base == 0 ? first : adj_up[row * gstride + base + lane];
-                    nl = lvl[nbv];
-                    ns = slot[nbv];
-                    if (wave == 0) nb_i[lane] = nbv;
-                }
-                __syncthreads();
-                ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, cnt, nb_i, nb_d, lane, wave);
-                __syncthreads();
-                // list order: the smallest (distance, position); strict '<' against the running best keeps the earliest of equal minima
-                const uint64_t key = (uint32_t)lane < cnt ? ((uint64_t)f32_key(nb_d[lane]) << 32) | (uint32_t)lane : ~0ull;
-                const uint32_t jm = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_min64(key));
-                const float dm = nb_d[jm];
-                if (dm < dbest) {
-                    dbest = dm;
-                    best = (uint32_t)__builtin_amdgcn_readlane((int)nbv, (int)jm);
-                    best_lvl = (uint32_t)__builtin_amdgcn_readlane((int)nl, (int)jm);
-                    best_slot = (uint32_t)__builtin_amdgcn_readlane((int)ns, (int)jm);
-                }
-            }
-            evals += dg;
-            if (best == cur) break;
-            cur = best;
-            dcur = dbest;
-            cur_lvl = best_lvl;
-            cur_slot = best_slot;
-        }
-    }
+    unsigned long long evals = 0;
+    const uint32_t cur = descend_body<RT, WPQ, U>(rows, ld, metric, lvl, slot, adj_up, deg_up, gstride, top, q, nchunks, nb_d, nb_i, lane, wave, evals);
     if (threadIdx.x == 0) {
         out_entry[qi] = cur;
         if (stats) atomicAdd(&stats[0], evals);
@@ -1251,8 +1284,8 @@ static uint32_t ef_waves_per_query(const zvdb_hip_index *h, int epl, uint32_t wi
 
 int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k,
                      uint32_t ef, uint32_t entry, uint64_t id_offset, uint64_t *d_ids,
-                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, const uint32_t *d_entries,
-                     bool reserve_only) {
+                     float *d_dist, uint32_t *d_count, unsigned long long *d_stats, hipStream_t s, uint32_t *d_entries,
+                     bool reserve_only, bool descend) {
     if (nq == 0) return ZVDB_OK;
     const uint32_t width = std::max(1u, std::min(4u, h->ef_width));  // ZVDB_OPT_EF_SEARCH_WIDTH (spec: orc_hnsw_search_ef_w)
     if (ef < k) ef = k;
@@ -1373,7 +1406,16 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     return rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = std::remove_cv_t<std::remove_pointer_t<decltype(rows)>>;
         uint32_t wpq_launch = 1;
+        // the entry descent (descend: `entry` is the graph's top node, d_entries the per-query entry buffer): inside the FIRST pass when
+        // that pass is the register-beam kernel's (EfDescend), else as its own launch ahead of the search
+        const char *fd_env = tuning("ZVDB_EF_FUSE_DESCENT");  // "0": the descent as its own launch (A/B, tests)
+        const bool fuse_descent = descend && epl != 0 && (two_pass || !safe_global) && !prof && !reserve_only && !(fd_env && fd_env[0] == '0');
+        if (descend && !fuse_descent && !reserve_only) ZV_CHECK(launch_descend(h, d_queries, nq, entry, d_entries, d_stats, s));
+        bool first_launch = true;
         auto go1 = [&](auto kern, uint32_t wparam, uint32_t hb, uint32_t pass, uint32_t *net_list) -> int {
+            EfDescend desc{};
+            if (fuse_descent && first_launch) desc = EfDescend{h->lvl, h->slot, h->adj_up, h->deg_up, d_entries, entry, 1u};
+            first_launch = false;
             // hb: table size as a power of two; the tight pass of the register-beam kernel may carry a slot count instead (hb == 0)
             const uint32_t slots = hb ? (1u << hb) : tight_slots;
             const size_t lds = lds_slots(slots);
@@ -1381,7 +1423,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(kern), lds));
             hipLaunchKernelGGL(kern, dim3(nq), dim3(64 * wpq_launch), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, hb, wparam, d_entries,
-                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, net_list, epl ? width_mode : width);
+                               pass, h->ef_hint_dev + bucket, static_cast<uint32_t *>(nullptr), 0u, net_list, epl ? width_mode : width, desc);
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
@@ -1396,7 +1438,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                 ZV_HIP(hipMemsetAsync(h->ef_visit_buf, 0, (size_t)nc * tb, s));
                 hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(nc), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride, (uint32_t)N,
                                    d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, gbits, efp, d_entries,
-                                   pass, h->ef_hint_dev + bucket, h->ef_visit_buf, (uint32_t)q0, static_cast<uint32_t *>(nullptr), width);
+                                   pass, h->ef_hint_dev + bucket, h->ef_visit_buf, (uint32_t)q0, static_cast<uint32_t *>(nullptr), width, EfDescend{});
                 ZV_HIP(hipGetLastError());
             }
             return ZVDB_OK;
@@ -1410,7 +1452,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             ZV_CHECK(set_dyn_lds(reinterpret_cast<const void *>(k_search_ef<RT, 0, true>), lds));
             hipLaunchKernelGGL((k_search_ef<RT, 0, true>), dim3(kEfNetBlocks), dim3(64), lds, s, rows, ld, h->dim, metric, h->adj, h->deg, h->gstride,
                                (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, ef_net_bits(h, ef), efp, d_entries,
-                               (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_net_buf + h->ef_net_list_words, 0u, h->ef_net_buf, width);
+                               (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_net_buf + h->ef_net_list_words, 0u, h->ef_net_buf, width, EfDescend{});
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         };
