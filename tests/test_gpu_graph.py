@@ -133,6 +133,30 @@ def test_large_beams_packed_visited_table_gather_merge_wide_workgroups(zv, oracl
                 assert (ev, pp) == counters, (k, ef, tune)
 
 
+def test_entry_descent_fused_into_the_search_equals_the_two_launch_form(zv, oracle):
+    """ENTRY_DESCEND: the first pass of the register-beam kernel runs the descent itself; ZVDB_EF_FUSE_DESCENT=0 launches k_descend
+    ahead of the search as before -- ids, distances, counts and both counters (descent + search evaluations, pops) are the same, and
+    the oracle's, also when a forced tiny visited table sends queries through the retry passes (which read the entry the first pass left)."""
+    n, d, M = 6000, 48, 8
+    rng = np.random.default_rng(5)
+    V = rng.random((n, d), dtype=np.float32)
+    idx = zv.Index(m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_MIRROR)
+    idx.add(V)
+    idx.build_graph(M, 48, zv.BF_I8, 21)
+    ref, levels, top = oracle.build_bulk_graph(V, M, 48, 21)
+    Q = rng.random((64, d), dtype=np.float32)
+    for k, ef, tune in ((10, 64, {}), (10, 300, {}), (10, 96, {"ZVDB_EF_TWO_PASS": "t8"}), (10, 600, {"ZVDB_EF_TWO_PASS": "s512"})):
+        got = {}
+        for fuse in ("1", "0"):
+            with zv.tuned(ZVDB_EF_FUSE_DESCENT=fuse, **tune):
+                got[fuse] = idx.search_graph(Q, k, ef=ef, entry=zv.ENTRY_DESCEND, with_stats=True)
+        a, b = got["1"], got["0"]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3], (k, ef, tune)
+        for qi, q in enumerate(Q[:16]):
+            ri, rd = ref.search_ef(q, k, ef, 0, ref.descend(q, 0, top))
+            assert np.array_equal(a[0][qi, :len(ri)], ri) and np.array_equal(a[1][qi, :len(ri)], rd), (k, ef, tune, qi)
+
+
 def test_search_width_hand_derived_on_the_device(zv, oracle):
     """The paper example of tests/test_oracle_graph_spec.py::test_search_width_hand_derived through the ABI: six points on a line,
     query 4.6, ef = 2 -- width 1 ends on [4, 2] after 3 pops / 4 evaluations, width 2 reaches [5, 4] after 6 / 6."""
