@@ -162,7 +162,9 @@ struct zvdb_hip_index {
     uint32_t *guess_flag_host = nullptr;  // hipHostMalloc'ed, mapped
     uint32_t *guess_flag_dev = nullptr;   // its device alias
     mutable uint32_t *ef_hint_dev = nullptr;   // [16] largest visited-set fill seen per ef bucket (ef_search.hip: kEfTight)
-    mutable uint32_t *ef_hint_host = nullptr;  // pinned copy, refreshed asynchronously after every ef launch
+    mutable uint32_t *ef_hint_host = nullptr;  // pinned copy, refreshed asynchronously after the first ef searches and then every 8th (a 64-byte
+                                               // copy is ~6 us of the launch stream; the hint only ever grows and is read by LATER calls)
+    mutable uint32_t ef_hint_calls = 0;
     unsigned long long *spec_wpos0 = nullptr, *spec_wposU = nullptr;  // speculative insert: per-list write stamps (layer 0 / upper slots)
     uint64_t spec_cap0 = 0, spec_capU = 0;
     uint32_t spec_epoch = 0;

@@ -1477,7 +1477,9 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                 ZV_CHECK(go1(kern, wparam, hash_bits, two_pass ? kEfRetryMark : kEfTight, h->ef_net_buf));
                 ZV_CHECK(go_net());
             }
-            ZV_HIP(hipMemcpyAsync(h->ef_hint_host, h->ef_hint_dev, 64, hipMemcpyDeviceToHost, s));  // read by a LATER call, never waited for
+            if (h->ef_hint_calls < 16 || (h->ef_hint_calls & 7u) == 0)
+                ZV_HIP(hipMemcpyAsync(h->ef_hint_host, h->ef_hint_dev, 64, hipMemcpyDeviceToHost, s));  // read by a LATER call, never waited for
+            h->ef_hint_calls += 1;
             ZV_CHECK(ef_scratch_end(h, s));
             return ZVDB_OK;
         };
@@ -1517,6 +1519,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
 // the graph changed wholesale (upload / bulk build / load): forget the visited-set fills seen on the old one
 void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s) {
     if (!h->ef_hint_dev) return;
+    h->ef_hint_calls = 0;
     (void)hipMemsetAsync(h->ef_hint_dev, 0, 64, s);
     (void)hipStreamSynchronize(s);  // (an in-flight copy of the old values must not land after the reset)
     std::memset(h->ef_hint_host, 0, 64);
