@@ -301,7 +301,7 @@ def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16
         rec_obj = {
             "search_width": width,
             "qps": batch / el, "ms_per_batch": el * 1e3, f"recall_at_{k}": rec, "dist_evals_per_query": ev / batch, "pops_per_query": pp / batch,
-            "roofline": {"bound": "hbm", "kernel": "k_search_ef_reg (ef_search.hip; + k_descend ahead of it, outside the timed kernel)",
+            "roofline": {"bound": "hbm", "kernel": "k_search_ef_reg (ef_search.hip; the entry descent runs inside its first pass: E counts its evaluations too)",
                          "kernel_ms_avg": kavg * 1e3, "timed_launches": kn, "achieved": nbytes / kavg / 1e9 if kavg > 0 else 0.0, "peak": 8000.0,
                          "unit": "GB/s", "frac": nbytes / kavg / 8e12 if kavg > 0 else 0.0,
                          "algorithmic_bytes_per_launch": nbytes, "bytes_rule": "E d sizeof(elt) + P M0 4 (SURVEY 8d), E / P counted in-kernel"}}
