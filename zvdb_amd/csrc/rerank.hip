@@ -184,8 +184,11 @@ __device__ __forceinline__ void rr_dma16(const unsigned char *src, uint32_t lds_
 // queries x 32 candidates x 3 KiB rows; rocprofv3 stats of `bench.py --mode bf16`): round 2's kernel 71.6 us; with the waits and the walk fixed (below) 41.7 us
 // (256 B x 64 rows), 40.3 us (512 B x 32 rows), 61.5 us (1 KiB x 32 rows: half the workgroups per CU); four stage buffers with three
 // chunks in flight 43.3 us -- what is left is the rate of 100 MB of scattered 256 .. 512-byte pieces (~3 TB/s), not round trips.
+// (amdgpu_waves_per_eu(1, 1): a 1,024-query launch is one wave per SIMD -- the LDS stage allows four workgroups per CU -- and its time is
+// the slowest wave's chain; told so, hipcc schedules for that instead of for occupancy: 79 -> 63 us per certified batch, A/B of four
+// builds on one box, r4.  48 loads in flight per lane for the further candidates measured 6 % SLOWER on top of it.)
 template <int KC, typename RT, int CHB = 256, int SR = 64>
-__global__ __launch_bounds__(64) void k_rerank_staged(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_rerank_staged(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
                                                       const float *__restrict__ queries, const uint32_t *__restrict__ cand,
                                                       uint32_t k, uint64_t id_offset, uint64_t *__restrict__ out_ids,
                                                       float *__restrict__ out_dist, uint32_t *__restrict__ out_count,
