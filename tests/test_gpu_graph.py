@@ -145,7 +145,10 @@ def test_entry_descent_fused_into_the_search_equals_the_two_launch_form(zv, orac
     idx.build_graph(M, 48, zv.BF_I8, 21)
     ref, levels, top = oracle.build_bulk_graph(V, M, 48, 21)
     Q = rng.random((64, d), dtype=np.float32)
-    for k, ef, tune in ((10, 64, {}), (10, 300, {}), (10, 96, {"ZVDB_EF_TWO_PASS": "t8"}), (10, 600, {"ZVDB_EF_TWO_PASS": "s512"})):
+    # (ZVDB_EF_DIRECT_NET=1: queries that fill the tight table go straight to the net pass, as searches do once an index knows its fills)
+    for k, ef, tune in ((10, 64, {}), (10, 300, {}), (10, 96, {"ZVDB_EF_TWO_PASS": "t8"}), (10, 600, {"ZVDB_EF_TWO_PASS": "s512"}),
+                        (10, 96, {"ZVDB_EF_TWO_PASS": "t8", "ZVDB_EF_DIRECT_NET": "1"}), (10, 600, {"ZVDB_EF_TWO_PASS": "s512", "ZVDB_EF_DIRECT_NET": "1"}),
+                        (10, 128, {"ZVDB_EF_DIRECT_NET": "1"}), (10, 128, {"ZVDB_EF_DIRECT_NET": "0"})):
         got = {}
         for fuse in ("1", "0"):
             with zv.tuned(ZVDB_EF_FUSE_DESCENT=fuse, **tune):

@@ -1469,6 +1469,16 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             }
             if (reserve_only) return ZVDB_OK;  // (zvdb_hip_search_graph_reserve: everything a launch of this shape allocates)
             ZV_CHECK(ef_scratch_begin(h, s));
+            // Once the fill of this ef bucket is known and the index has a few searches behind it, the tight table is sized for the largest
+            // fill seen (<= 74 % load) and a query that still fills it is an outlier: it goes STRAIGHT to the net (16 workgroups on global
+            // tables) -- the safe LDS pass between the two, an empty 5-us launch in practice, is left out.  ZVDB_EF_DIRECT_NET=0 / 1: tests.
+            const char *dn_env = tuning("ZVDB_EF_DIRECT_NET");
+            const bool direct_net = two_pass && !safe_global && (dn_env ? dn_env[0] == '1' : (seen != 0 && h->ef_hint_calls >= 16 && !tp_env));
+            if (direct_net) {
+                ZV_HIP(hipMemsetAsync(h->ef_net_buf, 0, 8, s));  // list count + pop cursor
+                ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight, h->ef_net_buf));
+                ZV_CHECK(go_net());
+            } else {
             if (two_pass) ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight, nullptr));
             if (safe_global) {
                 ZV_CHECK(go_global(two_pass ? kEfRetry : kEfSingle));
@@ -1476,6 +1486,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                 ZV_HIP(hipMemsetAsync(h->ef_net_buf, 0, 8, s));  // list count + pop cursor
                 ZV_CHECK(go1(kern, wparam, hash_bits, two_pass ? kEfRetryMark : kEfTight, h->ef_net_buf));
                 ZV_CHECK(go_net());
+            }
             }
             if (h->ef_hint_calls < 16 || (h->ef_hint_calls & 7u) == 0)
                 ZV_HIP(hipMemcpyAsync(h->ef_hint_host, h->ef_hint_dev, 64, hipMemcpyDeviceToHost, s));  // read by a LATER call, never waited for
