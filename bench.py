@@ -198,6 +198,20 @@ def reference_harness(zv):
         if qi < 200 and not (np.array_equal(first[qi][0], ci) and np.array_equal(first[qi][1], cd)):
             pc_same = False
     t_call = time.perf_counter() - t0
+    # the same calls straight through the C ABI (ctypes, preallocated outputs): what a compiled host -- the Zig binding, hnsw.hpp -- pays
+    import ctypes as C
+    from zvdb_amd import _lib
+    L = _lib.hip()
+    a_ids = np.zeros(K, dtype=np.uint64); a_dist = np.zeros(K, dtype=np.float32); a_cnt = np.zeros(1, dtype=np.uint32)
+    p_ids, p_dist, p_cnt = a_ids.ctypes.data_as(C.POINTER(C.c_uint64)), a_dist.ctypes.data_as(C.POINTER(C.c_float)), a_cnt.ctypes.data_as(C.POINTER(C.c_uint32))
+    qp = [Q[qi].ctypes.data_as(C.POINTER(C.c_float)) for qi in range(NQC)]
+    abi_same = True
+    t0 = time.perf_counter()
+    for qi in range(NQC):
+        _lib.check(L.zvdb_hip_search_graph(h.index._h, qp[qi], 1, D, K, 0, 0, p_ids, p_dist, p_cnt, None))
+        if qi < 200 and not (np.array_equal(first[qi][0], a_ids[:int(a_cnt[0])]) and np.array_equal(first[qi][1], a_dist[:int(a_cnt[0])])):
+            abi_same = False
+    t_abi = time.perf_counter() - t0
     cpu = {"search_qps": NQ / t_cpu, "insert_pts_per_s": P / t_ins_cpu}
     return {
         "shape": {"points": P, "dim": D, "queries": NQ, "k": K, "m": 16, "ef_construction": 200,
@@ -211,6 +225,7 @@ def reference_harness(zv):
                 "bit_exact_vs_oracle_first_200_queries": bool(same),
                 "search_per_call_qps": NQC / t_call, "search_per_call_us": t_call / NQC * 1e6, "search_per_call_queries": NQC,
                 "search_per_call_bit_exact_first_200": bool(pc_same),
+                "search_per_call_c_abi_qps": NQC / t_abi, "search_per_call_c_abi_us": t_abi / NQC * 1e6, "search_per_call_c_abi_bit_exact_first_200": bool(abi_same),
                 "insert_per_call_pts_per_s": NPC / t_ins_call, "insert_per_call_us": t_ins_call / NPC * 1e6, "insert_per_call_points": NPC,
                 "per_call_note": "one point / one query per API call through the Python mirror of HNSW(T) (the reference's calling pattern); "
                                  "the bulk numbers beside them are insert_many / one batched search of all queries"},
