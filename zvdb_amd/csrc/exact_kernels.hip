@@ -1134,12 +1134,20 @@ __device__ __forceinline__ bool compat_fast_body(
             float bd = __builtin_inff();
             uint32_t bp = 0xFFFFFFFFu, same = 0;
             if constexpr (LAT) {
-                uint64_t bk = ~0ull;
-                for (uint32_t i = lane; i < n; i += kWave) bk = umin64(bk, ((uint64_t)dist_order_key(fr_d[i]) << 32) | i);
-                bk = wave_min64(bk);
+                // ONE pass over the frontier: every lane keeps the two smallest (key, position) words of its entries; the minimum of the
+                // firsts is the pop, and it is unique iff no other first and no second carries its key (a lane's third entry cannot tie
+                // unless its second does).  Equal order keys = equal distances (-0 = +0); a NaN minimum gives the query up as before.
+                uint64_t k1 = ~0ull, k2 = ~0ull;
+                for (uint32_t i = lane; i < n; i += kWave) {
+                    const uint64_t key = ((uint64_t)dist_order_key(fr_d[i]) << 32) | i;
+                    if (key < k1) { k2 = k1; k1 = key; }
+                    else if (key < k2) k2 = key;
+                }
+                const uint64_t bk = wave_min64(k1);
+                const uint32_t bh = (uint32_t)(bk >> 32);
                 bp = (uint32_t)bk;
-                bd = fr_d[bp];
-                for (uint32_t b0 = 0; b0 < n; b0 += kWave) same += (uint32_t)__popcll(__ballot(b0 + lane < n && fr_d[b0 + lane] == bd));
+                const bool tie = (k1 != bk && (uint32_t)(k1 >> 32) == bh) || (k2 != ~0ull && (uint32_t)(k2 >> 32) == bh);
+                same = (__ballot(tie) != 0 || bh == 0xFFFFFFFFu) ? 2u : 1u;
             } else {
                 for (uint32_t i = lane; i < n; i += kWave) {
                     const float d = fr_d[i];
@@ -1157,6 +1165,7 @@ __device__ __forceinline__ bool compat_fast_body(
             }
             if (same != 1) { gave_up = true; break; }  // equal minima (or a NaN): the heap's layout decides -> exact emulation
             const uint32_t cid = fr_i[bp];
+            if constexpr (LAT) bd = fr_d[bp];  // (only lane 0 uses it: the load overlaps the list request below)
             __syncthreads();
             if (lane == 0) {
                 fr_d[bp] = fr_d[n - 1];
