@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 CORPUS_SEED = 0x5EED
 QUERY_SEED = 0xC0FFEE
-KERNEL_NAMES = {"bf16": "k_bf16_stream<48,1,false,64,0> (bf_bf16_stream.hip; shards >= 8 tiles per stream, dim <= 768; else k_bf_scan5<bf16>)",
+KERNEL_NAMES = {"bf16": "k_bf16_stream<48,1,false,KPV,0>, KPV = 64 / 128 / 256 list entries per stream = the survivors the certificate's level asks for (128 at level 2, the level of the benchmark's data) (bf_bf16_stream.hip; shards >= 8 tiles per stream, dim <= 768; else k_bf_scan5<bf16>)",
                 "f32": "k_bf_scan5<f32> (bruteforce.hip)",
                 "i8": "k_i8_stream<24> (bf_i8_stream.hip; shards >= 16 tiles per stream; else k_bf_scan5<i8>)",
                 "fp4": "k_fp4_stream<12,0,32> (bf_fp4_stream.hip)"}
