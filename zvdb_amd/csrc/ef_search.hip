@@ -587,6 +587,7 @@ __device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v) {  // lane i <- lan
 // workgroup barriers per window (window published in ctl[0] / distances done).  Same results, same counters; what it buys is
 // latency: a 1,024-query batch is one round of resident workgroups either way, its time is the slowest query's chain of pops.
 constexpr uint32_t kEfDone = 0xFFFFFFFFu;  // ctl[0]: no further window (a window has 1 .. 64 rows)
+constexpr uint32_t kEfFinal = 0xFFFFFFFEu;  // ctl[0]: the search is over -- share the exact re-evaluation of the final k (ctl[1] results), then leave
 template <typename RT, int EPL, int WPQ = 1, int PROF = 0, bool WIDE = false>
 __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 : 4) : WPQ == 2 ? 2 : 1) void k_search_ef_reg(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
@@ -643,6 +644,13 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
                 __syncthreads();  // (A) window published
                 const uint32_t nfh = ctl[0];
                 if (nfh == kEfDone) return;
+                if (nfh == kEfFinal) {  // the final k: this wave's share of the exact re-evaluation (below), then out
+                    const uint32_t nresh = ctl[1];
+                    for (uint32_t i = (uint32_t)lane * WPQ + (uint32_t)wave; i < nresh; i += kWave * WPQ)
+                        RD[i] = exact_dist_rt(metric, q, rows + (size_t)R[i] * ld, dim);
+                    __syncthreads();  // (B)
+                    return;
+                }
                 ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, nfh, nb_i, nb_d, lane, wave);
                 __syncthreads();  // (B) distances done
             }
@@ -1129,18 +1137,30 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
 }
         sync_w();
     }
-    release_helpers();
     stamp(4);
-    // the first k slots of W, re-evaluated with the exact reference arithmetic, ordered by (exact distance, id)
+    // the first k slots of W, re-evaluated with the exact reference arithmetic, ordered by (exact distance, id).  One lane walks one
+    // row in the reference's order; the helper waves take their share of the rows before they leave (k = 100 on 3-KB rows was one wave
+    // walking two rounds of rows: 0.1 ms of a 2.4-ms search, r3)
     const uint32_t nres = wn < k ? wn : k;
     if (nres > 0) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
             if ((uint32_t)(e * kWave + lane) < nres) R[e * kWave + lane] = (uint32_t)wkr[e];
+    }
+    // (up to 32 results stay with wave 0: for k = 10 the hand-over's barrier costs what the split saves -- A/B on one box; k = 100: +1-3 %)
+    const bool share = WPQ > 1 && nres > 32;  // wave-uniform
+    if constexpr (WPQ > 1) {
+        if (lane == 0) { ctl[0] = share ? kEfFinal : kEfDone; ctl[1] = nres; }
+        __syncthreads();  // (A) R and the hand-over are published
+    } else {
         sync_w();
-        for (uint32_t i = lane; i < nres; i += kWave)
+    }
+    if (nres > 0) {
+        const uint32_t step = share ? (uint32_t)WPQ : 1u;
+        for (uint32_t i = (uint32_t)lane * step; i < nres; i += kWave * step)  // (wave 0's share, or all)
             RD[i] = exact_dist_rt(metric, q, rows + (size_t)R[i] * ld, dim);
-        sync_w();
+        if (share) __syncthreads();  // (B) every share is in RD
+        else sync_w();
         for (uint32_t i = lane; i < nres; i += kWave) {
             const float di = RD[i];
             const uint32_t ii = R[i];
