@@ -494,8 +494,28 @@ def extras(args, zv, torch):
     return out
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the ranks OURSELVES -- one child
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` on a free rendezvous port of 127.0.0.1 -- before
+    this process has made any GPU call (nothing here imports torch.cuda state or the HIP library; a GPU-initialised process must
+    never exec).  Rank 0's JSON line reaches stdout through the inherited descriptor; the exit code is the child's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks (torch.distributed.run, 127.0.0.1:{port})", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
 
@@ -506,10 +526,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
     if not torch.cuda.is_available() or zv.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("ZVDB_BENCH_ONE_DEVICE") != "1" and local_rank >= zv.device_count():
+        raise SystemExit(f"bench.py rank {rank}: local rank {local_rank} but {zv.device_count()} GPU(s) visible: --gpus N needs N GPUs on this node")
     if os.environ.get("ZVDB_BENCH_ONE_DEVICE") == "1":
         local_rank = 0  # rehearsal of the N > 1 logic on a one-GPU box: every rank on cuda:0 (with ZVDB_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
@@ -520,6 +541,10 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "WORLD_SIZE" not in os.environ:  # (ZVDB_BENCH_FORCE_DIST=1 without a launcher: a one-rank group of our own)
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); free = sk.getsockname()[1]; sk.close()
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank), MASTER_PORT=str(free))
         backend = os.environ.get("ZVDB_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for the rehearsal above
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -606,6 +631,7 @@ def main():
     o_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
 
     GRAPH = "graph"  # `m` of a step: a brute-force screen mode, or the graph route
+    ag_sample, ag_events = [False], []  # all-gather timing on sampled steps (torch.distributed path; the ABI path times inside the library)
 
     def step(q, m, stats=0):
         if comm is not None:  # the whole sharded step inside libzvdb_hip (include/zvdb_hip.h: *_sharded_dev)
@@ -630,7 +656,13 @@ def main():
                 dist.all_gather_into_tensor(g_host, l_pack.cpu())
                 g_pack.copy_(g_host)
             else:
+                if ag_sample[0]:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 dist.all_gather_into_tensor(g_pack, l_pack)
+                if ag_sample[0]:
+                    e1.record()
+                    ag_events.append((e0, e1))
             zv.merge_topk_packed_dev(g_pack.data_ptr(), pk_bytes, world, B, K, o_ids.data_ptr(), o_dist.data_ptr(),
                                      o_cnt.data_ptr(), stream)
             return o_ids, o_dist
@@ -683,14 +715,21 @@ def main():
         sync()
         # the scan region of every 4th step is bracketed by HIP events on the launch stream (each event pair leaves two
         # ~6 us bubbles in the launch chain: sampling keeps the measurement from slowing what it measures)
+        del ag_events[:]
         t0 = time.perf_counter()
         for i in range(steps):
             idx.timing_enable((1 if i == 0 else 2) if i % 4 == 0 else 0)
+            if comm is not None:
+                comm.timing_enable((1 if i == 0 else 2) if i % 4 == 0 else 0)
+            ag_sample[0] = i % 4 == 0
             step(queries[total_steps if args.same_queries else (warmup + i) % total_steps], m)
         sync()
         el = time.perf_counter() - t0
         kms, kn = idx.timing_read()
         idx.timing_enable(False)
+        ag_sample[0] = False
+        if comm is not None:
+            comm.timing_enable(0)
         if dist_on:
             t = torch.tensor([el], dtype=torch.float64, device="cpu" if cpu_coll else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -706,6 +745,31 @@ def main():
             step(queries[settle % total_steps], mode)
         sync()
     elapsed, kern_ms, kern_n = timed(mode, args.steps, args.warmup)
+    # ---- who took part in the collective: what RCCL reports per rank + the PCI bus id of each rank's device, gathered over the ranks;
+    # the all-gather's own time from HIP events around it on the sampled steps of the timed region (max over ranks of the per-rank mean)
+    collective = None
+    if dist_on:
+        if comm is not None:
+            c_rank, c_ranks, bus = comm.query()
+            ag_us, ag_n = comm.timing_read()
+        else:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+            c_rank, c_ranks = dist.get_rank(), dist.get_world_size()
+            ag_us, ag_n = sum(a.elapsed_time(b) for a, b in ag_events) * 1e3, len(ag_events)
+        mine = {"rank": rank, "rccl_rank": c_rank, "rccl_ranks": c_ranks, "bus_id": bus, "all_gather_us": ag_us / max(ag_n, 1), "samples": ag_n}
+        every = [None] * world
+        if world > 1:
+            dist.all_gather_object(every, mine)
+        else:
+            every = [mine]
+        collective = {"ranks": min(e["rccl_ranks"] for e in every), "ranks_reporting": len(every),
+                      "rccl_ranks_seen": sorted(e["rccl_rank"] for e in every),
+                      "device_bus_ids": sorted(set(e["bus_id"] for e in every)), "distinct_devices": len(set(e["bus_id"] for e in every)),
+                      "all_gather_us": max(e["all_gather_us"] for e in every), "all_gather_us_per_rank": [e["all_gather_us"] for e in every],
+                      "all_gather_samples": min(e["samples"] for e in every), "bytes_per_rank": pk_bytes,
+                      "source": ("zvdb_hip_comm_query (ncclCommUserRank / ncclCommCount) + HIP events around ncclAllGather inside libzvdb_hip"
+                                 if comm is not None else "torch.distributed group + torch.cuda events around all_gather_into_tensor")}
     paths = {}
     if auto and not args.no_paths:
         for name, st in (("fp4", 8), ("i8", 8), ("f32", 2)):
@@ -843,6 +907,8 @@ def main():
                                "algorithmic_bytes_per_launch": nbytes, "dist_evals_per_query": g_ev / B, "pops_per_query": g_pp / B,
                                "bytes_rule": "E d sizeof(elt) + P M0 4 per query (SURVEY 8d), E / P counted in-kernel on this rank's shard"}
             out["metric"] = "QPS at recall@10>=0.95, 10Mx768 fp32, batch=1024 (graph route: recall as measured, see recall_at_10)"
+        if collective is not None:
+            out["collective"] = collective
         out["config"]["settle_batches_before_warmup"] = settle
         out["certificate"] = {**cert, "survivors_kept": {0: "32 (k <= 16) / 64", 1: 64, 2: 128, 3: 256}[cert["level"]],
                               "note": "queries = all that went through the certificate on the headline index (every leg); repaired = recomputed by the "

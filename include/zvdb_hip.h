@@ -398,6 +398,17 @@ int zvdb_hip_comm_unique_id(void *out_id /* ZVDB_COMM_ID_BYTES bytes */);
 int zvdb_hip_comm_create(uint32_t rank, uint32_t world, const void *unique_id, int32_t device /* -1 = current */, zvdb_hip_comm **out);
 void zvdb_hip_comm_destroy(zvdb_hip_comm *c);
 int zvdb_hip_comm_info(zvdb_hip_comm *c, uint32_t *out_rank, uint32_t *out_world);
+/* Everything zvdb_hip_comm_create can refuse on ONE rank (RCCL not loadable, no device, bad device index), without the collective:
+ * call it on every rank and agree on the outcome over the host's own channel BEFORE any rank enters zvdb_hip_comm_create -- a
+ * rank that failed alone would leave the others waiting in ncclCommInitRank. */
+int zvdb_hip_comm_precheck(int32_t device /* -1 = current */);
+/* What RCCL itself reports for this communicator (ncclCommUserRank / ncclCommCount) and the PCI bus id ("0000:05:00.0") of its
+ * device: gathered over the ranks, the evidence that N ranks on N distinct GPUs joined. */
+int zvdb_hip_comm_query(zvdb_hip_comm *c, uint32_t *out_rccl_rank, uint32_t *out_rccl_ranks, char *out_bus_id, uint32_t bus_id_bytes);
+/* HIP events around the ncclAllGather of the sharded calls, on the caller's stream (up to 64 samples): enable 1 = new measurement,
+ * 2 = resume, 0 = pause; read synchronises on the recorded events and returns their summed microseconds. */
+int zvdb_hip_comm_timing_enable(zvdb_hip_comm *c, int on);
+int zvdb_hip_comm_timing_read(zvdb_hip_comm *c, double *out_us_total, uint32_t *out_samples);
 /* bytes of device workspace the sharded calls need (packed send + receive buffers + the local search's own workspace) */
 int zvdb_hip_sharded_workspace(zvdb_hip_index *h, zvdb_hip_comm *c, uint32_t nq, uint32_t k, uint32_t mode, uint64_t *out_bytes);
 int zvdb_hip_search_bruteforce_sharded_dev(zvdb_hip_index *h, zvdb_hip_comm *c, const void *d_queries, uint32_t nq, uint32_t dim,

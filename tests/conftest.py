@@ -10,11 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "multiprocess: starts rank / torchrun / bench child processes (collected last)")
 
 
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) on a box without a device, so a plain `pytest` works on the CPU container.  Asking
     the library for the device count initialises nothing on a GPU box beyond what the tests do themselves."""
+    # Collection order = what `pytest -x` can hide.  First the fixtures that do NOT come from the oracle (hand-derived cases,
+    # the reference's own test cases, the golden vectors), then the kernel parity tests, LAST everything that starts other
+    # processes (ranks, torchrun, bench.py): a harness fault there can no longer mask a parity test.
+    def rank(it):
+        f = os.path.basename(str(it.fspath))
+        if "multiprocess" in it.keywords:
+            return 2
+        return 0 if f in ("test_hand_derived.py", "test_oracle_pins.py", "test_golden.py", "test_abi_symbols.py") else 1
+    items.sort(key=rank)  # (stable: file order inside a class is kept)
     gpu_items = [it for it in items if "gpu" in it.keywords]
     if not gpu_items:
         return

@@ -116,6 +116,42 @@ def test_exact_scan_alone_is_the_oracles_brute_force(zv, oracle, metric, n, d, n
     assert idx.cert_info()["repaired"] >= nq
 
 
+@pytest.mark.parametrize("metric", ["dot", "cosine"])
+@pytest.mark.parametrize("forced", [False, True])
+def test_zero_inner_products_under_dot_and_cosine(zv, oracle, metric, forced):
+    """Rows at distance exactly zero under dot / cosine: a zero query (every row ties at -(+0.0) = -0.0) and one-hot rows of which
+    fewer than k overlap the query (the k-th result has an exactly-zero inner product).  More than k' rows tie at the k-th key, so
+    the certificate cannot pass: the query is repaired by the exact scan -- whose bound must admit the rows AT the k-th distance,
+    however the zero is signed.  k results, the oracle's ids (ties by lower id) and the oracle's bit patterns (-0.0)."""
+    mt = zv.METRIC_DOT if metric == "dot" else zv.METRIC_COSINE
+    n, d, k = 3000, 64, 10
+    rng = np.random.default_rng(8)
+    V = np.zeros((n, d), dtype=np.float32)
+    V[np.arange(n), rng.integers(0, d, size=n)] = rng.integers(1, 4, size=n).astype(np.float32)   # one-hot rows
+    Q = np.zeros((6, d), dtype=np.float32)           # Q[0]: the zero query
+    Q[1, 3] = 1.0                                    # one coordinate: ~n/d rows overlap (more than k)
+    Q[2, :] = -1.0                                   # every product negative or zero: distances >= 0
+    Q[3, 5] = -2.0; Q[3, 9] = 1.0
+    Q[4] = rng.random(d, dtype=np.float32)
+    Vr = V.copy()
+    Vr[Vr[:, 7] != 0] = 0.0                          # a corpus where few rows overlap coordinate 7 ...
+    Vr[:4, :] = 0.0; Vr[:4, 7] = [3.0, 1.0, 2.0, 1.0]  # ... exactly 4 of them: fewer than k
+    Q[5, 7] = 1.0
+    for rows in (V, Vr):
+        idx = zv.Index(dim=d, metric=mt, flags=zv.FLAG_BF16_MIRROR)
+        idx.add(rows)
+        if forced:
+            idx.set_option(zv.OPT_CERT_FORCE_REPAIR, 1)
+        stored = np.stack([idx.get_vector(i) for i in range(n)]) if metric == "cosine" else rows
+        ri, rd, rc = oracle.bruteforce_topk(stored, Q, k, 1)
+        assert (rc == k).all()
+        for m in (zv.BF_F32, zv.BF_BF16, zv.BF_I8):
+            ids, dist, cnt = idx.search_bruteforce(Q, k, m)
+            _check(ids, dist, cnt, ri, rd, rc)
+            assert np.array_equal(dist.view(np.uint32), rd.view(np.uint32)), (m, dist, rd)   # -0.0 where the oracle writes -0.0
+        assert idx.cert_info()["repaired"] >= 1      # (the zero query cannot be certified: every row ties)
+
+
 def test_exact_scan_ties_by_lower_id(zv, oracle):
     rng = np.random.default_rng(4)
     base = rng.integers(0, 4, size=(700, 8)).astype(np.float32)

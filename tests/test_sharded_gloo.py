@@ -1,140 +1,25 @@
 """World-size-2 (and 3) gloo tests of the multi-GPU host logic on CPU: id-range shards, global id
 offsets, all-gather layout, k-way merge.  The compute inside each rank is the ORACLE here (the HIP
-backend needs a GPU); what is under test is zvdb_amd/sharded.py's collective + layout logic."""
-import os
-import socket
-import sys
-
-import numpy as np
+backend needs a GPU); what is under test is zvdb_amd/sharded.py's collective + layout logic.
+Every rank is a fresh child process (tests/_ranks.py -> tests/rank_worker.py), results come back as files."""
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from _ranks import run_ranks
 
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-class OracleShard:
-    def __init__(self, V_all, rank, world):
-        from zvdb_amd.sharded import shard_range
-        self.lo, self.hi = shard_range(len(V_all), world, rank)
-        self.V = V_all[self.lo:self.hi]
-
-    def local_search(self, queries, k, mode):
-        import oracle
-        ids, dd, cnt = oracle.bruteforce_topk(self.V, queries.numpy(), k)
-        pad = np.arange(k)[None, :] >= cnt[:, None]
-        ids = ids.astype(np.int64) + self.lo
-        ids[pad] = -1
-        dd[pad] = np.inf
-        return torch.from_numpy(ids), torch.from_numpy(dd), torch.from_numpy(cnt.astype(np.int32))
-
-    def merge(self, g_ids, g_dist, g_cnt, k):
-        import oracle
-        oi, od, oc = oracle.merge_topk(g_ids.numpy().astype(np.uint64), g_dist.numpy(),
-                                       g_cnt.numpy().astype(np.uint32), k)
-        return torch.from_numpy(oi.astype(np.int64)), torch.from_numpy(od), torch.from_numpy(oc.astype(np.int32))
-
-
-def _worker(rank, world, port, n, d, nq, k, ret):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import oracle
-    from zvdb_amd.sharded import ShardedSearch
-    V = oracle.uniform_rows(0x5EED, 0, n, d)
-    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
-    ss = ShardedSearch(OracleShard(V, rank, world))
-    ids, dd, cnt = ss.search(torch.from_numpy(Q), k)
-    ri, rd, rc = oracle.bruteforce_topk(V, Q, k)
-    ok = (np.array_equal(ids.numpy().astype(np.uint64)[:, :min(k, n)], ri[:, :min(k, n)])
-          and np.array_equal(dd.numpy()[:, :min(k, n)], rd[:, :min(k, n)])
-          and np.array_equal(cnt.numpy().astype(np.uint32), rc))
-    ret[rank] = bool(ok)
-    dist.barrier()
-    dist.destroy_process_group()
+pytestmark = pytest.mark.multiprocess
 
 
 @pytest.mark.parametrize("world,n,d,nq,k", [(2, 1001, 16, 9, 10), (3, 64, 8, 4, 10), (2, 5, 4, 3, 10)])
-def test_sharded_topk_allgather_merge(world, n, d, nq, k):
-    import oracle
-    oracle.build()
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, d, nq, k, ret), nprocs=world, join=True)
-    assert all(ret.get(r, False) for r in range(world)), dict(ret)
+def test_sharded_topk_allgather_merge(oracle, tmp_path, world, n, d, nq, k):
+    res = run_ranks("gloo_bruteforce", world, [n, d, nq, k], tmp_path, timeout=300)
+    assert len(res) == world and all(r["ok"] for r in res), res
 
 
-class OracleGraphShard(OracleShard):
-    """The graph route of a shard on the oracle: the shard's own bulk HNSW graph (no cross-shard edges), descent + ef search."""
-
-    def __init__(self, V_all, rank, world, M, efc, seed):
-        import oracle
-        super().__init__(V_all, rank, world)
-        self.ref, self.levels, self.top = oracle.build_bulk_graph(self.V, M, efc, seed)
-
-    def local_search(self, queries, k, mode, route="bruteforce", ef=64, entry=None):
-        if route != "graph":
-            return super().local_search(queries, k, mode)
-        Q = queries.numpy()
-        ids = np.full((len(Q), k), -1, dtype=np.int64)
-        dd = np.full((len(Q), k), np.inf, dtype=np.float32)
-        cnt = np.zeros(len(Q), dtype=np.int32)
-        for i, q in enumerate(Q):
-            a, b = self.ref.search_ef(q, k, ef, 0, self.ref.descend(q, 0, self.top))
-            ids[i, :len(a)] = a.astype(np.int64) + self.lo
-            dd[i, :len(a)] = b
-            cnt[i] = len(a)
-        return torch.from_numpy(ids), torch.from_numpy(dd), torch.from_numpy(cnt)
-
-
-def _graph_worker(rank, world, port, n, d, nq, k, ef, ret):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import oracle
-    from zvdb_amd.sharded import ShardedSearch
-    V = oracle.uniform_rows(0x5EED, 0, n, d)
-    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
-    ss = ShardedSearch(OracleGraphShard(V, rank, world, 8, 32, 3))
-    ids, dd, cnt = ss.search(torch.from_numpy(Q), k, route="graph", ef=ef)
-    # expected: every shard's list computed here, merged by the oracle
-    shards = [OracleGraphShard(V, r, world, 8, 32, 3) for r in range(world)]
-    per = [sh.local_search(torch.from_numpy(Q), k, 0, route="graph", ef=ef) for sh in shards]
-    gi = np.stack([p[0].numpy().astype(np.uint64) for p in per])
-    gd = np.stack([p[1].numpy() for p in per])
-    gc = np.stack([p[2].numpy().astype(np.uint32) for p in per])
-    mi, md, mc = oracle.merge_topk(gi, gd, gc, k)
-    ok = (np.array_equal(ids.numpy().astype(np.uint64), mi) and np.array_equal(dd.numpy(), md) and np.array_equal(cnt.numpy().astype(np.uint32), mc))
-    # sanity of the route itself: the merged graph result finds most of the exact neighbours on this small corpus
-    ri, _, _ = oracle.bruteforce_topk(V, Q, k)
-    rec = np.mean([len(set(mi[i][:mc[i]]) & set(ri[i])) / k for i in range(nq)])
-    ret[rank] = bool(ok) and rec >= 0.8
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_sharded_graph_route_allgather_merge():
+def test_sharded_graph_route_allgather_merge(oracle, tmp_path):
     """route="graph" through ShardedSearch at world size 2: per-shard graphs over the shards' own id ranges, global id offsets,
     one packed all-gather, k-way merge -- equal to the oracle's merge of the per-shard lists on every rank."""
-    import oracle
-    oracle.build()
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = _free_port()
-    mp.spawn(_graph_worker, args=(2, port, 1500, 16, 12, 10, 64, ret), nprocs=2, join=True)
-    assert all(ret.get(r, False) for r in range(2)), dict(ret)
+    res = run_ranks("gloo_graph", 2, [1500, 16, 12, 10, 64], tmp_path, timeout=600)
+    assert len(res) == 2 and all(r["ok"] for r in res), res
 
 
 def test_shard_ranges_partition_the_id_space():
@@ -145,3 +30,23 @@ def test_shard_ranges_partition_the_id_space():
             assert rs[0][0] == 0 and rs[-1][1] == n
             assert all(rs[i][1] == rs[i + 1][0] for i in range(g - 1))
             assert max(hi - lo for lo, hi in rs) - min(hi - lo for lo, hi in rs) <= 1
+
+
+def test_bench_bare_gpus_n_starts_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver may call it): bench.py starts
+    torch.distributed.run itself, before any GPU call.  Without GPUs the ranks refuse loudly (the product path has no CPU
+    fallback) and the parent's exit code is the launcher's -- non-zero, no JSON line, never a usage error about launchers."""
+    import os
+    import subprocess
+    import sys
+    import zvdb_amd
+    if zvdb_amd.device_count() >= 2:
+        pytest.skip("a multi-GPU box would run the real benchmark here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "20000", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-paths"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "starting 2 ranks" in r.stderr and "launch with torch.distributed.run" not in r.stderr + r.stdout
+    assert "needs a GPU" in r.stderr or "GPU(s) visible" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

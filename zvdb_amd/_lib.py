@@ -93,6 +93,10 @@ HIP_SYMBOLS = [
     ("zvdb_hip_comm_create", _i32, [_u32, _u32, _vp, C.c_int32, C.POINTER(_vp)]),
     ("zvdb_hip_comm_destroy", None, [_vp]),
     ("zvdb_hip_comm_info", _i32, [_vp, _u32p, _u32p]),
+    ("zvdb_hip_comm_precheck", _i32, [C.c_int32]),
+    ("zvdb_hip_comm_query", _i32, [_vp, _u32p, _u32p, C.c_char_p, _u32]),
+    ("zvdb_hip_comm_timing_enable", _i32, [_vp, _i32]),
+    ("zvdb_hip_comm_timing_read", _i32, [_vp, C.POINTER(C.c_double), _u32p]),
     ("zvdb_hip_sharded_workspace", _i32, [_vp, _vp, _u32, _u32, _u32, _u64p]),
     ("zvdb_hip_search_bruteforce_sharded_dev", _i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u64, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("zvdb_hip_search_graph_sharded_dev", _i32, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u64, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),

@@ -75,7 +75,9 @@ __global__ __launch_bounds__(XS_T) void k_exact_scan(const RT *__restrict__ rows
             uint64_t t = ~0ull - 1;  // no bound
             if ((uint32_t)tid < nqg) {
                 const uint32_t qi = flist[g0 + tid];
-                if (cur_count[qi] >= k) t = ((uint64_t)f32_key(cur_dist[(size_t)qi * k + k - 1]) << 32) | (uint32_t)(cur_ids[(size_t)qi * k + k - 1] - id_offset);
+                // (the re-rank writes a zero dot / cosine distance as -0.0 = -(+0.0); the words below are built from d + 0.0f, one key per
+                // value, so the bound is normalised the same way -- else every row at distance 0 would fall outside it)
+                if (cur_count[qi] >= k) t = ((uint64_t)f32_key(cur_dist[(size_t)qi * k + k - 1] + 0.0f) << 32) | (uint32_t)(cur_ids[(size_t)qi * k + k - 1] - id_offset);
             }
             thr[tid] = t;
             cnt[tid] = 0;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(XS_T) void k_exact_scan(const RT *__restrict__ rows
 }
 
 __global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restrict__ nflag, const uint32_t *__restrict__ flist, const uint64_t *__restrict__ partial,
-                                                         uint32_t B, uint32_t k, uint64_t id_offset, uint64_t *__restrict__ out_ids,
+                                                         uint32_t B, uint32_t k, int metric, uint64_t id_offset, uint64_t *__restrict__ out_ids,
                                                          float *__restrict__ out_dist, uint32_t *__restrict__ out_count, uint32_t *host_repaired) {
     const uint32_t f = blockIdx.x;
     if (f >= *nflag) return;
@@ -190,7 +192,10 @@ __global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restr
             uint32_t rank = 0;
             for (uint32_t j = 0; j < nres; ++j) rank += sel[j] < w ? 1u : 0u;
             out_ids[(size_t)qi * k + rank] = (uint64_t)(uint32_t)w + id_offset;
-            out_dist[(size_t)qi * k + rank] = f32_unkey((uint32_t)(w >> 32));
+            // a zero dot / cosine distance is -(+0.0) = -0.0 in the reference's arithmetic (the oracle and the re-rank write that);
+            // the words carry +0.0 so that a value has one key
+            const float dv = f32_unkey((uint32_t)(w >> 32));
+            out_dist[(size_t)qi * k + rank] = (metric != ZVDB_METRIC_L2SQ && dv == 0.0f) ? -0.0f : dv;
         }
     }
     for (uint32_t i = nres + lane; i < k; i += kWave) {
@@ -247,7 +252,7 @@ int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t 
     }));
     const size_t mlds = SEL_HIST_BYTES + 256 * 8 + (size_t)B * k * 8;
     if (mlds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scan_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-    hipLaunchKernelGGL(k_exact_scan_merge, dim3(nq), dim3(64), mlds, s, nflag, flist, reinterpret_cast<const uint64_t *>(scratch), B, k, id_offset, d_ids,
+    hipLaunchKernelGGL(k_exact_scan_merge, dim3(nq), dim3(64), mlds, s, nflag, flist, reinterpret_cast<const uint64_t *>(scratch), B, k, metric, id_offset, d_ids,
                        d_dist, d_count, host_repaired);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;

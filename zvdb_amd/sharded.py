@@ -51,8 +51,25 @@ class Comm:
     @classmethod
     def from_torch_distributed(cls, device_index: int, group=None) -> "Comm":
         """Rank 0 draws the unique id; torch.distributed (any backend) carries its 128 bytes to the other ranks."""
+        from . import _lib
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # (1) what a rank can fail on alone is checked on every rank and agreed on BEFORE the collective create: a rank that
+        # returned early from zvdb_hip_comm_create would leave the others waiting in ncclCommInitRank
+        mine = None
+        try:
+            _lib.check(_lib.hip().zvdb_hip_comm_precheck(device_index))
+        except Exception as e:
+            mine = f"rank {rank}: {type(e).__name__}: {e}"
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine, group=group)
+        else:
+            every = [mine]
+        bad = [m for m in every if m]
+        if bad:
+            raise RuntimeError("zvdb_hip_comm_precheck failed: " + "; ".join(bad))
+        # (2) the unique id: rank 0 draws it, the host channel carries its 128 bytes
         box = [None]
         if rank == 0:
             try:
@@ -64,6 +81,25 @@ class Comm:
         if isinstance(box[0], Exception):
             raise box[0]
         return cls(rank, world, box[0], device_index)
+
+    def query(self):
+        """(rank, ranks, bus id) as RCCL and HIP report them for this communicator (zvdb_hip_comm_query)."""
+        from . import _lib
+        r, n = C.c_uint32(0), C.c_uint32(0)
+        bus = C.create_string_buffer(64)
+        _lib.check(self._L.zvdb_hip_comm_query(self._h, C.byref(r), C.byref(n), bus, 64))
+        return r.value, n.value, bus.value.decode()
+
+    def timing_enable(self, on: int) -> None:
+        from . import _lib
+        _lib.check(self._L.zvdb_hip_comm_timing_enable(self._h, int(on)))
+
+    def timing_read(self):
+        """(summed microseconds, samples) of the timed ncclAllGather launches."""
+        from . import _lib
+        us, n = C.c_double(0.0), C.c_uint32(0)
+        _lib.check(self._L.zvdb_hip_comm_timing_read(self._h, C.byref(us), C.byref(n)))
+        return us.value, n.value
 
     def close(self) -> None:
         h, self._h = getattr(self, "_h", None), None
