@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument("--extras-points", type=int, default=100_000)
     ap.add_argument("--extras-graph-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the reference benchmark's dims x k sweep (part of the cpu_baseline leg, ~1 min)")
     ap.add_argument("--rehearse-shard-of", type=int, default=0, metavar="G",
                     help="(experiments, 1 GPU) time ONE shard of a G-way run: rows/G rows, the shard's survivor share")
     ap.add_argument("--same-queries", action="store_true", help="(experiments) every step answers the same query batch")
@@ -231,6 +232,71 @@ def reference_harness(zv):
                                  "the bulk numbers beside them are insert_many / one batched search of all queries"},
         "reference_published": {"search_qps": 2678.13, "insert_pts_per_s": 8392.22, "source": "benchmarks/benchmark.md:102-113 (unstated CPU)"},
     }
+
+
+def reference_sweep(zv):
+    """The sweep of the reference's own benchmark (benchmarks/single_threaded_benchmarks.zig:28-33: 100k points, dims {128, 512, 768,
+    1024}, k {10, 25, 50, 100}, through shared_benchmarks.zig:90-125: untimed build, timed searches), bounded: <= 2,000 queries per
+    cell, fewer where the reference's O(k^2) result re-sort (hnsw.zig:227-233) makes a CPU query cost milliseconds.  Per cell: the CPU
+    port (oracle, ONE thread, C loop over the queries), the HIP path batched (one call for all queries, host pointers) and per call
+    through the C ABI (the reference's calling pattern, shared_benchmarks.zig:104-109); the first 100 queries are compared bit for bit."""
+    import ctypes as C
+
+    import numpy as np
+
+    import oracle
+    from zvdb_amd import _lib
+
+    L = _lib.hip()
+    P = 100_000
+    NQ = {10: 2000, 25: 2000, 50: 2000, 100: 2000}
+    cells = {}
+    t_all = time.perf_counter()
+    for D in (128, 512, 768, 1024):
+        V = oracle.uniform_rows(CORPUS_SEED, 0, P, D)
+        Q = oracle.uniform_rows(QUERY_SEED, 0, max(NQ.values()), D)
+        ref = oracle.HNSW(16, 200)
+        t0 = time.perf_counter()
+        for r in V:
+            ref.insert(r, 0)
+        t_ins_cpu = time.perf_counter() - t0
+        h = zv.HNSW(16, 200)
+        t0 = time.perf_counter()
+        h.insert_many(V, np.zeros(P, dtype=np.int32))
+        t_ins_gpu = time.perf_counter() - t0
+        for K in (10, 25, 50, 100):
+            nq = NQ[K]
+            Qc = np.ascontiguousarray(Q[:nq])
+            t0 = time.perf_counter()
+            ci, cd, cn = ref.search_many(Qc, K, threads=1)
+            t_cpu = time.perf_counter() - t0
+            h.index.search_graph(Qc[:8], K)  # (first call of a shape: workspace)
+            t0 = time.perf_counter()
+            gi, gd, gc = h.index.search_graph(Qc, K)
+            t_gpu = time.perf_counter() - t0
+            a_ids = np.zeros(K, dtype=np.uint64); a_dist = np.zeros(K, dtype=np.float32); a_cnt = np.zeros(1, dtype=np.uint32)
+            p_ids, p_dist, p_cnt = a_ids.ctypes.data_as(C.POINTER(C.c_uint64)), a_dist.ctypes.data_as(C.POINTER(C.c_float)), a_cnt.ctypes.data_as(C.POINTER(C.c_uint32))
+            qp = [Qc[qi].ctypes.data_as(C.POINTER(C.c_float)) for qi in range(nq)]
+            same_call = True
+            npc = min(nq, 500)
+            t0 = time.perf_counter()
+            for qi in range(npc):
+                _lib.check(L.zvdb_hip_search_graph(h.index._h, qp[qi], 1, D, K, 0, 0, p_ids, p_dist, p_cnt, None))
+                if qi < 100:
+                    n = int(cn[qi])
+                    same_call = same_call and int(a_cnt[0]) == n and np.array_equal(ci[qi, :n], a_ids[:n]) and np.array_equal(cd[qi, :n], a_dist[:n])
+            t_call = time.perf_counter() - t0
+            same = all(int(gc[qi]) == int(cn[qi]) and np.array_equal(ci[qi, :int(cn[qi])], gi[qi, :int(cn[qi])]) and
+                       np.array_equal(cd[qi, :int(cn[qi])], gd[qi, :int(cn[qi])]) for qi in range(100))
+            cells[f"d{D}_k{K}"] = {"dim": D, "k": K, "queries": nq, "cpu_port_qps_1thread": nq / t_cpu, "gpu_batched_qps_host_api": nq / t_gpu,
+                                    "gpu_per_call_c_abi_qps": npc / t_call, "gpu_per_call_us": t_call / npc * 1e6, "per_call_queries": npc,
+                                    "bit_exact_first_100_batched": bool(same), "bit_exact_first_100_per_call": bool(same_call)}
+        cells[f"d{D}_insert"] = {"dim": D, "points": P, "cpu_port_pts_per_s": P / t_ins_cpu, "gpu_insert_many_pts_per_s": P / t_ins_gpu}
+        del h, ref
+    return {"source": "benchmarks/single_threaded_benchmarks.zig:28-33 through shared_benchmarks.zig:61-125 (100k points, m = 16, ef_construction = 200)",
+            "bounded": "2,000 queries per cell (the reference runs 10,000); per-call legs 500 queries",
+            "all_bit_exact": all(c.get("bit_exact_first_100_batched", True) and c.get("bit_exact_first_100_per_call", True) for c in cells.values()),
+            "wall_s": time.perf_counter() - t_all, "cells": cells}
 
 
 def make_rows(zv, torch, g, n, dim, structured, dev, stream, nq, lo=0, hi=None):
@@ -574,14 +640,19 @@ def main():
         idx.set_option(zv.OPT_CERTIFY, 0)
     if args.cert_level:
         idx.set_option(zv.OPT_CERT_MIN_LEVEL, args.cert_level)
-    total_steps = args.warmup + args.steps
+    # Query batches, all distinct, none seen twice by the index: [0, S) settle the index's adaptive state (untimed, accounted for in the
+    # line), [S, S + W) warm-up, [S + W, S + W + K) the timed steps, then R batches on which recall is measured AFTER the timed region.
+    S_SETTLE = 32 if (not args.no_certify and not graph) else 0
+    R_RECALL = 4
+    total_steps = S_SETTLE + args.warmup + args.steps   # index of the first recall batch
+    n_batches = total_steps + R_RECALL
     if args.data == "rank12":
-        q1 = make_rows(zv, torch, idx, N, D, True, dev, stream, (total_steps + 1) * B, lo, hi)
-        queries = q1.view(total_steps + 1, B, D)
+        q1 = make_rows(zv, torch, idx, N, D, True, dev, stream, n_batches * B, lo, hi)
+        queries = q1.view(n_batches, B, D)
     else:
         idx.add_synthetic(n_local, D, CORPUS_SEED, first_row=lo)  # rows [lo, hi) of the global stream
-        queries = torch.empty((total_steps + 1, B, D), dtype=torch.float32, device=dev)
-        zv.fill_synthetic_dev(queries.data_ptr(), (total_steps + 1) * B, D, QUERY_SEED, 0, stream)
+        queries = torch.empty((n_batches, B, D), dtype=torch.float32, device=dev)
+        zv.fill_synthetic_dev(queries.data_ptr(), n_batches * B, D, QUERY_SEED, 0, stream)
     if world > 1 or args.rehearse_shard_of > 1:
         idx.set_shard_count(world if world > 1 else args.rehearse_shard_of)  # the approximate screen keeps this shard's share of the survivor budget
     t_build = 0.0
@@ -679,15 +750,18 @@ def main():
     gt_mode = (zv.BF_F32 if K <= 56 else zv.BF_I8) if not graph else zv.BF_I8
     for _ in range(2 if graph else 0):  # (the certificate's survivor level settles)
         step(queries[total_steps], gt_mode)
-    gt_ids, _ = step(queries[total_steps], gt_mode)
-    gt_ids = gt_ids.clone()
-    b = gt_ids.cpu().numpy()
+    gt = []
+    for r in range(R_RECALL):
+        gt_ids, _ = step(queries[total_steps + r], gt_mode)
+        torch.cuda.synchronize()
+        gt.append(gt_ids.cpu().numpy().copy())
+    b = gt[0]
 
-    def recall_of(m):
-        gi, gd = step(queries[total_steps], m)
+    def recall_of(m, r=0):
+        gi, gd = step(queries[total_steps + r], m)
         torch.cuda.synchronize()
         an = gi.cpu().numpy()
-        return float(np.mean([len(set(an[i]) & set(b[i])) / K for i in range(B)])), an, gd.cpu().numpy().copy()
+        return float(np.mean([len(set(an[i]) & set(gt[r][i])) / K for i in range(B)])), an, gd.cpu().numpy().copy()
 
     if graph:
         auto = False
@@ -709,22 +783,29 @@ def main():
     chk_q = queries[total_steps].cpu().numpy()
 
     # ---- timed region ----------------------------------------------------------------------------
-    def timed(m, steps, warmup):
+    step_ms = []  # per-step times of the last timed() call (events on the launch stream between the steps)
+
+    def timed(m, steps, warmup, base=S_SETTLE):
+        span = max(total_steps - base, 1)
         for i in range(warmup):
-            step(queries[total_steps if args.same_queries else i % total_steps], m)
+            step(queries[total_steps if args.same_queries else base + i % span], m)
         sync()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         # the scan region of every 4th step is bracketed by HIP events on the launch stream (each event pair leaves two
         # ~6 us bubbles in the launch chain: sampling keeps the measurement from slowing what it measures)
         del ag_events[:]
         t0 = time.perf_counter()
+        marks[0].record()
         for i in range(steps):
             idx.timing_enable((1 if i == 0 else 2) if i % 4 == 0 else 0)
             if comm is not None:
                 comm.timing_enable((1 if i == 0 else 2) if i % 4 == 0 else 0)
             ag_sample[0] = i % 4 == 0
-            step(queries[total_steps if args.same_queries else (warmup + i) % total_steps], m)
+            step(queries[total_steps if args.same_queries else base + (warmup + i) % span], m)
+            marks[i + 1].record()
         sync()
         el = time.perf_counter() - t0
+        step_ms[:] = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         kms, kn = idx.timing_read()
         idx.timing_enable(False)
         ag_sample[0] = False
@@ -739,12 +820,31 @@ def main():
     # The index adapts to its data during its first batches of a route (survivor level of the certificate, the guessed thresholds'
     # margin, the scan's per-XCD row split): those batches are part of bringing the index up, like building its mirrors, and run here,
     # untimed and ahead of the W warm-up steps -- `certificate.level` / `.repaired` in the line say where it settled.
-    settle = 0
-    if not args.no_certify and mode != GRAPH:
-        for settle in range(1, 33):
-            step(queries[settle % total_steps], mode)
-        sync()
+    settle = S_SETTLE if mode != GRAPH else 0
+    settle_ms, settle_rep = [], []
+    rep_before = idx.cert_info()["repaired"]
+    for i in range(settle):
+        t0 = time.perf_counter()
+        step(queries[i], mode)
+        torch.cuda.synchronize()
+        settle_ms.append((time.perf_counter() - t0) * 1e3)
+        rep_now = idx.cert_info()["repaired"]
+        settle_rep.append(rep_now - rep_before)
+        rep_before = rep_now
+    sync()
     elapsed, kern_ms, kern_n = timed(mode, args.steps, args.warmup)
+    rep_timed = idx.cert_info()["repaired"] - rep_before  # queries repaired by the exact scan inside warm-up + timed region
+    step_ms_max = max(step_ms) if step_ms else 0.0
+    if dist_on:
+        t = torch.tensor([step_ms_max], dtype=torch.float64, device="cpu" if cpu_coll else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        step_ms_max = float(t.item())
+    step_ms_headline = list(step_ms)
+    # recall of the headline route in the state the timed region ran in: R fresh batches against the ground-truth route
+    recalls = [recall_of(mode, r)[0] for r in range(R_RECALL)]
+    recall = float(np.mean(recalls))
+    if args.mode in ("bf16", "f32") and auto:
+        assert min(recalls) == 1.0, f"headline route must be recall-exact, measured {recalls}"
     # ---- who took part in the collective: what RCCL reports per rank + the PCI bus id of each rank's device, gathered over the ranks;
     # the all-gather's own time from HIP events around it on the sampled steps of the timed region (max over ranks of the per-rank mean)
     collective = None
@@ -779,7 +879,7 @@ def main():
             torch.cuda.synchronize()
             a2 = g_ids2.cpu().numpy()
             rec2 = float(np.mean([len(set(a2[i]) & set(b[i])) / K for i in range(B)]))
-            el2, km2, kn2 = timed(MODES[name], st, 1)
+            el2, km2, kn2 = timed(MODES[name], st, 1, base=0)  # (batches the headline has already answered: these legs are not the metric)
             kavg2 = km2 / max(kn2, 1)
             ach2 = 2.0 * B * n_local * D / (kavg2 * 1e-3) / 1e12
             paths[name] = {"value": B * st / el2, "unit": "QPS", "steps": st, "recall_at_10": rec2,
@@ -842,12 +942,15 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_max": step_ms_max,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": args.mode,
             "data": "synthetic",
             "recall_at_10": recall,
+            "recall_batches": {"batches": R_RECALL, "queries": R_RECALL * B, "per_batch": recalls,
+                               "note": "measured after the timed region on batches the index had not seen, against the ground-truth route"},
             "config": {
                 "workload": (f"{N}x{D} fp32 corpus (U[0,1) seeded), batch={B}, k={K}: brute-force "
                              f"{args.mode}-MFMA screen (mirror of the fp32 rows) + fused threshold top-k' + exact fp32 re-rank"),
@@ -910,6 +1013,19 @@ def main():
         if collective is not None:
             out["collective"] = collective
         out["config"]["settle_batches_before_warmup"] = settle
+        rb = [i for i, r in enumerate(settle_rep) if r > 0]
+        clean = [m for m, r in zip(settle_ms, settle_rep) if r == 0]
+        out["settle"] = {"batches": settle, "settle_ms_total": sum(settle_ms), "repair_batches": len(rb),
+                         "repaired_queries": int(sum(settle_rep)), "ms_per_repair_batch": (sum(settle_ms[i] for i in rb) / len(rb)) if rb else None,
+                         "ms_per_clean_batch": (sum(clean) / len(clean)) if clean else None,
+                         "ms_max_batch": max(settle_ms) if settle_ms else None,
+                         "last_repair_batch": (rb[-1] if rb else None), "repaired_per_batch": settle_rep,
+                         "repaired_queries_in_warmup_and_timed_steps": int(rep_timed),
+                         "step_ms_min_median_max": ([min(step_ms_headline), sorted(step_ms_headline)[len(step_ms_headline) // 2], max(step_ms_headline)]
+                                                    if step_ms_headline else None),
+                         "note": "every batch of the run is distinct: the index never answers a batch twice.  Settle batches are untimed (bringing the "
+                                 "index up: the certificate's survivor level climbs on its first batches) and each is synchronised and timed on "
+                                 "the host here; a repair batch = one in which the exact scan recomputed >= 1 query"}
         out["certificate"] = {**cert, "survivors_kept": {0: "32 (k <= 16) / 64", 1: 64, 2: 128, 3: 256}[cert["level"]],
                               "note": "queries = all that went through the certificate on the headline index (every leg); repaired = recomputed by the "
                                       "exact scan (expected only while the survivor level settles in the warm-up)"}
@@ -925,6 +1041,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, chk_ids, chk_dist, chk_q)
             del ws
             out["cpu_baseline"]["reference_harness"] = reference_harness(zv)
+            if not args.no_sweep:
+                out["cpu_baseline"]["reference_harness"]["sweep"] = reference_sweep(zv)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

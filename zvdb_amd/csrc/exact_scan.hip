@@ -20,13 +20,24 @@ namespace zvdb {
 
 namespace {
 
-// XS_QB (template): queries per pass over a row range -- the rows are read once per XS_QB listed queries; 8, or 2 for rows so wide that 8
-// queries do not fit the LDS
-constexpr int XS_CAP = 512;   // buffered (dist, id) words per query and block
-constexpr int XS_T = 256;     // rows per tile = threads per block
-constexpr uint32_t XS_POOL = 8192;  // B k <= this many words in the merge
+// ---- geometry ---------------------------------------------------------------------------------------------------------------
+constexpr int XS_T = 512;            // threads per block = rows per tile (a lane owns one row of the tile)
+constexpr int XS_CHUNK = 128;        // bytes of a row per chunk: one cache line (32 fp32 / 64 bf16 elements; rows are padded to whole lines)
+constexpr int XS_ROWB = XS_CHUNK + 16;  // LDS bytes per row of the tile: 36 dwords -- the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads
+constexpr int XS_PIECES = XS_CHUNK / 16;  // 16-byte pieces per row and chunk; also pieces per thread and chunk of the coalesced fill (512 x 8 = 4,096)
+constexpr int XS_PRUNERS = 4;        // waves that prune (each with its own histogram + staging)
+constexpr uint32_t XS_POOL = 6144;   // words per merge round in LDS (+ 256 kept)
 
-// compact the <= XS_CAP words of buf to their k smallest (k <= 256) and return the k-th; one wave
+typedef float xs_f2 __attribute__((ext_vector_type(2)));
+
+template <typename RT> struct xs_epc { static constexpr int v = XS_CHUNK / (int)sizeof(RT); };  // elements per chunk
+
+// buffered (dist, id) words per listed query and block: twice the result count (a prune keeps k), at least 64
+__host__ __device__ inline uint32_t xs_cap(uint32_t k) { uint32_t c = 64; while (c < 2 * k) c <<= 1; return c; }
+// queries that share one pass over the rows: as many as the LDS holds buffers for (64 for k <= 32, 32 for k <= 128, 16 for k <= 256)
+__host__ __device__ inline uint32_t xs_nq_max(uint32_t k) { const uint32_t c = xs_cap(k); return c <= 64 ? 64u : c <= 256 ? 32u : 16u; }
+
+// compact the n <= 512 words of buf to their k smallest (k <= 256) and return the k-th; one wave
 __device__ __forceinline__ uint64_t xs_prune(uint64_t *buf, uint32_t n, uint32_t k, uint32_t *hist, uint64_t *tmp, int lane) {
     const uint32_t E = (n + kWave - 1) / kWave;
     const uint64_t T = wave_kth_key<0>([&](uint32_t e) { const uint32_t i = e * kWave + lane; return i < n ? buf[i] : ~0ull; }, E, k, hist, lane);
@@ -45,110 +56,233 @@ __device__ __forceinline__ uint64_t xs_prune(uint64_t *buf, uint32_t n, uint32_t
     return T;
 }
 
-template <typename RT, int XS_QB>
-__global__ __launch_bounds__(XS_T) void k_exact_scan(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric, uint32_t N,
-                                                     const float *__restrict__ queries, const uint32_t *__restrict__ nflag,
-                                                     const uint32_t *__restrict__ flist, uint32_t k, uint64_t id_offset,
-                                                     const uint64_t *__restrict__ cur_ids, const float *__restrict__ cur_dist,
-                                                     const uint32_t *__restrict__ cur_count, uint64_t *__restrict__ partial,
-                                                     uint32_t rows_per_block, uint32_t dim_pad) {
-    const uint32_t nf = *nflag;
-    if (nf == 0) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *qs = reinterpret_cast<float *>(smem);                                   // [XS_QB][dim_pad]
-    uint64_t *buf = reinterpret_cast<uint64_t *>(qs + (size_t)XS_QB * dim_pad);    // [XS_QB][XS_CAP]
-    uint64_t *tmp = buf + XS_QB * XS_CAP;                                          // [4 waves][256]
-    uint64_t *thr = tmp + 4 * 256;                                                 // [XS_QB]
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + XS_QB);                     // [XS_QB]
-    uint32_t *hist = cnt + XS_QB;                                                  // [4 waves][256]
+struct XsArgs {
+    const void *rows; uint32_t ld, dim; int metric; uint32_t N;
+    const float *queries; const uint32_t *flist; uint32_t k; uint64_t id_offset;
+    const uint64_t *cur_ids; const float *cur_dist; const uint32_t *cur_count; uint64_t *partial;
+    uint32_t rows_per_block, cap;
+};
+
+// One pass of a block over its row range for the listed queries [g0, g0 + nqg), nqg <= NQ: NQ running sums per lane, in registers.
+// The rows stream through LDS a cache line per row at a time: 512 rows x 128 B fetched coalesced (8 lanes per line) two chunks
+// ahead into registers, written to a padded LDS image, and each lane then walks ITS row's line out of LDS in the reference's order;
+// the same chunk of all NQ queries sits beside it in LDS, element-major, so that one broadcast ds_read_b128 feeds four queries and
+// the three operations of hnsw.zig:188-189 run as packed fp32 pairs (v_pk_add / v_pk_mul / v_pk_add: two queries per instruction,
+// each component rounded on its own -- the arithmetic and its order per (query, row) are the scalar loop's).
+template <typename RT, int NQ>
+__device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t nqg, unsigned char *smem) {
+    constexpr int EPC = xs_epc<RT>::v;            // elements per chunk
+    constexpr int QG = NQ * EPC / 4;                   // 4-element granules of the query chunk: granule g = (elements 4 (g / NQ) .. + 3, query g % NQ)
+    constexpr int QPT = (QG + XS_T - 1) / XS_T;        // granules per thread and chunk
+    const RT *rows = static_cast<const RT *>(a.rows);
+    unsigned char *tile = smem;                                              // [XS_T][XS_ROWB]
+    float *qs = reinterpret_cast<float *>(tile + XS_T * XS_ROWB);            // [EPC][NQ]   (element-major)
+    uint64_t *buf = reinterpret_cast<uint64_t *>(qs + EPC * NQ);             // [NQ][cap]
+    uint64_t *tmp = buf + (size_t)NQ * a.cap;                                // [XS_PRUNERS][256]
+    uint64_t *thr = tmp + XS_PRUNERS * 256;                                  // [NQ]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + NQ);                  // [NQ]
+    uint32_t *hist = cnt + NQ;                                               // [XS_PRUNERS][256]
+    uint32_t *qrow = hist + XS_PRUNERS * 256;                                // [NQ] row of the query in `queries`, ~0 = none
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t B = gridDim.x, b = blockIdx.x;
-    const uint32_t r_begin = b * rows_per_block, r_end = min(N, r_begin + rows_per_block);
-    for (uint32_t g0 = blockIdx.y * XS_QB; g0 < nf; g0 += gridDim.y * XS_QB) {
-        const uint32_t nqg = min((uint32_t)XS_QB, nf - g0);
-        __syncthreads();
-        for (uint32_t i = tid; i < XS_QB * dim_pad; i += XS_T) {
-            const uint32_t j = i / dim_pad, c = i - j * dim_pad;
-            qs[i] = (j < nqg && c < dim) ? queries[(size_t)flist[g0 + j] * dim + c] : 0.0f;
+    const uint32_t B = gridDim.x, b = blockIdx.x, k = a.k, cap = a.cap;
+    const uint32_t r_begin = b * a.rows_per_block, r_end = min(a.N, r_begin + a.rows_per_block);
+    const uint32_t ntiles = r_end > r_begin ? (r_end - r_begin + XS_T - 1) / XS_T : 0;
+    const uint32_t nch = a.ld / EPC;               // chunks per row (ld is a whole number of lines)
+    const uint32_t total = ntiles * nch;           // the block's chunk stream: tile-major
+    __syncthreads();                               // (the previous pass has left the LDS)
+    if (tid < NQ) {
+        uint64_t t = ~0ull - 1;  // no bound
+        uint32_t qr = ~0u;
+        if ((uint32_t)tid < nqg) {
+            const uint32_t qi = a.flist[g0 + tid];
+            qr = qi;
+            // start bound: the k-th result the screen route returned -- real rows, so an upper bound of the true k-th.  (The re-rank
+            // writes a zero dot / cosine distance as -0.0 = -(+0.0); the words of this kernel are built from d + 0.0f, one key per
+            // value, so the bound is normalised the same way -- else every row at distance 0 would fall outside it.)
+            if (a.cur_count[qi] >= k) t = ((uint64_t)f32_key(a.cur_dist[(size_t)qi * k + k - 1] + 0.0f) << 32) | (uint32_t)(a.cur_ids[(size_t)qi * k + k - 1] - a.id_offset);
         }
-        if (tid < XS_QB) {
-            uint64_t t = ~0ull - 1;  // no bound
-            if ((uint32_t)tid < nqg) {
-                const uint32_t qi = flist[g0 + tid];
-                // (the re-rank writes a zero dot / cosine distance as -0.0 = -(+0.0); the words below are built from d + 0.0f, one key per
-                // value, so the bound is normalised the same way -- else every row at distance 0 would fall outside it)
-                if (cur_count[qi] >= k) t = ((uint64_t)f32_key(cur_dist[(size_t)qi * k + k - 1] + 0.0f) << 32) | (uint32_t)(cur_ids[(size_t)qi * k + k - 1] - id_offset);
+        thr[tid] = t;
+        cnt[tid] = 0;
+        qrow[tid] = qr;
+    }
+    __syncthreads();
+    // ---- the two streams: row pieces (8 per thread and chunk) and query elements (QPT per thread and chunk) --------------------
+    const uint32_t fr = (uint32_t)tid >> 3, fp = (uint32_t)tid & 7;   // fill: rows fr + 64 i of the tile, piece fp
+    uint4 ra[XS_PIECES], rb[XS_PIECES];
+    float4 qa[QPT];
+    auto fetch_rows = [&](uint4 (&r)[XS_PIECES], uint32_t c) __attribute__((always_inline)) {
+        if (c >= total) return;
+        const uint32_t t = c / nch, cc = c - t * nch;
+        const uint32_t r0 = r_begin + t * XS_T;
+#pragma unroll
+        for (int i = 0; i < XS_PIECES; ++i) {
+            const uint32_t row = min(r0 + fr + 64u * i, a.N - 1);   // (rows past the end: any valid row; their lanes append nothing)
+            r[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(rows + (size_t)row * a.ld) + (size_t)cc * XS_CHUNK + fp * 16);
+        }
+    };
+    auto fetch_q = [&](uint32_t c) __attribute__((always_inline)) {
+        if (c >= total) return;
+        const uint32_t cc = c % nch;
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const uint32_t g = (uint32_t)tid + XS_T * i;          // consecutive threads: consecutive queries (the LDS image is element-major)
+            const uint32_t j = g % NQ, col = cc * EPC + 4 * (g / NQ);
+            const uint32_t qr = g < (uint32_t)QG ? qrow[j] : ~0u;
+            const float *src = a.queries + (size_t)(qr != ~0u ? qr : 0) * a.dim;
+            // (padding: (0 - 0)^2 = +0.0 and 0 * x = +-0.0 leave a running sum as it is -- it starts at +0.0 and never becomes -0.0)
+            qa[i].x = (qr != ~0u && col + 0 < a.dim) ? src[col + 0] : 0.0f;
+            qa[i].y = (qr != ~0u && col + 1 < a.dim) ? src[col + 1] : 0.0f;
+            qa[i].z = (qr != ~0u && col + 2 < a.dim) ? src[col + 2] : 0.0f;
+            qa[i].w = (qr != ~0u && col + 3 < a.dim) ? src[col + 3] : 0.0f;
+        }
+    };
+    auto store = [&](const uint4 (&r)[XS_PIECES]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XS_PIECES; ++i) *reinterpret_cast<uint4 *>(tile + (size_t)(fr + 64u * i) * XS_ROWB + fp * 16) = r[i];
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const uint32_t g = (uint32_t)tid + XS_T * i;
+            if (g < (uint32_t)QG) {
+                float *dst = qs + 4 * (g / NQ) * NQ + g % NQ;
+                dst[0] = qa[i].x; dst[NQ] = qa[i].y; dst[2 * NQ] = qa[i].z; dst[3 * NQ] = qa[i].w;
             }
-            thr[tid] = t;
-            cnt[tid] = 0;
         }
-        __syncthreads();
-        for (uint32_t r0 = r_begin; r0 < r_end; r0 += XS_T) {
-            const uint32_t row = r0 + tid;
-            if (row < r_end) {
-                const RT *v = rows + (size_t)row * ld;
-                float sum[XS_QB];
+    };
+    xs_f2 sum[NQ / 2];
 #pragma unroll
-                for (int j = 0; j < XS_QB; ++j) sum[j] = 0.0f;
-                const uint32_t d4 = dim & ~3u;
-                uint32_t i = 0;
-#pragma unroll 4
-                for (; i < d4; i += 4) {
-                    const float4 x = row_load4(v + i);
+    for (int j = 0; j < NQ / 2; ++j) sum[j] = xs_f2{0.0f, 0.0f};
+    const unsigned char *myrow = tile + (size_t)tid * XS_ROWB;
+    const bool l2 = a.metric == ZVDB_METRIC_L2SQ;
+    auto elem = [&](auto l2c, float x, uint32_t el) __attribute__((always_inline)) {   // one element of the lane's row against the NQ queries
+        const xs_f2 xx = xs_f2{x, x};
 #pragma unroll
-                    for (int j = 0; j < XS_QB; ++j) {
-                        const float4 a = *reinterpret_cast<const float4 *>(qs + (size_t)j * dim_pad + i);
-                        if (metric == ZVDB_METRIC_L2SQ) {
-                            float t = a.x - x.x; t = t * t; sum[j] = sum[j] + t;
-                            t = a.y - x.y; t = t * t; sum[j] = sum[j] + t;
-                            t = a.z - x.z; t = t * t; sum[j] = sum[j] + t;
-                            t = a.w - x.w; t = t * t; sum[j] = sum[j] + t;
-                        } else {
-                            float t = a.x * x.x; sum[j] = sum[j] + t;
-                            t = a.y * x.y; sum[j] = sum[j] + t;
-                            t = a.z * x.z; sum[j] = sum[j] + t;
-                            t = a.w * x.w; sum[j] = sum[j] + t;
-                        }
-                    }
-                }
-                for (; i < dim; ++i) {
-                    const float x = row_elem(v, i);
+        for (int jq = 0; jq < NQ / 4; ++jq) {
+            const float4 q4 = *reinterpret_cast<const float4 *>(qs + el * NQ + 4 * jq);
+            const xs_f2 q01 = xs_f2{q4.x, q4.y}, q23 = xs_f2{q4.z, q4.w};
+            if constexpr (decltype(l2c)::value) {
+                xs_f2 t0 = q01 - xx; t0 = t0 * t0; sum[2 * jq] = sum[2 * jq] + t0;
+                xs_f2 t1 = q23 - xx; t1 = t1 * t1; sum[2 * jq + 1] = sum[2 * jq + 1] + t1;
+            } else {
+                const xs_f2 t0 = q01 * xx; sum[2 * jq] = sum[2 * jq] + t0;
+                const xs_f2 t1 = q23 * xx; sum[2 * jq + 1] = sum[2 * jq + 1] + t1;
+            }
+        }
+    };
+    auto compute_m = [&](auto l2c) __attribute__((always_inline)) {
+#pragma unroll 2
+        for (int p = 0; p < XS_PIECES; ++p) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(myrow + p * 16);
+            if constexpr (sizeof(RT) == 4) {
+                elem(l2c, __uint_as_float(w.x), 4 * p); elem(l2c, __uint_as_float(w.y), 4 * p + 1);
+                elem(l2c, __uint_as_float(w.z), 4 * p + 2); elem(l2c, __uint_as_float(w.w), 4 * p + 3);
+            } else {
+                elem(l2c, bf16_lo(w.x), 8 * p); elem(l2c, bf16_hi(w.x), 8 * p + 1); elem(l2c, bf16_lo(w.y), 8 * p + 2); elem(l2c, bf16_hi(w.y), 8 * p + 3);
+                elem(l2c, bf16_lo(w.z), 8 * p + 4); elem(l2c, bf16_hi(w.z), 8 * p + 5); elem(l2c, bf16_lo(w.w), 8 * p + 6); elem(l2c, bf16_hi(w.w), 8 * p + 7);
+            }
+        }
+    };
+    auto compute = [&]() __attribute__((always_inline)) {
+        if (l2) compute_m(std::true_type{}); else compute_m(std::false_type{});
+    };
+    // a tile's rows are done: every (dist, id) word within its query's bound goes to that query's buffer; a buffer that overflows is
+    // pruned to its k best (which tightens the bound) and the lanes still holding a word try again -- nothing is ever dropped
+    auto flush = [&](uint32_t t) __attribute__((always_inline)) {
+        const uint32_t row = r_begin + t * XS_T + tid;
+        unsigned long long pend = 0;
+        if (row < r_end) pend = nqg >= 64 ? ~0ull : ((1ull << nqg) - 1);
+        for (;;) {
 #pragma unroll
-                    for (int j = 0; j < XS_QB; ++j) {
-                        const float a = qs[(size_t)j * dim_pad + i];
-                        if (metric == ZVDB_METRIC_L2SQ) { float t = a - x; t = t * t; sum[j] = sum[j] + t; }
-                        else { const float t = a * x; sum[j] = sum[j] + t; }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < XS_QB; ++j) {
-                    if ((uint32_t)j >= nqg) break;
-                    const float d = (metric == ZVDB_METRIC_L2SQ ? sum[j] : -sum[j]) + 0.0f;  // (-0 -> +0: one key per value)
+            for (int j = 0; j < NQ; ++j) {
+                if (pend >> j & 1) {
+                    const float sj = sum[j >> 1][j & 1];
+                    const float d = (l2 ? sj : -sj) + 0.0f;  // (-0 -> +0: one key per value)
                     const uint64_t w = ((uint64_t)f32_key(d) << 32) | row;
+                    bool done = true;
                     if (w <= thr[j]) {
                         const uint32_t slot = atomicAdd(&cnt[j], 1u);
-                        buf[(size_t)j * XS_CAP + slot] = w;  // (slot < XS_CAP: a tile adds <= 256 to a buffer pruned to <= 256)
+                        if (slot < cap) buf[(size_t)j * cap + slot] = w; else done = false;
+                    }
+                    if (done) pend &= ~(1ull << j);
+                }
+            }
+            __syncthreads();
+            if (wave < XS_PRUNERS) {
+                for (uint32_t j = (uint32_t)wave; j < nqg; j += XS_PRUNERS) {
+                    if (cnt[j] > cap) {   // some append did not fit: keep the k best of the cap buffered, new bound = the k-th
+                        const uint64_t T = xs_prune(buf + (size_t)j * cap, cap, k, hist + wave * 256, tmp + wave * 256, lane);
+                        if (lane == 0) { cnt[j] = k; thr[j] = T; }
                     }
                 }
             }
-            __syncthreads();
-            for (uint32_t j = (uint32_t)wave; j < nqg; j += XS_T / kWave) {  // wave w prunes queries w, w + 4, ...
-                if (cnt[j] > (uint32_t)(XS_CAP - XS_T)) {
-                    const uint64_t T = xs_prune(buf + (size_t)j * XS_CAP, cnt[j], k, hist + wave * 256, tmp + wave * 256, lane);
-                    if (lane == 0) { cnt[j] = k; thr[j] = T; }
-                }
-            }
-            __syncthreads();
+            if (!__syncthreads_or(pend != 0)) break;
         }
-        for (uint32_t j = (uint32_t)wave; j < nqg; j += XS_T / kWave) {
-            uint32_t n = cnt[j];
-            if (n > k) { xs_prune(buf + (size_t)j * XS_CAP, n, k, hist + wave * 256, tmp + wave * 256, lane); n = k; }
-            uint64_t *out = partial + ((size_t)(g0 + j) * B + b) * k;
-            for (uint32_t i = lane; i < k; i += kWave) out[i] = i < n ? buf[(size_t)j * XS_CAP + i] : ~0ull;
+#pragma unroll
+        for (int j = 0; j < NQ / 2; ++j) sum[j] = xs_f2{0.0f, 0.0f};
+    };
+    // ---- the pipeline: chunk c in LDS, c + 1 and c + 2 in flight in registers ---------------------------------------------------
+    fetch_rows(ra, 0); fetch_q(0);
+    if (total > 0) store(ra);
+    fetch_rows(ra, 1);
+    fetch_rows(rb, 2);
+    __syncthreads();
+    uint32_t cc = 0, t = 0;
+    for (uint32_t c = 0; c < total; c += 2) {
+        // even step: LDS holds c; ra = c + 1, rb = c + 2
+        fetch_q(c + 1);
+        compute();
+        if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
+        if (c + 1 >= total) break;
+        store(ra);
+        fetch_rows(ra, c + 3);
+        __syncthreads();
+        // odd step: LDS holds c + 1; rb = c + 2, ra = c + 3
+        fetch_q(c + 2);
+        compute();
+        if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
+        if (c + 2 >= total) break;
+        store(rb);
+        fetch_rows(rb, c + 4);
+        __syncthreads();
+    }
+    // ---- the block's <= k best per query -> its partial list -----------------------------------------------------------------------
+    __syncthreads();
+    if (wave < XS_PRUNERS) {
+        for (uint32_t j = (uint32_t)wave; j < nqg; j += XS_PRUNERS) {
+            uint32_t n = min(cnt[j], cap);
+            if (n > k) { xs_prune(buf + (size_t)j * cap, n, k, hist + wave * 256, tmp + wave * 256, lane); n = k; }
+            uint64_t *out = a.partial + ((size_t)(g0 + j) * B + b) * k;
+            for (uint32_t i = lane; i < k; i += kWave) out[i] = i < n ? buf[(size_t)j * cap + i] : ~0ull;
         }
     }
 }
 
+// LDS bytes of a pass with NQ queries (host + device agree)
+template <typename RT>
+__host__ __device__ inline size_t xs_lds(uint32_t nq_pass, uint32_t cap) {
+    return (size_t)XS_T * XS_ROWB + (size_t)xs_epc<RT>::v * nq_pass * 4 + (size_t)nq_pass * cap * 8 + XS_PRUNERS * 256 * 8 + (size_t)nq_pass * 8 +
+           (size_t)nq_pass * 4 + XS_PRUNERS * 256 * 4 + (size_t)nq_pass * 4 + 16;
+}
+
+// grid (B row ranges, Y workers over the groups of listed queries) x 512 threads.  The list's length is read on the device: empty (the
+// common case) -> return at once; else groups of up to nq_max queries share one pass over the rows, and a short list takes the
+// instantiation with as few running sums as it needs (8 / 16 / 32 / 64).
+template <typename RT>
+__global__ __launch_bounds__(XS_T) void k_exact_scan(XsArgs a, const uint32_t *__restrict__ nflag, uint32_t nq_max) {
+    const uint32_t nf = *nflag;
+    if (nf == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t per = min(nq_max, nf <= 8 ? 8u : nf <= 16 ? 16u : nf <= 32 ? 32u : 64u);   // (wave-uniform, block-uniform)
+    for (uint32_t g0 = blockIdx.y * per; g0 < nf; g0 += gridDim.y * per) {
+        const uint32_t nqg = min(per, nf - g0);
+        if (per == 8) xs_pass<RT, 8>(a, g0, nqg, smem);
+        else if (per == 16) xs_pass<RT, 16>(a, g0, nqg, smem);
+        else if (per == 32) xs_pass<RT, 32>(a, g0, nqg, smem);
+        else xs_pass<RT, 64>(a, g0, nqg, smem);
+    }
+}
+
+// one wave per listed query: the B partial lists (k words each, ~0 = none) -> exact top-k -> the query's result slots.  The lists go
+// through LDS in rounds of up to XS_POOL words beside the best k so far, so B is not bounded by the LDS.
 __global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restrict__ nflag, const uint32_t *__restrict__ flist, const uint64_t *__restrict__ partial,
                                                          uint32_t B, uint32_t k, int metric, uint64_t id_offset, uint64_t *__restrict__ out_ids,
                                                          float *__restrict__ out_dist, uint32_t *__restrict__ out_count, uint32_t *host_repaired) {
@@ -157,46 +291,54 @@ __global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     uint64_t *sel = reinterpret_cast<uint64_t *>(smem + SEL_HIST_BYTES);  // [256]
-    uint64_t *pool = sel + 256;                                           // [B k]
+    uint64_t *pool = sel + 256;                                           // [256 + XS_POOL]
     const int lane = threadIdx.x;
     const uint32_t n = B * k;
     const uint64_t *p = partial + (size_t)f * n;
-    uint32_t nv_l = 0;
-    for (uint32_t i = lane; i < n; i += kWave) {
-        const uint64_t w = p[i];
-        pool[i] = w;
-        nv_l += w != ~0ull ? 1u : 0u;
-    }
-    uint32_t nv = nv_l;
+    uint32_t have = 0;   // valid words kept at the front of the pool (<= k)
+    for (uint32_t base = 0; base < n; base += XS_POOL) {
+        const uint32_t m = min(XS_POOL, n - base);
+        uint32_t nv_l = 0;
+        for (uint32_t i = lane; i < m; i += kWave) {
+            const uint64_t w = p[base + i];
+            pool[have + i] = w;
+            nv_l += w != ~0ull ? 1u : 0u;
+        }
+        uint32_t nv = nv_l;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor(nv, off);
-    __syncthreads();
-    const uint32_t nres = min(nv, k);
-    const uint32_t qi = flist[f];
-    if (nres > 0) {
-        const uint32_t E = (n + kWave - 1) / kWave;
-        const uint64_t T = wave_kth_key<0>([&](uint32_t e) { const uint32_t i = e * kWave + lane; return i < n ? pool[i] : ~0ull; }, E, nres, hist, lane);
-        uint32_t base = 0;
-        for (uint32_t e = 0; e < E; ++e) {
-            const uint32_t i = e * kWave + lane;
-            const uint64_t w = i < n ? pool[i] : ~0ull;
-            const bool s = w <= T;
-            const unsigned long long m = __ballot(s);
-            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-            if (s && pos < 256u) sel[pos] = w;
-            base += (uint32_t)__popcll(m);
-        }
+        for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor(nv, off);
         __syncthreads();
-        for (uint32_t i = lane; i < nres; i += kWave) {  // (dist, id) words are distinct: the rank is the position
-            const uint64_t w = sel[i];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < nres; ++j) rank += sel[j] < w ? 1u : 0u;
-            out_ids[(size_t)qi * k + rank] = (uint64_t)(uint32_t)w + id_offset;
-            // a zero dot / cosine distance is -(+0.0) = -0.0 in the reference's arithmetic (the oracle and the re-rank write that);
-            // the words carry +0.0 so that a value has one key
-            const float dv = f32_unkey((uint32_t)(w >> 32));
-            out_dist[(size_t)qi * k + rank] = (metric != ZVDB_METRIC_L2SQ && dv == 0.0f) ? -0.0f : dv;
+        const uint32_t tot = have + m, valid = have + nv, keep = min(valid, k);
+        if (keep > 0) {
+            const uint32_t E = (tot + kWave - 1) / kWave;
+            const uint64_t T = wave_kth_key<0>([&](uint32_t e) { const uint32_t i = e * kWave + lane; return i < tot ? pool[i] : ~0ull; }, E, keep, hist, lane);
+            uint32_t cb = 0;
+            for (uint32_t e = 0; e < E; ++e) {
+                const uint32_t i = e * kWave + lane;
+                const uint64_t w = i < tot ? pool[i] : ~0ull;
+                const bool s = w <= T;
+                const unsigned long long mk = __ballot(s);
+                const uint32_t pos = cb + (uint32_t)__popcll(mk & ((1ull << lane) - 1));
+                if (s && pos < 256u) sel[pos] = w;
+                cb += (uint32_t)__popcll(mk);
+            }
+            __syncthreads();
+            for (uint32_t i = lane; i < keep; i += kWave) pool[i] = sel[i];
+            __syncthreads();
         }
+        have = keep;
+    }
+    const uint32_t nres = have;
+    const uint32_t qi = flist[f];
+    for (uint32_t i = lane; i < nres; i += kWave) {  // (dist, id) words are distinct: the rank is the position
+        const uint64_t w = pool[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nres; ++j) rank += pool[j] < w ? 1u : 0u;
+        out_ids[(size_t)qi * k + rank] = (uint64_t)(uint32_t)w + id_offset;
+        // a zero dot / cosine distance is -(+0.0) = -0.0 in the reference's arithmetic (the oracle and the re-rank write that);
+        // the words carry +0.0 so that a value has one key
+        const float dv = f32_unkey((uint32_t)(w >> 32));
+        out_dist[(size_t)qi * k + rank] = (metric != ZVDB_METRIC_L2SQ && dv == 0.0f) ? -0.0f : dv;
     }
     for (uint32_t i = nres + lane; i < k; i += kWave) {
         out_ids[(size_t)qi * k + i] = ~0ull;
@@ -208,13 +350,12 @@ __global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restr
     }
 }
 
-// row ranges (= partial lists per listed query): B k <= XS_POOL words in the merge, and nq B k words of scratch kept under 64 MiB for large
-// batches (down to 16 ranges: the grid's second dimension -- query groups -- carries the parallelism then)
+// row ranges (= partial lists per listed query): two per CU when the scratch allows (nq B k words kept under 128 MiB for large batches,
+// never fewer than 16 ranges)
 uint32_t xs_blocks(uint32_t nq, uint32_t k) {
     k = std::max(k, 1u);
-    const uint32_t by_pool = std::max(1u, std::min(1024u, XS_POOL / k));
-    const uint64_t by_mem = (64ull << 20) / (8ull * k * std::max(nq, 1u));
-    return std::max<uint32_t>(std::min<uint32_t>(by_pool, 16u), (uint32_t)std::min<uint64_t>(by_pool, by_mem));
+    const uint64_t by_mem = (128ull << 20) / (8ull * k * std::max(nq, 1u));
+    return (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(512, by_mem));
 }
 
 }  // namespace
@@ -233,24 +374,27 @@ int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t 
     const uint32_t rpb = round_up((N + B - 1) / B, XS_T);
     B = (N + rpb - 1) / rpb;
     const int metric = h->metric == ZVDB_METRIC_L2SQ ? ZVDB_METRIC_L2SQ : ZVDB_METRIC_DOT;
-    const uint32_t dim_pad = round_up(std::max(h->dim, 1u), 4);
-    auto lds_for = [&](size_t qb) { return qb * dim_pad * 4 + qb * XS_CAP * 8 + 4 * 256 * 8 + qb * 8 + qb * 4 + 4 * 256 * 4 + 16; };
-    const uint32_t QB = lds_for(8) <= 128 * 1024 ? 8u : 2u;
-    const size_t lds = lds_for(QB);
-    if (lds > 160 * 1024) { set_error("exact scan: dimension too large for the query tile"); return ZVDB_ERR_UNSUPPORTED; }
-    const uint32_t Y = std::max(1u, std::min((nq + QB - 1) / QB, std::max(1u, 2048u / B)));
+    const uint32_t cap = xs_cap(k);
+    // the queries of one pass: what the LDS holds buffers for, and no more running sums than the batch can list
+    uint32_t nq_pass = xs_nq_max(k);
+    while (nq_pass > 8 && nq_pass / 2 >= nq) nq_pass /= 2;
+    const uint32_t Y = std::max(1u, std::min((nq + nq_pass - 1) / nq_pass, std::max(1u, 1024u / B)));
     ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = row_elem_t<decltype(rows)>;
-        auto go = [&](auto kern) -> int {
-            if (lds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(B, Y), dim3(XS_T), lds, s, rows, ld, h->dim, metric, N, d_queries, nflag, flist, k, id_offset, d_ids,
-                               d_dist, d_count, reinterpret_cast<uint64_t *>(scratch), rpb, dim_pad);
-            ZV_HIP(hipGetLastError());
-            return ZVDB_OK;
-        };
-        return QB == 8 ? go(k_exact_scan<RT, 8>) : go(k_exact_scan<RT, 2>);
+        const size_t lds = xs_lds<RT>(nq_pass, cap);
+        if (lds > 160 * 1024) { set_error("exact scan: LDS plan of %zu bytes", lds); return ZVDB_ERR_UNSUPPORTED; }
+        XsArgs a;
+        a.rows = rows; a.ld = ld; a.dim = h->dim; a.metric = metric; a.N = N;
+        a.queries = d_queries; a.flist = flist; a.k = k; a.id_offset = id_offset;
+        a.cur_ids = d_ids; a.cur_dist = d_dist; a.cur_count = d_count; a.partial = reinterpret_cast<uint64_t *>(scratch);
+        a.rows_per_block = rpb; a.cap = cap;
+        auto kern = k_exact_scan<RT>;
+        if (lds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(B, Y), dim3(XS_T), lds, s, a, nflag, nq_pass);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
     }));
-    const size_t mlds = SEL_HIST_BYTES + 256 * 8 + (size_t)B * k * 8;
+    const size_t mlds = SEL_HIST_BYTES + 256 * 8 + (size_t)(256 + std::min<uint64_t>(XS_POOL, (uint64_t)B * k)) * 8;
     if (mlds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scan_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
     hipLaunchKernelGGL(k_exact_scan_merge, dim3(nq), dim3(64), mlds, s, nflag, flist, reinterpret_cast<const uint64_t *>(scratch), B, k, metric, id_offset, d_ids,
                        d_dist, d_count, host_repaired);
