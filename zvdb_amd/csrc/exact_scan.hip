@@ -29,13 +29,18 @@ constexpr int XS_PRUNERS = 4;        // waves that prune (each with its own hist
 constexpr uint32_t XS_POOL = 6144;   // words per merge round in LDS (+ 256 kept)
 
 typedef float xs_f2 __attribute__((ext_vector_type(2)));
+typedef float xs_f4 __attribute__((ext_vector_type(4)));
+
+// N values that live in registers: an array member indexed only by unrolled loops
+template <typename T, int N> struct XsRegs { T v[N]; };
 
 template <typename RT> struct xs_epc { static constexpr int v = XS_CHUNK / (int)sizeof(RT); };  // elements per chunk
 
 // buffered (dist, id) words per listed query and block: twice the result count (a prune keeps k), at least 64
 __host__ __device__ inline uint32_t xs_cap(uint32_t k) { uint32_t c = 64; while (c < 2 * k) c <<= 1; return c; }
-// queries that share one pass over the rows: as many as the LDS holds buffers for (64 for k <= 32, 32 for k <= 128, 16 for k <= 256)
-__host__ __device__ inline uint32_t xs_nq_max(uint32_t k) { const uint32_t c = xs_cap(k); return c <= 64 ? 64u : c <= 256 ? 32u : 16u; }
+// queries that share one pass over the rows: as many as the LDS holds buffers for (32 for k <= 128, 16 for k <= 256) and the
+// register file running sums for (64 sums spill)
+__host__ __device__ inline uint32_t xs_nq_max(uint32_t k) { const uint32_t c = xs_cap(k); return c <= 256 ? 32u : 16u; }
 
 // compact the n <= 512 words of buf to their k smallest (k <= 256) and return the k-th; one wave
 __device__ __forceinline__ uint64_t xs_prune(uint64_t *buf, uint32_t n, uint32_t k, uint32_t *hist, uint64_t *tmp, int lane) {
@@ -106,23 +111,27 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
         qrow[tid] = qr;
     }
     __syncthreads();
-    // ---- the two streams: row pieces (8 per thread and chunk) and query elements (QPT per thread and chunk) --------------------
+    // ---- the two streams: row pieces (8 per thread and chunk) and query granules (QPT per thread and chunk), held in registers between
+    // their fetch and their LDS store.  (ext-vector element types: HIP's uint4 / float4 structs inside a by-value aggregate end up in
+    // scratch memory -- load, wait, scratch store -- where ext vectors stay in registers.)
+    using Regs = XsRegs<u32x4, XS_PIECES>;
+    using QRegs = XsRegs<xs_f4, QPT>;
     const uint32_t fr = (uint32_t)tid >> 3, fp = (uint32_t)tid & 7;   // fill: rows fr + 64 i of the tile, piece fp
-    uint4 ra[XS_PIECES], rb[XS_PIECES];
-    float4 qa[QPT];
-    auto fetch_rows = [&](uint4 (&r)[XS_PIECES], uint32_t c) __attribute__((always_inline)) {
-        if (c >= total) return;
+    const unsigned char *rows_b = reinterpret_cast<const unsigned char *>(rows);
+    const size_t row_bytes = (size_t)a.ld * sizeof(RT);
+    const uint32_t n_last = a.N - 1;
+    auto fetch_rows = [&](uint32_t c) __attribute__((always_inline)) -> Regs {
+        c = min(c, total - 1);   // (past the end of the stream: the last chunk again -- loads without a branch, never stored)
         const uint32_t t = c / nch, cc = c - t * nch;
-        const uint32_t r0 = r_begin + t * XS_T;
+        Regs r;
 #pragma unroll
-        for (int i = 0; i < XS_PIECES; ++i) {
-            const uint32_t row = min(r0 + fr + 64u * i, a.N - 1);   // (rows past the end: any valid row; their lanes append nothing)
-            r[i] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(rows + (size_t)row * a.ld) + (size_t)cc * XS_CHUNK + fp * 16);
-        }
+        for (int i = 0; i < XS_PIECES; ++i)   // (rows past the end: the last row; their lanes append nothing)
+            r.v[i] = *reinterpret_cast<const u32x4 *>(rows_b + (size_t)min(r_begin + t * XS_T + fr + 64u * i, n_last) * row_bytes + (size_t)cc * XS_CHUNK + fp * 16);
+        return r;
     };
-    auto fetch_q = [&](uint32_t c) __attribute__((always_inline)) {
-        if (c >= total) return;
-        const uint32_t cc = c % nch;
+    auto fetch_q = [&](uint32_t c) __attribute__((always_inline)) -> QRegs {
+        QRegs qa;
+        const uint32_t cc = min(c, total - 1) % nch;
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const uint32_t g = (uint32_t)tid + XS_T * i;          // consecutive threads: consecutive queries (the LDS image is element-major)
@@ -130,21 +139,22 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
             const uint32_t qr = g < (uint32_t)QG ? qrow[j] : ~0u;
             const float *src = a.queries + (size_t)(qr != ~0u ? qr : 0) * a.dim;
             // (padding: (0 - 0)^2 = +0.0 and 0 * x = +-0.0 leave a running sum as it is -- it starts at +0.0 and never becomes -0.0)
-            qa[i].x = (qr != ~0u && col + 0 < a.dim) ? src[col + 0] : 0.0f;
-            qa[i].y = (qr != ~0u && col + 1 < a.dim) ? src[col + 1] : 0.0f;
-            qa[i].z = (qr != ~0u && col + 2 < a.dim) ? src[col + 2] : 0.0f;
-            qa[i].w = (qr != ~0u && col + 3 < a.dim) ? src[col + 3] : 0.0f;
+            qa.v[i].x = (qr != ~0u && col + 0 < a.dim) ? src[col + 0] : 0.0f;
+            qa.v[i].y = (qr != ~0u && col + 1 < a.dim) ? src[col + 1] : 0.0f;
+            qa.v[i].z = (qr != ~0u && col + 2 < a.dim) ? src[col + 2] : 0.0f;
+            qa.v[i].w = (qr != ~0u && col + 3 < a.dim) ? src[col + 3] : 0.0f;
         }
+        return qa;
     };
-    auto store = [&](const uint4 (&r)[XS_PIECES]) __attribute__((always_inline)) {
+    auto store = [&](const Regs &r, const QRegs &qa) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < XS_PIECES; ++i) *reinterpret_cast<uint4 *>(tile + (size_t)(fr + 64u * i) * XS_ROWB + fp * 16) = r[i];
+        for (int i = 0; i < XS_PIECES; ++i) *reinterpret_cast<u32x4 *>(tile + (size_t)(fr + 64u * i) * XS_ROWB + fp * 16) = r.v[i];
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const uint32_t g = (uint32_t)tid + XS_T * i;
             if (g < (uint32_t)QG) {
                 float *dst = qs + 4 * (g / NQ) * NQ + g % NQ;
-                dst[0] = qa[i].x; dst[NQ] = qa[i].y; dst[2 * NQ] = qa[i].z; dst[3 * NQ] = qa[i].w;
+                dst[0] = qa.v[i].x; dst[NQ] = qa.v[i].y; dst[2 * NQ] = qa.v[i].z; dst[3 * NQ] = qa.v[i].w;
             }
         }
     };
@@ -157,7 +167,7 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
         const xs_f2 xx = xs_f2{x, x};
 #pragma unroll
         for (int jq = 0; jq < NQ / 4; ++jq) {
-            const float4 q4 = *reinterpret_cast<const float4 *>(qs + el * NQ + 4 * jq);
+            const xs_f4 q4 = *reinterpret_cast<const xs_f4 *>(qs + el * NQ + 4 * jq);
             const xs_f2 q01 = xs_f2{q4.x, q4.y}, q23 = xs_f2{q4.z, q4.w};
             if constexpr (decltype(l2c)::value) {
                 xs_f2 t0 = q01 - xx; t0 = t0 * t0; sum[2 * jq] = sum[2 * jq] + t0;
@@ -171,7 +181,7 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
     auto compute_m = [&](auto l2c) __attribute__((always_inline)) {
 #pragma unroll 2
         for (int p = 0; p < XS_PIECES; ++p) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(myrow + p * 16);
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(myrow + p * 16);
             if constexpr (sizeof(RT) == 4) {
                 elem(l2c, __uint_as_float(w.x), 4 * p); elem(l2c, __uint_as_float(w.y), 4 * p + 1);
                 elem(l2c, __uint_as_float(w.z), 4 * p + 2); elem(l2c, __uint_as_float(w.w), 4 * p + 3);
@@ -189,7 +199,7 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
     auto flush = [&](uint32_t t) __attribute__((always_inline)) {
         const uint32_t row = r_begin + t * XS_T + tid;
         unsigned long long pend = 0;
-        if (row < r_end) pend = nqg >= 64 ? ~0ull : ((1ull << nqg) - 1);
+        if (row < r_end) pend = (1ull << nqg) - 1;   // (nqg <= 32)
         for (;;) {
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
@@ -219,30 +229,47 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
 #pragma unroll
         for (int j = 0; j < NQ / 2; ++j) sum[j] = xs_f2{0.0f, 0.0f};
     };
-    // ---- the pipeline: chunk c in LDS, c + 1 and c + 2 in flight in registers ---------------------------------------------------
-    fetch_rows(ra, 0); fetch_q(0);
-    if (total > 0) store(ra);
-    fetch_rows(ra, 1);
-    fetch_rows(rb, 2);
-    __syncthreads();
-    uint32_t cc = 0, t = 0;
-    for (uint32_t c = 0; c < total; c += 2) {
-        // even step: LDS holds c; ra = c + 1, rb = c + 2
-        fetch_q(c + 1);
-        compute();
-        if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
-        if (c + 1 >= total) break;
-        store(ra);
-        fetch_rows(ra, c + 3);
-        __syncthreads();
-        // odd step: LDS holds c + 1; rb = c + 2, ra = c + 3
-        fetch_q(c + 2);
-        compute();
-        if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
-        if (c + 2 >= total) break;
-        store(rb);
-        fetch_rows(rb, c + 4);
-        __syncthreads();
+    // ---- the pipeline: chunk c in LDS; c + 1 (and, with <= 16 running sums, c + 2) in flight in registers.  A pass with 32 sums is
+    // bound by its arithmetic (and by the register file: 32 sums + two chunks in flight + the walk's temporaries would spill) ---------
+    if (total > 0) {
+        Regs ra = fetch_rows(0);
+        QRegs qa = fetch_q(0);
+        store(ra, qa);
+        ra = fetch_rows(1);
+        uint32_t cc = 0, t = 0;
+        if constexpr (NQ <= 16) {
+            Regs rb = fetch_rows(2);
+            __syncthreads();
+            for (uint32_t c = 0; c < total; c += 2) {
+                // even step: LDS holds c; ra = c + 1, rb = c + 2
+                qa = fetch_q(c + 1);
+                compute();
+                if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
+                if (c + 1 >= total) break;
+                store(ra, qa);
+                ra = fetch_rows(c + 3);
+                __syncthreads();
+                // odd step: LDS holds c + 1; rb = c + 2, ra = c + 3
+                qa = fetch_q(c + 2);
+                compute();
+                if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
+                if (c + 2 >= total) break;
+                store(rb, qa);
+                rb = fetch_rows(c + 4);
+                __syncthreads();
+            }
+        } else {
+            __syncthreads();
+            for (uint32_t c = 0; c < total; ++c) {
+                qa = fetch_q(c + 1);
+                compute();
+                if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
+                if (c + 1 >= total) break;
+                store(ra, qa);
+                ra = fetch_rows(c + 2);
+                __syncthreads();
+            }
+        }
     }
     // ---- the block's <= k best per query -> its partial list -----------------------------------------------------------------------
     __syncthreads();
@@ -265,19 +292,18 @@ __host__ __device__ inline size_t xs_lds(uint32_t nq_pass, uint32_t cap) {
 
 // grid (B row ranges, Y workers over the groups of listed queries) x 512 threads.  The list's length is read on the device: empty (the
 // common case) -> return at once; else groups of up to nq_max queries share one pass over the rows, and a short list takes the
-// instantiation with as few running sums as it needs (8 / 16 / 32 / 64).
+// instantiation with as few running sums as it needs (8 / 16 / 32).
 template <typename RT>
 __global__ __launch_bounds__(XS_T) void k_exact_scan(XsArgs a, const uint32_t *__restrict__ nflag, uint32_t nq_max) {
     const uint32_t nf = *nflag;
     if (nf == 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t per = min(nq_max, nf <= 8 ? 8u : nf <= 16 ? 16u : nf <= 32 ? 32u : 64u);   // (wave-uniform, block-uniform)
+    const uint32_t per = min(nq_max, nf <= 8 ? 8u : nf <= 16 ? 16u : 32u);   // (wave-uniform, block-uniform)
     for (uint32_t g0 = blockIdx.y * per; g0 < nf; g0 += gridDim.y * per) {
         const uint32_t nqg = min(per, nf - g0);
         if (per == 8) xs_pass<RT, 8>(a, g0, nqg, smem);
         else if (per == 16) xs_pass<RT, 16>(a, g0, nqg, smem);
-        else if (per == 32) xs_pass<RT, 32>(a, g0, nqg, smem);
-        else xs_pass<RT, 64>(a, g0, nqg, smem);
+        else xs_pass<RT, 32>(a, g0, nqg, smem);
     }
 }
 
