@@ -69,6 +69,9 @@ def parse_args():
                          "benchmark shape (compat-mode HNSW search, 128-d, k = 10) on GPU and CPU; adds ~1-2 min")
     ap.add_argument("--extras-points", type=int, default=100_000)
     ap.add_argument("--extras-graph-rows", type=int, default=1_000_000)
+    ap.add_argument("--tuning", action="append", default=[], metavar="NAME=VALUE",
+                    help="(experiments) a tuning switch of the library's launch code, set through zvdb_hip_set_tuning before anything runs "
+                         "(the library does not read the environment); repeatable; recorded in the line under config.tuning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the reference benchmark's dims x k sweep (part of the cpu_baseline leg, ~1 min)")
     ap.add_argument("--rehearse-shard-of", type=int, default=0, metavar="G",
@@ -588,6 +591,9 @@ def main():
     import zvdb_amd as zv
     from zvdb_amd import _lib
 
+    for kv in args.tuning:
+        name, _, value = kv.partition("=")
+        zv.set_tuning(name, value)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -992,6 +998,8 @@ def main():
             },
         }
         out["config"]["route"] = args.route
+        if args.tuning:
+            out["config"]["tuning"] = args.tuning
         out["config"]["row_dtype"] = args.row_dtype
         out["config"]["data"] = args.data
         out["config"]["collective"] = ("zvdb_hip_search_*_sharded_dev (ncclAllGather inside libzvdb_hip)" if comm is not None else

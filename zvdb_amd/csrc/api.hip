@@ -309,6 +309,11 @@ int zvdb_hip_create(const zvdb_hip_config *cfg, zvdb_hip_index **out) {
     zvdb_hip_index *h = new (std::nothrow) zvdb_hip_index();
     if (!h) return ZVDB_ERR_OOM;
     h->device = dev;
+    {
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        h->cu_count = (uint32_t)std::max(cus, 1);
+    }
     h->metric = cfg->metric;
     h->m = cfg->m;
     h->ef_construction = cfg->ef_construction;
@@ -363,6 +368,7 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->ef_visit_buf);
     (void)hipFree(h->ef_net_buf);
     if (h->ef_event) (void)hipEventDestroy(h->ef_event);
+    if (h->cert_event) (void)hipEventDestroy(h->cert_event);
     (void)hipFree(h->spec_wpos0);
     (void)hipFree(h->spec_wposU);
     if (h->ins_host) (void)hipHostFree(h->ins_host);

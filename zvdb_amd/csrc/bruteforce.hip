@@ -554,6 +554,9 @@ uint32_t ncross = 0;
 // prove that it has the kp best -> defq[q] = 1, its repair threshold tau_out[q] = "no bound" and *flag = 1 (the
 // gated repair scan re-reads the corpus for those queries only); other queries get tau_out[q] = 0 ("nothing
 // passes").  vmode 2 (repair merge, lists [l0, l0 + S)): a no-op unless *flag, and then only for defq queries.
+// vmode 3 (verification under the certificate): a deficient query is handed to the certificate's own repair -- its k'-th key is
+// written as 0, which no safe key undercuts, so the re-rank lists it and the exact scan recomputes it (exact_scan.hip): no
+// gated repair scan / repair merge launches behind this one.
 __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict__ partial,
                                                      const uint32_t *__restrict__ pcnt, uint32_t S, uint32_t Stot,
                                                      uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
                                                      uint32_t *__restrict__ cert_nflag = nullptr /* the repair list's counter: reset here, ahead of the re-rank that fills it */,
                                                      uint32_t lw = kWave /* lists taken per round (one lane each): cap >= kp + lw * lkp -- 16 for the wide lists keeps the pool at
                                                                             17 - 35 KB instead of 67 - 133 KB, i.e. 4+ workgroups per CU instead of 1 - 2 */) {
-    if (cert_nflag && vmode != 2 && blockIdx.x == 0 && threadIdx.x == 0) *cert_nflag = 0;
+    if (cert_nflag && vmode != 2 && blockIdx.x == 0 && threadIdx.x == 0) { cert_nflag[0] = 0; cert_nflag[1] = 0; }  // ([1]: the exact scan's finished-block counter)
     if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
             uint64_t mxl = 0;
             for (uint32_t i = lane; i < n; i += kWave) mxl = umax64(mxl, pool[i]);
             const uint64_t mx = wave_max64(mxl);
-            if (lane == 0) kth_out[q] = n >= kp ? (uint32_t)(mx >> 32) : 0xFFFFFFFFu;
+            if (lane == 0) kth_out[q] = n >= kp ? (uint32_t)(mx >> 32) : vmode == 3 ? 0u : 0xFFFFFFFFu;
         }
     } else if (cand_ids) {
         for (uint32_t i = lane; i < lkp; i += kWave) {
@@ -642,7 +645,9 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
             cand_ids[(size_t)q * lkp + i] = k == ~0ull ? 0xFFFFFFFFu : (uint32_t)k;
         }
     }
-    if (vmode == 1) {
+    if (vmode == 3) {
+        if (lane == 0 && n < kp && host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the next guesses are looser)
+    } else if (vmode == 1) {
         if (lane == 0) {
             const bool deficient = n < kp;
             defq[q] = deficient ? 1u : 0u;
@@ -678,13 +683,11 @@ double norm_quantile(double p) {
 // queries -> operand layout of the scan: [nq_pad][row_bytes], zero padded.
 // mode 0: fp32 copy; 1: bf16 RNE; 2: int8 with the index's quantisation (q_lo, q_inv, affine);
 // 3: fp4 codes, two per byte (q_lo = the index's p_mid, q_inv = p_scale; row_elems counts BYTES here).
-__global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict__ q, uint32_t nq,
-                                                         uint32_t dim, unsigned char *__restrict__ out,
-                                                         uint32_t nq_pad, uint32_t row_elems, int mode,
-                                                         float q_lo, float q_inv, int affine) {
+__device__ __forceinline__ void bf_prep_queries_body(const float *__restrict__ q, uint32_t nq, uint32_t dim, unsigned char *__restrict__ out,
+                                                     uint32_t nq_pad, uint32_t row_elems, int mode, float q_lo, float q_inv, int affine,
+                                                     uint64_t first, uint64_t stride) {
     const uint64_t total = (uint64_t)nq_pad * row_elems;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t t = first; t < total; t += stride) {
         const uint32_t r = (uint32_t)(t / row_elems), c = (uint32_t)(t - (uint64_t)r * row_elems);
         if (mode == 3) {
             uint32_t b = 0;
@@ -712,6 +715,14 @@ __global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict
             reinterpret_cast<float *>(out)[t] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_bf_prep_queries(const float *__restrict__ q, uint32_t nq,
+                                                         uint32_t dim, unsigned char *__restrict__ out,
+                                                         uint32_t nq_pad, uint32_t row_elems, int mode,
+                                                         float q_lo, float q_inv, int affine) {
+    bf_prep_queries_body(q, nq, dim, out, nq_pad, row_elems, mode, q_lo, q_inv, affine, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                         (uint64_t)gridDim.x * blockDim.x);
 }
 
 // dot / cosine with a quantised screen (int8, fp4): the ranking does not depend on the query's length, the quantiser does --
@@ -835,11 +846,17 @@ constexpr int SG_Q = 4, SG_SPLIT = 16;
 template <typename RT>
 __global__ __launch_bounds__(256) void k_sample_guess(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, const float *__restrict__ norm /* null: dot */,
                                                       uint32_t N, const float *__restrict__ queries, uint32_t nq, uint32_t nsamp, float z,
-                                                      uint32_t *__restrict__ verify_flag, double *__restrict__ part /* [SG_SPLIT][nq pad SG_Q][2] */) {
+                                                      uint32_t *__restrict__ verify_flag, double *__restrict__ part /* [SG_SPLIT][nq pad SG_Q][2] */,
+                                                      unsigned char *__restrict__ prep_out /* null: the scan's query operand is written elsewhere */,
+                                                      uint32_t nq_pad, uint32_t row_elems, int prep_mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *q = reinterpret_cast<float *>(smem);                      // [SG_Q][ld], zero padded like the rows (ld: a multiple of 32)
     double *red = reinterpret_cast<double *>(q + (size_t)SG_Q * ld);  // [4 waves][SG_Q][2]
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
+    // the scan's query operand (fp32 copy / bf16, zero padded), this workgroup's share: one launch fewer per batch (k_bf_prep_queries)
+    if (prep_out)
+        bf_prep_queries_body(queries, nq, dim, prep_out, nq_pad, row_elems, prep_mode, 0.0f, 1.0f, 0,
+                             ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, (uint64_t)gridDim.x * gridDim.y * 256);
     const uint32_t q0 = blockIdx.x * SG_Q;
     for (uint32_t i = threadIdx.x; i < SG_Q * ld; i += 256) {
         const uint32_t qi = q0 + i / ld, c = i % ld;
@@ -1069,6 +1086,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                            i8m ? 0.0f : h->p_mid);  // (fp4 rows are centred on their mean: the quantiser subtracts it again)
         d_queries = qs;
     }
+    bool prep_folded = false;  // the staged guessed-threshold route writes the operand inside its sampling kernel
+    auto do_prep = [&]() -> int {
+    if (prep_folded) return ZVDB_OK;
     if (f7 || s4) {
         ZV_CHECK(launch_fp4s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else if (sb) {
@@ -1084,6 +1104,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                            p.nq_pad, p.row_elems, (int)mode, mode == ZVDB_BF_FP4 ? h->p_mid : h->q_lo,
                            mode == ZVDB_BF_FP4 ? h->p_scale : h->q_inv, l2 ? 1 : 0);
     }
+    return ZVDB_OK;
+    };
     // screen key: L2 -> |v|^2 - 2 q.v ; dot / cosine -> -q.v (no norm term)
     const int alpha_i = l2 ? -2 : -1;
     const uint32_t N = (uint32_t)h->count;
@@ -1112,6 +1134,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool staged_guess = !guess_pipe && !stream_route && !guess_off && (mode == ZVDB_BF_F32 || mode == ZVDB_BF_BF16) &&
                               kpv == (uint32_t)KP && p.NT >= 8 * p.S && !(debug_flags() & ~(16u | 32u)) &&
                               (size_t)SG_Q * std::max(h->ld, h->ldh) * 4 <= 128 * 1024;  // (k_sample_guess keeps 4 padded queries in LDS)
+    prep_folded = staged_guess && d_queries == d_queries_exact && [] { const char *e = tuning("ZVDB_BF_FOLD_PREP"); return !e || e[0] != '0'; }();
+    ZV_CHECK(do_prep());
     if (!guess_pipe && !staged_guess) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
     uint32_t kp_used = (uint32_t)KP;
@@ -1122,6 +1146,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t *nflag = cert ? reinterpret_cast<uint32_t *>(ws + p.off_cert) : nullptr;
     uint32_t *flist = cert ? reinterpret_cast<uint32_t *>(ws + p.off_cert + 256) : nullptr;
     if (cert) ZV_CHECK(ensure_cert_stats(h, mode, s));
+    // under the certificate a query whose guessed threshold was too tight goes to the exact scan instead of a gated second scan + merge
+    // (ZVDB_BF_CERT_DEFER=0: the gated pair, as without the certificate)
+    const bool cert_defer = cert && [] { const char *e = tuning("ZVDB_BF_CERT_DEFER"); return !e || e[0] != '0'; }();
     auto finish = [&](uint32_t kp_valid) -> int {
         if (!cert) return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid);
         CertArgs ca;
@@ -1236,6 +1263,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            if (cert_defer) {  // a guess that was too tight for a query is repaired by the certificate's exact scan: two launches fewer per batch
+                hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
+                                   kp, cap, 0u, 3, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
+                timing_end(h, s);
+                ZV_HIP(hipGetLastError());
+                return finish(kp);
+            }
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
                                kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
@@ -1264,7 +1298,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 double *part = reinterpret_cast<double *>(cand);  // (cand is free until the scan)
                 const uint32_t ns_eff = std::min(nsamp, N) >= 64 ? std::min(nsamp, N) / 64 * 64 : std::min(nsamp, N);
                 hipLaunchKernelGGL(k_sample_guess<RT>, dim3(groups, SG_SPLIT), dim3(256), lds, s, rws, ld, h->dim,
-                                   l2 ? ((h->flags & ZVDB_FLAG_BF16_ROWS) ? h->norm_h : h->norm) : (const float *)nullptr, N, d_queries_exact, nq, nsamp, z, vflag, part);
+                                   l2 ? ((h->flags & ZVDB_FLAG_BF16_ROWS) ? h->norm_h : h->norm) : (const float *)nullptr, N, d_queries_exact, nq, nsamp, z, vflag, part,
+                                   prep_folded ? q_op : (unsigned char *)nullptr, p.nq_pad, p.row_elems, (int)mode);
                 hipLaunchKernelGGL(k_sample_tau, dim3((nq + 255) / 256), dim3(256), 0, s, part, groups, nq, ns_eff, z, tau_g);
                 ZV_HIP(hipGetLastError());
                 return ZVDB_OK;
@@ -1294,6 +1329,13 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            if (cert_defer) {
+                hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 3, vflag, defq,
+                                   h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
+                timing_end(h, s);
+                ZV_HIP(hipGetLastError());
+                return finish(kp);
+            }
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 1, vflag, defq,
                                h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             ZV_CHECK(scan1(tau_rep, p.S, vflag));

@@ -104,6 +104,7 @@ struct zvdb_hip_index {
     std::mutex mu;
     int device = 0;
     uint32_t dim = 0, ld = 0, ldh = 0;
+    uint32_t cu_count = 0;  // compute units of the index's device (the graph search plans its queries per CU with it)
     uint32_t metric = 0, m = 16, ef_construction = 200, gstride = 16, flags = 0;
     uint64_t count = 0, cap = 0;
     float *rows = nullptr;
@@ -195,6 +196,8 @@ struct zvdb_hip_index {
     // mirror (device words; data_kernels.hip: ensure_cert_stats), valid while cert_count[mode] == count
     uint32_t *cert_dev = nullptr;  // [4][2] float bit patterns
     uint64_t cert_count[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    hipEvent_t cert_event = nullptr;   // behind the last k_cert_stats: certified searches on other streams wait for it before they read the words
+    bool cert_event_set = false;
     bool cert_on = true;           // ZVDB_OPT_CERTIFY
     uint32_t cert_level = 0;       // survivors kept per query: 0 = as few as the route allows, 1: 64, 2: 128, 3: 256 -- raised when a batch needed the exact scan
     uint32_t cert_level_min = 0;   // ZVDB_OPT_CERT_MIN_LEVEL

@@ -652,7 +652,13 @@ int ensure_cert_stats(zvdb_hip_index *h, uint32_t mode, hipStream_t s) {
         ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->cert_dev), 8 * sizeof(uint32_t)));
         ZV_HIP(hipMemsetAsync(h->cert_dev, 0, 8 * sizeof(uint32_t), s));
     }
-    if (h->cert_count[mode] == h->count) return ZVDB_OK;
+    if (h->cert_count[mode] == h->count) {
+        // computed already -- but perhaps by a call on ANOTHER stream that has only been enqueued: a certified search reads the
+        // words on its own stream, so it waits for the event recorded behind the kernel that filled them (a no-op once complete)
+        if (h->cert_event_set) ZV_HIP(hipStreamWaitEvent(s, h->cert_event, 0));
+        return ZVDB_OK;
+    }
+    if (h->cert_event_set) ZV_HIP(hipStreamWaitEvent(s, h->cert_event, 0));  // (another mode's statistics may still be in flight on another stream: same words' neighbours, same memset unit)
     ZV_HIP(hipMemsetAsync(h->cert_dev + 2 * mode, 0, 2 * sizeof(uint32_t), s));
     if (h->count > 0)
         ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
@@ -662,6 +668,9 @@ int ensure_cert_stats(zvdb_hip_index *h, uint32_t mode, hipStream_t s) {
             ZV_HIP(hipGetLastError());
             return ZVDB_OK;
         }));
+    if (!h->cert_event) ZV_HIP(hipEventCreateWithFlags(&h->cert_event, hipEventDisableTiming));
+    ZV_HIP(hipEventRecord(h->cert_event, s));
+    h->cert_event_set = true;
     h->cert_count[mode] = h->count;
     return ZVDB_OK;
 }

@@ -6,6 +6,7 @@
 // Traversal distances are the oracle's 16-way blocked sums, un-contracted (-ffp-contract=off + the pragma below); the final k are
 // re-evaluated with the reference's sequential arithmetic (exact_dist.h).
 #include <cstring>
+#include <string>
 #include "common.h"
 #include "wave_select.h"
 #include "exact_dist.h"
@@ -589,7 +590,10 @@ __device__ __forceinline__ uint64_t wave_shr1_64(uint64_t v) {  // lane i <- lan
 constexpr uint32_t kEfDone = 0xFFFFFFFFu;  // ctl[0]: no further window (a window has 1 .. 64 rows)
 constexpr uint32_t kEfFinal = 0xFFFFFFFEu;  // ctl[0]: the search is over -- share the exact re-evaluation of the final k (ctl[1] results), then leave
 template <typename RT, int EPL, int WPQ = 1, int PROF = 0, bool WIDE = false>
-__global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 : 4) : WPQ == 2 ? 2 : 1) void k_search_ef_reg(
+#ifndef ZVDB_EF_WPE2
+#define ZVDB_EF_WPE2 2   /* waves per SIMD the two-wave workgroups are compiled for (A/B: (EPL <= 4 ? 3 : 2) caps them at 168 VGPRs = six queries per CU) */
+#endif
+__global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 : 4) : WPQ == 2 ? ZVDB_EF_WPE2 : 1) void k_search_ef_reg(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,
     const uint32_t *__restrict__ adj, const uint32_t *__restrict__ deg, uint32_t gstride,
     uint32_t N, const float *__restrict__ queries, uint32_t k, uint32_t ef, uint32_t entry,
@@ -1321,7 +1325,16 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     if (const char *hb_env = tuning("ZVDB_EF_HASH_BITS")) hash_bits = (uint32_t)std::max(8, std::min(15, atoi(hb_env)));  // (experiment)
     const uint32_t efp = round_up(ef, kWave), kpad = round_up(std::max(k, 1u), kWave);
     // beam in registers up to ef = 1024 (k_search_ef_reg), in LDS beyond (k_search_ef); ZVDB_EF_BEAM=lds forces the LDS kernel
-    const char *beam_env = tuning("ZVDB_EF_BEAM");  // (read per call: the parity test switches it)
+    // (switch values that are consulted again further down are COPIED here: tuning() hands out pointers into a small per-thread ring
+    // that later lookups overwrite)
+    std::string beam_s, gv_s, tp_s;
+    auto tuning_copy = [](const char *name, std::string &hold) -> const char * {
+        const char *e = tuning(name);
+        if (!e) return nullptr;
+        hold = e;
+        return hold.c_str();
+    };
+    const char *beam_env = tuning_copy("ZVDB_EF_BEAM", beam_s);  // (read per call: the parity test switches it)
     const bool beam_lds = beam_env && beam_env[0] == 'l';
     const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : ef <= 1024 ? 16 : 0;
     auto lds_slots = [&](uint64_t slots) -> size_t {  // LDS of a query with a visited table of `slots` entries
@@ -1334,7 +1347,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     // an index-owned buffer, the batch in chunks of <= 2 GiB) -- slower per pop, but it serves only what the tight LDS pass
     // handed back (or the first batch of an ef bucket, which establishes the fill), and nothing overflows: before, such searches
     // ran one wave per CU on a table clamped to the LDS and failed with "visited set exhausted" beyond it.
-    const char *gv_env = tuning("ZVDB_EF_GLOBAL_VISITED");  // "1" / "0": force / forbid the global safe pass (tests; read per call)
+    const char *gv_env = tuning_copy("ZVDB_EF_GLOBAL_VISITED", gv_s);  // "1" / "0": force / forbid the global safe pass (tests; read per call)
     uint32_t lds_cap_bits = 15;
     while (lds_bytes(lds_cap_bits) > 160 * 1024 && lds_cap_bits > 8) --lds_cap_bits;
     const bool safe_global = gv_env ? gv_env[0] == '1' : lds_bytes(hash_bits) > 80 * 1024;
@@ -1350,7 +1363,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     uint32_t bucket = 0;
     while ((1u << bucket) < ef && bucket < 15) ++bucket;
     const uint32_t seen = __atomic_load_n(&h->ef_hint_host[bucket], __ATOMIC_RELAXED);
-    const char *tp_env = tuning("ZVDB_EF_TWO_PASS");  // "0": always the safe table; "t<bits>": force the tight table (tests; read per call)
+    const char *tp_env = tuning_copy("ZVDB_EF_TWO_PASS", tp_s);  // "0": always the safe table; "t<bits>": force the tight table (tests; read per call)
     const uint32_t safe_rank = safe_global ? 32u : hash_bits;  // (a global safe table is "larger" than any LDS one)
     uint32_t tight_bits = safe_rank;
     if (tp_env && tp_env[0] == 't') {
@@ -1397,7 +1410,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             const uint64_t fit = ((per - lds_slots(0)) / 4) & ~63ull;
             return fit >= smin ? fit : 0;
         };
-        static const uint32_t ncu = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)std::max(v, 1); }();
+        const uint32_t ncu = std::max(h->cu_count, 1u);  // (of the index's own device, read at create)
         // queries per CU under a register limit of vlim workgroups: the MOST whose table holds the fill, and of those the FEWEST that
         // take no more rounds for this batch (a larger table probes less); 0: the fill does not fit the LDS
         auto plan = [&](uint32_t vlim) -> uint32_t {
@@ -1551,8 +1564,11 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
 void ef_hint_reset(const zvdb_hip_index *h, hipStream_t s) {
     if (!h->ef_hint_dev) return;
     h->ef_hint_calls = 0;
+    // (an in-flight copy of the old values must not land after the reset -- and the search that makes it may run on a CALLER's stream:
+    // wait for the last search's event, not only for this stream)
+    if (h->ef_event_set) (void)hipEventSynchronize(h->ef_event);
     (void)hipMemsetAsync(h->ef_hint_dev, 0, 64, s);
-    (void)hipStreamSynchronize(s);  // (an in-flight copy of the old values must not land after the reset)
+    (void)hipStreamSynchronize(s);
     std::memset(h->ef_hint_host, 0, 64);
 }
 

@@ -3,13 +3,18 @@
 // one lane walks one row, strictly ascending, sub / mul / add rounded separately -- this file is built with
 // -ffp-contract=off), ties by lower id.  No screen, no mirror, no MFMA: what it returns is the definition of a10.
 //
-//   k_exact_scan        grid (B row ranges, Y query-group workers) x 256 threads: a lane owns a row of the tile and walks it once
-//                       for XS_QB queries held in LDS; (dist, id) words that do not exceed the query's bound (start: the k-th result
-//                       the screen route returned -- real rows, so an upper bound of the true k-th) go to an LDS buffer, pruned by an
-//                       exact radix select when it fills; each block leaves its <= k best per query
-//   k_exact_scan_merge  one wave per listed query: the B partial lists -> exact top-k -> the query's result slots
-// Both read the list's length on the device: with an empty list (the common case) they return at once.
-// Cost when it runs: N dim 3 vector operations per listed query (0.7 ms at 10M x 768) on top of one pass over the rows.
+//   k_exact_scan   grid (B row ranges, Y workers over groups of listed queries) x 512 threads.  Up to 32 listed queries share ONE pass
+//                  over the rows: a lane owns a row of the 512-row tile and keeps one running sum per query in registers; the rows
+//                  stream through LDS a cache line per row at a time (fetched coalesced, two chunks ahead), the same chunk of every
+//                  query beside them, and the reference's three operations run as packed fp32 pairs (two queries per instruction,
+//                  each component rounded on its own).  (dist, id) words within the query's bound (start: the k-th result the screen
+//                  route returned -- real rows, so an upper bound of the true k-th) go to an LDS buffer, pruned by an exact radix
+//                  select when it fills (nothing is ever dropped: a lane whose word did not fit tries again after the prune); each
+//                  block leaves its <= k best per query, and the block that finishes LAST merges the B partial lists of every listed
+//                  query into the result slots (no second launch).
+// The list's length is read on the device: with an empty list (the common case) the launch returns at once.
+// Cost when it runs (10M x 768 fp32 rows): one pass over the rows per 32 listed queries, ~10 ms (the 128-byte pieces of a tile's rows
+// are scattered reads: ~3 TB/s), up to 8 queries inside that time; 32 queries ~ the arithmetic's 3 N dim operations each.
 #include "common.h"
 #include "wave_select.h"
 #include "exact_dist.h"
@@ -26,7 +31,6 @@ constexpr int XS_CHUNK = 128;        // bytes of a row per chunk: one cache line
 constexpr int XS_ROWB = XS_CHUNK + 16;  // LDS bytes per row of the tile: 36 dwords -- the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads
 constexpr int XS_PIECES = XS_CHUNK / 16;  // 16-byte pieces per row and chunk; also pieces per thread and chunk of the coalesced fill (512 x 8 = 4,096)
 constexpr int XS_PRUNERS = 4;        // waves that prune (each with its own histogram + staging)
-constexpr uint32_t XS_POOL = 6144;   // words per merge round in LDS (+ 256 kept)
 
 typedef float xs_f2 __attribute__((ext_vector_type(2)));
 typedef float xs_f4 __attribute__((ext_vector_type(4)));
@@ -65,6 +69,7 @@ struct XsArgs {
     const void *rows; uint32_t ld, dim; int metric; uint32_t N;
     const float *queries; const uint32_t *flist; uint32_t k; uint64_t id_offset;
     const uint64_t *cur_ids; const float *cur_dist; const uint32_t *cur_count; uint64_t *partial;
+    uint64_t *out_ids; float *out_dist; uint32_t *out_count; uint32_t *host_repaired;   // (the result slots: the same arrays the bound was read from)
     uint32_t rows_per_block, cap;
 };
 
@@ -290,51 +295,31 @@ __host__ __device__ inline size_t xs_lds(uint32_t nq_pass, uint32_t cap) {
            (size_t)nq_pass * 4 + XS_PRUNERS * 256 * 4 + (size_t)nq_pass * 4 + 16;
 }
 
-// grid (B row ranges, Y workers over the groups of listed queries) x 512 threads.  The list's length is read on the device: empty (the
-// common case) -> return at once; else groups of up to nq_max queries share one pass over the rows, and a short list takes the
-// instantiation with as few running sums as it needs (8 / 16 / 32).
-template <typename RT>
-__global__ __launch_bounds__(XS_T) void k_exact_scan(XsArgs a, const uint32_t *__restrict__ nflag, uint32_t nq_max) {
-    const uint32_t nf = *nflag;
-    if (nf == 0) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t per = min(nq_max, nf <= 8 ? 8u : nf <= 16 ? 16u : 32u);   // (wave-uniform, block-uniform)
-    for (uint32_t g0 = blockIdx.y * per; g0 < nf; g0 += gridDim.y * per) {
-        const uint32_t nqg = min(per, nf - g0);
-        if (per == 8) xs_pass<RT, 8>(a, g0, nqg, smem);
-        else if (per == 16) xs_pass<RT, 16>(a, g0, nqg, smem);
-        else xs_pass<RT, 32>(a, g0, nqg, smem);
-    }
-}
-
-// one wave per listed query: the B partial lists (k words each, ~0 = none) -> exact top-k -> the query's result slots.  The lists go
-// through LDS in rounds of up to XS_POOL words beside the best k so far, so B is not bounded by the LDS.
-__global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restrict__ nflag, const uint32_t *__restrict__ flist, const uint64_t *__restrict__ partial,
-                                                         uint32_t B, uint32_t k, int metric, uint64_t id_offset, uint64_t *__restrict__ out_ids,
-                                                         float *__restrict__ out_dist, uint32_t *__restrict__ out_count, uint32_t *host_repaired) {
-    const uint32_t f = blockIdx.x;
-    if (f >= *nflag) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
-    uint64_t *sel = reinterpret_cast<uint64_t *>(smem + SEL_HIST_BYTES);  // [256]
-    uint64_t *pool = sel + 256;                                           // [256 + XS_POOL]
-    const int lane = threadIdx.x;
-    const uint32_t n = B * k;
-    const uint64_t *p = partial + (size_t)f * n;
+// The partial lists of listed query f (B lists of k words, ~0 = none) -> exact top-k -> the query's result slots; one wave, its own
+// LDS (XS_MERGE_LDS bytes).  The lists go through LDS in rounds of XS_MPOOL words beside the best k so far.  (One wave: its LDS
+// operations complete in order, a load sees every store issued before it.)
+constexpr uint32_t XS_MPOOL = 2048;
+constexpr uint32_t XS_MERGE_LDS = SEL_HIST_BYTES + 256 * 8 + (256 + XS_MPOOL) * 8;
+constexpr int XS_MERGERS = 4;   // waves of the last block that merge
+__device__ __forceinline__ void xs_merge(const XsArgs &a, uint32_t f, uint32_t B, unsigned char *lds, int lane) {
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds);
+    uint64_t *sel = reinterpret_cast<uint64_t *>(lds + SEL_HIST_BYTES);  // [256]
+    uint64_t *pool = sel + 256;                                          // [256 + XS_MPOOL]
+    const uint32_t k = a.k, n = B * k;
+    const uint64_t *p = a.partial + (size_t)f * n;
     uint32_t have = 0;   // valid words kept at the front of the pool (<= k)
-    for (uint32_t base = 0; base < n; base += XS_POOL) {
-        const uint32_t m = min(XS_POOL, n - base);
+    for (uint32_t base = 0; base < n; base += XS_MPOOL) {
+        const uint32_t m = min(XS_MPOOL, n - base);
         uint32_t nv_l = 0;
         for (uint32_t i = lane; i < m; i += kWave) {
-            const uint64_t w = p[base + i];
+            const uint64_t w = __builtin_nontemporal_load(p + base + i);
             pool[have + i] = w;
             nv_l += w != ~0ull ? 1u : 0u;
         }
         uint32_t nv = nv_l;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor(nv, off);
-        __syncthreads();
-        const uint32_t tot = have + m, valid = have + nv, keep = min(valid, k);
+        const uint32_t tot = have + m, keep = min(have + nv, k);
         if (keep > 0) {
             const uint32_t E = (tot + kWave - 1) / kWave;
             const uint64_t T = wave_kth_key<0>([&](uint32_t e) { const uint32_t i = e * kWave + lane; return i < tot ? pool[i] : ~0ull; }, E, keep, hist, lane);
@@ -342,38 +327,68 @@ __global__ __launch_bounds__(64) void k_exact_scan_merge(const uint32_t *__restr
             for (uint32_t e = 0; e < E; ++e) {
                 const uint32_t i = e * kWave + lane;
                 const uint64_t w = i < tot ? pool[i] : ~0ull;
-                const bool s = w <= T;
-                const unsigned long long mk = __ballot(s);
+                const bool sl = w <= T;
+                const unsigned long long mk = __ballot(sl);
                 const uint32_t pos = cb + (uint32_t)__popcll(mk & ((1ull << lane) - 1));
-                if (s && pos < 256u) sel[pos] = w;
+                if (sl && pos < 256u) sel[pos] = w;
                 cb += (uint32_t)__popcll(mk);
             }
-            __syncthreads();
             for (uint32_t i = lane; i < keep; i += kWave) pool[i] = sel[i];
-            __syncthreads();
         }
         have = keep;
     }
     const uint32_t nres = have;
-    const uint32_t qi = flist[f];
+    const uint32_t qi = a.flist[f];
     for (uint32_t i = lane; i < nres; i += kWave) {  // (dist, id) words are distinct: the rank is the position
         const uint64_t w = pool[i];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < nres; ++j) rank += pool[j] < w ? 1u : 0u;
-        out_ids[(size_t)qi * k + rank] = (uint64_t)(uint32_t)w + id_offset;
+        a.out_ids[(size_t)qi * k + rank] = (uint64_t)(uint32_t)w + a.id_offset;
         // a zero dot / cosine distance is -(+0.0) = -0.0 in the reference's arithmetic (the oracle and the re-rank write that);
         // the words carry +0.0 so that a value has one key
         const float dv = f32_unkey((uint32_t)(w >> 32));
-        out_dist[(size_t)qi * k + rank] = (metric != ZVDB_METRIC_L2SQ && dv == 0.0f) ? -0.0f : dv;
+        a.out_dist[(size_t)qi * k + rank] = (a.metric != ZVDB_METRIC_L2SQ && dv == 0.0f) ? -0.0f : dv;
     }
     for (uint32_t i = nres + lane; i < k; i += kWave) {
-        out_ids[(size_t)qi * k + i] = ~0ull;
-        out_dist[(size_t)qi * k + i] = __builtin_inff();
+        a.out_ids[(size_t)qi * k + i] = ~0ull;
+        a.out_dist[(size_t)qi * k + i] = __builtin_inff();
     }
     if (lane == 0) {
-        out_count[qi] = nres;
-        if (host_repaired) __hip_atomic_fetch_add(host_repaired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        a.out_count[qi] = nres;
+        if (a.host_repaired) __hip_atomic_fetch_add(a.host_repaired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// grid (B row ranges, Y workers over the groups of listed queries) x 512 threads.  The list's length is read on the device: empty (the
+// common case) -> return at once; else groups of up to nq_max queries share one pass over the rows, and a short list takes the
+// instantiation with as few running sums as it needs (8 / 16 / 32).  The block that finishes LAST (a counter next to the list's
+// length, reset by the merge kernels of the screen and by its last user) merges the partial lists of every listed query into the
+// result slots: no second launch -- the release / acquire fences around the counter are paid only when there is a list.
+template <typename RT>
+__global__ __launch_bounds__(XS_T) void k_exact_scan(XsArgs a, uint32_t *__restrict__ nflag, uint32_t nq_max) {
+    const uint32_t nf = nflag[0];
+    if (nf == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_last;
+    const uint32_t per = min(nq_max, nf <= 8 ? 8u : nf <= 16 ? 16u : 32u);   // (block-uniform)
+    for (uint32_t g0 = blockIdx.y * per; g0 < nf; g0 += gridDim.y * per) {
+        const uint32_t nqg = min(per, nf - g0);
+        if (per == 8) xs_pass<RT, 8>(a, g0, nqg, smem);
+        else if (per == 16) xs_pass<RT, 16>(a, g0, nqg, smem);
+        else xs_pass<RT, 32>(a, g0, nqg, smem);
+    }
+    __syncthreads();   // (every wave's partial lists are stored)
+    if (threadIdx.x == 0) {
+        __threadfence();   // release: this block's lists before its count
+        s_last = atomicAdd(nflag + 1, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();       // acquire: every block's lists
+    if (threadIdx.x == 0) nflag[1] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave < XS_MERGERS)
+        for (uint32_t f = (uint32_t)wave; f < nf; f += XS_MERGERS) xs_merge(a, f, gridDim.x, smem + (size_t)wave * XS_MERGE_LDS, lane);
 }
 
 // row ranges (= partial lists per listed query): two per CU when the scratch allows (nq B k words kept under 128 MiB for large batches,
@@ -391,6 +406,7 @@ uint64_t exact_scan_scratch_bytes(uint32_t nq, uint32_t k) { return (uint64_t)nq
 int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t k, uint64_t id_offset, const uint32_t *nflag,
                       const uint32_t *flist, void *scratch, uint64_t scratch_bytes, uint64_t *d_ids, float *d_dist, uint32_t *d_count,
                       uint32_t *host_repaired, hipStream_t s) {
+    // (nflag: [0] the list's length, [1] the finished-block counter of the scan -- both reset by the screen's merge kernels)
     if (nq == 0 || k == 0 || h->count == 0) return ZVDB_OK;
     if (k > 256) { set_error("exact scan: k <= 256"); return ZVDB_ERR_UNSUPPORTED; }
     const uint32_t N = (uint32_t)h->count;
@@ -407,23 +423,20 @@ int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t 
     const uint32_t Y = std::max(1u, std::min((nq + nq_pass - 1) / nq_pass, std::max(1u, 1024u / B)));
     ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = row_elem_t<decltype(rows)>;
-        const size_t lds = xs_lds<RT>(nq_pass, cap);
+        const size_t lds = std::max<size_t>(xs_lds<RT>(nq_pass, cap), (size_t)XS_MERGERS * XS_MERGE_LDS);
         if (lds > 160 * 1024) { set_error("exact scan: LDS plan of %zu bytes", lds); return ZVDB_ERR_UNSUPPORTED; }
         XsArgs a;
         a.rows = rows; a.ld = ld; a.dim = h->dim; a.metric = metric; a.N = N;
         a.queries = d_queries; a.flist = flist; a.k = k; a.id_offset = id_offset;
         a.cur_ids = d_ids; a.cur_dist = d_dist; a.cur_count = d_count; a.partial = reinterpret_cast<uint64_t *>(scratch);
+        a.out_ids = d_ids; a.out_dist = d_dist; a.out_count = d_count; a.host_repaired = host_repaired;
         a.rows_per_block = rpb; a.cap = cap;
         auto kern = k_exact_scan<RT>;
         if (lds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(B, Y), dim3(XS_T), lds, s, a, nflag, nq_pass);
+        hipLaunchKernelGGL(kern, dim3(B, Y), dim3(XS_T), lds, s, a, const_cast<uint32_t *>(nflag), nq_pass);
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
     }));
-    const size_t mlds = SEL_HIST_BYTES + 256 * 8 + (size_t)(256 + std::min<uint64_t>(XS_POOL, (uint64_t)B * k)) * 8;
-    if (mlds > 64 * 1024) ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_scan_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-    hipLaunchKernelGGL(k_exact_scan_merge, dim3(nq), dim3(64), mlds, s, nflag, flist, reinterpret_cast<const uint64_t *>(scratch), B, k, metric, id_offset, d_ids,
-                       d_dist, d_count, host_repaired);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }
