@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--tuning", action="append", default=[], metavar="NAME=VALUE",
                     help="(experiments) a tuning switch of the library's launch code, set through zvdb_hip_set_tuning before anything runs "
                          "(the library does not read the environment); repeatable; recorded in the line under config.tuning")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="collect the scan's HBM traffic in THIS run: two child runs of this command under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; "
+                         "started before this process touches the GPU), ~1.5 min more; default: the stamped file under profiles/")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the reference benchmark's dims x k sweep (part of the cpu_baseline leg, ~1 min)")
     ap.add_argument("--rehearse-shard-of", type=int, default=0, metavar="G",
@@ -581,10 +584,44 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def measure_traffic(args):
+    """FETCH_SIZE and WRITE_SIZE of the scan kernel's dispatches, one rocprofv3 --pmc child run each (separate passes, --kernel-trace
+    only: MI355X_MICROARCH.md), of this command with --steps 3 --warmup 1 and no secondary legs.  Called before this process has
+    touched the GPU (a GPU-initialised process must not exec; a child started from here is fine).  FETCH_SIZE is doubled (gfx950
+    counts the 128-B requests of wide coalesced reads at 64 B).  Returns None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    res = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="zvdb_pmc_")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--mode", "bf16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-paths", "--rows", str(args.rows), "--dim", str(args.dim),
+               "--batch", str(args.batch), "--k", str(args.k)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not f:
+            shutil.rmtree(d, ignore_errors=True)
+            return None
+        vals = [float(x["Counter_Value"]) for x in csv.DictReader(open(f[0])) if x["Counter_Name"] == c and "k_bf16_stream<48, 1, false" in x["Kernel_Name"]]
+        shutil.rmtree(d, ignore_errors=True)
+        if not vals:
+            return None
+        res[c] = sum(vals) / len(vals) * 1024.0   # (the counter is reported in KB)
+    fb, wb = 2.0 * res["FETCH_SIZE"], res["WRITE_SIZE"]
+    return {"hbm_bytes_per_step": fb + wb, "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate child passes, "
+                                                     "mean over the scan kernel's dispatches"}
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    measured_traffic = measure_traffic(args) if (args.measure_traffic and args.gpus == 1 and "WORLD_SIZE" not in os.environ) else None
     import numpy as np
     import torch
 
@@ -932,14 +969,27 @@ def main():
         kavg = kern_ms / max(kern_n, 1) * 1e-3
         achieved = flops / kavg / 1e12 if kavg > 0 else 0.0
         peak = PEAK_TFLOPS[args.mode]
+        # HBM traffic of the scan per launch (PMC): read from the round's committed profile ONLY if that file was measured on this
+        # kernel -- it is stamped with the kernel's symbol and the sha256 of the kernel's source file, and a mismatch is refused
+        # (traffic = null, said in traffic_source) rather than quoted stale.  `--measure-traffic` collects it in this run instead.
         traffic, traffic_src = None, None
-        for rnd in ("r4", "r3", "r2", "r1"):
-            tf = os.path.join(ROOT, "profiles", rnd, "traffic_10Mx768.json")
-            if world == 1 and traffic is None and os.path.exists(tf):
-                tj = json.load(open(tf)).get(args.mode)
+        if world == 1 and args.mode == "bf16":
+            import hashlib
+            ksrc = os.path.join(ROOT, "zvdb_amd", "csrc", "bf_bf16_stream.hip")
+            sha = hashlib.sha256(open(ksrc, "rb").read()).hexdigest() if os.path.exists(ksrc) else None
+            if args.measure_traffic and measured_traffic is not None:
+                traffic, traffic_src = measured_traffic["hbm_bytes_per_step"], measured_traffic["source"]
+            else:
+                tf = os.path.join(ROOT, "profiles", "r5", "traffic_10Mx768.json")
+                tj = json.load(open(tf)).get("bf16") if os.path.exists(tf) else None
                 if tj and (tj["rows"], tj["dim"], tj["batch"]) == (N, D, B):
-                    traffic = tj["hbm_bytes_per_step"]
-                    traffic_src = f"profiles/{rnd}/traffic_10Mx768.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes)"
+                    if tj.get("kernel_source_sha256") == sha:
+                        traffic = tj["hbm_bytes_per_step"]
+                        traffic_src = ("profiles/r5/traffic_10Mx768.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes; "
+                                       f"stamped kernel {tj.get('kernel')}, source sha256 {sha[:12]} = this tree's)")
+                    else:
+                        traffic_src = ("profiles/r5/traffic_10Mx768.json REFUSED: measured on another version of bf_bf16_stream.hip "
+                                       f"(file {str(tj.get('kernel_source_sha256'))[:12]}, tree {str(sha)[:12]}); run tools/prof_r5.sh or --measure-traffic")
         out = {
             "metric": "QPS at recall@10>=0.95, 10Mx768 fp32, batch=1024",
             "value": qps,
