@@ -591,7 +591,7 @@ constexpr uint32_t kEfDone = 0xFFFFFFFFu;  // ctl[0]: no further window (a windo
 constexpr uint32_t kEfFinal = 0xFFFFFFFEu;  // ctl[0]: the search is over -- share the exact re-evaluation of the final k (ctl[1] results), then leave
 template <typename RT, int EPL, int WPQ = 1, int PROF = 0, bool WIDE = false>
 #ifndef ZVDB_EF_WPE2
-#define ZVDB_EF_WPE2 2   /* waves per SIMD the two-wave workgroups are compiled for (A/B: (EPL <= 4 ? 3 : 2) caps them at 168 VGPRs = six queries per CU) */
+#define ZVDB_EF_WPE2 2   /* waves per SIMD the two-wave workgroups are compiled for.  (EPL <= 4 ? 3 : 2) -- a cap of 168 VGPRs, six resident queries per CU instead of four at EPL 4 -- measured 0 .. 6 % SLOWER at batch 1,024 and 4,096 (profiles/r5/ef_vgpr_cap_ab.txt) */
 #endif
 __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 : 4) : WPQ == 2 ? ZVDB_EF_WPE2 : 1) void k_search_ef_reg(
     const RT *__restrict__ rows, uint32_t ld, uint32_t dim, int metric,

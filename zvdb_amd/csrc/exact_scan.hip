@@ -13,8 +13,9 @@
 //                  block leaves its <= k best per query, and the block that finishes LAST merges the B partial lists of every listed
 //                  query into the result slots (no second launch).
 // The list's length is read on the device: with an empty list (the common case) the launch returns at once.
-// Cost when it runs (10M x 768 fp32 rows): one pass over the rows per 32 listed queries, ~10 ms (the 128-byte pieces of a tile's rows
-// are scattered reads: ~3 TB/s), up to 8 queries inside that time; 32 queries ~ the arithmetic's 3 N dim operations each.
+// Cost when it runs (10M x 768 fp32 rows, profiles/r5/exact_scan_ab.txt): one pass over the rows per 32 listed queries; a list of <= 8
+// queries 7.9 ms (3.9 TB/s: the 128-byte pieces of a tile's rows are scattered reads for the memory), 16 queries 14.3 ms, 32 queries
+// 26.4 ms = 0.82 ms per query (the arithmetic: 3 N dim operations per query; r4: 10 ms per 8 queries, one pass per 8).
 #include "common.h"
 #include "wave_select.h"
 #include "exact_dist.h"
@@ -237,41 +238,44 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
     // ---- the pipeline: chunk c in LDS; c + 1 (and, with <= 16 running sums, c + 2) in flight in registers.  A pass with 32 sums is
     // bound by its arithmetic (and by the register file: 32 sums + two chunks in flight + the walk's temporaries would spill) ---------
     if (total > 0) {
+        // (vmcnt counts in issue order: a store waits for everything issued BEFORE the youngest load it needs -- so the small query
+        // fetch of chunk c + 1 is issued ahead of the row fetch of chunk c + 2, and a store leaves that row fetch in flight)
         Regs ra = fetch_rows(0);
         QRegs qa = fetch_q(0);
         store(ra, qa);
         ra = fetch_rows(1);
+        qa = fetch_q(1);
         uint32_t cc = 0, t = 0;
         if constexpr (NQ <= 16) {
             Regs rb = fetch_rows(2);
             __syncthreads();
             for (uint32_t c = 0; c < total; c += 2) {
-                // even step: LDS holds c; ra = c + 1, rb = c + 2
-                qa = fetch_q(c + 1);
+                // even step: LDS holds c; in flight, oldest first: ra = rows c + 1, qa = queries c + 1, rb = rows c + 2
                 compute();
                 if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
                 if (c + 1 >= total) break;
                 store(ra, qa);
+                qa = fetch_q(c + 2);
                 ra = fetch_rows(c + 3);
                 __syncthreads();
-                // odd step: LDS holds c + 1; rb = c + 2, ra = c + 3
-                qa = fetch_q(c + 2);
+                // odd step: LDS holds c + 1; in flight: rb = rows c + 2, qa = queries c + 2, ra = rows c + 3
                 compute();
                 if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
                 if (c + 2 >= total) break;
                 store(rb, qa);
+                qa = fetch_q(c + 3);
                 rb = fetch_rows(c + 4);
                 __syncthreads();
             }
         } else {
             __syncthreads();
             for (uint32_t c = 0; c < total; ++c) {
-                qa = fetch_q(c + 1);
                 compute();
                 if (++cc == nch) { cc = 0; flush(t++); } else __syncthreads();
                 if (c + 1 >= total) break;
                 store(ra, qa);
                 ra = fetch_rows(c + 2);
+                qa = fetch_q(c + 2);
                 __syncthreads();
             }
         }
@@ -287,6 +291,12 @@ __device__ __forceinline__ void xs_pass(const XsArgs &a, uint32_t g0, uint32_t n
         }
     }
 }
+
+// (Measured and removed in round 5: a second pass for lists of <= 8 queries in which a lane is a (row, query) PAIR and the tile holds
+// 1 KiB of each of 64 rows, fetched as whole contiguous KiB -- meant to turn the 128-byte pieces of the pass above into long reads.
+// 10.4 - 10.8 ms per pass at 10M x 768 against 7.9 ms here, fp32 and bf16 rows alike, A/B of two builds on one box
+// (profiles/r5/exact_scan_ab.txt): the walk's 256 dependent adds per chunk and its two LDS reads per four elements cost more than the
+// longer pieces gain.)
 
 // LDS bytes of a pass with NQ queries (host + device agree)
 template <typename RT>
