@@ -1177,7 +1177,11 @@ __device__ __forceinline__ bool compat_fast_body(
             nres += 1;
             pops += 1;
             __syncthreads();
-            // (the degree and the first 64 list slots are requested together: both depend on cid only)
+            // (the degree and the first 64 list slots are requested together: both depend on cid only.  r5, measured and removed: every
+            // frontier entry carrying its node's list -- requested when the node enters the frontier, beside its row, so that a pop
+            // reads its list from LDS: 33 -> 46 us per call (profiles/r5/per_call_list_prefetch_ab.txt).  A wave's loads retire in
+            // issue order, so the 16 cold list requests of a step sit in front of the row walk's loads; the lists of the nodes
+            // that ARE popped -- the entry point's neighbourhood, the same for every query -- were L2 hits all along.)
             const uint32_t nb0 = (uint32_t)lane < gstride ? adj[(size_t)cid * gstride + lane] : 0u;
             const uint32_t dg = deg[cid];                                   // :216 layer 0
             for (uint32_t base = 0; base < dg; base += kWave) {
