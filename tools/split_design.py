@@ -6,7 +6,7 @@ import re
 import sys
 import textwrap
 
-W = 120
+W = 120  # (bytes, not characters: the notes are full of multi-byte symbols)
 src = open(sys.argv[1]).read().split("\n")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
