@@ -4,15 +4,28 @@ No content change: paragraphs and list items are re-wrapped; a table whose rows 
 import os
 import re
 import sys
-import textwrap
 
 W = 120  # (bytes, not characters: the notes are full of multi-byte symbols)
 src = open(sys.argv[1]).read().split("\n")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def blen(s):
+    return len(s.encode())
+
+
 def wrap(text, first="", rest=""):
-    return textwrap.wrap(text, W, initial_indent=first, subsequent_indent=rest, break_long_words=False, break_on_hyphens=False) or [first.rstrip()]
+    """greedy wrap to W BYTES (words are never broken)"""
+    lines, cur, empty = [], first, True
+    for w in text.split():
+        cand = cur + ("" if empty else " ") + w
+        if empty or blen(cand) <= W:
+            cur, empty = cand, False
+        else:
+            lines.append(cur)
+            cur = rest + w
+    lines.append(cur if not empty else first.rstrip())
+    return lines
 
 
 def cells(row):
@@ -20,7 +33,7 @@ def cells(row):
 
 
 def table(rows):
-    if all(len(r) <= W for r in rows):
+    if all(blen(r) <= W for r in rows):
         return rows
     head = cells(rows[0])
     out = []
@@ -59,7 +72,7 @@ def convert(lines):
             rest = " " * len(first)
             para = [l[len(first):] if m else l.strip()]
             j = i + 1
-            while j < len(lines) and lines[j].strip() and not re.match(r"^(\s*(?:[*\-]|\d+\.)\s+|#|\||```)", lines[j]):
+            while j < len(lines) and lines[j].strip() and not re.match(r"^(\s*(?:[*\-]|\d+\.)\s+|#|\||```|\s+\*[^*]+:\*\s)", lines[j]):
                 para.append(lines[j].strip())
                 j += 1
             out += wrap(" ".join(para), first, rest)
@@ -94,5 +107,5 @@ for name, parts in FILES.items():
     text = "\n".join(convert(body)).rstrip() + "\n"
     text = f"<!-- part of the design notes: index in /DESIGN.md (split from the single file of rounds 1-4; content unchanged) -->\n\n" + text
     open(os.path.join(root, "docs", "design", name), "w").write(text)
-    long = sum(1 for l in text.split("\n") if len(l) > W)
+    long = sum(1 for l in text.split("\n") if blen(l) > W)
     print(f"{name}: {len(text.split(chr(10)))} lines, {long} over {W}")
