@@ -153,7 +153,10 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
     res = {}
     for name, env in {"guess": {}, "cascade": {"ZVDB_BF_GUESS": "0"}, "staged": {"ZVDB_BF_FP4_KERNEL": "v6"}, "shape16": {"ZVDB_BF_FP4_SHAPE": "16"},
                       "i8staged": {"ZVDB_BF_I8_KERNEL": "v6"},
-                      "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2"}}.items():
+                      "tight": {"ZVDB_BF_GUESS_ZSHIFT": "-3"}, "loose": {"ZVDB_BF_GUESS_ZSHIFT": "2"},
+                      # r5: under the certificate a deficient guess is repaired by the exact scan ("tight" above); the gated re-scan +
+                      # merge pair it replaced stays behind a switch (and serves uncertified / fp4 calls), as does the separate prep launch
+                      "tight_gated": {"ZVDB_BF_GUESS_ZSHIFT": "-3", "ZVDB_BF_CERT_DEFER": "0"}, "prep_launch": {"ZVDB_BF_FOLD_PREP": "0"}}.items():
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, "-c", tuning_prelude(env) + code, str(out), metric], cwd=root, capture_output=True, text=True)
         assert r.returncode == 0, name + ": " + r.stdout + r.stderr
@@ -161,7 +164,7 @@ def test_bruteforce_fp4_guessed_thresholds_verified_and_repaired(zv, oracle, tmp
     base = res["cascade"]
     rec = np.mean([len(set(base["i"][q]) & set(base["e"][q])) / 10 for q in range(300)])
     assert rec >= (0.95 if metric == "l2" else 0.5), rec  # (dot on all-positive U[0,1) data ranks by norm: a hard case for 4 bits)
-    for name in ("guess", "staged", "shape16", "tight", "loose"):
+    for name in ("guess", "staged", "shape16", "tight", "loose", "tight_gated", "prep_launch"):
         assert np.array_equal(res[name]["i"], base["i"]), name
         assert np.array_equal(res[name]["d"], base["d"]), name
         assert np.array_equal(res[name]["c"], base["c"]), name
