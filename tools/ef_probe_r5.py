@@ -17,6 +17,10 @@ import zvdb_amd as zv
 dev = torch.device("cuda", 0)
 s = torch.cuda.current_stream().cuda_stream
 tag = sys.argv[1] if len(sys.argv) > 1 else "tree"
+for kv in os.environ.get("EF_PROBE_TUNING", "").split(","):   # e.g. EF_PROBE_TUNING=ZVDB_EF_WPQ=3 (library switches go through the ABI)
+    if "=" in kv:
+        zv.set_tuning(*kv.split("=", 1))
+        tag += "/" + kv.split("=", 1)[1]
 legs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["A", "B"]
 M = 16
 

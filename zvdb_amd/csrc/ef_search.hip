@@ -1299,7 +1299,7 @@ static uint32_t ef_waves_per_query(const zvdb_hip_index *h, int epl, uint32_t wi
     uint32_t wq = (h->flags & ZVDB_FLAG_BF16_ROWS) ? 2u : 4u;
     bool forced = false;
     if (const char *we = tuning("ZVDB_EF_WPQ")) { wq = (uint32_t)atoi(we); forced = true; }
-    if (wq != 1 && wq != 2 && wq != 4 && wq != 8) wq = 1;
+    if (wq != 1 && wq != 2 && wq != 4 && wq != 8) wq = 1;   // (r5: THREE waves -- 12 per CU at 168 VGPRs, no spills -- measured 0 .. 19 % slower than two on bf16 rows, profiles/r5/ef_three_waves_ab.txt)
     if (epl < 8 && wq == 8) wq = 4;                       // (not instantiated)
     if (epl >= 8 && width <= 1 && wq >= 4) wq = 2;        // the wide workgroups exist for the search-width loop only
     if (epl >= 8 && width > 1 && !forced) wq = lds_g == 1 ? 8u : lds_g == 2 ? 4u : 2u;  // (lds_g: queries per CU of the two-wave plan)
