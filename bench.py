@@ -428,24 +428,10 @@ def c2_leg(zv, torch, dev, stream, k, modes=("f32",), steps=20):
         kms, kn = idx.timing_read()
         idx.timing_enable(False)
         ach = 2.0 * B2 * N2 * D2 / (kms / kn * 1e-3) / 1e12
-        # the same batches issued alternately on TWO streams with a workspace and result arrays each (the *_dev entry points are
-        # stream-asynchronous; tests/test_gpu_bruteforce.py runs this pattern): the sampling / merge / re-rank launches of one batch
-        # overlap the scan of the next -- what a caller that pipelines its batches gets; reported beside the one-stream number
-        s2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        ws2 = [ws, torch.empty(ws_b, dtype=torch.uint8, device=dev)]
-        o2 = [(ids, dd, cnt), (torch.empty_like(ids), torch.empty_like(dd), torch.empty_like(cnt))]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            j = i & 1
-            idx.search_bruteforce_dev(q.data_ptr(), B2, D2, k, m, 0, ws2[j].data_ptr(), ws_b, o2[j][0].data_ptr(), o2[j][1].data_ptr(), o2[j][2].data_ptr(), s2[j].cuda_stream)
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t0
-        same2 = bool(torch.equal(o2[0][0], o2[1][0]) and torch.equal(o2[0][1], o2[1][1]))
-        del ws2, o2
+        # (r5: the same batches alternated over TWO streams, a workspace each -- hoping a batch's small launches would overlap the next
+        # batch's scan -- measured 353k QPS against 396k on one stream: two scans resident at once slow each other more than the
+        # overlap saves; not reported)
         out[name] = {"qps": B2 * steps / el, "ms_per_batch": el / steps * 1e3,
-                     "two_streams": {"qps": B2 * steps / el2, "ms_per_batch": el2 / steps * 1e3, "same_results_on_both_streams": same2,
-                                     "note": "batches alternate between two streams with their own workspaces: a batch's small launches overlap the next batch's scan"},
                      "roofline": {"bound": "mfma", "kernel": "k_bf_scan5<f32> / k_i8_stream<0> (fp32 MFMA)" if name == "f32" else KERNEL_NAMES[name],
                                   "kernel_ms_avg": kms / kn, "timed_regions": kn, "achieved": ach, "peak": PEAK_TFLOPS[name],
                                   "unit": "TFLOP/s" if name != "i8" else "TOP/s", "frac": ach / PEAK_TFLOPS[name]}}
@@ -974,7 +960,7 @@ def main():
                                                        **{kk: vv for kk, vv in gl.items() if kk not in ("build_s", "build_rows_per_s")}, "graph": "the index of " + nm}
         c2 = c2_leg(zv, torch, dev, stream, K, modes=("f32", "bf16"))[0]
         paths["c2_1Mx128_b256_f32"] = {"value": c2["f32"]["qps"], "unit": "QPS", "rows": c2["rows"], "dim": c2["dim"], "batch": c2["batch"],
-                                       "ms_per_batch": c2["f32"]["ms_per_batch"], "two_streams": c2["f32"]["two_streams"], "roofline": c2["f32"]["roofline"],
+                                       "ms_per_batch": c2["f32"]["ms_per_batch"], "roofline": c2["f32"]["roofline"],
                                        "certificate": c2["certificate"]}
         # the same shape on the bf16 screen: since r4 its results are CERTIFIED to be the fp32 route's (proof per query or exact scan)
         paths["c2_1Mx128_b256_bf16_certified"] = {"value": c2["bf16"]["qps"], "unit": "QPS", "rows": c2["rows"], "dim": c2["dim"], "batch": c2["batch"],
