@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("fuzz_compat.py", 16, 12),       # reference-compat insert on every layer + search, incl. tie-heavy grids
     ("fuzz_ef.py", 24, 7),            # ef-mode beam search on random kNN graphs vs the oracle's ef spec: fp32 / bf16 rows, register and LDS beam kernels
     ("fuzz_stream.py", 6, 14),        # large shards: stream kernels (bf16 / int8 / fp4), guessed + verified thresholds, wide k
+    ("fuzz_exact_scan.py", 24, 5),    # the certificate's repair pass alone: ragged shapes, 1 .. 100 listed queries, k up to 240, ties, every metric, bf16 rows
 ])
 def test_seeded_fuzz_sweep(script, cases, seed):
     import zvdb_amd
