@@ -36,6 +36,110 @@ KERNEL_NAMES = {"bf16": "k_bf16_stream<48,1,false,KPV,0>, KPV = 64 / 128 / 256 l
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "i8": 5000.0, "fp4": 10000.0}  # dense MFMA peaks (i8 = 2x, fp4 = 4x bf16 per clock), MI355X_MICROARCH.md
 ELT_BYTES = {"bf16": 2.0, "f32": 4.0, "i8": 1.0, "fp4": 0.5}
 
+LINE_LIMIT = 4096  # bytes of the final stdout line (the driver's record keeps the tail of stdout only: r5 lost a 20 KB line)
+
+
+def _r(x, nd=4):
+    """Round floats for the compact line (full precision stays in the full record)."""
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 2}g}") if abs(x) < 1 else round(x, nd)
+    return x
+
+
+def compact_line(out, full_name):
+    """The contract line: the metric, the workload, `roofline` and `cpu_baseline` objects with numbers and short names only.
+    Everything else (secondary routes, the reference benchmark's 16-cell sweep, per-batch settle lists, explanatory notes)
+    is in the full record `full_name`."""
+    cfg, rf = out["config"], out["roofline"]
+    kern = rf.get("kernel", "")
+    kern = kern.split(",")[0].split(" (")[0].split("<")[0]
+    line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_max", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data", "recall_at_10") if k in out}
+    line["config"] = {"workload": cfg["workload"][:160]}
+    for k in ("rows", "dim", "batch", "k", "route", "row_dtype", "data", "parallelism", "settle_batches_before_warmup", "ef", "M", "tuning"):
+        if cfg.get(k) is not None:
+            line["config"][k] = cfg[k]
+    line["roofline"] = {"bound": rf["bound"], "kernel": kern}
+    for k in ("achieved", "peak", "unit", "frac", "traffic", "kernel_ms_avg", "timed_regions", "algorithmic_flops_per_launch",
+              "algorithmic_bytes_per_launch", "hbm_achieved_GBps", "dist_evals_per_query", "pops_per_query"):
+        if k in rf:
+            line["roofline"][k] = _r(rf[k])
+    cb = out.get("cpu_baseline")
+    if cb is None:
+        line["cpu_baseline"] = None
+    else:
+        c = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
+        c["sample"] = str(cb.get("sample", ""))[:200]
+        for k in ("gpu_result_check", "sample_rows_missed_by_gpu", "full_check"):
+            if k in cb:
+                c[k] = cb[k] if not isinstance(cb[k], str) else cb[k][:80]
+        rh = cb.get("reference_harness")
+        if rh:
+            h = {"shape": "%dx%d, %d queries, k=%d (shared_benchmarks.zig:61-125)" % (rh["shape"]["points"], rh["shape"]["dim"], rh["shape"]["queries"], rh["shape"]["k"]),
+                 "cpu_search_qps": _r(rh["cpu"]["search_qps"], 1), "cpu_insert_pts_per_s": _r(rh["cpu"]["insert_pts_per_s"], 1), "cpu_cores": rh["cpu"]["cores"],
+                 "gpu_search_qps_batched": _r(rh["gpu"].get("search_qps_batched_host_api"), 1),
+                 "gpu_insert_many_pts_per_s": _r(rh["gpu"].get("insert_many_pts_per_s"), 1),
+                 "gpu_search_per_call_us": _r(rh["gpu"].get("search_per_call_c_abi_us"), 2),
+                 "gpu_insert_per_call_us": _r(rh["gpu"].get("insert_per_call_us"), 2),
+                 "bit_exact": bool(rh["gpu"].get("bit_exact_vs_oracle_first_200_queries")) and bool(rh["gpu"].get("search_per_call_c_abi_bit_exact_first_200", True))}
+            sw = rh.get("sweep")
+            if sw:
+                cells = {n: c_ for n, c_ in sw["cells"].items() if "cpu_port_qps_1thread" in c_}
+                worst = min(cells, key=lambda n: cells[n]["gpu_batched_qps_host_api"] / cells[n]["cpu_port_qps_1thread"]) if cells else None
+                h["sweep"] = {"cells": len(sw["cells"]), "all_bit_exact": sw["all_bit_exact"]}
+                if worst:
+                    w = cells[worst]
+                    h["sweep"]["worst_cell"] = {"cell": worst, "cpu_qps": _r(w["cpu_port_qps_1thread"], 1), "gpu_batched_qps": _r(w["gpu_batched_qps_host_api"], 1),
+                                                "gpu_per_call_us": _r(w.get("gpu_per_call_us"), 2)}
+            c["reference_harness"] = h
+        line["cpu_baseline"] = c
+    if "certificate" in out:
+        ce = out["certificate"]
+        line["certificate"] = {k: ce[k] for k in ("queries", "repaired", "level", "survivors_kept") if k in ce}
+    if "settle" in out:
+        st = out["settle"]
+        line["settle"] = {k: _r(st[k]) for k in ("batches", "settle_ms_total", "repaired_queries", "repaired_queries_in_warmup_and_timed_steps") if k in st}
+    if "collective" in out:
+        co = out["collective"]
+        line["collective"] = {k: _r(co[k]) for k in ("ranks", "ranks_reporting", "distinct_devices", "all_gather_us", "bytes_per_rank") if k in co}
+        line["collective"]["via"] = "rccl_in_lib" if "ncclAllGather" in co.get("source", "") else "torch.distributed"
+    if "paths" in out:
+        line["paths"] = {}
+        for n, p in out["paths"].items():
+            e = {"value": _r(p["value"], 1)}
+            if isinstance(p.get("roofline"), dict):
+                e["frac"] = _r(p["roofline"]["frac"])
+            for rk in ("recall_at_10", "recall_at_k"):
+                if rk in p:
+                    e["recall"] = _r(p[rk])
+            line["paths"][n] = e
+    if out.get("headline_note"):
+        line["headline_note"] = out["headline_note"][:160]
+    line["full_record"] = full_name
+    s = json.dumps(line, separators=(",", ":"))
+    for drop in ("paths", "settle", "certificate"):  # (never expected: the line above is ~3 KB)
+        if len(s) >= LINE_LIMIT and drop in line:
+            del line[drop]
+            s = json.dumps(line, separators=(",", ":"))
+    assert len(s) < LINE_LIMIT, f"contract line is {len(s)} bytes"
+    return s
+
+
+def emit(out):
+    """Full record -> bench_full.json (beside the script, and under gpurun_out/ so it travels back from a GPU box); the compact
+    contract line -> the LAST line of stdout."""
+    full = json.dumps(out)
+    name = "bench_full.json"
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
+    sys.stdout.flush()
+    print(compact_line(out, name), flush=True)
+
 
 def parse_args():
     ap = argparse.ArgumentParser()
@@ -984,16 +1088,19 @@ def main():
             if args.measure_traffic and measured_traffic is not None:
                 traffic, traffic_src = measured_traffic["hbm_bytes_per_step"], measured_traffic["source"]
             else:
-                tf = os.path.join(ROOT, "profiles", "r5", "traffic_10Mx768.json")
-                tj = json.load(open(tf)).get("bf16") if os.path.exists(tf) else None
-                if tj and (tj["rows"], tj["dim"], tj["batch"]) == (N, D, B):
+                # (the newest round's file whose stamp matches this tree's kernel source wins; a file measured on another version is refused)
+                for rnd in ("r6", "r5"):
+                    tf = os.path.join(ROOT, "profiles", rnd, "traffic_10Mx768.json")
+                    tj = json.load(open(tf)).get("bf16") if os.path.exists(tf) else None
+                    if not tj or (tj["rows"], tj["dim"], tj["batch"]) != (N, D, B):
+                        continue
                     if tj.get("kernel_source_sha256") == sha:
                         traffic = tj["hbm_bytes_per_step"]
-                        traffic_src = ("profiles/r5/traffic_10Mx768.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes; "
+                        traffic_src = (f"profiles/{rnd}/traffic_10Mx768.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes; "
                                        f"stamped kernel {tj.get('kernel')}, source sha256 {sha[:12]} = this tree's)")
-                    else:
-                        traffic_src = ("profiles/r5/traffic_10Mx768.json REFUSED: measured on another version of bf_bf16_stream.hip "
-                                       f"(file {str(tj.get('kernel_source_sha256'))[:12]}, tree {str(sha)[:12]}); run tools/prof_r5.sh or --measure-traffic")
+                        break
+                    traffic_src = (f"profiles/{rnd}/traffic_10Mx768.json REFUSED: measured on another version of bf_bf16_stream.hip "
+                                   f"(file {str(tj.get('kernel_source_sha256'))[:12]}, tree {str(sha)[:12]}); run tools/prof_r6.sh or --measure-traffic")
         out = {
             "metric": "QPS at recall@10>=0.95, 10Mx768 fp32, batch=1024",
             "value": qps,
@@ -1037,14 +1144,14 @@ def main():
                 "timed_regions": kern_n,
                 "region": ("per step: sample-moments launch + threshold guess + ONE scan of the whole shard (stream kernel) + verifying merge "
                            "+ gated repair scan/merge (no-ops when the guess held); the scan is ~99 % of the region "
-                           "(profiles/r4/: rocprofv3 kernel stats of this command)" if args.mode in ("fp4", "i8", "bf16") else
+                           "(profiles/r6/bench_10Mx768_bf16_stream_kernel_stats.csv: rocprofv3 kernel stats of this command)" if args.mode in ("fp4", "i8", "bf16") else
                            "per step: row-sample moments (k_sample_guess) + thresholds + ONE scan of the whole shard (staged 256 x 256 kernel) + verifying "
                            "merge + gated repair scan/merge (no-ops when the guess held)"),
                 "peak_note": ("spec dense fp4 MFMA peak; tools/mfma_peak_bench.hip measures 6.7 PFLOP/s for back-to-back "
                               "v_mfma_scale_f32_32x32x64_f8f6f4 on random operands (the chip lowers its clock under load)" if args.mode == "fp4" else
                               "spec dense bf16 MFMA peak (2.4 GHz); on random bf16 operands the chip is power-limited: the bare "
                               "v_mfma_f32_32x32x16_bf16 loop holds 1.99 PFLOP/s (profiles/r1/mfma_peak_bench.txt) and this kernel's loop "
-                              "holds ~1.85 GHz with the MFMA pipes busy 0.82 of the cycles (rocprofv3 SQ counters: profiles/r3/pmc_mfma_utilisation_bf16_stream.txt; the scan loop is unchanged in r4)" if args.mode == "bf16" else None),
+                              "holds ~1.85 GHz with the MFMA pipes busy 0.82 of the cycles (rocprofv3 SQ counters: profiles/r3/pmc_mfma_utilisation_bf16_stream.txt)" if args.mode == "bf16" else None),
                 "hbm_achieved_GBps": float(n_local) * D * ELT_BYTES[args.mode] / kavg / 1e9 if kavg > 0 else 0.0,
                 "hbm_peak_GBps": 8000.0,
                 "algorithmic_flops_per_launch": flops,
@@ -1105,7 +1212,11 @@ def main():
             out["cpu_baseline"]["reference_harness"] = reference_harness(zv)
             if not args.no_sweep:
                 out["cpu_baseline"]["reference_harness"]["sweep"] = reference_sweep(zv)
-        print(json.dumps(out), flush=True)
+        elif world > 1:
+            # N > 1: the CPU leg runs at N = 1 only (the contract's rule); the key is still carried so that every line has the same shape
+            out["cpu_baseline"] = {"value": None, "unit": "QPS", "cores": 0, "kind": "port",
+                                   "sample": "not timed at N > 1: rank 0 runs the bounded CPU sample at N = 1 only (see the N = 1 line)"}
+        emit(out)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

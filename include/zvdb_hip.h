@@ -365,7 +365,8 @@ typedef struct zvdb_hip_cert_info {
     uint64_t rerank_rows; /* diagnostic (tuning ZVDB_CERT_DEBUG=1): candidate rows the re-rank evaluated exactly, modulo 2^32 */
     uint32_t rerank_cycles[5]; /* diagnostic: 100-MHz ticks of every 64th query's re-rank, summed per phase: query constants, first
                                   (staged) batch, further candidates, final bound, ranking + output */
-    uint32_t reserved_;
+    uint32_t guess_misses; /* queries whose guessed threshold was too tight (repaired by the exact scan when a batch has <= 32 of them -- those also
+                              count under `repaired` -- else by one gated re-scan of the corpus); they do not raise `level` */
     uint32_t bound_checked;    /* diagnostic (tuning ZVDB_CERT_DEBUG=3): evaluated candidates whose screen key was held against the bound of */
     uint32_t bound_violations; /* their own exact distance, and how many exceeded it (must be 0: the inequality of bf_cert.h on real hardware) */
 } zvdb_hip_cert_info;

@@ -33,7 +33,7 @@ class SearchStats(C.Structure):
 class CertInfo(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("batches", C.c_uint64), ("repaired", C.c_uint64),
                 ("level", C.c_uint32), ("enabled", C.c_uint32), ("rerank_rows", C.c_uint64),
-                ("rerank_cycles", C.c_uint32 * 5), ("reserved_", C.c_uint32),
+                ("rerank_cycles", C.c_uint32 * 5), ("guess_misses", C.c_uint32),
                 ("bound_checked", C.c_uint32), ("bound_violations", C.c_uint32)]
 
 

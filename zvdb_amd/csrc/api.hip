@@ -1669,6 +1669,7 @@ int zvdb_hip_bruteforce_cert_info(zvdb_hip_index *h, zvdb_hip_cert_info *out) {
     out->enabled = h->cert_on ? 1u : 0u;
     out->rerank_rows = h->cert_host ? (uint64_t)__atomic_load_n(h->cert_host + 2, __ATOMIC_RELAXED) : 0;
     for (int i = 0; i < 5; ++i) out->rerank_cycles[i] = h->cert_host ? __atomic_load_n(h->cert_host + 3 + i, __ATOMIC_RELAXED) : 0;
+    out->guess_misses = h->cert_host ? __atomic_load_n(h->cert_host + 10, __ATOMIC_RELAXED) : 0;
     out->bound_checked = h->cert_host ? __atomic_load_n(h->cert_host + 8, __ATOMIC_RELAXED) : 0;
     out->bound_violations = h->cert_host ? __atomic_load_n(h->cert_host + 9, __ATOMIC_RELAXED) : 0;
     return ZVDB_OK;

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
 // moments -> guessed threshold tau = -(mean acc) + z sigma per query (see k_fp4_guess); mom = [block][256][2] + [block] rows
 __global__ __launch_bounds__(64) void k_bf16_guess(const float *__restrict__ mom, uint32_t nblocks, uint32_t QT, uint32_t S, uint32_t nq,
                                                    float z, uint32_t *__restrict__ tau_g, uint32_t *__restrict__ verify_flag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) { verify_flag[0] = 0; verify_flag[1] = 0; }  // ([1]: deficient queries of the batch)
     const int lane = threadIdx.x;
     const uint32_t qg = blockIdx.x, qt = qg / T2, q = qg % T2;
     double s1 = 0.0, s2 = 0.0, n = 0.0;

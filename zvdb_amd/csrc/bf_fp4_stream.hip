@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void k_fp4_stream(
 __global__ __launch_bounds__(64) void k_fp4_guess(const float *__restrict__ mom, uint32_t nblocks, uint32_t QT, uint32_t S,
                                                   uint32_t nq, float z, uint32_t *__restrict__ tau_g,
         uint32_t *__restrict__ verify_flag /* cleared here: saves a memset launch */) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) { verify_flag[0] = 0; verify_flag[1] = 0; }  // ([1]: deficient queries of the batch)
     const int lane = threadIdx.x;
     const uint32_t qg = blockIdx.x, qt = qg / T2, q = qg % T2;
     double s1 = 0.0, s2 = 0.0, n = 0.0;

@@ -555,8 +555,9 @@ uint32_t ncross = 0;
 // gated repair scan re-reads the corpus for those queries only); other queries get tau_out[q] = 0 ("nothing
 // passes").  vmode 2 (repair merge, lists [l0, l0 + S)): a no-op unless *flag, and then only for defq queries.
 // vmode 3 (verification under the certificate): a deficient query is handed to the certificate's own repair -- its k'-th key is
-// written as 0, which no safe key undercuts, so the re-rank lists it and the exact scan recomputes it (exact_scan.hip): no
-// gated repair scan / repair merge launches behind this one.
+// written as 0, which no safe key undercuts, so the re-rank lists it and the exact scan recomputes it (exact_scan.hip) -- as long
+// as the batch has at most defer_max of them; beyond that *flag is raised and the gated pair behind this launch (repair scan +
+// vmode-2 merge, both no-ops otherwise) repairs them all with one more read of the corpus.
 __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict__ partial,
                                                      const uint32_t *__restrict__ pcnt, uint32_t S, uint32_t Stot,
                                                      uint32_t *__restrict__ cand_ids, uint32_t *__restrict__ tau_out,
@@ -568,7 +569,9 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
                                                      uint32_t *__restrict__ kth_out = nullptr /* ... and the k'-th key per query (0xFFFFFFFF: fewer than k' rows exist) */,
                                                      uint32_t *__restrict__ cert_nflag = nullptr /* the repair list's counter: reset here, ahead of the re-rank that fills it */,
                                                      uint32_t lw = kWave /* lists taken per round (one lane each): cap >= kp + lw * lkp -- 16 for the wide lists keeps the pool at
-                                                                            17 - 35 KB instead of 67 - 133 KB, i.e. 4+ workgroups per CU instead of 1 - 2 */) {
+                                                                            17 - 35 KB instead of 67 - 133 KB, i.e. 4+ workgroups per CU instead of 1 - 2 */,
+                                                     uint32_t *__restrict__ miss_ctr = nullptr /* vmode 3, mapped host memory: guess misses (cumulative; cert_info.guess_misses) */,
+                                                     uint32_t defer_max = 0xFFFFFFFFu /* vmode 3: more deficient queries than this in the batch -> *flag = 1 (gated pair) */) {
     if (cert_nflag && vmode != 2 && blockIdx.x == 0 && threadIdx.x == 0) { cert_nflag[0] = 0; cert_nflag[1] = 0; }  // ([1]: the exact scan's finished-block counter)
     if (vmode == 2 && (*flag == 0 || defq[blockIdx.x] == 0)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -646,7 +649,20 @@ __global__ __launch_bounds__(64) void k_bf_merge_sel(const uint64_t *__restrict_
         }
     }
     if (vmode == 3) {
-        if (lane == 0 && n < kp && host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the next guesses are looser)
+        // a few stragglers go to the exact scan (their k'-th key 0 makes the re-rank list them); a batch with MORE than defer_max
+        // of them (a guess too tight for the whole batch: distribution shift) raises *flag instead, and the gated repair scan +
+        // repair merge behind this launch re-read the corpus once for all of them -- an exact scan per query would cost
+        // ~0.8 ms x the batch at 10M x 768.  flag[1] counts the deficient queries of this batch (zeroed by the guess kernel).
+        if (lane == 0) {
+            const bool deficient = n < kp;
+            if (defq) defq[q] = deficient ? 1u : 0u;
+            if (tau_out) tau_out[q] = deficient ? 0xFFFFFFFFu : 0u;
+            if (deficient) {
+                if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the next guesses are looser)
+                if (miss_ctr) __hip_atomic_fetch_add(miss_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (flag && atomicAdd(flag + 1, 1u) == defer_max) atomicOr(flag, 1u);
+            }
+        }
     } else if (vmode == 1) {
         if (lane == 0) {
             const bool deficient = n < kp;
@@ -852,7 +868,7 @@ __global__ __launch_bounds__(256) void k_sample_guess(const RT *__restrict__ row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *q = reinterpret_cast<float *>(smem);                      // [SG_Q][ld], zero padded like the rows (ld: a multiple of 32)
     double *red = reinterpret_cast<double *>(q + (size_t)SG_Q * ld);  // [4 waves][SG_Q][2]
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && verify_flag) verify_flag[0] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && verify_flag) { verify_flag[0] = 0; verify_flag[1] = 0; }
     // the scan's query operand (fp32 copy / bf16, zero padded), this workgroup's share: one launch fewer per batch (k_bf_prep_queries)
     if (prep_out)
         bf_prep_queries_body(queries, nq, dim, prep_out, nq_pad, row_elems, prep_mode, 0.0f, 1.0f, 0,
@@ -1149,6 +1165,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // under the certificate a query whose guessed threshold was too tight goes to the exact scan instead of a gated second scan + merge
     // (ZVDB_BF_CERT_DEFER=0: the gated pair, as without the certificate)
     const bool cert_defer = cert && [] { const char *e = tuning("ZVDB_BF_CERT_DEFER"); return !e || e[0] != '0'; }();
+    // ... for at most this many queries of a batch (an exact scan per query: ~0.8 ms each at 10M x 768); a batch with more of them
+    // is repaired by the gated scan + merge pair, which then follows the verifying merge as two no-op launches
+    const uint32_t defer_max = [] { const char *e = tuning("ZVDB_BF_DEFER_MAX"); return e ? (uint32_t)atoi(e) : 32u; }();
     auto finish = [&](uint32_t kp_valid) -> int {
         if (!cert) return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid);
         CertArgs ca;
@@ -1263,15 +1282,18 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
             if (mlds > 64 * 1024)
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-            if (cert_defer) {  // a guess that was too tight for a query is repaired by the certificate's exact scan: two launches fewer per batch
+            if (cert_defer) {  // a guess that was too tight for a FEW queries is repaired by the certificate's exact scan ...
                 hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
-                                   kp, cap, 0u, 3, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
-                timing_end(h, s);
-                ZV_HIP(hipGetLastError());
-                return finish(kp);
+                                   kp, cap, 0u, 3, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw, h->cert_hdev + 10, defer_max);
+                if (nq <= defer_max) {  // (... and a batch this small cannot hold more than a few: two launches fewer)
+                    timing_end(h, s);
+                    ZV_HIP(hipGetLastError());
+                    return finish(kp);
+                }
+            } else {
+                hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
+                                   kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             }
-            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, SS, Stot, cand_ids, tau_rep,
-                               kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (sf) ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
@@ -1331,13 +1353,16 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 ZV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_merge_sel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
             if (cert_defer) {
                 hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 3, vflag, defq,
+                                   h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw, h->cert_hdev + 10, defer_max);
+                if (nq <= defer_max) {
+                    timing_end(h, s);
+                    ZV_HIP(hipGetLastError());
+                    return finish(kp);
+                }
+            } else {
+                hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 1, vflag, defq,
                                    h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
-                timing_end(h, s);
-                ZV_HIP(hipGetLastError());
-                return finish(kp);
             }
-            hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, tau_rep, kp, cap, 0u, 1, vflag, defq,
-                               h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             ZV_CHECK(scan1(tau_rep, p.S, vflag));
             hipLaunchKernelGGL(k_bf_merge_sel, dim3(nq), dim3(64), mlds, s, partial, pcnt, p.S, Stot, cand_ids, (uint32_t *)nullptr, kp, cap, p.S, 2, vflag,
                                defq, (uint32_t *)nullptr, kpv, ckeys, kth, nflag, mlw);

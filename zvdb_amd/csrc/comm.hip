@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <new>
 #include <string>
 
 #include "common.h"
@@ -90,6 +91,17 @@ struct zvdb_hip_comm {
 
 using namespace zvdb;
 
+namespace {
+// puts the calling thread back on the device it was on
+struct DeviceGuard {
+    int prev;
+    explicit DeviceGuard(int p) : prev(p) {}
+    ~DeviceGuard() { (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+}  // namespace
+
 extern "C" {
 
 int zvdb_hip_comm_unique_id(void *out_id) {
@@ -119,15 +131,16 @@ int zvdb_hip_comm_create(uint32_t rank, uint32_t world, const void *unique_id, i
     int prev = 0;
     ZV_HIP(hipGetDevice(&prev));
     if (device < 0) device = prev;
+    DeviceGuard guard(prev);  // the calling thread's current device is the caller's business: restored on every way out
     ZV_HIP(hipSetDevice(device));
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof(id));
-    zvdb_hip_comm *c = new zvdb_hip_comm;
+    zvdb_hip_comm *c = new (std::nothrow) zvdb_hip_comm;
+    if (!c) { set_error("comm_create: out of memory"); return ZVDB_ERR_OOM; }
     c->rank = rank;
     c->world = world;
     c->device = device;
     ncclResult_t r = rccl().CommInitRank(&c->comm, (int)world, id, (int)rank);
-    (void)hipSetDevice(prev);  // the calling thread's current device is the caller's business
     if (r != ncclSuccess) {
         set_error("ncclCommInitRank failed: %s", rccl().GetErrorString(r));
         delete c;
@@ -209,7 +222,14 @@ static int gather_and_merge(zvdb_hip_comm *c, unsigned char *ws, uint32_t nq, ui
     const bool timed = c->timing_on && c->timing_n < (uint32_t)zvdb_hip_comm::kTimingSlots;
     const uint32_t slot = c->timing_n;
     if (timed) {
-        if (!c->ev0[slot]) { ZV_HIP(hipEventCreate(&c->ev0[slot])); ZV_HIP(hipEventCreate(&c->ev1[slot])); }
+        if (!c->ev0[slot]) {  // (events belong to the communicator's device, whatever device the calling thread is on)
+            int prev = 0;
+            ZV_HIP(hipGetDevice(&prev));
+            DeviceGuard guard(prev);
+            ZV_HIP(hipSetDevice(c->device));
+            ZV_HIP(hipEventCreate(&c->ev0[slot]));
+            ZV_HIP(hipEventCreate(&c->ev1[slot]));
+        }
         ZV_HIP(hipEventRecord(c->ev0[slot], s));
     }
     ZV_NCCL(rccl().AllGather(ws, ws + pb, pb, ncclUint8, c->comm, s));

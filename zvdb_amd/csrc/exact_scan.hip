@@ -387,6 +387,7 @@ __global__ __launch_bounds__(XS_T) void k_exact_scan(XsArgs a, uint32_t *__restr
         else if (per == 16) xs_pass<RT, 16>(a, g0, nqg, smem);
         else xs_pass<RT, 32>(a, g0, nqg, smem);
     }
+    __threadfence();   // every wave that wrote partial lists: its own stores are out (agent scope) before the barrier lets thread 0 count
     __syncthreads();   // (every wave's partial lists are stored)
     if (threadIdx.x == 0) {
         __threadfence();   // release: this block's lists before its count
@@ -434,7 +435,8 @@ int launch_exact_scan(const zvdb_hip_index *h, const float *d_queries, uint32_t 
     ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = row_elem_t<decltype(rows)>;
         const size_t lds = std::max<size_t>(xs_lds<RT>(nq_pass, cap), (size_t)XS_MERGERS * XS_MERGE_LDS);
-        if (lds > 160 * 1024) { set_error("exact scan: LDS plan of %zu bytes", lds); return ZVDB_ERR_UNSUPPORTED; }
+        // (gfx950 only: the 512-row tile alone is 72 KB and a 32-query pass plans ~160 KB -- the CDNA4 LDS; a device with less fails here, loudly)
+        if (lds > 160 * 1024) { set_error("exact scan: LDS plan of %zu bytes exceeds the 160 KB of a gfx950 CU", lds); return ZVDB_ERR_UNSUPPORTED; }
         XsArgs a;
         a.rows = rows; a.ld = ld; a.dim = h->dim; a.metric = metric; a.N = N;
         a.queries = d_queries; a.flist = flist; a.k = k; a.id_offset = id_offset;

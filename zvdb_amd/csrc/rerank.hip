@@ -26,7 +26,9 @@ __device__ __forceinline__ void cert_verdict(const CertArgs &cert, uint32_t qi, 
     if (!cert.force && (kth == 0xFFFFFFFFu || ks < kth)) return;  // every row is a survivor / no row left out can reach the top-k
     const uint32_t slot = atomicAdd(cert.nflag, 1u);
     cert.flist[slot] = qi;
-    if (cert.host_flag) __hip_atomic_store(cert.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // kth == 0: not a failed proof but a guess miss handed over by the verifying merge (k_bf_merge_sel vmode 3) -- it loosens the
+    // next guesses through its own flag and says nothing about the survivors the proof needs: the level stays where it is
+    if (cert.host_flag && kth != 0u) __hip_atomic_store(cert.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // number of valid entries of the LDS lists [0, n) (n a multiple of 4, the arrays 16-byte aligned) that precede (di, ii) in
 // (distance, id) order.  Four entries per 16-byte LDS read, four reads in flight: the plain one-entry loop is a chain of dependent

@@ -228,7 +228,7 @@ class Index:
         check(self._L.zvdb_hip_bruteforce_cert_info(self._h, C.byref(ci)))
         return {"queries": ci.queries, "batches": ci.batches, "repaired": ci.repaired, "level": ci.level,
                 "enabled": bool(ci.enabled), "rerank_rows": ci.rerank_rows, "rerank_cycles": list(ci.rerank_cycles),
-                "bound_checked": ci.bound_checked, "bound_violations": ci.bound_violations}
+                "guess_misses": ci.guess_misses, "bound_checked": ci.bound_checked, "bound_violations": ci.bound_violations}
 
     def set_screen_survivors(self, survivors: int) -> None:
         """Minimum number of fp4-screen survivors re-ranked exactly per query (0 = from k; 64, 128 or 256)."""
