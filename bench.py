@@ -180,6 +180,9 @@ def parse_args():
                     help="collect the scan's HBM traffic in THIS run: two child runs of this command under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; "
                          "started before this process touches the GPU), ~1.5 min more; default: the stamped file under profiles/")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-check", action="store_true",
+                    help="cpu_baseline leg: also check 16 queries of the headline batch against the oracle's exact top-k over ALL rows "
+                         "(corpus regenerated slice by slice on the host threads; ~30 s more at 10M x 768)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the reference benchmark's dims x k sweep (part of the cpu_baseline leg, ~1 min)")
     ap.add_argument("--rehearse-shard-of", type=int, default=0, metavar="G",
                     help="(experiments, 1 GPU) time ONE shard of a G-way run: rows/G rows, the shard's survivor share")
@@ -239,7 +242,16 @@ def cpu_baseline(args, gpu_ids, gpu_dist, q_host):
             if dist[qi, j] < kth and int(ids[qi, j]) not in got:
                 missed += 1  # a sampled row beats the GPU's k-th result: a recall miss of the screen
     qps_sample = nqs / dt
+    full = None
+    if args.full_check:   # (off by default: ~30 s on 16 cores at 10M x 768) 16 queries against the exact top-k over EVERY row
+        t1 = time.perf_counter()
+        nf = min(16, len(q_host))
+        fi, fd, _ = oracle.bruteforce_topk_synthetic(CORPUS_SEED, args.rows, args.dim, q_host[:nf], args.k, threads=threads)
+        same = bool(np.array_equal(fi, gpu_ids[:nf]) and np.array_equal(fd.view(np.uint32), np.ascontiguousarray(gpu_dist[:nf]).view(np.uint32)))
+        full = (f"{'ok' if same else 'MISMATCH'}: {nf} queries, ids and distance bit patterns vs the oracle's exact top-{args.k} over all {args.rows} rows "
+                f"({time.perf_counter() - t1:.1f} s, {threads} threads)")
     return {
+        **({"full_check": full} if full else {}),
         "value": qps_sample * (ns / args.rows),
         "unit": "QPS",
         "cores": threads,

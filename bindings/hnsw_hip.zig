@@ -6,6 +6,11 @@
 //! `zig build test` after applying bindings/build.zig.patch.  Its C++ twin, zvdb_amd/host/hnsw.hpp, has the same structure,
 //! is compiled and is what tests/cpp/test_hnsw_host.cpp (the reference's src/test_hnsw.zig restated) runs against.
 //!
+//! Beside the four reference signatures the struct has the two calls through which a device is worth having -- `insertMany`
+//! and `searchMany` (ids + distances, no Node copies): one launch per batch instead of one launch + one synchronisation per
+//! point / query.  They are the 1:1 twins of `HNSW::insert_many` / `HNSW::search_many` in hnsw.hpp, which are compiled and
+//! tested (tests/cpp/test_hnsw_host.cpp: bulk_calls_equal_per_call).
+//!
 //! What stays in Zig (north_star: "host-side graph bookkeeping stays in Zig"): ids, the owned copy of every point (search
 //! results alias it, test_hnsw.zig:67), every layer's adjacency lists, the level RNG, the mutex, error mapping.
 //! What runs on the GPU: `distance` (hnsw.zig:182-192) at every call site, the greedy neighbour-list scans
@@ -129,6 +134,86 @@ pub const HNSW_f32 = struct {
         const level = randomLevel(); // :78
         if (self.use_device_layers) return self.insertDeviceLayers(point, id, level);
         return self.insertStepByStep(point, id, level);
+    }
+
+    /// n inserts with the result of n `insert` calls in this order (extension: hnsw.zig:73 takes one point per call).
+    /// `points` is n rows of `dim` floats, row-major.  ONE `zvdb_hip_insert_batch` call carries the whole batch -- every layer's
+    /// scan, connect and shrinkConnections (:85-108) for all n points inside the device -- and the mirror then adopts, per point
+    /// and layer, the lists the device reports (the same records `insertDeviceLayers` reads for one point).  This is where the
+    /// device wins: ~470k inserts/s against ~43k/s through per-call `insert` (one launch + one synchronisation each) and
+    /// ~200k/s for the reference on one CPU core (100k x 128, INTEGRATION.md 3).  Twin: `HNSW::insert_many` (hnsw.hpp).
+    /// Only for an index on the device-layers binding (the default); a step-by-step index takes `insert` per point.
+    pub fn insertMany(self: *Self, points: []const f32, dim: usize) !void {
+        self.mutex.lock(); // :74-75
+        defer self.mutex.unlock();
+        if (dim == 0 or points.len % dim != 0) return error.DeviceError;
+        const n = points.len / dim;
+        if (n == 0) return;
+        try self.ensureDevice(dim);
+        if (!self.use_device_layers) return error.DeviceError;
+        const levels = try self.allocator.alloc(u32, n);
+        defer self.allocator.free(levels);
+        var total: usize = 0;
+        for (levels) |*lv| { // :78, drawn here in insertion order: the binding owns the RNG
+            const level = randomLevel();
+            lv.* = @intCast(level);
+            total += level + 1;
+        }
+        const rw = 4 + self.m; // record = {ep, owner's list length, ep's list length, ep has the layer, ep's list[m]}
+        const nrec = try self.allocator.alloc(u32, n);
+        defer self.allocator.free(nrec);
+        const recs = try self.allocator.alloc(u32, total * rw);
+        defer self.allocator.free(recs);
+        var first: u64 = 0;
+        try check(c.zvdb_hip_insert_batch(self.dev, points.ptr, @intCast(dim), n, levels.ptr, &first, nrec.ptr, recs.ptr, total));
+        std.debug.assert(first == self.nodes.count());
+        try self.nodes.items.ensureUnusedCapacity(n);
+        var r: usize = 0; // cursor into the records: point i owns nrec[i] of them, lowest layer first
+        for (0..n) |i| {
+            const id = self.nodes.count(); // :77
+            const level: usize = levels[i];
+            const node = try Node.init(self.allocator, id, points[i * dim ..][0..dim], level); // :79
+            self.nodes.items.appendAssumeCapacity(node); // :82 (the list owns it from here: `deinit` frees it)
+            if (self.entry_point != null) { // :84
+                for (0..nrec[i]) |l| { // layers 0 .. min(level, max_level): where connect ran (:106)
+                    const rec = recs[r * rw ..][0..rw];
+                    r += 1;
+                    const ep: usize = rec[0];
+                    const own = &self.nodes.items.items[id].connections[l];
+                    own.clearRetainingCapacity();
+                    if (rec[1] != 0) try own.append(ep);
+                    if (rec[3] != 0) {
+                        const lst = &self.nodes.items.items[ep].connections[l];
+                        lst.clearRetainingCapacity();
+                        for (rec[4 .. 4 + rec[2]]) |nb| try lst.append(nb);
+                    }
+                }
+            } else {
+                self.entry_point = id; // :110-112
+            }
+            if (level > self.max_level) self.max_level = level; // :114-116
+        }
+    }
+
+    /// nq searches in ONE device launch (extension: hnsw.zig:194 takes one query per call): for query q the ids and squared-L2
+    /// distances `search(queries[q], k)` would return, in its order, in `out_ids[q * k ..][0 .. out_count[q]]` /
+    /// `out_dist[...]` (unused slots: maxInt(u64) / +inf; fewer than k results are legal, test_hnsw.zig:122-125).  No `Node`
+    /// copies: a caller that wants the points reads `nodes.get(id).?.point`.  Per call through `search` the device answers one
+    /// query in ~34 us (a launch + a synchronisation; the reference on one CPU core: 12.5-13.7 us); through this call
+    /// it answers ~9M queries per second (100k x 128, k = 10: INTEGRATION.md 3).  Twin: `HNSW::search_many` (hnsw.hpp).
+    pub fn searchMany(self: *Self, queries: []const f32, dim: usize, k: usize, out_ids: []u64, out_dist: []f32, out_count: []u32) !void {
+        self.mutex.lock(); // :195-196
+        defer self.mutex.unlock();
+        if (dim == 0 or queries.len % dim != 0) return error.DeviceError;
+        const nq = queries.len / dim;
+        if (out_ids.len < nq * k or out_dist.len < nq * k or out_count.len < nq) return error.DeviceError;
+        @memset(out_count[0..nq], 0);
+        @memset(out_ids[0 .. nq * k], std.math.maxInt(u64));
+        @memset(out_dist[0 .. nq * k], std.math.inf(f32));
+        const entry = self.entry_point orelse return; // :201: an empty index answers nothing
+        if (nq == 0 or k == 0) return;
+        // ef = 0: the reference-compat expansion (:201-233) per query, one wave each, all queries in one launch
+        try check(c.zvdb_hip_search_graph(self.dev, queries.ptr, @intCast(nq), @intCast(dim), @intCast(k), 0, entry, out_ids.ptr, out_dist.ptr, out_count.ptr, null));
     }
 
     /// The whole of :85-108 in one device call; the mirror adopts what the device settled on.

@@ -296,6 +296,33 @@ def bruteforce_topk(V, Q, k: int, metric: int = 0):
     return ids, dist, cnt
 
 
+def bruteforce_topk_synthetic(seed: int, n: int, dim: int, Q, k: int, metric: int = 0, slice_rows: int = 125_000, threads: int = 16):
+    """Exact top-k of every query of Q over ALL n rows of the synthetic corpus `seed`, without holding the corpus: the rows are
+    regenerated slice by slice (uniform_rows), each slice answered by bruteforce_topk (hnsw.zig:182-192 distances, ties by lower
+    id), the per-slice lists merged by merge_topk.  Slices run on `threads` host threads (the C calls release the GIL).
+    10M x 768 x 16 queries: ~30 s on 16 cores.  Test / bench checker only."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    Q = _f32(Q)
+    nq = Q.shape[0]
+    firsts = list(range(0, n, slice_rows))
+    threads = max(1, min(threads, len(firsts), os.cpu_count() or 1))
+
+    def work(first):
+        rows = min(slice_rows, n - first)
+        V = uniform_rows(seed, first, rows, dim)
+        i, d, c = bruteforce_topk(V, Q, k, metric)
+        i += np.uint64(first)
+        return i, d, c
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(work, firsts))
+    ids = np.stack([p[0] for p in parts])
+    dist = np.stack([p[1] for p in parts])
+    cnt = np.stack([p[2] for p in parts])
+    return merge_topk(ids, dist, cnt, k)
+
+
 def merge_topk(ids, dist, count, k: int):
     ids = np.ascontiguousarray(ids, dtype=np.uint64)
     dist = _f32(dist)

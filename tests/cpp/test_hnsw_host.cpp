@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <thread>
 #include <vector>
@@ -136,6 +137,42 @@ static void consistency() {  // :275-317
     }
     std::puts("ok consistency");
 }
+// the bulk calls (extension; `insertMany` / `searchMany` of bindings/hnsw_hip.zig): the same index and the same answers as the
+// per-call API, in one device launch per batch
+static void bulk_calls_equal_per_call() {
+    const int n = 3000, d = 64, nq = 257, k = 10;
+    std::vector<float> pts((size_t)n * d), qs((size_t)nq * d);
+    std::uniform_real_distribution<float> unif(0.0f, 1.0f);
+    for (auto &v : pts) v = unif(g_rng);
+    for (auto &v : qs) v = unif(g_rng);
+    std::vector<int> levels(n);
+    for (int i = 0; i < n; ++i) levels[i] = (i * 7919) % 5 == 0 ? 1 + i % 3 : 0;
+    H a(16, 200), b(16, 200);
+    for (int i = 0; i < n; ++i) {
+        a.set_next_level(levels[i]);
+        a.insert(pts.data() + (size_t)i * d, d);
+    }
+    b.insert_many(pts.data(), n, d, levels.data());
+    EXPECT(a.count() == b.count() && a.max_level == b.max_level && a.entry_point == b.entry_point);
+    for (int i = 0; i < n; i += 37) EXPECT(a.connections(i) == b.connections(i));
+    std::vector<uint64_t> ids((size_t)nq * k);
+    std::vector<float> dist((size_t)nq * k);
+    std::vector<uint32_t> cnt(nq);
+    b.search_many(qs.data(), nq, d, k, ids.data(), dist.data(), cnt.data());
+    for (int q = 0; q < nq; ++q) {
+        auto r = a.search(qs.data() + (size_t)q * d, d, k);
+        EXPECT(r.size() == cnt[q]);
+        for (size_t j = 0; j < r.size(); ++j) {
+            EXPECT(r[j].id == ids[(size_t)q * k + j]);
+            EXPECT(a.last_distances()[j] == dist[(size_t)q * k + j]);
+            EXPECT(std::memcmp(r[j].point, b.point(ids[(size_t)q * k + j]), d * sizeof(float)) == 0);
+        }
+    }
+    H e(16, 200);  // an empty index answers nothing (hnsw.zig:201)
+    e.search_many(qs.data(), 3, d, k, ids.data(), dist.data(), cnt.data());
+    EXPECT(cnt[0] == 0 && cnt[1] == 0 && cnt[2] == 0 && ids[0] == ~0ull);
+    std::puts("ok bulk_calls_equal_per_call");
+}
 static void dimension_mismatch_panics() {  // hnsw.zig:183-185
     H h(16, 200);
     h.insert({1, 2, 3});
@@ -158,6 +195,7 @@ int main(int argc, char **argv) {
     single_point();
     edge_cases();
     dimension_mismatch_panics();
+    bulk_calls_equal_per_call();
     memory_leaks();
     large_dataset();
     consistency();

@@ -212,3 +212,42 @@ def test_the_bound_holds_on_every_row_the_rerank_evaluates(zv, oracle, metric):
                     idx.search_bruteforce(Q, k, m)
             ci = idx.cert_info()
             assert ci["bound_checked"] >= 12 * nq * k and ci["bound_violations"] == 0, (name, ci)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "i8", "f32"])
+def test_guess_misses_keep_the_level_and_a_batch_full_of_them_takes_one_rescan(zv, oracle, tuning, mode):
+    """A guessed threshold that is too tight is not a failed proof.  (1) A batch in which EVERY query's guess misses (forced:
+    ZVDB_BF_GUESS_ZSHIFT=-3; 256 > the 32 the exact scan takes) is repaired by the gated re-scan + merge behind the verifying merge:
+    no exact scans (`repaired` unchanged), `guess_misses` counts them, results = the oracle's.  (2) A small batch of misses (16 <=
+    32) goes to the exact scan: `repaired` counts them too.  (3) Neither raises the certificate's survivor level: the next
+    ordinary batch runs at the level the index had settled on (round 5 raised it for thousands of batches)."""
+    n, d, k = 600_000, 96, 10
+    m = {"bf16": zv.BF_BF16, "i8": zv.BF_I8, "f32": zv.BF_F32}[mode]
+    idx = zv.Index(dim=d, capacity=n, flags=zv.FLAG_BF16_MIRROR)
+    idx.add_synthetic(n, d, 0x5EED)
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    for b in range(4):  # (the level settles)
+        idx.search_bruteforce(oracle.uniform_rows(0xC0FFEE, b * 256, 256, d), k, m)
+    before = idx.cert_info()
+    tuning("ZVDB_BF_GUESS_ZSHIFT", "-3")
+    Q = oracle.uniform_rows(0xC0FFEE, 4 * 256, 256, d)
+    ids, dist, cnt = idx.search_bruteforce(Q, k, m)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q[:24], k)
+    _check(ids[:24], dist[:24], cnt[:24], ri, rd, rc)
+    mid = idx.cert_info()
+    assert mid["guess_misses"] - before["guess_misses"] >= 200, (before, mid)      # (nearly) every query missed ...
+    assert mid["repaired"] == before["repaired"], (before, mid)                      # ... and none went through an exact scan
+    Q2 = oracle.uniform_rows(0xC0FFEE, 5 * 256, 16, d)
+    ids2, dist2, cnt2 = idx.search_bruteforce(Q2, k, m)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q2, k)
+    _check(ids2, dist2, cnt2, ri, rd, rc)
+    small = idx.cert_info()
+    misses = small["guess_misses"] - mid["guess_misses"]
+    assert misses >= 12 and small["repaired"] - mid["repaired"] == misses, (mid, small)   # stragglers: the exact scan took them
+    tuning("ZVDB_BF_GUESS_ZSHIFT", None)
+    Q3 = oracle.uniform_rows(0xC0FFEE, 6 * 256, 256, d)
+    ids3, dist3, cnt3 = idx.search_bruteforce(Q3, k, m)
+    ri, rd, rc = oracle.bruteforce_topk(V, Q3[:24], k)
+    _check(ids3[:24], dist3[:24], cnt3[:24], ri, rd, rc)
+    after = idx.cert_info()
+    assert after["level"] == before["level"], (before, after)

@@ -448,3 +448,42 @@ def test_compat_search_from_two_streams(zv, oracle):
         torch.cuda.synchronize()
         got = [t.cpu().numpy() for t in ga + gb]
         assert all(np.array_equal(a, b) for a, b in zip(want, got))
+
+
+def test_search_many_equals_per_call_search(zv, oracle):
+    """HNSW.search_many (one zvdb_hip_search_graph launch for the whole batch; `searchMany` of bindings/hnsw_hip.zig, `search_many` of
+    hnsw.hpp) returns, per query, the ids / distances / count of search(): both equal to the oracle's hnsw.zig:194-236, also with
+    k larger than the index (fewer than k results, test_hnsw.zig:122-125) and on an empty index."""
+    n, d, m, nq = 2_000, 48, 8, 130
+    rng = np.random.default_rng(77)
+    V = rng.random((n, d), dtype=np.float32)
+    Q = rng.random((nq, d), dtype=np.float32)
+    ref = oracle.HNSW(m, 200, level_seed=3)
+    for r in V:
+        ref.insert(r)
+    levels = np.array([ref.node_level(i) for i in range(n)], dtype=np.int32)
+    h = zv.HNSW(m, 200)
+    h.insert_many(V, levels)
+    for k in (1, 10, 64):
+        ids, dist, cnt = h.search_many(Q, k)
+        assert ids.shape == (nq, k) and dist.shape == (nq, k) and cnt.shape == (nq,)
+        for qi in range(nq):
+            ri, rd = ref.search(Q[qi], k)
+            c = int(cnt[qi])
+            assert c == len(ri) and np.array_equal(ids[qi, :c], ri) and np.array_equal(dist[qi, :c], rd), (k, qi)
+            assert np.all(ids[qi, c:] == np.uint64(0xFFFFFFFFFFFFFFFF)) and np.all(np.isinf(dist[qi, c:]))
+            if qi % 13 == 0:
+                pi, pd = h.search_ids(Q[qi], k)
+                assert np.array_equal(pi, ids[qi, :c]) and np.array_equal(pd, dist[qi, :c])
+    small = zv.HNSW(m, 200)
+    small.insert_many(V[:5], np.zeros(5, dtype=np.int32))
+    ids, dist, cnt = small.search_many(Q[:7], 10)
+    r5 = oracle.HNSW(m, 200, level_seed=3)
+    for r in V[:5]:
+        r5.insert(r, 0)
+    for qi in range(7):
+        ri, rd = r5.search(Q[qi], 10)
+        assert int(cnt[qi]) == len(ri) <= 5 and np.array_equal(ids[qi, :len(ri)], ri)
+    empty = zv.HNSW(m, 200)
+    ids, dist, cnt = empty.search_many(Q[:3], 4)
+    assert np.all(cnt == 0) and np.all(ids == np.uint64(0xFFFFFFFFFFFFFFFF))

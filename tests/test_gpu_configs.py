@@ -156,8 +156,8 @@ def test_c3_graph_route_m16_ef128_d768_batch1024_vs_oracle_spec(zv, oracle):
 
 def test_c3_full_size_10m_x_768_headline_route_properties(zv, oracle):
     """The headline route (bf16 stream screen + exact re-rank) at BASELINE's full size: k results per query, ascending, every
-    returned distance bit-equal to the oracle's a1 distance on the regenerated row, and no row of a 250k-row sample beats a
-    query's k-th result without being in it (what bench.py's checker does, as a test)."""
+    returned distance bit-equal to the oracle's a1 distance on the regenerated row, and for 16 of the queries ids and distances equal
+    to the oracle's exact top-10 over every one of the 10M rows."""
     n, d, nq, k = 10_000_000, 768, 1024, 10
     idx = zv.Index(dim=d, capacity=n, flags=zv.FLAG_BF16_MIRROR)
     idx.add_synthetic(n, d, 0x5EED)
@@ -169,14 +169,14 @@ def test_c3_full_size_10m_x_768_headline_route_properties(zv, oracle):
         for j in range(k):
             row = oracle.uniform_rows(0x5EED, int(ids[qi, j]), 1, d)[0]
             assert oracle.distance(Q[qi], row) == dist[qi, j]
-    ns, qs = 250_000, list(range(0, nq, 64))
-    for first in (0, 7_000_000):  # two slices of the corpus
-        V = oracle.uniform_rows(0x5EED, first, ns, d)
-        ri, rd, _ = _oracle_topk_mt(oracle, V, Q[qs], k)
-        for r, qi in enumerate(qs):
-            got = set(int(x) for x in ids[qi])
-            for j in range(k):
-                assert not (rd[r, j] < dist[qi, k - 1] and int(ri[r, j]) + first not in got), (qi, j)
+    # 16 queries against the oracle's exact top-10 over ALL 10M rows (the corpus regenerated in slices on the host threads, a running
+    # top-k per query across the slices): ids and distance bit patterns equal -- at BASELINE's own size the route is certified by more
+    # than its own bound and a sample of rows
+    qs = list(range(0, nq, 64))
+    ri, rd, rc = oracle.bruteforce_topk_synthetic(0x5EED, n, d, Q[qs], k)
+    assert np.all(rc == k)
+    assert np.array_equal(ids[qs], ri), [(qi, ids[qi], ri[r]) for r, qi in enumerate(qs) if not np.array_equal(ids[qi], ri[r])][:2]
+    assert np.array_equal(dist[qs].view(np.uint32), rd.view(np.uint32))
     # and the int8 route (an independent screen) returns the same neighbours at this size
     i8, d8, _ = idx.search_bruteforce(Q, k, zv.BF_I8)
     assert np.array_equal(i8, ids) and np.array_equal(d8, dist)

@@ -112,6 +112,7 @@ HOST_SYMBOLS = [
     ("zvdb_host_hnsw_insert_many", _i32, [_vp, _f32p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]),
     ("zvdb_host_hnsw_search", _i32, [_vp, _f32p, C.c_size_t, C.c_size_t, _u64p, _f32p,
                                       C.POINTER(C.c_size_t), _u64p, _u64p]),
+    ("zvdb_host_hnsw_search_many", _i32, [_vp, _f32p, C.c_size_t, C.c_size_t, C.c_size_t, _u64p, _f32p, _u32p]),
     ("zvdb_host_hnsw_count", C.c_size_t, [_vp]),
     ("zvdb_host_hnsw_dim", C.c_size_t, [_vp]),
     ("zvdb_host_hnsw_max_level", C.c_size_t, [_vp]),

@@ -100,6 +100,22 @@ class HNSW:
         self.last_evals, self.last_pops = ev.value, pp.value
         return ids[:n.value].copy(), dist[:n.value].copy()
 
+    def search_many(self, queries, k: int):
+        """nq searches in ONE device launch: (ids [nq][k] u64, dist [nq][k] f32, count [nq] u32), the results of nq search() calls
+        without the Node copies (HNSW::search_many, hnsw.hpp; `searchMany` of bindings/hnsw_hip.zig).  Extension: hnsw.zig:194 takes
+        one query per call."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2:
+            raise ValueError("queries must be [nq][dim]")
+        nq = q.shape[0]
+        ids = np.full((nq, max(k, 1)), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+        dist = np.full((nq, max(k, 1)), np.inf, dtype=np.float32)
+        cnt = np.zeros(max(nq, 1), dtype=np.uint32)
+        self._check(self._L.zvdb_host_hnsw_search_many(
+            self._p, q.ctypes.data_as(C.POINTER(C.c_float)), nq, q.shape[1], k,
+            ids.ctypes.data_as(C.POINTER(C.c_uint64)), dist.ctypes.data_as(C.POINTER(C.c_float)), cnt.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return ids[:, :k], dist[:, :k], cnt[:nq]
+
     def count(self) -> int:
         return int(self._L.zvdb_host_hnsw_count(self._p))
 

@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -287,6 +288,25 @@ class HNSW<float> {
         return result;
     }
     std::vector<Node> search(const std::vector<float> &q, size_t k) { return search(q.data(), q.size(), k); }
+
+    // nq searches in ONE device launch (extension: the reference has no batch call, hnsw.zig:194 takes one query): the same
+    // results as nq search() calls -- ids and distances only, no Node copies (callers that want the points read them through
+    // point(id)).  out_ids / out_dist: nq x k, row-major, unused slots id = UINT64_MAX / +inf; out_count[q] <= k results of
+    // query q (fewer than k are legal, test_hnsw.zig:122-125).  Where the device wins: one launch answers the whole batch
+    // (millions of queries per second) while a search() call pays a launch + a synchronisation per query.
+    void search_many(const float *queries, size_t nq, size_t len, size_t k, uint64_t *out_ids, float *out_dist, uint32_t *out_count) {
+        std::lock_guard<std::mutex> g(mu_);                                    // :195-196
+        for (size_t q = 0; q < nq; ++q) out_count[q] = 0;
+        if (!entry_point || k == 0 || nq == 0) {                               // :201: an empty index answers nothing
+            for (size_t i = 0; i < nq * k; ++i) { out_ids[i] = ~0ull; out_dist[i] = std::numeric_limits<float>::infinity(); }
+            return;
+        }
+        if (len != dim_) throw Panic("Mismatched dimensions in distance calculation");
+        check(zvdb_hip_search_graph(h_, queries, (uint32_t)nq, (uint32_t)len, (uint32_t)k, /*ef=*/0, /*entry=*/*entry_point,
+                                    out_ids, out_dist, out_count, &last_stats_));
+    }
+    // the owned copy of a point (what a search result's Node.point aliases)
+    const float *point(size_t id) const { return id < points_.size() ? points_[id].get() : nullptr; }
 
     // distances of the last search's results (the reference recomputes them in its tests)
     const std::vector<float> &last_distances() const { return last_dist_; }

@@ -68,6 +68,11 @@ int zvdb_host_hnsw_search(void *p, const float *query, size_t len, size_t k, uin
     });
 }
 
+int zvdb_host_hnsw_search_many(void *p, const float *queries, size_t nq, size_t len, size_t k, uint64_t *out_ids, float *out_dist,
+                               uint32_t *out_count) {
+    return guard([&] { static_cast<H *>(p)->search_many(queries, nq, len, k, out_ids, out_dist, out_count); });
+}
+
 size_t zvdb_host_hnsw_count(void *p) { return static_cast<H *>(p)->count(); }
 size_t zvdb_host_hnsw_dim(void *p) { return static_cast<H *>(p)->dim(); }
 size_t zvdb_host_hnsw_max_level(void *p) { return static_cast<H *>(p)->max_level; }
