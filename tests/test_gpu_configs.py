@@ -80,6 +80,88 @@ def test_bf16_stream_route_exact(zv, oracle, n, d, nq, k, metric):
     assert np.array_equal(bi, bi2) and np.array_equal(bd, bd2)
 
 
+# ---- the fp32 register-resident-query scan (bf_f32_regq.hip): batches of more than 128 queries, dim <= 128, large shards ----
+@pytest.mark.parametrize("n,d,nq,k,metric", [
+    (1_000_000, 128, 256, 10, "l2"),    # BASELINE configs[1]: KS = 16, one query tile, 122.07 groups per stream
+    (600_000, 96, 300, 10, "l2"),       # KS = 16 with zero-padded k-steps, two query tiles (the second 44 queries: idle waves)
+    (530_003, 64, 261, 48, "l2"),       # KS = 8; nothing a multiple of anything; k = the 64-survivor maximum
+    (300_017, 128, 1000, 100, "l2"),    # four query tiles, k' = 128 lists
+    (600_000, 40, 300, 200, "l2"),      # k' = 256 lists
+    (600_000, 96, 300, 10, "dot"),
+    (400_000, 120, 520, 25, "cosine"),
+])
+def test_f32_regq_route_exact(zv, oracle, tuning, n, d, nq, k, metric):
+    """The fp32 screen's register-resident-query kernel against (a) the staged fp32 kernel of the same library
+    (ZVDB_BF_F32_KERNEL=v6: learned or sampled thresholds, another accumulation order) on the whole batch, (b) the oracle's exact
+    top-k on sampled queries, (c) itself on a second batch of the warm mirror -- ids, distances, counts, bit for bit."""
+    m = {"l2": zv.METRIC_L2SQ, "dot": zv.METRIC_DOT, "cosine": zv.METRIC_COSINE}[metric]
+    shift = 0.0 if metric == "l2" else 0.5
+    idx = zv.Index(metric=m)
+    idx.add_synthetic(n, d, 0x5EED)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d) - np.float32(shift)
+    bi, bd, bc = idx.search_bruteforce(Q, k, zv.BF_F32)
+    assert np.all(bc == k) and np.all(bi < n) and np.all(np.diff(bd, axis=1) >= 0)
+    if k <= 56:  # (the staged fp32 route stops at k = 56; beyond: the int8 route, exact on L2)
+        tuning("ZVDB_BF_F32_KERNEL", "v6")
+        ei, ed, ec = idx.search_bruteforce(Q, k, zv.BF_F32)
+        tuning("ZVDB_BF_F32_KERNEL", None)
+        assert np.array_equal(bi, ei) and np.array_equal(bd, ed) and np.array_equal(bc, ec)
+    elif metric == "l2":
+        ei, ed, ec = idx.search_bruteforce(Q, k, zv.BF_I8)
+        assert np.array_equal(bi, ei) and np.array_equal(bd, ed) and np.array_equal(bc, ec)
+    sel = [0, 1, 31, 32, nq // 2, nq - 2, nq - 1]
+    if metric != "cosine":
+        V = oracle.uniform_rows(0x5EED, 0, n, d)
+        ri, rd, _ = _oracle_topk_mt(oracle, V, np.ascontiguousarray(Q[sel]), k, metric=0 if metric == "l2" else 1)
+        assert np.array_equal(bi[sel], ri) and np.array_equal(bd[sel], rd)
+    bi2, bd2, _ = idx.search_bruteforce(Q, k, zv.BF_F32)
+    assert np.array_equal(bi, bi2) and np.array_equal(bd, bd2)
+
+
+def test_f32_regq_guess_too_tight_too_loose_and_descending_rows(zv, oracle, tuning):
+    """The register-query scan under a guess forced far too tight (every query deficient: the gated re-scan runs the same kernel
+    with no bound), far too loose (prune rounds through the out-of-line select, the group loop left and re-entered), and on rows
+    in DESCENDING order of distance to the queries (every group beats the bound learned so far: prunes throughout)."""
+    n, d, nq, k = 400_000, 72, 290, 10
+    idx = zv.Index()
+    idx.add_synthetic(n, d, 0x5EED)
+    V = oracle.uniform_rows(0x5EED, 0, n, d)
+    Q = oracle.uniform_rows(0xC0FFEE, 0, nq, d)
+    sel = [0, 63, 64, 255, 256, 289]
+    ri, rd, _ = _oracle_topk_mt(oracle, V, np.ascontiguousarray(Q[sel]), k)
+    base = idx.search_bruteforce(Q, k, zv.BF_F32)
+    assert np.array_equal(base[0][sel], ri) and np.array_equal(base[1][sel], rd)
+    for z in ("-3", "2.5"):
+        tuning("ZVDB_BF_GUESS_ZSHIFT", z)
+        got = idx.search_bruteforce(Q, k, zv.BF_F32)
+        assert all(np.array_equal(a, b) for a, b in zip(got, base)), z
+    tuning("ZVDB_BF_GUESS_ZSHIFT", None)
+    # thresholds measured per batch on a row sample (the 128-query kernel's moments mode) instead of derived from the rows' moments
+    tuning("ZVDB_BF_F32_GUESS", "sample")
+    got = idx.search_bruteforce(Q, k, zv.BF_F32)
+    assert all(np.array_equal(a, b) for a, b in zip(got, base))
+    tuning("ZVDB_BF_F32_GUESS", None)
+    before = idx.cert_info()
+    for b in range(6):  # the derived thresholds hold on fresh batches: no guess misses, no repairs
+        Qb = oracle.uniform_rows(0xC0FFEE, (b + 1) * nq, nq, d)
+        gi, gd, _ = idx.search_bruteforce(Qb, k, zv.BF_F32)
+        if b == 5:
+            ri2, rd2, _ = _oracle_topk_mt(oracle, V, np.ascontiguousarray(Qb[sel]), k)
+            assert np.array_equal(gi[sel], ri2) and np.array_equal(gd[sel], rd2)
+    after = idx.cert_info()
+    assert after["guess_misses"] == before["guess_misses"] and after["repaired"] == before["repaired"], (before, after)
+    # rows sorted by DEscending distance to a point near all queries: the later a row, the closer
+    c = np.full(d, 0.5, dtype=np.float32)
+    order = np.argsort(-((V - c) ** 2).sum(axis=1), kind="stable")
+    W = np.ascontiguousarray(V[order])
+    idx2 = zv.Index()
+    idx2.add(W)
+    Qc = (c + 0.01 * (Q - 0.5)).astype(np.float32)
+    gi, gd, gc = idx2.search_bruteforce(Qc, k, zv.BF_F32)
+    ri, rd, rc = _oracle_topk_mt(oracle, W, np.ascontiguousarray(Qc[sel]), k)
+    assert np.array_equal(gi[sel], ri) and np.array_equal(gd[sel], rd) and np.all(gc == k)
+
+
 def test_bf16_stream_guess_verified_repaired_and_staged_agree(zv, oracle, tmp_path):
     """One scan against GUESSED thresholds, verified by the merge, repaired by a gated re-scan: the default, a guess forced
     far too tight (every query repaired), far too loose (prune rounds through the out-of-line select) and the staged kernel

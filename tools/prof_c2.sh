@@ -2,7 +2,7 @@
 # per-launch timeline of one BASELINE configs[1] step (1M x 128 fp32, batch 256, fp32 screen): tools/c2_trace.py under rocprofv3
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/prof_r4_c2
+OUT=$R/gpurun_out/r6c/prof_c2
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $R/tools/c2_trace.py > $OUT/out.txt 2>&1
 python3 $R/tools/trace_step.py $OUT/stats | tee $OUT/step_trace.txt

@@ -365,6 +365,8 @@ void zvdb_hip_destroy(zvdb_hip_index *h) {
     (void)hipFree(h->ef_hint_dev);
     (void)hipFree(h->rows_ff);
     (void)hipFree(h->norm_ff);
+    (void)hipFree(h->kstat);
+    (void)hipFree(h->kstat_acc);
     (void)hipFree(h->ef_visit_buf);
     (void)hipFree(h->ef_net_buf);
     if (h->ef_event) (void)hipEventDestroy(h->ef_event);

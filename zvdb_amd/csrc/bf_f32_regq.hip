@@ -1,0 +1,482 @@
+// bf_f32_regq.hip -- the EXACT-ARITHMETIC fp32 MFMA screen of the brute-force route (BASELINE configs[1]: 1M x 128
+// fp32, batch 256) for short rows: REGISTER-RESIDENT QUERIES, the corpus streamed HBM -> registers, no LDS staging and no barrier.
+// No reference symbol (hnsw.zig has no brute force); results are pinned by the oracle's exact top-k through the certificate
+// (bf_cert.h: its rounding bound holds for ANY accumulation order) and the exact fp32 re-rank (hnsw.zig:182-192 arithmetic).
+//
+// Why a third fp32 kernel.  At 128 dimensions the staged 256 x 256 tile (k_bf_scan5<0>: both operands through LDS, a barrier per
+// slice) and the 128-query stream kernel (k_i8_stream<0>: queries resident in LDS, two workgroups per stream) both sit at 0.65 -
+// 0.68 of the fp32-MFMA peak on configs[1] (profiles/r5/c2_1Mx128_f32_passes.txt).  v_mfma_f32_32x32x2_f32 is a 64-cycle
+// instruction that takes ONE VGPR per operand: a wave's 32 queries x 128 dimensions are 64 VGPRs -- they stay in registers for the
+// whole launch; 8 waves = 256 queries per workgroup, one workgroup per CU, so a batch of 256 reads the corpus ONCE (the 128-query
+// kernel: twice, through the L2).  Every wave reads every row: a 32-row group is KS contiguous KiB of the fragment-order mirror
+// (rows_ff, shared with k_i8_stream<0>), one coalesced global_load_dwordx4 per 4 MFMAs (256 matrix-pipe cycles), prefetched a whole
+// group ahead in a register ring; the 8 waves of a workgroup ask for the same lines (the first miss fills the L1 / L2, the rest
+// hit).  No wave reads what another wave wrote: NO barrier, NO LDS in the steady state -- SIMD partners drift apart and fill each
+// other's selection epilogues.  Work is split by 32-row GROUPS (31,250 at 1M rows: 122.07 per CU, a 0.8 % tail) instead of 256-row
+// tiles (15.26 per CU: 5 %).
+//
+// Layout (k_f32_pack_frag, bf_i8_stream.hip): piece (group g, k-step j, lane l) = 16 bytes = elements 8 j + 4 (l >> 5) + [0, 4) of
+// row / query 32 g + (l & 31); a group holds its KS pieces contiguously (KS KiB).  Component c of a piece feeds one 32x32x2 MFMA.
+// Keys: acc starts at -|v|^2 / 2 (0 for dot / cosine; -inf for rows past N) and accumulates q.v: acc = -key, pass <=> acc > -tau.
+// Accumulator layout (32x32 f32): lane l holds query (column) l & 31, rows 8 (r >> 2) + 4 (l >> 5) + (r & 3) for r = 0 .. 15.
+// Selection state (per-(workgroup, query) kept list + append buffer in global memory, exact (key, id) radix select) is shared with
+// the other scan kernels (bf_select.h); a wave owns its 32 queries: appends and prune rounds involve that wave only.
+#include <algorithm>
+#include <type_traits>
+#include "common.h"
+#include "wave_select.h"
+#include "bf_select.h"
+#include "stream_common.h"
+#include "row_types.h"
+
+namespace zvdb {
+
+namespace {
+
+constexpr int RQ_NW = 8;                   // waves per workgroup (2 per SIMD)
+constexpr int RQ_CAP = NSUB * SUBCAP;      // append-buffer entries per (workgroup, query)
+constexpr int RQ_HW = 384, RQ_MARK = 64;   // prune request mark; queries above MARK are pruned in a round
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int KPV>
+__host__ __device__ constexpr uint32_t rq_lds_bytes() {
+    return T2 * 4 * 3 + RQ_NW * NSUB * 4 + 16 + RQ_NW * sel_scratch_bytes<KPV>();
+}
+
+// The operand ring's loads and waits, by inline asm (saddr form: uniform base + 32-bit lane offset).  HAZARD: hipcc believes a register
+// written by rq_load16 is valid when the asm statement ends; it lands only behind an rq_vm_wait tied to the same register.  The kernel
+// must not spill or copy ring registers inside the group loop (197 of 256 VGPRs: checked with tools/kernel_resources.py).
+__device__ __forceinline__ void rq_load16(u32x4 &d, uint32_t voff, gbytes_t sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void rq_load4(float &d, uint32_t voff, gbytes_t sbase) {
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void rq_vm_wait(u32x4 &d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
+template <int N> __device__ __forceinline__ void rq_vm_wait_f(float &d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
+template <int R> __device__ __forceinline__ void rq_vm_drain(u32x4 (&a)[R]) {
+    static_assert(R == 8 || R == 16, "operand list below");
+    if constexpr (R == 8)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                     "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+
+// Exact prune of the calling wave's 32 queries whose append buffer passed MARK.  Out of line and cold: the scan keeps the query
+// fragments and the operand ring live, an inlined radix select would push the allocator into spilling them in the hot loop.
+// (Per-wave select scratch: the LDS is otherwise unused, so no lock as in bf_bf16_stream.hip.)
+template <int KPV>
+__device__ __attribute__((noinline, cold)) void rq_prune_wave(uint64_t *kept, uint32_t *tau_g, uint32_t kp, uint32_t lds_state /* LDS address of tau_f */) {
+    float *tau_f = (float *)(__attribute__((address_space(3))) float *)(size_t)lds_state;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(tau_f + T2);
+    uint32_t *nkept = cnt + T2;
+    uint32_t *subw = nkept + T2;
+    unsigned char *sel = reinterpret_cast<unsigned char *>(subw + RQ_NW * NSUB + 4);
+    uint64_t *subs = kept + (size_t)T2 * KPMAX;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my appends have left the wave
+    for (int qi = 0; qi < 32; ++qi) {
+        const int q = wave * 32 + qi;
+        const uint32_t c = min(lds_load_u32(cnt + q), (uint32_t)RQ_CAP);
+        if (c > (uint32_t)RQ_MARK) {
+            if (lane < NSUB) subw[wave * NSUB + lane] = min(c - min(c, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
+            if (lane == 0) cnt[q] = 0;
+            prune_query<false, true, KPV>(kept, subs, tau_f, nkept, subw + wave * NSUB, q, lane, kp, tau_g, sel + wave * sel_scratch_bytes<KPV>());
+        }
+    }
+}
+
+// KS = 8-element k-steps (1-KiB pieces) per row: 8 / 16 / 32 (dim <= 64 / 128 / 256).  GATED = 1: the same code under its own symbol
+// for the gated repair launch (a no-op unless the verification failed), so that profiler statistics do not average no-ops into the scan.
+template <int KS, int KPV = KP, int GATED = 0>
+__global__ __launch_bounds__(512, 2) void k_f32_regq(
+    const unsigned char *__restrict__ Qf /* [query group of 32][KS][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
+    const float *__restrict__ vnorm /* [rows padded]: sum v^2 (0: dot / cosine), +inf past N */, uint32_t N, uint32_t nq, uint32_t QT,
+    uint32_t S, uint32_t G /* 32-row groups */, uint64_t *__restrict__ cand, uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all,
+    uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, const uint32_t *__restrict__ gate) {
+    if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
+    constexpr int R = KS < 16 ? KS : 16;  // operand ring: pieces in flight per wave (a whole group at <= 128 dimensions)
+    static_assert(KS == R, "the wait counts of the group loop assume a ring of one whole group");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tau_f = reinterpret_cast<float *>(smem);              // exclusive bound: pass <=> key < tau
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(tau_f + T2);    // append slots handed out since the query's last prune
+    uint32_t *nkept = cnt + T2;
+    uint32_t *subw = nkept + T2;                                 // per wave: prune_query's view of one append buffer
+    unsigned char *sel = reinterpret_cast<unsigned char *>(subw + RQ_NW * NSUB + 4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t fr = lane & 31, fh = lane >> 5;
+
+    // block -> (stream s, query tile qt): the QT workgroups of a stream share (blockIdx % 8), i.e. one XCD under round-robin
+    // placement, and fetch the same groups at about the same time (one HBM fetch, QT - 1 L2 hits)
+    const uint32_t b = blockIdx.x;
+    const uint32_t x = b & 7, jb = b >> 3;
+    const uint32_t qt = jb % QT;
+    const uint32_t s = (jb / QT) * 8 + x;
+    const uint32_t g0 = (uint32_t)(((uint64_t)s * G) / S), g1 = (uint32_t)(((uint64_t)(s + 1) * G) / S);  // my groups (ids ascend along a stream)
+    uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
+    uint64_t *kept = cand + (size_t)b * BLKV_ENTRIES;
+    uint64_t *subs = kept + (size_t)T2 * KPMAX;
+
+    for (int tq = tid; tq < T2; tq += 512) {
+        const bool live = (qt * T2 + tq) < nq;
+        const uint32_t g = (tau_g && live) ? __hip_atomic_load(tau_g + tq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        float t0 = live ? __builtin_inff() : -__builtin_inff();
+        if (g != 0xFFFFFFFFu) t0 = fminf(t0, f32_unkey(g + 1));
+        tau_f[tq] = t0;
+        cnt[tq] = 0;
+        nkept[tq] = 0;
+    }
+    __syncthreads();  // (the only barrier ahead of the stream end)
+
+    const unsigned char *qsrc = Qf + ((size_t)(qt * (T2 / 32) + wave) * KS) * 1024 + lane * 16;
+    const uint32_t lane16 = (uint32_t)lane * 16;
+    const uint32_t lds_state = (uint32_t)(size_t)(lptr_t)tau_f;
+    constexpr size_t gbytes = (size_t)KS * 1024;
+    // a wave whose 32 queries are all past nq has nothing to select: it still runs (its registers are there), but never passes
+    auto load_norm = [&](uint32_t g) -> float { return vnorm[(size_t)32 * g + fr]; };  // |v|^2 of row 32 g + fr (rows past N: +inf)
+
+    uint32_t g = g0;
+    // The group loop is entered once per launch and once more after every prune round of this wave: a prune is a CALL and nothing of
+    // the loop's register state lives across it (bf_bf16_stream.hip found hipcc spilling the query fragments around an inlined one).
+    while (g < g1) {
+        u32x4 B[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
+        const float thr = -tau_f[wave * 32 + fr];
+        u32x4 A[R];
+        {
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes);
+#pragma unroll
+            for (int j = 0; j < R; ++j) A[j] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + j * 1024);
+        }
+        f32x16 init;  // start values of the group about to be multiplied: -|v|^2 / 2 of the register's row
+        {
+            const float vn = load_norm(g);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0), as an instruction the waitcnt pass sees: the ring is primed
+        bool want_prune = false;
+        do {
+            const uint32_t gn = min(g + 1, g1 - 1);  // (past the stream end: a harmless re-read of its last group)
+            // pieces J + R .. of this group (KS > R) and 0 .. of the next: the slot a piece frees is refilled a whole ring ahead
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes + (size_t)R * 1024);
+            const gbytes_t nxt = uniform_ptr(Vf + (size_t)gn * gbytes);
+            const gbytes_t nrm = uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)32 * gn));
+            f32x16 acc = init;
+            float vn_next;
+            __builtin_amdgcn_sched_barrier(0);
+            // one piece = 4 MFMAs (256 matrix-pipe cycles), then the ring slot it freed is refilled.  Loads and their waits are inline asm
+            // tied to the ring registers (rq_load16 / rq_vm_wait): written as plain loads hipcc either hoists all of them to the top of the
+            // iteration into a second copy of the ring (256 VGPRs, spills) or rotates a ring slot through a v_mov behind an
+            // s_waitcnt vmcnt(0) at the loop head -- a drain of the whole ring per group.  Steady state: R + 1 loads (R pieces and
+            // the next group's norms) are younger than the piece about to be multiplied: s_waitcnt vmcnt(R + 1 - 1) ... see below.
+            static_for<KS>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                constexpr int SL = J % R;
+                rq_vm_wait<R>(A[SL]);  // slot SL was refilled R pieces ago; R loads (R - 1 pieces + one norm load per KS pieces) are younger
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].x), __uint_as_float(B[J].x), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].y), __uint_as_float(B[J].y), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].z), __uint_as_float(B[J].z), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].w), __uint_as_float(B[J].w), acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (J + R < KS) rq_load16(A[SL], lane16, cur + (size_t)J * 1024);
+                else rq_load16(A[SL], lane16, nxt + (size_t)(J + R - KS) * 1024);
+                if constexpr (J == 0) rq_load4(vn_next, fr * 4, nrm);  // (in ring order: consumed behind the last MFMA)
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // start values of the next group while the last MFMAs drain (the norm load: KS - 1 pieces are younger)
+            rq_vm_wait_f<KS - 1>(vn_next);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn_next, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
+            __builtin_amdgcn_sched_barrier(0);
+            // selection of the finished group (32 rows x my 32 queries): the rare pass path appends to the queries' buffers
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            if (__ballot(m > thr)) {
+                bool need = false;
+                const uint32_t q = (uint32_t)wave * 32 + fr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (acc[r] > thr) {
+                        const uint32_t sl = atomicAdd(cnt + q, 1u);
+                        const uint32_t id = 32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
+                        if (sl < (uint32_t)RQ_CAP) subs[(size_t)q * RQ_CAP + sl] = ((uint64_t)f32_key(-acc[r]) << 32) | id;
+                        need |= sl == (uint32_t)RQ_HW;
+                    }
+                }
+                if (__ballot(need)) want_prune = true;  // (<= 32 more appends per query before the loop is left: RQ_CAP holds them)
+            }
+            ++g;
+        } while (g < g1 && !want_prune);
+        rq_vm_drain(A);  // loads still in flight land in the ring's registers: nothing behind this point may see them in flight
+        if (want_prune) rq_prune_wave<KPV>(kept, tau_g, kp, lds_state);
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {   // stream end: lane-per-query copy when nothing needs selecting, else the radix select (a wave's own 32 queries: no rendezvous)
+        unsigned char *selw = sel + wave * sel_scratch_bytes<KPV>();
+        const uint32_t q = (uint32_t)wave * 32 + fr;
+        const uint32_t qg = qt * T2 + q;
+        const bool mine = lane < 32 && qg < nq;
+        const uint32_t c = mine ? min(lds_load_u32(cnt + q), (uint32_t)RQ_CAP) : 0u;
+        const uint32_t nk = mine ? nkept[q] : 0u;
+        const bool simple = mine && nk + c <= (uint32_t)KPV;
+        if (simple) {
+            uint64_t *dst = partial + ((size_t)qg * Stot + list_base + s) * KPV;
+            for (uint32_t e = 0; e < nk; ++e) dst[e] = kept[(size_t)q * KPV + e];
+            for (uint32_t e = 0; e < c; ++e) dst[nk + e] = subs[(size_t)q * RQ_CAP + e];
+            for (uint32_t e = nk + c; e < (uint32_t)KPV; ++e) dst[e] = ~0ull;
+            pcnt[(size_t)qg * Stot + list_base + s] = nk + c;
+        }
+        unsigned long long todo = __ballot(mine && !simple);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t q2 = (uint32_t)wave * 32 + (uint32_t)l;
+            const uint32_t qg2 = qt * T2 + q2;
+            const uint32_t c2 = min(lds_load_u32(cnt + q2), (uint32_t)RQ_CAP);
+            if (lane < NSUB) subw[wave * NSUB + lane] = min(c2 - min(c2, (uint32_t)(lane * SUBCAP)), (uint32_t)SUBCAP);
+            prune_query<false, true, KPV>(kept, subs, tau_f, nkept, subw + wave * NSUB, q2, lane, kp, nullptr, selw);
+#pragma unroll
+            for (int ci = 0; ci < KPV / 64; ++ci)
+                partial[((size_t)qg2 * Stot + list_base + s) * KPV + lane + 64 * ci] = kept[(size_t)q2 * KPV + lane + 64 * ci];
+            if (lane == 0) pcnt[(size_t)qg2 * Stot + list_base + s] = nkept[q2];
+        }
+    }
+}
+
+// ---- thresholds from the corpus' second moments ---------------------------------------------------------------------------
+// The guessed-threshold pipeline needs, per query, mean and variance of the screen key over the rows (tau = mean + z sigma,
+// k_bf16_guess's rule).  The stream kernels measure them per batch by scanning a sample of the rows with the batch's queries
+// (a moments launch + a guess launch: 27 + 9 us of a 540-us configs[1] step).  For short rows they follow from moments of the
+// ROWS alone, computed once per mirror build: key = n - q.v with n = |v|^2 / 2 (dot / cosine: n = 0), so
+//   mean = E[n] - q.mu,   var = Var(n) - 2 q.c + q' Sigma q,   mu = E[v], c = Cov(n, v), Sigma = Cov(v)
+// -- one wave per query reads the D x D matrix (64 KB at 128 dimensions, L2-resident) inside ONE small launch per batch.
+// What a guess gets wrong is verified and repaired as before; results do not depend on it (tested: = the sampled guess).
+constexpr uint32_t RQ_STAT_RUNS = 512;     // sampled runs of 32 consecutive rows, evenly spread over the shard (16,384 rows)
+constexpr uint32_t RQ_STAT_BLOCKS = 64;
+
+// acc (double): [0] rows, [1] sum n, [2] sum n^2, [3, 3 + D) sum x_i, [3 + D, 3 + 2 D) sum n x_i, [3 + 2 D, 3 + 2 D + D^2) sum x_i x_j
+template <typename RT>
+__global__ __launch_bounds__(256) void k_rq_stats_acc(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, uint32_t D, uint64_t N, int l2,
+                                                      uint32_t runs, double *__restrict__ acc) {
+    __shared__ float x[32][129];
+    __shared__ float nr[32];
+    __shared__ uint32_t nvalid;
+    const int tid = threadIdx.x;
+    const uint64_t G = (N + 31) / 32;
+    constexpr int EPT = 128 * 128 / 256;  // pair sums per thread at D = 128
+    double s2[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) s2[e] = 0.0;
+    double s1 = 0.0, sn1 = 0.0, cn = 0.0, sn = 0.0, snn = 0.0;
+    const uint32_t npairs = D * D;
+    for (uint32_t r = blockIdx.x; r < runs; r += gridDim.x) {
+        const uint64_t g = (uint64_t)r * G / runs;
+        __syncthreads();
+        for (uint32_t t = tid; t < 32 * D; t += 256) {
+            const uint32_t rr = t / D, i = t % D;
+            const uint64_t row = 32 * g + rr;
+            x[rr][i] = (row < N && i < dim) ? row_elem(rows + row * ld, i) : 0.0f;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float a = 0.0f;
+            if (l2)
+                for (uint32_t i = 0; i < D; ++i) a += x[tid][i] * x[tid][i];
+            nr[tid] = 0.5f * a;
+        }
+        if (tid == 0) nvalid = (uint32_t)min((uint64_t)32, N - 32 * g);
+        __syncthreads();
+        const uint32_t nv = nvalid;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const uint32_t pe = (uint32_t)tid + 256u * e;
+            if (pe < npairs) {
+                const uint32_t i = pe / D, j = pe % D;
+                float a = 0.0f;
+                for (uint32_t rr = 0; rr < nv; ++rr) a += x[rr][i] * x[rr][j];
+                s2[e] += (double)a;
+            }
+        }
+        if ((uint32_t)tid < D) {
+            float a = 0.0f, b = 0.0f;
+            for (uint32_t rr = 0; rr < nv; ++rr) { a += x[rr][tid]; b += nr[rr] * x[rr][tid]; }
+            s1 += (double)a;
+            sn1 += (double)b;
+        }
+        if (tid == 0) {
+            for (uint32_t rr = 0; rr < nv; ++rr) { sn += (double)nr[rr]; snn += (double)nr[rr] * (double)nr[rr]; }
+            cn += (double)nv;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t pe = (uint32_t)tid + 256u * e;
+        if (pe < npairs) atomicAdd(acc + 3 + 2 * D + pe, s2[e]);
+    }
+    if ((uint32_t)tid < D) { atomicAdd(acc + 3 + tid, s1); atomicAdd(acc + 3 + D + tid, sn1); }
+    if (tid == 0) { atomicAdd(acc + 0, cn); atomicAdd(acc + 1, sn); atomicAdd(acc + 2, snn); }
+}
+
+// kstat (float): [0] E[n], [1] Var(n), [2, 2 + D) mu, [2 + D, 2 + 2 D) c = Cov(n, v), [2 + 2 D, ...) Sigma (D x D, symmetric)
+__global__ __launch_bounds__(256) void k_rq_stats_fin(const double *__restrict__ acc, uint32_t D, float *__restrict__ kstat) {
+    const double n = acc[0] > 0.0 ? acc[0] : 1.0;
+    const double en = acc[1] / n;
+    for (uint32_t t = threadIdx.x; t < D * D; t += 256) {
+        const uint32_t i = t / D, j = t % D;
+        kstat[2 + 2 * D + t] = (float)(acc[3 + 2 * D + t] / n - (acc[3 + i] / n) * (acc[3 + j] / n));
+    }
+    for (uint32_t i = threadIdx.x; i < D; i += 256) {
+        kstat[2 + i] = (float)(acc[3 + i] / n);
+        kstat[2 + D + i] = (float)(acc[3 + D + i] / n - en * (acc[3 + i] / n));
+    }
+    if (threadIdx.x == 0) {
+        kstat[0] = (float)en;
+        kstat[1] = (float)fmax(acc[2] / n - en * en, 0.0);
+    }
+}
+
+// one workgroup of 4 waves per query: tau_g[q] = key(mean + z sigma) of the screen key over the rows, from the rows' moments (header of
+// this section).  Wave w walks rows [w D / 4, (w + 1) D / 4) of Sigma for the lane's columns (coalesced: lanes = consecutive columns; a
+// single wave walking all D rows is one dependent chain of D L2 round trips: 19 us per batch instead of 6).
+__global__ __launch_bounds__(256) void k_rq_guess(const float *__restrict__ queries, uint32_t nq, uint32_t dim, uint32_t D, const float *__restrict__ kstat,
+                                                  float z, int l2, uint32_t *__restrict__ tau_g, uint32_t *__restrict__ verify_flag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) { verify_flag[0] = 0; verify_flag[1] = 0; }  // ([1]: deficient queries of the batch)
+    __shared__ float q[128];
+    __shared__ double part[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t qi = blockIdx.x;
+    if ((uint32_t)tid < D) q[tid] = (uint32_t)tid < dim ? queries[(size_t)qi * dim + tid] : 0.0f;
+    __syncthreads();
+    const float *mu = kstat + 2, *c = kstat + 2 + D, *Sg = kstat + 2 + 2 * D;
+    const uint32_t j0 = (uint32_t)w * (D / 4), j1 = j0 + D / 4;
+    double qmu = 0.0, qc = 0.0, qsq = 0.0;
+    for (uint32_t i = lane; i < D; i += 64) {
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+        for (uint32_t j = j0; j < j1; j += 4) {  // (D / 4 is a multiple of 4: D = 64 or 128)
+            t0 += Sg[(size_t)j * D + i] * q[j];
+            t1 += Sg[(size_t)(j + 1) * D + i] * q[j + 1];
+            t2 += Sg[(size_t)(j + 2) * D + i] * q[j + 2];
+            t3 += Sg[(size_t)(j + 3) * D + i] * q[j + 3];
+        }
+        qsq += (double)q[i] * (double)((t0 + t1) + (t2 + t3));
+        if (w == 0) {
+            qmu += (double)q[i] * (double)mu[i];
+            qc += (double)q[i] * (double)c[i];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        qmu += __shfl_xor(qmu, off);
+        qc += __shfl_xor(qc, off);
+        qsq += __shfl_xor(qsq, off);
+    }
+    if (lane == 0) { part[w][0] = qmu; part[w][1] = qc; part[w][2] = qsq; }
+    __syncthreads();
+    if (tid == 0) {
+        qmu = part[0][0];
+        qc = part[0][1];
+        qsq = (part[0][2] + part[1][2]) + (part[2][2] + part[3][2]);
+        uint32_t out = 0xFFFFFFFFu;  // no bound
+        const double mean = (l2 ? (double)kstat[0] : 0.0) - qmu;
+        const double var = l2 ? (double)kstat[1] - 2.0 * qc + qsq : qsq;
+        if (var > 0.0) {
+            const float tk = (float)(mean + (double)z * sqrt(var));
+            if (tk == tk && fabsf(tk) < 3.0e38f) out = f32_key(tk);
+        }
+        tau_g[qi] = out;
+    }
+}
+
+template <int KS, int KPV>
+int rq_launch_geo(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand, uint64_t *partial,
+                  uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
+    constexpr uint32_t lds = rq_lds_bytes<KPV>();
+    static_assert(lds <= 64 * 1024, "LDS budget");
+    const uint32_t G = (uint32_t)((h->count + 31) / 32);
+    const float *vn = h->norm_ff;  // (k_f32_frag_norms: zeros for dot / cosine, +inf past the last row)
+    auto go = [&](auto kern) -> int {
+        hipLaunchKernelGGL(kern, dim3(QT * S), dim3(512), lds, s, q_op, h->rows_ff, vn, (uint32_t)h->count, nq, QT, S, G, cand, partial, tau_g, kp,
+                           list_base, Stot, pcnt, gate);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    };
+    if constexpr (KPV == KP) {
+        if (gate) return go(k_f32_regq<KS, KP, 1>);
+    }
+    return go(k_f32_regq<KS, KPV, 0>);
+}
+
+template <int KPV>
+int rq_launch(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand, uint64_t *partial,
+              uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
+    const uint32_t KS = f32s_ksteps(h->dim);
+    if (KS == 8) return rq_launch_geo<8, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    if (KS == 16) return rq_launch_geo<16, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    set_error("fp32 register-query scan: dim %u has no instantiation", h->dim);
+    return ZVDB_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// fp32 screens of 5 .. 128 dimensions; ZVDB_BF_F32_KERNEL=v6 (staged) / stream (the 128-query kernel) select the older kernels
+bool f32rq_eligible(const zvdb_hip_index *h) {
+    const char *e = tuning("ZVDB_BF_F32_KERNEL");
+    if (e && ((e[0] == 'v' && e[1] == '6') || e[0] == 's')) return false;
+    return h->dim > 4 && h->dim <= 128;
+}
+
+// the rows' moments behind k_rq_guess: rebuilt with the fragment mirror (lazily, when rows were added)
+int ensure_f32rq_stats(zvdb_hip_index *h, hipStream_t s) {
+    if (h->kstat && h->kstat_count == h->count) return ZVDB_OK;
+    if (h->count == 0) return ZVDB_OK;
+    const uint32_t D = f32s_ksteps(h->dim) * 8;
+    const size_t nacc = 3 + 2 * (size_t)D + (size_t)D * D, nst = 2 + 2 * (size_t)D + (size_t)D * D;
+    if (!h->kstat) {
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->kstat_acc), (3 + 2 * 128 + 128 * 128) * sizeof(double)));
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->kstat), (2 + 2 * 128 + 128 * 128) * sizeof(float)));
+    }
+    (void)nst;
+    ZV_HIP(hipMemsetAsync(h->kstat_acc, 0, nacc * sizeof(double), s));
+    const uint64_t G = (h->count + 31) / 32;
+    const uint32_t runs = (uint32_t)std::min<uint64_t>(RQ_STAT_RUNS, G);
+    const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
+    ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
+        using RT = row_elem_t<decltype(rows)>;
+        hipLaunchKernelGGL(k_rq_stats_acc<RT>, dim3(std::min(runs, RQ_STAT_BLOCKS)), dim3(256), 0, s, rows, ld, h->dim, D, h->count, l2 ? 1 : 0, runs, h->kstat_acc);
+        ZV_HIP(hipGetLastError());
+        return ZVDB_OK;
+    }));
+    hipLaunchKernelGGL(k_rq_stats_fin, dim3(1), dim3(256), 0, s, h->kstat_acc, D, h->kstat);
+    ZV_HIP(hipGetLastError());
+    h->kstat_count = h->count;
+    return ZVDB_OK;
+}
+
+// thresholds of a batch from the rows' moments: ONE launch (it also clears the verify flag, like the other guess kernels)
+int launch_f32rq_guess(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
+    const uint32_t D = f32s_ksteps(h->dim) * 8;
+    hipLaunchKernelGGL(k_rq_guess, dim3(nq), dim3(256), 0, s, d_queries, nq, h->dim, D, h->kstat, z, h->metric == ZVDB_METRIC_L2SQ ? 1 : 0, tau_g, verify_flag);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
+// QT = tiles of 256 queries; S = streams (QT * S workgroups); the mirror is the 128-query kernel's (ensure_f32_frag_mirror)
+int launch_f32rq_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand, uint64_t *partial,
+                      uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, uint32_t kpv,
+                      hipStream_t s) {
+    if (kpv == (uint32_t)KPMAX) return rq_launch<KPMAX>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    if (kpv == (uint32_t)KPW) return rq_launch<KPW>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    return rq_launch<KP>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+}
+
+}  // namespace zvdb

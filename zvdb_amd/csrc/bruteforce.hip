@@ -1070,7 +1070,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // -- measured: +13 % at 64 dimensions, +0 .. 5 % at 128 (both designs sit at ~0.68 there: DESIGN 3, K4), for a mirror as large as
     // the rows; so: by default up to 64 dimensions, and wherever k > 112 needs its wider lists; ZVDB_BF_F32_KERNEL=stream: up to 128
     const bool sf_wide = [] { const char *e = tuning("ZVDB_BF_F32_KERNEL"); return e && e[0] == 's'; }();
-    const bool sf = mode == ZVDB_BF_F32 && f32s_eligible(h) && ((big8 && (h->dim <= 64 || sf_wide)) || k > (uint32_t)KPW - 16);
+    // fp32, dim <= 128, batches of more than 128 queries on large shards: the register-resident-query scan (bf_f32_regq.hip) -- 256
+    // queries per workgroup in registers, the corpus HBM -> registers once per batch tile, no LDS staging, no barrier; work split by
+    // 32-row groups.  (Smaller batches: half of its waves would carry no query -- the 128-query kernel / the staged kernel serve them.)
+    const bool sr = mode == ZVDB_BF_F32 && f32rq_eligible(h) && !guess_off && p.NT >= 8 * p.S && nq > 128 && !(debug_flags() & 64);
+    const bool sf = !sr && mode == ZVDB_BF_F32 && f32s_eligible(h) && ((big8 && (h->dim <= 64 || sf_wide)) || k > (uint32_t)KPW - 16);
     // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
     // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
     // (from 8 tiles = 64 row groups per stream: BASELINE configs[1], 1M x 128 at batch 256 = 256 streams of 15 tiles, rides it)
@@ -1078,7 +1082,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool sb_big = !guess_off && p.NT >= 8 * p.S;
     const bool sb = mode == ZVDB_BF_BF16 && bf16s_eligible(h) && !(debug_flags() & 64) && (sb_big || k > (uint32_t)KPW - 16);
     if (sb) ZV_CHECK(ensure_bf16_frag_mirror(h, s));
-    if (sf) ZV_CHECK(ensure_f32_frag_mirror(h, s));
+    if (sf || sr) ZV_CHECK(ensure_f32_frag_mirror(h, s));
+    // its thresholds: from the rows' second moments, one small launch per batch (ZVDB_BF_F32_GUESS=sample: the 128-query kernel's sampling mode + k_i8_guess)
+    const bool sr_moments = sr && [] { const char *e = tuning("ZVDB_BF_F32_GUESS"); return !e || e[0] != 's'; }();
+    if (sr_moments) ZV_CHECK(ensure_f32rq_stats(h, s));
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
     if (ws_bytes < p.total) {
@@ -1111,7 +1118,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
         ZV_CHECK(launch_bf16s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else if (s8) {
         ZV_CHECK(launch_i8s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
-    } else if (sf) {
+    } else if (sf || sr) {
         ZV_CHECK(launch_f32s_prep_queries(h, d_queries, nq, p.nq_pad, q_op, s));
     } else {
         const uint64_t total = (uint64_t)p.nq_pad * p.row_elems;
@@ -1128,11 +1135,11 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t nlists = p.S, stot_lists = p.S;
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
-    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4 || sf) && big8) || (sb && sb_big);
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4 || sf) && big8) || (sb && sb_big) || sr;
     // k' = 64 survivors per query (one per lane of the selects) carry k <= 48 (56 with the exact fp32 screen); the stream
     // kernels also run with k' = 128 (two entries per lane), which carries k <= 112 -- on large shards inside the guessed-
     // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
-    const bool stream_route = f7 || s8 || s4 || sb || sf;
+    const bool stream_route = f7 || s8 || s4 || sb || sf || sr;
     // (the staged kernel has the same two list widths; the v1 kernel kept for A/B has only k' = 64)
     // The stream kernels go on to k' = 256 (four entries per lane): k <= 240, and the fp4 screen uses it from k > 64
     // (recall@100: 0.84 with 128 survivors).
@@ -1265,6 +1272,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             if (sb) {
                 ZV_CHECK(launch_bf16s_guess(h, q_op, nq, p.QT, SS, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            } else if (sr) {  // (moments by the 128-query kernel's sampling mode: same mirror, same packed queries, thresholds per global query)
+                if (sr_moments) ZV_CHECK(launch_f32rq_guess(h, d_queries, nq, z, tau_g, vflag, s));
+                else ZV_CHECK(launch_f32s_guess(h, q_op, nq, p.QT8, p.S8, p.NT, mom, z, tau_g, vflag, s));
+                ZV_CHECK(launch_f32rq_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             } else if (s8) {
                 ZV_CHECK(launch_i8s_guess(h, q_op, nq, p.QT8, SS, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
@@ -1295,6 +1306,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                                    kp, cap, 0u, 1, vflag, defq, h->guess_flag_dev, kpv, ckeys, kth, nflag, mlw);
             }
             if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
+            else if (sr) ZV_CHECK(launch_f32rq_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s8) ZV_CHECK(launch_i8s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (sf) ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_rep, kp, SS, Stot, pcnt, vflag, kpv, s));

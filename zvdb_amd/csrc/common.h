@@ -147,6 +147,10 @@ struct zvdb_hip_index {
     unsigned char *rows_ff = nullptr;
     float *norm_ff = nullptr;  // [cap_ff] sum v^2 (0: dot / cosine), +inf past count
     uint64_t cap_ff = 0, count_ff = 0;
+    // moments of the rows behind the register-query fp32 scan's guessed thresholds (bf_f32_regq.hip: k_rq_guess): E[n], Var(n), mu, Cov(n, v), Cov(v)
+    float *kstat = nullptr;
+    double *kstat_acc = nullptr;
+    uint64_t kstat_count = ~0ull;
     // fp4 (E2M1) scalar-quantised mirror for ZVDB_BF_FP4 (lazy, like the int8 one)
     unsigned char *rows_p = nullptr;  // [cap_p][ldp] bytes, 2 codes per byte (low nibble = even element), ldp = round_up(dim, 256) / 2
     float *norm_p = nullptr;          // [cap_p] sum of the squared fp4 VALUES (exact in fp32)
@@ -342,6 +346,13 @@ int launch_f32s_prep_queries(const zvdb_hip_index *h, const float *d_queries, ui
 int launch_f32s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                      uint64_t *cand, uint64_t *partial, uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot,
                      uint32_t *pcnt, const uint32_t *gate, uint32_t kpv, hipStream_t s);
+// the register-resident-query fp32 scan (bf_f32_regq.hip): 256-query tiles, the same fragment-order mirror and packed queries
+bool f32rq_eligible(const zvdb_hip_index *h);
+int ensure_f32rq_stats(zvdb_hip_index *h, hipStream_t s);
+int launch_f32rq_guess(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
+int launch_f32rq_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand, uint64_t *partial,
+                      uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, uint32_t kpv,
+                      hipStream_t s);
 int launch_f32s_guess(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint32_t nt,
                       float *mom, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
 int launch_i8s_prep_queries(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op,
