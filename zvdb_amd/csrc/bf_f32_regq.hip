@@ -348,25 +348,39 @@ __global__ __launch_bounds__(256) void k_rq_stats_fin(const double *__restrict__
 // one workgroup of 4 waves per query: tau_g[q] = key(mean + z sigma) of the screen key over the rows, from the rows' moments (header of
 // this section).  Wave w walks rows [w D / 4, (w + 1) D / 4) of Sigma for the lane's columns (coalesced: lanes = consecutive columns; a
 // single wave walking all D rows is one dependent chain of D L2 round trips: 19 us per batch instead of 6).
+// The same launch writes the scan's operand (k_f32_pack_frag's layout: piece (group, k-step j, lane l) = elements 8 j + 4 (l >> 5) + [0, 4)
+// of query 32 group + (l & 31)): blocks nq .. nq_pad - 1 write the zero rows of the padding and no threshold.
 __global__ __launch_bounds__(256) void k_rq_guess(const float *__restrict__ queries, uint32_t nq, uint32_t dim, uint32_t D, const float *__restrict__ kstat,
-                                                  float z, int l2, uint32_t *__restrict__ tau_g, uint32_t *__restrict__ verify_flag) {
+                                                  float z, int l2, uint32_t *__restrict__ tau_g, uint32_t *__restrict__ verify_flag,
+                                                  unsigned char *__restrict__ q_op) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) { verify_flag[0] = 0; verify_flag[1] = 0; }  // ([1]: deficient queries of the batch)
-    __shared__ float q[128];
+    __shared__ __attribute__((aligned(16))) float q[128];
     __shared__ double part[4][3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t qi = blockIdx.x;
-    if ((uint32_t)tid < D) q[tid] = (uint32_t)tid < dim ? queries[(size_t)qi * dim + tid] : 0.0f;
+    if ((uint32_t)tid < D) q[tid] = ((uint32_t)tid < dim && qi < nq) ? queries[(size_t)qi * dim + tid] : 0.0f;
     __syncthreads();
+    if (q_op && (uint32_t)tid < D / 4) {  // 16-byte chunk t = elements [4 t, 4 t + 4): k-step t / 2, half t & 1
+        const uint32_t KS = D / 8, j = (uint32_t)tid >> 1, hh = (uint32_t)tid & 1;
+        *reinterpret_cast<u32x4 *>(q_op + ((size_t)(qi >> 5) * KS + j) * 1024 + (hh * 32 + (qi & 31)) * 16) = *reinterpret_cast<const u32x4 *>(q + 4 * tid);
+    }
+    if (qi >= nq) return;
     const float *mu = kstat + 2, *c = kstat + 2 + D, *Sg = kstat + 2 + 2 * D;
     const uint32_t j0 = (uint32_t)w * (D / 4), j1 = j0 + D / 4;
     double qmu = 0.0, qc = 0.0, qsq = 0.0;
     for (uint32_t i = lane; i < D; i += 64) {
         float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-        for (uint32_t j = j0; j < j1; j += 4) {  // (D / 4 is a multiple of 4: D = 64 or 128)
-            t0 += Sg[(size_t)j * D + i] * q[j];
-            t1 += Sg[(size_t)(j + 1) * D + i] * q[j + 1];
-            t2 += Sg[(size_t)(j + 2) * D + i] * q[j + 2];
-            t3 += Sg[(size_t)(j + 3) * D + i] * q[j + 3];
+        for (uint32_t j = j0; j < j1; j += 16) {  // (D / 4 = 16 or 32 rows per wave; 16 independent loads in flight, then the sums)
+            float sv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sv[e] = Sg[(size_t)(j + e) * D + i];
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                t0 += sv[e] * q[j + e];
+                t1 += sv[e + 1] * q[j + e + 1];
+                t2 += sv[e + 2] * q[j + e + 2];
+                t3 += sv[e + 3] * q[j + e + 3];
+            }
         }
         qsq += (double)q[i] * (double)((t0 + t1) + (t2 + t3));
         if (w == 0) {
@@ -462,10 +476,12 @@ int ensure_f32rq_stats(zvdb_hip_index *h, hipStream_t s) {
     return ZVDB_OK;
 }
 
-// thresholds of a batch from the rows' moments: ONE launch (it also clears the verify flag, like the other guess kernels)
-int launch_f32rq_guess(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s) {
+// thresholds of a batch from the rows' moments + the scan's packed queries: ONE launch (it also clears the verify flag, like the other guess kernels)
+int launch_f32rq_guess(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op, float z, uint32_t *tau_g,
+                       uint32_t *verify_flag, hipStream_t s) {
     const uint32_t D = f32s_ksteps(h->dim) * 8;
-    hipLaunchKernelGGL(k_rq_guess, dim3(nq), dim3(256), 0, s, d_queries, nq, h->dim, D, h->kstat, z, h->metric == ZVDB_METRIC_L2SQ ? 1 : 0, tau_g, verify_flag);
+    hipLaunchKernelGGL(k_rq_guess, dim3(q_op ? nq_pad : nq), dim3(256), 0, s, d_queries, nq, h->dim, D, h->kstat, z, h->metric == ZVDB_METRIC_L2SQ ? 1 : 0, tau_g,
+                       verify_flag, q_op);
     ZV_HIP(hipGetLastError());
     return ZVDB_OK;
 }

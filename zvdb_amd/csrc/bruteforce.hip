@@ -1157,7 +1157,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool staged_guess = !guess_pipe && !stream_route && !guess_off && (mode == ZVDB_BF_F32 || mode == ZVDB_BF_BF16) &&
                               kpv == (uint32_t)KP && p.NT >= 8 * p.S && !(debug_flags() & ~(16u | 32u)) &&
                               (size_t)SG_Q * std::max(h->ld, h->ldh) * 4 <= 128 * 1024;  // (k_sample_guess keeps 4 padded queries in LDS)
-    prep_folded = staged_guess && d_queries == d_queries_exact && [] { const char *e = tuning("ZVDB_BF_FOLD_PREP"); return !e || e[0] != '0'; }();
+    prep_folded = (staged_guess && d_queries == d_queries_exact && [] { const char *e = tuning("ZVDB_BF_FOLD_PREP"); return !e || e[0] != '0'; }()) ||
+                  sr_moments;  // (k_rq_guess packs the queries it reads)
     ZV_CHECK(do_prep());
     if (!guess_pipe && !staged_guess) ZV_HIP(hipMemsetAsync(ws + p.off_taug, 0xFF, round_up64((uint64_t)p.nq_pad * 4, 256), s));
     if (debug_flags() & (16 | 32)) ZV_HIP(hipMemsetAsync(ws + p.off_taug + (size_t)p.nq_pad * 4, 0, 128, s));
@@ -1174,7 +1175,10 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const bool cert_defer = cert && [] { const char *e = tuning("ZVDB_BF_CERT_DEFER"); return !e || e[0] != '0'; }();
     // ... for at most this many queries of a batch (an exact scan per query: ~0.8 ms each at 10M x 768); a batch with more of them
     // is repaired by the gated scan + merge pair, which then follows the verifying merge as two no-op launches
-    const uint32_t defer_max = [] { const char *e = tuning("ZVDB_BF_DEFER_MAX"); return e ? (uint32_t)atoi(e) : 32u; }();
+    // The fp32 screen defers EVERY miss: its scan runs at the fp32-MFMA rate, so an exact scan per query of a whole batch costs ~7 scans
+    // (bounded; measured 3.5 ms for 256 queries at 1M x 128 against a 0.5-ms step), while the two no-op launches of the pair cost
+    // 9 us of EVERY 0.52-ms configs[1] step.  On the bf16 / int8 screens the same ratio is 80 - 160 scans: they keep the pair.
+    const uint32_t defer_max = [&] { const char *e = tuning("ZVDB_BF_DEFER_MAX"); return e ? (uint32_t)atoi(e) : mode == ZVDB_BF_F32 ? 0xFFFFFFFFu : 32u; }();
     auto finish = [&](uint32_t kp_valid) -> int {
         if (!cert) return launch_rerank(h, d_queries_exact, nq, cand_ids, kpv, k, id_offset, d_ids, d_dist, d_count, s, kp_valid);
         CertArgs ca;
@@ -1273,7 +1277,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
                 ZV_CHECK(launch_bf16s_guess(h, q_op, nq, p.QT, SS, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             } else if (sr) {  // (moments by the 128-query kernel's sampling mode: same mirror, same packed queries, thresholds per global query)
-                if (sr_moments) ZV_CHECK(launch_f32rq_guess(h, d_queries, nq, z, tau_g, vflag, s));
+                if (sr_moments) ZV_CHECK(launch_f32rq_guess(h, d_queries, nq, p.nq_pad, q_op, z, tau_g, vflag, s));
                 else ZV_CHECK(launch_f32s_guess(h, q_op, nq, p.QT8, p.S8, p.NT, mom, z, tau_g, vflag, s));
                 ZV_CHECK(launch_f32rq_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             } else if (s8) {

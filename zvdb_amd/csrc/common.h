@@ -349,7 +349,8 @@ int launch_f32s_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
 // the register-resident-query fp32 scan (bf_f32_regq.hip): 256-query tiles, the same fragment-order mirror and packed queries
 bool f32rq_eligible(const zvdb_hip_index *h);
 int ensure_f32rq_stats(zvdb_hip_index *h, hipStream_t s);
-int launch_f32rq_guess(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, float z, uint32_t *tau_g, uint32_t *verify_flag, hipStream_t s);
+int launch_f32rq_guess(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t nq_pad, unsigned char *q_op, float z, uint32_t *tau_g,
+                       uint32_t *verify_flag, hipStream_t s);
 int launch_f32rq_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, uint32_t QT, uint32_t S, uint64_t *cand, uint64_t *partial,
                       uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, uint32_t kpv,
                       hipStream_t s);
