@@ -11,7 +11,7 @@ case "$UNIT" in exact_kernels|ef_search|rerank|graph_build|exact_scan) EXTRA="-f
 mkdir -p /tmp/var_$1
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include $EXTRA $2 -c $UNIT.hip -o /tmp/var_$1/$UNIT.o > /tmp/var_$1/log 2>&1
 OBJS=""
-for o in api exact_kernels ef_search rerank data_kernels bruteforce bf_fp4_stream bf_i8_stream bf_bf16_stream graph_build exact_scan comm; do
+for o in api exact_kernels ef_search rerank data_kernels bruteforce bf_fp4_stream bf_i8_stream bf_bf16_stream bf_f32_regq graph_build exact_scan comm; do
   if [ "$o" = "$UNIT" ]; then OBJS="$OBJS /tmp/var_$1/$UNIT.o"; else OBJS="$OBJS build/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_$1.so $OBJS -ldl

@@ -256,6 +256,10 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
         for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
         thr0 = -tau_f[wave * 32 + fc];
         thr1 = -tau_f[wave * 32 + 16 + fc];
+#ifdef ZVDB_ABL_NOPASS  // (timing-only ablation, WRONG results: nothing passes the selection test, so both sides of a barrier A/B select alike)
+        thr0 = thr1 = __builtin_inff();
+        asm volatile("" : "+v"(thr0), "+v"(thr1));  // (opaque: the MFMAs stay)
+#endif
         __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0), as an instruction the waitcnt pass sees
         {   // prime the ring with unit `it` (visible: its pieces were drained ahead of a barrier this wave has passed)
             const uint32_t base = lds0 + slot * SLOT + lane16;
@@ -297,7 +301,9 @@ __global__ __launch_bounds__(512, 2) void k_bf16_stream(
         };
         do {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of units it and it + 1
+#ifndef ZVDB_ABL_NOBARRIER  // (timing-only ablation of round 6, WRONG results: the ceiling of any scheme that splits or relaxes this barrier -- profiles/r6/bf16_stream_ab.txt)
         __builtin_amdgcn_s_barrier();                      // ... everyone's; and everyone is done reading unit it - 1
+#endif
         const uint32_t un = min(u0 + it + 2, u1 - 1);
         const gbytes_t nsrc = uniform_ptr(Vf + (size_t)un * F * 1024 + (size_t)wave * 1024);
         const uint32_t ndst = lds0 + (slot >= 1 ? slot - 1 : 2) * SLOT + (uint32_t)wave * 1024;
