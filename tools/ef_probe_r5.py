@@ -57,7 +57,7 @@ if "A" in legs:
     g = zv.Index(dim=D, capacity=N, m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_MIRROR | zv.FLAG_BF16_ROWS)
     q = bench.make_rows(zv, torch, g, N, D, True, dev, s, 4096)
     g.build_graph(M, 64, zv.BF_I8, 7)
-    g.set_option(zv.OPT_EF_SEARCH_WIDTH, 4)
+    g.set_option(zv.OPT_EF_SEARCH_WIDTH, int(os.environ.get("EF_PROBE_WIDTH", "4")))
     for B, ef in ((1024, 128), (1024, 256), (1024, 512), (4096, 128)):
         r = run(g, q, B, D, K, ef, 2)
         print(f"{tag:>10} A 1Mx768 bf16 rank12 bulk  batch {B:5d} ef {ef:4d}: kernel {r['kernel_ms']:.4f} ms  {r['qps']:9.0f} QPS  {r['TBps']:.3f} TB/s = {r['TBps'] / 8:.3f}  E {r['E']:.0f}  chk {r['checksum']}", flush=True)
@@ -67,7 +67,7 @@ if "B" in legs:
     g = zv.Index(dim=D, capacity=N, metric=zv.METRIC_COSINE, m=2 * M, graph_stride=2 * M, flags=zv.FLAG_BF16_MIRROR | zv.FLAG_BF16_ROWS)
     q = bench.make_rows(zv, torch, g, N, D, True, dev, s, 1024)
     g.build_graph(M, 64, zv.BF_I8, 7)
-    g.set_option(zv.OPT_EF_SEARCH_WIDTH, 4)
+    g.set_option(zv.OPT_EF_SEARCH_WIDTH, int(os.environ.get("EF_PROBE_WIDTH", "4")))
     for B, ef in ((1024, 256), (1024, 512)):
         r = run(g, q, B, D, K, ef, 2, reps=5)
         print(f"{tag:>10} B 2Mx1536 cos bf16 k100     batch {B:5d} ef {ef:4d}: kernel {r['kernel_ms']:.4f} ms  {r['qps']:9.0f} QPS  {r['TBps']:.3f} TB/s = {r['TBps'] / 8:.3f}  E {r['E']:.0f}  chk {r['checksum']}", flush=True)

@@ -616,9 +616,9 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
     uint64_t *Wt = reinterpret_cast<uint64_t *>(q + dim_pad);    // [64 EPL] merge scatter buffer: keys ...
     uint32_t *Ft = reinterpret_cast<uint32_t *>(Wt + kWave * EPL);  // [64 EPL] ... and expanded flags
     uint32_t *hash = Ft + kWave * EPL;
-    float *nb_d = reinterpret_cast<float *>(hash + hash_size);
-    uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + kWave);
-    uint32_t *R = nb_i + kWave;                          // [kpad] result ids
+    float *nb_d = reinterpret_cast<float *>(hash + hash_size);   // [2 x 64] (a search-width step evaluates both windows' fresh entries in one distance phase)
+    uint32_t *nb_i = reinterpret_cast<uint32_t *>(nb_d + 2 * kWave);
+    uint32_t *R = nb_i + 2 * kWave;                      // [kpad] result ids
     float *RD = reinterpret_cast<float *>(R + kpad);     // [kpad] their exact distances
     uint32_t *ctl = reinterpret_cast<uint32_t *>(RD + kpad);  // [4] window hand-over to the helper waves (WPQ > 1)
     constexpr bool LMERGE = EPL >= 8;  // (at 4 blocks -- ef = 256 -- the gather merge measured the same as the merge by ranks: A/B on one box) large beams: Wt / Ft always hold the beam and a window merges by gather (merge_lds below)
@@ -988,6 +988,60 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
                 stamp(0);  // next-to-expand
                 // one window: <= 64 list entries (one lane each) -> visited test-and-set, the fresh ones compacted, their distances (shared
                 // with the helper waves), the beam update.  false: the visited table is full and a later launch serves the query.
+                // beam update with one window's candidates (ck: one key per lane, ~0 = none): the best ef of (W u candidates) stay
+                auto merge_cands = [&](uint64_t ck) {
+                    const bool pass = ck != ~0ull && (wn < ef || ck < worst);
+                    unsigned long long todo = __ballot(pass);
+                    const uint32_t na = (uint32_t)__popcll(todo);
+                    if constexpr (LMERGE) {
+                        if (na != 0) merge_lds(ck, pass, todo, na);
+                    } else if (na == 1) {
+                        insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
+                    } else if (na > 1) {
+                        // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
+                        // below it); new slot of a candidate = #(W entries below it) + #(candidates below it) -- per candidate two readlanes,
+                        // a compare + add per block and per candidate lane, and a ballot/popcount per block, ~16 instructions against ~70
+                        // for an insertion; then one scatter through LDS (slots >= ef fall off: the best ef of the union stay).
+                        uint32_t shift[EPL], crank = 0, wless = 0;
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) shift[e] = 0;
+                        while (todo) {
+                            const int l = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            const uint64_t ckl = readlane64(ck, l);
+                            uint32_t below = 0;
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e) {
+                                const bool valid = (uint32_t)(e * kWave + lane) < wn;
+                                shift[e] += (valid && ckl < wkr[e]) ? 1u : 0u;
+                                below += (uint32_t)__popcll(__ballot(valid && wkr[e] < ckl));
+                            }
+                            crank += ckl < ck ? 1u : 0u;
+                            if (lane == l) wless = below;
+                        }
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const uint32_t slot = (uint32_t)(e * kWave + lane), np = slot + shift[e];
+                            if (slot < wn && np < ef) { Wt[np] = wkr[e]; Ft[np] = (uint32_t)(xm[e] >> lane) & 1u; }
+                        }
+                        if (pass && wless + crank < ef) { Wt[wless + crank] = ck; Ft[wless + crank] = 0; }
+                        wn = min(wn + na, ef);
+                        sync_w();
+    #pragma unroll
+                        for (int e = 0; e < EPL; ++e) {
+                            const uint32_t slot = (uint32_t)(e * kWave + lane);
+                            const bool live = slot < wn;
+                            if (live) wkr[e] = Wt[slot];
+                            xm[e] = __ballot(live && Ft[slot] != 0);
+                        }
+                        if (wn == ef) {
+    #pragma unroll
+                            for (int e = 0; e < EPL; ++e)
+                                if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
+                        }
+                    }
+                    stamp(3);  // beam update
+                };
                 auto window = [&](bool valid, uint32_t nbl, uint32_t cnt, bool prefetch_ok) -> bool {
                     sync_w();
                     if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
@@ -1042,57 +1096,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
                     stamp(2);  // blocked distances of the fresh neighbours
                     uint64_t ck = ~0ull;
                     if ((fb >> lane) & 1ull) ck = ((uint64_t)f32_key(nb_d[lane]) << 32) | nb_i[lane];
-                    const bool pass = ck != ~0ull && (wn < ef || ck < worst);
-                    unsigned long long todo = __ballot(pass);
-                    const uint32_t na = (uint32_t)__popcll(todo);
-                    if constexpr (LMERGE) {
-                        if (na != 0) merge_lds(ck, pass, todo, na);
-                    } else if (na == 1) {
-                        insert_sorted(readlane64(ck, __builtin_ctzll(todo)));
-                    } else if (na > 1) {
-                        // several candidates: ONE merge by ranks instead of na insertions.  new slot of a W entry = its slot + #(candidates
-                        // below it); new slot of a candidate = #(W entries below it) + #(candidates below it) -- per candidate two readlanes,
-                        // a compare + add per block and per candidate lane, and a ballot/popcount per block, ~16 instructions against ~70
-                        // for an insertion; then one scatter through LDS (slots >= ef fall off: the best ef of the union stay).
-                        uint32_t shift[EPL], crank = 0, wless = 0;
-    #pragma unroll
-                        for (int e = 0; e < EPL; ++e) shift[e] = 0;
-                        while (todo) {
-                            const int l = __builtin_ctzll(todo);
-                            todo &= todo - 1;
-                            const uint64_t ckl = readlane64(ck, l);
-                            uint32_t below = 0;
-    #pragma unroll
-                            for (int e = 0; e < EPL; ++e) {
-                                const bool valid = (uint32_t)(e * kWave + lane) < wn;
-                                shift[e] += (valid && ckl < wkr[e]) ? 1u : 0u;
-                                below += (uint32_t)__popcll(__ballot(valid && wkr[e] < ckl));
-                            }
-                            crank += ckl < ck ? 1u : 0u;
-                            if (lane == l) wless = below;
-                        }
-    #pragma unroll
-                        for (int e = 0; e < EPL; ++e) {
-                            const uint32_t slot = (uint32_t)(e * kWave + lane), np = slot + shift[e];
-                            if (slot < wn && np < ef) { Wt[np] = wkr[e]; Ft[np] = (uint32_t)(xm[e] >> lane) & 1u; }
-                        }
-                        if (pass && wless + crank < ef) { Wt[wless + crank] = ck; Ft[wless + crank] = 0; }
-                        wn = min(wn + na, ef);
-                        sync_w();
-    #pragma unroll
-                        for (int e = 0; e < EPL; ++e) {
-                            const uint32_t slot = (uint32_t)(e * kWave + lane);
-                            const bool live = slot < wn;
-                            if (live) wkr[e] = Wt[slot];
-                            xm[e] = __ballot(live && Ft[slot] != 0);
-                        }
-                        if (wn == ef) {
-    #pragma unroll
-                            for (int e = 0; e < EPL; ++e)
-                                if ((ef - 1) >> 6 == (uint32_t)e) worst = readlane64(wkr[e], (int)((ef - 1) & 63));
-                        }
-                    }
-                    stamp(3);  // beam update
+                    merge_cands(ck);
                     return true;
                 };
                 const uint32_t per = (uint32_t)kWave / max(gstride, 1u);  // whole lists that fit one window
@@ -1101,17 +1105,87 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
                     // lists' worth of row fetches per dependent step.  The beam is a set, so merging the candidates of several lists
                     // together equals the spec's list-by-list insertion.
                     pre_id = 0xFFFFFFFFu;
-                    for (uint32_t s0 = 0; s0 < nsel; s0 += per) {
+                    // (r6) ALL the step's lists are requested before its first window runs: the picks are known (and marked) up front, so
+                    // the second window's list fetch -- a dependent random read that used to sit between the first window's merge and its own
+                    // visited pass -- is in flight during the first window's distance phase.  At most two windows (per >= 2, nsel <= 4).
+                    // (Measured and dropped, profiles/r6/ef_fused_step_ab.txt: requesting the NEXT step's likely lists ahead of the distance phase
+                    // as well -- the width-1 loop's speculation -- -6 %; widths up to 8 (four windows per phase): nothing at batch 1,024, -8 % at
+                    // batch 4,096 for the extra LDS.)
+                    const uint32_t w = (uint32_t)lane / gstride, j = (uint32_t)lane - w * gstride;
+                    uint32_t nblv[2] = {0, 0}, dgv[2] = {0, 0};
+                    const uint32_t nwin = (nsel + per - 1) / per;
+#pragma unroll
+                    for (uint32_t wi = 0; wi < 2; ++wi) {
+                        const uint32_t s0 = wi * per;
+                        if (s0 >= nsel) break;
                         const uint32_t nl = min(per, nsel - s0);
-                        const uint32_t w = (uint32_t)lane / gstride, j = (uint32_t)lane - w * gstride;
                         const bool live = w < nl;
                         const uint32_t iw = s0 + w;
                         const uint32_t cw = iw == 0 ? cids[0] : iw == 1 ? cids[1] : iw == 2 ? cids[2] : cids[3];
-                        uint32_t nbl = 0, dgw = 0;
-                        if (live) { nbl = adj[(size_t)cw * gstride + j]; dgw = min(deg[cw], gstride); }
-                        const bool valid = live && j < dgw;
+                        if (live) { nblv[wi] = adj[(size_t)cw * gstride + j]; dgv[wi] = min(deg[cw], gstride); }
+                    }
+                    // ONE distance phase per step: both windows' lists go through the visited test-and-set first (it does not depend on the
+                    // beam), their fresh entries sit side by side in nb_i, one phase evaluates them all (one ramp-up of the row gathers and
+                    // one barrier pair with the helper waves per step instead of two; 16-row passes are filled across the windows), then
+                    // the windows' candidates merge in list order -- window 1's acceptance test sees the beam window 0's merge left, as in
+                    // the spec's list-by-list insertion.  E / P and results unchanged (tests: the oracle's orc_hnsw_search_ef_w).
+                    uint32_t nfw[2] = {0, 0}, tot = 0;
+#pragma unroll
+                    for (uint32_t wi = 0; wi < 2; ++wi) {
+                        if (wi >= nwin) break;
+                        const uint32_t nl = min(per, nsel - wi * per);
+                        const bool valid = w < nl && j < dgv[wi];
                         const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
-                        if (cnt != 0 && !window(valid, nbl, cnt, false)) return;
+                        if (cnt == 0) continue;
+                        sync_w();
+                        if (hash_used + cnt >= hash_limit) overflow = true;  // wave-uniform
+                        if (overflow && (pass == kEfTight || pass == kEfRetryMark)) {  // the launch behind this one serves the query
+                            if (lane == 0) ef_mark_again(out_count, qi, net_list);
+                            release_helpers();
+                            return;
+                        }
+                        bool fresh1 = false, full1 = false;
+                        if (valid && !overflow) fresh1 = visit(nblv[wi], full1);
+                        if constexpr (EPL >= 8) {
+                            if (__ballot(full1)) {  // a region of the packed table is full: the launch behind this one serves the query
+                                if (pass == kEfTight || pass == kEfRetryMark) {
+                                    if (lane == 0) ef_mark_again(out_count, qi, net_list);
+                                    release_helpers();
+                                    return;
+                                }
+                                overflow = true;
+                            }
+                        }
+                        const unsigned long long fb0 = __ballot(fresh1);
+                        if (fresh1) nb_i[tot + (uint32_t)__popcll(fb0 & ((1ull << lane) - 1ull))] = nblv[wi];
+                        const uint32_t nf = (uint32_t)__popcll(fb0);
+                        nfw[wi] = nf;
+                        tot += nf;
+                        hash_used += nf;
+                        evals += nf;
+                    }
+                    if (WPQ > 1 && tot != 0) {
+                        if (lane == 0) ctl[0] = tot;
+                        __syncthreads();  // (A) the step's entries published to the helper waves
+                    } else {
+                        sync_w();
+                    }
+                    stamp(1);  // list loads + visited test-and-set
+                    if (tot != 0) {
+                        ef_window_distances<RT, WPQ, U>(rows, ld, q, nchunks, metric, tot, nb_i, nb_d, lane, 0);
+                        __syncthreads();  // (B) distances done
+                        stamp(2);  // blocked distances of the fresh neighbours
+                        uint32_t off = 0;
+#pragma unroll
+                        for (uint32_t wi = 0; wi < 2; ++wi) {
+                            if (wi >= nwin) break;
+                            const uint32_t nf = nfw[wi];
+                            if (nf == 0) continue;
+                            uint64_t ck = ~0ull;
+                            if ((uint32_t)lane < nf) ck = ((uint64_t)f32_key(nb_d[off + lane]) << 32) | nb_i[off + lane];
+                            merge_cands(ck);
+                            off += nf;
+                        }
                     }
                 } else {
                     for (uint32_t s = 0; s < nsel; ++s) {
@@ -1338,7 +1412,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
     const bool beam_lds = beam_env && beam_env[0] == 'l';
     const int epl = beam_lds ? 0 : ef <= 128 ? 2 : ef <= 256 ? 4 : ef <= 512 ? 8 : ef <= 1024 ? 16 : 0;
     auto lds_slots = [&](uint64_t slots) -> size_t {  // LDS of a query with a visited table of `slots` entries
-        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * slots + 8ull * kWave + 8ull * kpad + 16 + (epl >= 8 ? 8ull * kWave + 8ull * epl : 0);  // (+ Cs, Mb of merge_lds)
+        if (epl) return 4ull * dim_pad + 12ull * kWave * epl + 4ull * slots + 16ull * kWave + 8ull * kpad + 16 + (epl >= 8 ? 8ull * kWave + 8ull * epl : 0);  // (+ Cs, Mb of merge_lds)
         return 4ull * dim_pad + 2ull * efp * 8 + 2ull * efp * 4 + 1024 + 4ull * slots + 8ull * kWave;
     };
     auto lds_bytes = [&](uint32_t hb) -> size_t { return lds_slots(1ull << hb); };
