@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 CORPUS_SEED = 0x5EED
 QUERY_SEED = 0xC0FFEE
 KERNEL_NAMES = {"bf16": "k_bf16_stream<48,1,false,KPV,0>, KPV = 64 / 128 / 256 list entries per stream = the survivors the certificate's level asks for (128 at level 2, the level of the benchmark's data) (bf_bf16_stream.hip; shards >= 8 tiles per stream, dim <= 768; else k_bf_scan5<bf16>)",
-                "f32": "k_bf_scan5<f32> (bruteforce.hip)",
+                "f32": "k_bf_scan5<f32> (bruteforce.hip; dim <= 128 and batches > 128: k_f32_regq, bf_f32_regq.hip)",
                 "i8": "k_i8_stream<24> (bf_i8_stream.hip; shards >= 16 tiles per stream; else k_bf_scan5<i8>)",
                 "fp4": "k_fp4_stream<12,0,32> (bf_fp4_stream.hip)"}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "i8": 5000.0, "fp4": 10000.0}  # dense MFMA peaks (i8 = 2x, fp4 = 4x bf16 per clock), MI355X_MICROARCH.md
@@ -516,7 +516,7 @@ def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16
     return out
 
 
-def c2_leg(zv, torch, dev, stream, k, modes=("f32",), steps=20):
+def c2_leg(zv, torch, dev, stream, k, modes=("f32",), steps=200):
     """BASELINE configs[1]: 1M x 128 fp32 brute force, batch 256 (MFMA distance kernel + wavefront top-k), per exact screen."""
     N2, D2, B2 = 1_000_000, 128, 256
     MODES = {"bf16": zv.BF_BF16, "f32": zv.BF_F32, "i8": zv.BF_I8}
@@ -532,7 +532,7 @@ def c2_leg(zv, torch, dev, stream, k, modes=("f32",), steps=20):
     out = {"rows": N2, "dim": D2, "batch": B2, "k": k}
     for name in modes:
         m = MODES[name]
-        for _ in range(4):
+        for _ in range(40):  # (a 0.5-ms step: 20 timed steps behind 4 warm-ups measured the clock ramp -- 433k QPS where 200 behind 40 measure 490k)
             idx.search_bruteforce_dev(q.data_ptr(), B2, D2, k, m, 0, ws.data_ptr(), ws_b, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), stream)
         torch.cuda.synchronize()
         idx.timing_enable(True)
@@ -548,7 +548,8 @@ def c2_leg(zv, torch, dev, stream, k, modes=("f32",), steps=20):
         # batch's scan -- measured 353k QPS against 396k on one stream: two scans resident at once slow each other more than the
         # overlap saves; not reported)
         out[name] = {"qps": B2 * steps / el, "ms_per_batch": el / steps * 1e3,
-                     "roofline": {"bound": "mfma", "kernel": "k_bf_scan5<f32> / k_i8_stream<0> (fp32 MFMA)" if name == "f32" else KERNEL_NAMES[name],
+                     "roofline": {"bound": "mfma", "kernel": "k_f32_regq<16> (bf_f32_regq.hip: register-resident queries, fp32 MFMA)" if name == "f32" else KERNEL_NAMES[name],
+                                  "region": "moments guess + packed queries (one launch) + ONE scan + verifying merge" if name == "f32" else None,
                                   "kernel_ms_avg": kms / kn, "timed_regions": kn, "achieved": ach, "peak": PEAK_TFLOPS[name],
                                   "unit": "TFLOP/s" if name != "i8" else "TOP/s", "frac": ach / PEAK_TFLOPS[name]}}
     out["certificate"] = idx.cert_info()
@@ -726,7 +727,8 @@ def measure_traffic(args):
         if r.returncode != 0 or not f:
             shutil.rmtree(d, ignore_errors=True)
             return None
-        vals = [float(x["Counter_Value"]) for x in csv.DictReader(open(f[0])) if x["Counter_Name"] == c and "k_bf16_stream<48, 1, false" in x["Kernel_Name"]]
+        vals = [float(x["Counter_Value"]) for x in csv.DictReader(open(f[0]))
+                if x["Counter_Name"] == c and "k_bf16_stream<48, 1, false" in x["Kernel_Name"] and ", 1>(" not in x["Kernel_Name"]]  # (", 1>": the gated no-op launch)
         shutil.rmtree(d, ignore_errors=True)
         if not vals:
             return None

@@ -19,8 +19,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- pytho
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/bench_10Mx768_bf16_stream_kernel_stats.csv
 ( echo "# launches of one headline step in order (rocprofv3 --kernel-trace of python3 bench.py --mode bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-paths)"; python3 $R/tools/trace_step.py $OUT/stats ) > $OUT/bench_10Mx768_bf16_stream_passes.txt 2>&1
 rm -rf $OUT/stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $R/tools/c2_trace.py > /dev/null 2> $OUT/prof3.err || { tail -5 $OUT/prof3.err; exit 1; }
-( echo "# launches of one configs[1] step in order (1M x 128 fp32, batch 256, fp32 screen; rocprofv3 --kernel-trace of tools/c2_trace.py)"; python3 $R/tools/trace_step.py $OUT/stats ) > $OUT/c2_1Mx128_f32_passes.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $R/tools/c2_trace.py 400 > /dev/null 2> $OUT/prof3.err || { tail -5 $OUT/prof3.err; exit 1; }
+( echo "# launches of one configs[1] step in order (1M x 128 fp32, batch 256, fp32 screen; rocprofv3 --kernel-trace --stats of tools/c2_trace.py 400: the LAST of 400 steps, clocks warm)"; python3 $R/tools/trace_step.py $OUT/stats; echo "# kernel stats of the same run (all 400 steps): name, calls, average us, min us, max us"; python3 - <<PY
+import csv, glob
+f = glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if any(k in r["Name"] for k in ("k_f32_regq", "k_rq_guess", "k_bf_merge_sel", "k_rerank", "k_exact_scan")):
+        nm = r["Name"].replace("zvdb::", "").replace("(anonymous namespace)::", "").split("(")[0]
+        print(f"{nm:48s} {r['Calls']:>5s} {float(r['AverageNs']) / 1e3:9.1f} {float(r['MinNs']) / 1e3:9.1f} {float(r['MaxNs']) / 1e3:9.1f}")
+PY
+) > $OUT/c2_1Mx128_f32_passes.txt 2>&1
 rm -rf $OUT/stats
 echo "kernel stats done"
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -33,7 +41,7 @@ KEY = "k_bf16_stream<48, 1, false"
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{OUT}/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c and KEY in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c and KEY in r["Kernel_Name"] and ", 1>(" not in r["Kernel_Name"]]  # (", 1>": the gated no-op launch)
     per[c] = [float(r["Counter_Value"]) for r in rows]
     name = rows[0]["Kernel_Name"].split("(")[0]
 fb = 2.0 * sum(per["FETCH_SIZE"]) / len(per["FETCH_SIZE"]) * 1024
