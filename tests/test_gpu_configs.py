@@ -87,8 +87,13 @@ def test_bf16_stream_route_exact(zv, oracle, n, d, nq, k, metric):
     (530_003, 64, 261, 48, "l2"),       # KS = 8; nothing a multiple of anything; k = the 64-survivor maximum
     (300_017, 128, 1000, 100, "l2"),    # four query tiles, k' = 128 lists
     (600_000, 40, 300, 200, "l2"),      # k' = 256 lists
+    (500_000, 256, 256, 10, "l2"),      # KS = 32: 128 VGPRs of queries, a ring of a quarter group
+    (400_003, 200, 300, 48, "l2"),      # KS = 28 (ring of 7) with zero-padded k-steps
+    (400_000, 160, 257, 10, "l2"),      # KS = 20 (ring of 10)
+    (400_000, 170, 300, 10, "l2"),      # KS = 24 (ring of 8)
     (600_000, 96, 300, 10, "dot"),
     (400_000, 120, 520, 25, "cosine"),
+    (300_000, 250, 270, 10, "dot"),
 ])
 def test_f32_regq_route_exact(zv, oracle, tuning, n, d, nq, k, metric):
     """The fp32 screen's register-resident-query kernel against (a) the staged fp32 kernel of the same library

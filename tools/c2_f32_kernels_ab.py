@@ -34,6 +34,8 @@ def leg(N, D, B, reps):
     ref = (ids.clone(), dd.clone())
     res = {}
     settings = [("regq", {}), ("regq_sampled", {"ZVDB_BF_F32_GUESS": "sample"}), ("regq_nogated", {"ZVDB_BF_DEFER_MAX": "1000000"}), ("stream", {"ZVDB_BF_F32_KERNEL": "stream"}), ("v6_staged", {"ZVDB_BF_F32_KERNEL": "v6"})]
+    if D > 128:
+        settings = [("regq", {}), ("v6_staged", {"ZVDB_BF_F32_KERNEL": "v6"})]
     for rnd in range(3):
         for name, sw in settings:
             with zv.tuned(**sw):

@@ -55,13 +55,10 @@ __device__ __forceinline__ void rq_load4(float &d, uint32_t voff, gbytes_t sbase
 }
 template <int N> __device__ __forceinline__ void rq_vm_wait(u32x4 &d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
 template <int N> __device__ __forceinline__ void rq_vm_wait_f(float &d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
-template <int R> __device__ __forceinline__ void rq_vm_drain(u32x4 (&a)[R]) {
-    static_assert(R == 8 || R == 16, "operand list below");
-    if constexpr (R == 8)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-    else
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
-                     "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+template <int R> __device__ __forceinline__ void rq_vm_drain(u32x4 (&a)[R]) {  // every ring register is tied: nothing behind sees a load in flight
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]));
+#pragma unroll
+    for (int i = 1; i < R; ++i) asm volatile("" : "+v"(a[i]));
 }
 
 // Exact prune of the calling wave's 32 queries whose append buffer passed MARK.  Out of line and cold: the scan keeps the query
@@ -89,7 +86,7 @@ __device__ __attribute__((noinline, cold)) void rq_prune_wave(uint64_t *kept, ui
     }
 }
 
-// KS = 8-element k-steps (1-KiB pieces) per row: 8 / 16 / 32 (dim <= 64 / 128 / 256).  GATED = 1: the same code under its own symbol
+// KS = 8-element k-steps (1-KiB pieces) per row: 8 / 16 (dim <= 64 / 128), 20 / 24 / 28 / 32 (dim <= 160 / 192 / 224 / 256).  GATED = 1: the same code under its own symbol
 // for the gated repair launch (a no-op unless the verification failed), so that profiler statistics do not average no-ops into the scan.
 template <int KS, int KPV = KP, int GATED = 0>
 __global__ __launch_bounds__(512, 2) void k_f32_regq(
@@ -98,8 +95,10 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
     uint32_t S, uint32_t G /* 32-row groups */, uint64_t *__restrict__ cand, uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all,
     uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, const uint32_t *__restrict__ gate) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
-    constexpr int R = KS < 16 ? KS : 16;  // operand ring: pieces in flight per wave (a whole group at <= 128 dimensions)
-    static_assert(KS == R, "the wait counts of the group loop assume a ring of one whole group");
+    // operand ring: pieces in flight per wave.  A whole group at <= 128 dimensions; rows of 129 .. 256 dimensions (KS = 20 / 24 / 28 / 32: the
+    // queries take 80 .. 128 VGPRs, a ring of 16 spills at 32) keep 7 .. 10 pieces = 7 .. 10 KiB, ~4,000 cycles, ahead
+    constexpr int R = KS <= 16 ? KS : KS == 20 ? 10 : KS == 28 ? 7 : 8;
+    static_assert(KS % R == 0, "ring wrap");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tau_f = reinterpret_cast<float *>(smem);              // exclusive bound: pass <=> key < tau
     uint32_t *cnt = reinterpret_cast<uint32_t *>(tau_f + T2);    // append slots handed out since the query's last prune
@@ -180,7 +179,10 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
             static_for<KS>([&](auto jc) {
                 constexpr int J = decltype(jc)::value;
                 constexpr int SL = J % R;
-                rq_vm_wait<R>(A[SL]);  // slot SL was refilled R pieces ago; R loads (R - 1 pieces + one norm load per KS pieces) are younger
+                // slot SL was refilled R pieces ago: R - 1 younger pieces, + the norm load (issued behind piece 0's refill, once per group) when it
+                // falls inside that window: always with a ring of a whole group; with a shorter ring for pieces 1 .. R only
+                constexpr int W = (KS == R || (J >= 1 && J <= R)) ? R : R - 1;
+                rq_vm_wait<W>(A[SL]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].x), __uint_as_float(B[J].x), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].y), __uint_as_float(B[J].y), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].z), __uint_as_float(B[J].z), acc, 0, 0, 0);
@@ -268,60 +270,49 @@ constexpr uint32_t RQ_STAT_BLOCKS = 64;
 template <typename RT>
 __global__ __launch_bounds__(256) void k_rq_stats_acc(const RT *__restrict__ rows, uint32_t ld, uint32_t dim, uint32_t D, uint64_t N, int l2,
                                                       uint32_t runs, double *__restrict__ acc) {
-    __shared__ float x[32][129];
-    __shared__ float nr[32];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *x = reinterpret_cast<float *>(smem);   // [32][D + 1]
+    float *nr = x + 32 * (D + 1);                 // [32]
     __shared__ uint32_t nvalid;
     const int tid = threadIdx.x;
     const uint64_t G = (N + 31) / 32;
-    constexpr int EPT = 128 * 128 / 256;  // pair sums per thread at D = 128
-    double s2[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) s2[e] = 0.0;
+    const uint32_t npairs = D * D, xs = D + 1;
     double s1 = 0.0, sn1 = 0.0, cn = 0.0, sn = 0.0, snn = 0.0;
-    const uint32_t npairs = D * D;
     for (uint32_t r = blockIdx.x; r < runs; r += gridDim.x) {
         const uint64_t g = (uint64_t)r * G / runs;
         __syncthreads();
         for (uint32_t t = tid; t < 32 * D; t += 256) {
             const uint32_t rr = t / D, i = t % D;
             const uint64_t row = 32 * g + rr;
-            x[rr][i] = (row < N && i < dim) ? row_elem(rows + row * ld, i) : 0.0f;
+            x[rr * xs + i] = (row < N && i < dim) ? row_elem(rows + row * ld, i) : 0.0f;
         }
         __syncthreads();
         if (tid < 32) {
             float a = 0.0f;
             if (l2)
-                for (uint32_t i = 0; i < D; ++i) a += x[tid][i] * x[tid][i];
+                for (uint32_t i = 0; i < D; ++i) a += x[tid * xs + i] * x[tid * xs + i];
             nr[tid] = 0.5f * a;
         }
         if (tid == 0) nvalid = (uint32_t)min((uint64_t)32, N - 32 * g);
         __syncthreads();
         const uint32_t nv = nvalid;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const uint32_t pe = (uint32_t)tid + 256u * e;
-            if (pe < npairs) {
-                const uint32_t i = pe / D, j = pe % D;
-                float a = 0.0f;
-                for (uint32_t rr = 0; rr < nv; ++rr) a += x[rr][i] * x[rr][j];
-                s2[e] += (double)a;
-            }
+        // the run's 32-row partial of every pair sum goes straight to the fp64 accumulator (one-off work per mirror build: 8M atomics at D = 128)
+        for (uint32_t pe = tid; pe < npairs; pe += 256) {
+            const uint32_t i = pe / D, j = pe % D;
+            float a = 0.0f;
+            for (uint32_t rr = 0; rr < nv; ++rr) a += x[rr * xs + i] * x[rr * xs + j];
+            atomicAdd(acc + 3 + 2 * D + pe, (double)a);
         }
         if ((uint32_t)tid < D) {
-            float a = 0.0f, b = 0.0f;
-            for (uint32_t rr = 0; rr < nv; ++rr) { a += x[rr][tid]; b += nr[rr] * x[rr][tid]; }
+            float a = 0.0f, b2 = 0.0f;
+            for (uint32_t rr = 0; rr < nv; ++rr) { a += x[rr * xs + tid]; b2 += nr[rr] * x[rr * xs + tid]; }
             s1 += (double)a;
-            sn1 += (double)b;
+            sn1 += (double)b2;
         }
         if (tid == 0) {
             for (uint32_t rr = 0; rr < nv; ++rr) { sn += (double)nr[rr]; snn += (double)nr[rr] * (double)nr[rr]; }
             cn += (double)nv;
         }
-    }
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const uint32_t pe = (uint32_t)tid + 256u * e;
-        if (pe < npairs) atomicAdd(acc + 3 + 2 * D + pe, s2[e]);
     }
     if ((uint32_t)tid < D) { atomicAdd(acc + 3 + tid, s1); atomicAdd(acc + 3 + D + tid, sn1); }
     if (tid == 0) { atomicAdd(acc + 0, cn); atomicAdd(acc + 1, sn); atomicAdd(acc + 2, snn); }
@@ -354,7 +345,7 @@ __global__ __launch_bounds__(256) void k_rq_guess(const float *__restrict__ quer
                                                   float z, int l2, uint32_t *__restrict__ tau_g, uint32_t *__restrict__ verify_flag,
                                                   unsigned char *__restrict__ q_op) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && verify_flag) { verify_flag[0] = 0; verify_flag[1] = 0; }  // ([1]: deficient queries of the batch)
-    __shared__ __attribute__((aligned(16))) float q[128];
+    __shared__ __attribute__((aligned(16))) float q[256];
     __shared__ double part[4][3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t qi = blockIdx.x;
@@ -370,12 +361,12 @@ __global__ __launch_bounds__(256) void k_rq_guess(const float *__restrict__ quer
     double qmu = 0.0, qc = 0.0, qsq = 0.0;
     for (uint32_t i = lane; i < D; i += 64) {
         float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
-        for (uint32_t j = j0; j < j1; j += 16) {  // (D / 4 = 16 or 32 rows per wave; 16 independent loads in flight, then the sums)
-            float sv[16];
+        for (uint32_t j = j0; j < j1; j += 8) {  // (D / 4 = 16 .. 64 rows per wave, a multiple of 8; 8 independent loads in flight per column, then the sums)
+            float sv[8];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sv[e] = Sg[(size_t)(j + e) * D + i];
+            for (int e = 0; e < 8; ++e) sv[e] = Sg[(size_t)(j + e) * D + i];
 #pragma unroll
-            for (int e = 0; e < 16; e += 4) {
+            for (int e = 0; e < 8; e += 4) {
                 t0 += sv[e] * q[j + e];
                 t1 += sv[e + 1] * q[j + e + 1];
                 t2 += sv[e + 2] * q[j + e + 2];
@@ -436,17 +427,21 @@ int rq_launch(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, u
     const uint32_t KS = f32s_ksteps(h->dim);
     if (KS == 8) return rq_launch_geo<8, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
     if (KS == 16) return rq_launch_geo<16, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    if (KS == 20) return rq_launch_geo<20, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    if (KS == 24) return rq_launch_geo<24, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    if (KS == 28) return rq_launch_geo<28, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    if (KS == 32) return rq_launch_geo<32, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
     set_error("fp32 register-query scan: dim %u has no instantiation", h->dim);
     return ZVDB_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-// fp32 screens of 5 .. 128 dimensions; ZVDB_BF_F32_KERNEL=v6 (staged) / stream (the 128-query kernel) select the older kernels
+// fp32 screens of 5 .. 256 dimensions; ZVDB_BF_F32_KERNEL=v6 (staged) / stream (the 128-query kernel) select the older kernels
 bool f32rq_eligible(const zvdb_hip_index *h) {
     const char *e = tuning("ZVDB_BF_F32_KERNEL");
     if (e && ((e[0] == 'v' && e[1] == '6') || e[0] == 's')) return false;
-    return h->dim > 4 && h->dim <= 128;
+    return h->dim > 4 && h->dim <= 256;
 }
 
 // the rows' moments behind k_rq_guess: rebuilt with the fragment mirror (lazily, when rows were added)
@@ -455,18 +450,18 @@ int ensure_f32rq_stats(zvdb_hip_index *h, hipStream_t s) {
     if (h->count == 0) return ZVDB_OK;
     const uint32_t D = f32s_ksteps(h->dim) * 8;
     const size_t nacc = 3 + 2 * (size_t)D + (size_t)D * D, nst = 2 + 2 * (size_t)D + (size_t)D * D;
-    if (!h->kstat) {
-        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->kstat_acc), (3 + 2 * 128 + 128 * 128) * sizeof(double)));
-        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->kstat), (2 + 2 * 128 + 128 * 128) * sizeof(float)));
+    if (!h->kstat) {  // (sized by the index's dimension, which never changes)
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->kstat_acc), nacc * sizeof(double)));
+        ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->kstat), nst * sizeof(float)));
     }
-    (void)nst;
     ZV_HIP(hipMemsetAsync(h->kstat_acc, 0, nacc * sizeof(double), s));
     const uint64_t G = (h->count + 31) / 32;
     const uint32_t runs = (uint32_t)std::min<uint64_t>(RQ_STAT_RUNS, G);
     const bool l2 = h->metric == ZVDB_METRIC_L2SQ;
     ZV_CHECK(rows_dispatch(h, [&](auto rows, uint32_t ld) -> int {
         using RT = row_elem_t<decltype(rows)>;
-        hipLaunchKernelGGL(k_rq_stats_acc<RT>, dim3(std::min(runs, RQ_STAT_BLOCKS)), dim3(256), 0, s, rows, ld, h->dim, D, h->count, l2 ? 1 : 0, runs, h->kstat_acc);
+        hipLaunchKernelGGL(k_rq_stats_acc<RT>, dim3(std::min(runs, RQ_STAT_BLOCKS)), dim3(256), (32 * (D + 1) + 32) * sizeof(float), s, rows, ld, h->dim, D, h->count,
+                           l2 ? 1 : 0, runs, h->kstat_acc);
         ZV_HIP(hipGetLastError());
         return ZVDB_OK;
     }));

@@ -600,7 +600,8 @@ int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint
     return launch_i8_stream<3, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
 // ---- the same 128-query kernel with fp32 MFMAs on a fragment-order fp32 mirror: dim <= 128 (KS = 8, 16) -------------------------
-uint32_t f32s_ksteps(uint32_t dim) { return dim <= 64 ? 8u : 16u; }
+// (beyond 128 dimensions -- the register-query scan only, bf_f32_regq.hip -- whole 32-element steps: 20 / 24 / 28 / 32 pieces for <= 160 / 192 / 224 / 256)
+uint32_t f32s_ksteps(uint32_t dim) { return dim <= 64 ? 8u : dim <= 128 ? 16u : (dim + 31) / 32 * 4; }
 bool f32s_eligible(const zvdb_hip_index *h) {
     const bool off = [] { const char *e = tuning("ZVDB_BF_F32_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 4 && h->dim <= 128;

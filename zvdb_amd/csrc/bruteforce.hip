@@ -812,7 +812,7 @@ BfPlan make_plan(const zvdb_hip_index *h, uint32_t nq, uint32_t mode, uint32_t k
     off += round_up64(std::max<uint64_t>((uint64_t)p.nq_pad * p.row_bytes,
                                          mode == ZVDB_BF_FP4 && (fp4s_eligible(h) || fp4s128_eligible(h)) ? fp4s_query_bytes(h, p.nq_pad)
                                          : mode == ZVDB_BF_I8 && i8s_eligible(h) ? i8s_query_bytes(h, p.nq_pad)
-                                         : mode == ZVDB_BF_F32 && f32s_eligible(h) ? f32s_query_bytes(h, p.nq_pad)
+                                         : mode == ZVDB_BF_F32 && (f32s_eligible(h) || f32rq_eligible(h)) ? f32s_query_bytes(h, p.nq_pad)
                                          : mode == ZVDB_BF_BF16 && bf16s_eligible(h) ? bf16s_query_bytes(h, p.nq_pad) : 0), 256);
     p.off_cand = off;
     // (after the scan the region is free: the exact scan behind the certificate keeps its partial lists here)
@@ -1070,7 +1070,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // -- measured: +13 % at 64 dimensions, +0 .. 5 % at 128 (both designs sit at ~0.68 there: DESIGN 3, K4), for a mirror as large as
     // the rows; so: by default up to 64 dimensions, and wherever k > 112 needs its wider lists; ZVDB_BF_F32_KERNEL=stream: up to 128
     const bool sf_wide = [] { const char *e = tuning("ZVDB_BF_F32_KERNEL"); return e && e[0] == 's'; }();
-    // fp32, dim <= 128, batches of more than 128 queries on large shards: the register-resident-query scan (bf_f32_regq.hip) -- 256
+    // fp32, dim <= 256, batches of more than 128 queries on large shards: the register-resident-query scan (bf_f32_regq.hip) -- 256
     // queries per workgroup in registers, the corpus HBM -> registers once per batch tile, no LDS staging, no barrier; work split by
     // 32-row groups.  (Smaller batches: half of its waves would carry no query -- the 128-query kernel / the staged kernel serve them.)
     const bool sr = mode == ZVDB_BF_F32 && f32rq_eligible(h) && !guess_off && p.NT >= 8 * p.S && nq > 128 && !(debug_flags() & 64);
@@ -1084,7 +1084,8 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     if (sb) ZV_CHECK(ensure_bf16_frag_mirror(h, s));
     if (sf || sr) ZV_CHECK(ensure_f32_frag_mirror(h, s));
     // its thresholds: from the rows' second moments, one small launch per batch (ZVDB_BF_F32_GUESS=sample: the 128-query kernel's sampling mode + k_i8_guess)
-    const bool sr_moments = sr && [] { const char *e = tuning("ZVDB_BF_F32_GUESS"); return !e || e[0] != 's'; }();
+    const bool sr_moments = sr && (h->dim > 128 /* (the sampling mode is the 128-query kernel's: dim <= 128) */ ||
+                                   [] { const char *e = tuning("ZVDB_BF_F32_GUESS"); return !e || e[0] != 's'; }());
     if (sr_moments) ZV_CHECK(ensure_f32rq_stats(h, s));
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
     if (mode == ZVDB_BF_FP4) ZV_CHECK((f7 || s4) ? ensure_fp4_frag_mirror(h, s) : ensure_fp4_mirror(h, s));
