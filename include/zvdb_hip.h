@@ -265,8 +265,9 @@ int zvdb_hip_search_graph(zvdb_hip_index *h, const float *queries, uint32_t nq, 
  * k <= 112 on every route and dimension (k <= 48, 56 with ZVDB_BF_F32, keep
  * k' = 64 survivors per query; larger k -- the approximate ZVDB_BF_FP4 screen
  * from k > 32 -- keep k' = 128); k <= 240 on the stream routes (ZVDB_BF_I8 and
- * ZVDB_BF_BF16 with dim <= 768, ZVDB_BF_F32 with dim <= 128, ZVDB_BF_FP4 with
- * dim <= 1536: k' = 256, the fp4 screen from k > 64); else ZVDB_ERR_UNSUPPORTED. */
+ * ZVDB_BF_BF16 with dim <= 768, ZVDB_BF_F32 with dim <= 128 (<= 256 for batches of
+ * more than 128 queries), ZVDB_BF_FP4 with dim <= 1536: k' = 256, the fp4 screen
+ * from k > 64); else ZVDB_ERR_UNSUPPORTED. */
 int zvdb_hip_search_bruteforce(zvdb_hip_index *h, const float *queries, uint32_t nq, uint32_t dim,
                                uint32_t k, uint32_t mode,
                                uint64_t *out_ids, float *out_dist, uint32_t *out_count);

@@ -7,7 +7,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for c in range(cases):
-    d = int(rng.choice([64, 96, 100, 128, 192, 200, 384, 768]))
+    d = int(rng.choice([64, 96, 100, 128, 160, 192, 200, 256, 384, 768]))
     n = int(rng.choice([262144, 262145, 300001, 500000, 777777, 1000003]))
     n = min(n, int(1.0e8 // d))
     nq = int(rng.choice([1, 255, 256, 257, 700, 1024, 1100]))
@@ -45,6 +45,13 @@ for c in range(cases):
             if metric == 0:
                 if not (np.array_equal(b16[qi], ri[j]) and np.array_equal(db16[qi], rd[j])): ok = False
             elif len(set(b16[qi]) & set(ri[j])) / k < 0.95: ok = False
+    if k <= 112 or d <= 128 or (d <= 256 and nq > 128):  # the fp32 screen: register-query scan (dim <= 256, batches > 128), 128-query stream kernel, staged kernel
+        f32, df32, cf32 = idx.search_bruteforce(Q, k, zv.BF_F32)
+        if not np.all(cf32 == k): ok = False
+        for j, qi in enumerate(sel):
+            if metric == 0:
+                if not (np.array_equal(f32[qi], ri[j]) and np.array_equal(df32[qi], rd[j])): ok = False
+            elif len(set(f32[qi]) & set(ri[j])) / k < 0.95: ok = False
     a4, d4, c4 = idx.search_bruteforce(Q, k, zv.BF_FP4)
     if not (np.all(c4 == k) and np.all(np.diff(d4, axis=1) >= 0)): ok = False
     rec = np.mean([len(set(a4[qi]) & set(ri[j])) / k for j, qi in enumerate(sel)])

@@ -1554,6 +1554,7 @@ int zvdb_hip_storage_info(zvdb_hip_index *h, uint64_t *out_row_bytes, uint64_t *
         if (h->rows_pf) b += h->cap_pf * fp4s_ksteps(h->dim) * 32 + h->cap_pf * 4;
         if (h->rows_hf) b += h->cap_hf * bf16s_ksteps(h->dim) * 32 + (h->cap_hf + 64) * 4;
         if (h->rows_ff) b += h->cap_ff * f32s_ksteps(h->dim) * 32 + h->cap_ff * 4;
+        if (h->kstat) { const uint64_t D = f32s_ksteps(h->dim) * 8; b += (2 + 2 * D + D * D) * 4 + (3 + 2 * D + D * D) * 8; }  // (moments behind k_rq_guess)
         b += h->ef_visit_bytes + (h->ef_net_list_words + h->ef_net_table_words) * 4 + (h->spec_cap0 + h->spec_capU) * 8;  // ef-search net / global visited tables, speculative-insert stamps
         *out_resident_bytes = b;
     }

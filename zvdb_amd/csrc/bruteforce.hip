@@ -1073,7 +1073,9 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     // fp32, dim <= 256, batches of more than 128 queries on large shards: the register-resident-query scan (bf_f32_regq.hip) -- 256
     // queries per workgroup in registers, the corpus HBM -> registers once per batch tile, no LDS staging, no barrier; work split by
     // 32-row groups.  (Smaller batches: half of its waves would carry no query -- the 128-query kernel / the staged kernel serve them.)
-    const bool sr = mode == ZVDB_BF_F32 && f32rq_eligible(h) && !guess_off && p.NT >= 8 * p.S && nq > 128 && !(debug_flags() & 64);
+    // (smaller shards with k beyond the staged kernel's 112: one flooding scan of the same kernel, like the bf16 / int8 stream routes)
+    const bool sr_big = !guess_off && p.NT >= 8 * p.S;
+    const bool sr = mode == ZVDB_BF_F32 && f32rq_eligible(h) && nq > 128 && !(debug_flags() & 64) && (sr_big || k > (uint32_t)KPW - 16);
     const bool sf = !sr && mode == ZVDB_BF_F32 && f32s_eligible(h) && ((big8 && (h->dim <= 64 || sf_wide)) || k > (uint32_t)KPW - 16);
     // bf16: the register-resident-query stream kernel (bf_bf16_stream.hip) serves large shards of <= 768 dimensions inside the
     // guessed-threshold pipeline; small shards and wider rows stay on the staged kernel over the row-major bf16 mirror
@@ -1084,7 +1086,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     if (sb) ZV_CHECK(ensure_bf16_frag_mirror(h, s));
     if (sf || sr) ZV_CHECK(ensure_f32_frag_mirror(h, s));
     // its thresholds: from the rows' second moments, one small launch per batch (ZVDB_BF_F32_GUESS=sample: the 128-query kernel's sampling mode + k_i8_guess)
-    const bool sr_moments = sr && (h->dim > 128 /* (the sampling mode is the 128-query kernel's: dim <= 128) */ ||
+    const bool sr_moments = sr && sr_big && (h->dim > 128 /* (the sampling mode is the 128-query kernel's: dim <= 128) */ ||
                                    [] { const char *e = tuning("ZVDB_BF_F32_GUESS"); return !e || e[0] != 's'; }());
     if (sr_moments) ZV_CHECK(ensure_f32rq_stats(h, s));
     if (mode == ZVDB_BF_I8) ZV_CHECK(s8 ? ensure_i8_frag_mirror(h, s) : ensure_i8_mirror(h, s));
@@ -1136,7 +1138,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     uint32_t nlists = p.S, stot_lists = p.S;
     // shared thresholds start at "no bound"; the guessed-threshold pipeline overwrites every live entry itself (k_*_guess),
     // so it skips this launch (and clears its verify flag inside the guess kernel): two fewer launches per batch
-    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4 || sf) && big8) || (sb && sb_big) || sr;
+    const bool guess_pipe = (f7 && !guess_off && p.NT >= 16 * p.S && !(debug_flags() & 64)) || ((s8 || s4 || sf) && big8) || (sb && sb_big) || (sr && sr_big);
     // k' = 64 survivors per query (one per lane of the selects) carry k <= 48 (56 with the exact fp32 screen); the stream
     // kernels also run with k' = 128 (two entries per lane), which carries k <= 112 -- on large shards inside the guessed-
     // threshold pipeline, on small ones as ONE flooding scan (no bound to start with; the prune rounds learn it)
@@ -1148,7 +1150,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
     const uint32_t kpv = !wide_k ? (uint32_t)KP : widest ? (uint32_t)KPMAX : (uint32_t)KPW;
     if (k > (kpv != (uint32_t)KP ? kpv - 16 : kmax)) {
         set_error("brute force supports k <= %u on this route (k' = %u candidates are re-ranked exactly; k <= %d on the stream routes: "
-                  "ZVDB_BF_I8 / ZVDB_BF_BF16 with dim <= 768, ZVDB_BF_F32 with dim <= 128, ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
+                  "ZVDB_BF_I8 / ZVDB_BF_BF16 with dim <= 768, ZVDB_BF_F32 with dim <= 128 (<= 256 for batches of more than 128 queries), ZVDB_BF_FP4 with dim <= 1536)", kpv != (uint32_t)KP ? kpv - 16 : kmax, kpv, KPMAX - 16);
         return ZVDB_ERR_UNSUPPORTED;
     }
     // The float screens of the STAGED kernel (fp32; bf16 on rows the stream kernel does not take) ride the same guessed +
@@ -1394,6 +1396,7 @@ int launch_bruteforce(zvdb_hip_index *h, const float *d_queries, uint32_t nq, ui
             else if (sf) ZV_CHECK(launch_f32s_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else if (s4) ZV_CHECK(launch_fp4s128_scan(h, q_op, nq, p.QT8, SS, p.NT, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else if (sb) ZV_CHECK(launch_bf16s_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
+            else if (sr) ZV_CHECK(launch_f32rq_scan(h, q_op, nq, p.QT, SS, cand, partial, tau_g, kp, 0, Stot, pcnt, nullptr, kpv, s));
             else ZV_CHECK(launch_fp4s_scan(h, q_op, nq, p.QT, SS, p.NT, cand, partial, tau_g, kp, 0, 0, Stot, pcnt, nullptr, kpv, s));
             const uint32_t mlw = kpv == (uint32_t)KP ? 64u : 16u, cap = kp + mlw * kpv;
             const size_t mlds = SEL_HIST_BYTES + std::max<size_t>((size_t)kpv * 8, SEL_STAGE_BYTES) + (size_t)cap * 8;
