@@ -43,6 +43,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{OUT}/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c and KEY in r["Kernel_Name"] and ", 1>(" not in r["Kernel_Name"]]  # (", 1>": the gated no-op launch)
     per[c] = [float(r["Counter_Value"]) for r in rows]
+    per[c] = [v for v in per[c] if v > 0.01 * max(per[c])]   # (the gated repair launch shares the symbol's prefix: a no-op that moves nothing)
     name = rows[0]["Kernel_Name"].split("(")[0]
 fb = 2.0 * sum(per["FETCH_SIZE"]) / len(per["FETCH_SIZE"]) * 1024
 wb = sum(per["WRITE_SIZE"]) / len(per["WRITE_SIZE"]) * 1024
