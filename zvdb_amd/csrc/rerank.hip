@@ -78,6 +78,9 @@ __global__ __launch_bounds__(64) void k_rerank(const RT *__restrict__ rows, uint
     float *dk_slot = reinterpret_cast<float *>(ck + kc);
     const int lane = threadIdx.x;
     const uint32_t qi = blockIdx.x;
+    // (the exact scan's finished-block counter is zero when its launch behind this one starts, whatever an earlier launch left: the merges
+    // that normally reset it are one place, this is the other -- nothing between the two reads it)
+    if (cert.kth && qi == 0 && threadIdx.x == 0) cert.nflag[1] = 0;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
     __syncthreads();
@@ -214,6 +217,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     float *dk_slot = reinterpret_cast<float *>(ck + kc);
     const int lane = threadIdx.x;
     const uint32_t qi = blockIdx.x;
+    // (the exact scan's finished-block counter is zero when its launch behind this one starts, whatever an earlier launch left: the merges
+    // that normally reset it are one place, this is the other -- nothing between the two reads it)
+    if (cert.kth && qi == 0 && threadIdx.x == 0) cert.nflag[1] = 0;
     const float *qg = queries + (size_t)qi * dim;
     for (uint32_t i = lane; i < dim_pad; i += kWave) q[i] = i < dim ? qg[i] : 0.0f;
 #pragma unroll
