@@ -467,6 +467,8 @@ int ensure_f32rq_stats(zvdb_hip_index *h, hipStream_t s) {
     }));
     hipLaunchKernelGGL(k_rq_stats_fin, dim3(1), dim3(256), 0, s, h->kstat_acc, D, h->kstat);
     ZV_HIP(hipGetLastError());
+    // (a search of this index on ANOTHER stream may follow at once: the moments are complete before this call returns -- once per mirror build)
+    ZV_HIP(hipStreamSynchronize(s));
     h->kstat_count = h->count;
     return ZVDB_OK;
 }
