@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64 * WPQ, WPQ == 8 ? 1 : WPQ == 4 ? (EPL >= 8 ? 2 :
     for (uint32_t i = threadIdx.x; i < hash_size; i += kWave * WPQ) hash[i] = 0;
     __syncthreads();
     const uint32_t nchunks = (dim + 3) / 4;
-    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : (WPQ >= 4 ? 1 : 4 / WPQ);  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32; two rows per group at WPQ = 2 measured 24 % SLOWER with a search width, r4)
+    constexpr int U = sizeof(RT) == 2 ? (WPQ == 1 ? 2 : 1) : (WPQ >= 4 ? 1 : 4 / WPQ);  // rows per lane group and step: 16 rows per step (bf16 rows, WPQ = 4: 32; two rows per group at WPQ = 2 measured 24 % SLOWER with a search width, r4; r6, with one distance phase per step: 25 - 92 spilled registers, -24 .. -42 %)
     if (desc.on) {  // the entry descent of this query, by all waves of the workgroup (wave-uniform branch); later passes find the entry in entries_out
         unsigned long long dev = 0;
         entry = descend_body<RT, WPQ, U>(rows, ld, metric, desc.lvl, desc.slot, desc.adj_up, desc.deg_up, gstride, desc.top, q, nchunks, nb_d, nb_i, lane, wave, dev);
