@@ -1,0 +1,16 @@
+"""Build-time guards that need no GPU (hipcc cross-compiles gfx950 here)."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_f32_regq_group_loop_keeps_its_shape_in_every_instantiation():
+    """tools/check_ring_regs.py on bf_f32_regq.hip: inside the group loop of every k_f32_regq instantiation the ring waits are counted
+    (no s_waitcnt vmcnt(0)), no ring register is copied, nothing is spilled, 4 MFMAs per ring load.  (The loads are compiler-visible, so
+    this guards SPEED; the copies it looks for are what made the round's first, inline-asm form of the ring wrong once in ~10^5 queries.)"""
+    spec = importlib.util.spec_from_file_location("check_ring_regs", os.path.join(ROOT, "tools", "check_ring_regs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen, bad = mod.check(verbose=False)
+    assert seen == 24 and not bad, bad[:5]

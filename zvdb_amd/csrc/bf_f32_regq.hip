@@ -9,8 +9,8 @@
 // instruction that takes ONE VGPR per operand: a wave's 32 queries x 128 dimensions are 64 VGPRs -- they stay in registers for the
 // whole launch; 8 waves = 256 queries per workgroup, one workgroup per CU, so a batch of 256 reads the corpus ONCE (the 128-query
 // kernel: twice, through the L2).  Every wave reads every row: a 32-row group is KS contiguous KiB of the fragment-order mirror
-// (rows_ff, shared with k_i8_stream<0>), one coalesced global_load_dwordx4 per 4 MFMAs (256 matrix-pipe cycles), prefetched a whole
-// group ahead in a register ring; the 8 waves of a workgroup ask for the same lines (the first miss fills the L1 / L2, the rest
+// (rows_ff, shared with k_i8_stream<0>), one coalesced global_load_dwordx4 per 4 MFMAs (256 matrix-pipe cycles), prefetched half
+// a group ahead in a register ring; the 8 waves of a workgroup ask for the same lines (the first miss fills the L1 / L2, the rest
 // hit).  No wave reads what another wave wrote: NO barrier, NO LDS in the steady state -- SIMD partners drift apart and fill each
 // other's selection epilogues.  Work is split by 32-row GROUPS (31,250 at 1M rows: 122.07 per CU, a 0.8 % tail) instead of 256-row
 // tiles (15.26 per CU: 5 %).
@@ -44,21 +44,12 @@ __host__ __device__ constexpr uint32_t rq_lds_bytes() {
     return T2 * 4 * 3 + RQ_NW * NSUB * 4 + 16 + RQ_NW * sel_scratch_bytes<KPV>();
 }
 
-// The operand ring's loads and waits, by inline asm (saddr form: uniform base + 32-bit lane offset).  HAZARD: hipcc believes a register
-// written by rq_load16 is valid when the asm statement ends; it lands only behind an rq_vm_wait tied to the same register.  The kernel
-// must not spill or copy ring registers inside the group loop (197 of 256 VGPRs: checked with tools/kernel_resources.py).
-__device__ __forceinline__ void rq_load16(u32x4 &d, uint32_t voff, gbytes_t sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void rq_load4(float &d, uint32_t voff, gbytes_t sbase) {
-    asm volatile("global_load_dword %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
-}
-template <int N> __device__ __forceinline__ void rq_vm_wait(u32x4 &d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
-template <int N> __device__ __forceinline__ void rq_vm_wait_f(float &d) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N)); }
-template <int R> __device__ __forceinline__ void rq_vm_drain(u32x4 (&a)[R]) {  // every ring register is tied: nothing behind sees a load in flight
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]));
-#pragma unroll
-    for (int i = 1; i < R; ++i) asm volatile("" : "+v"(a[i]));
+// An append's store by inline asm: hipcc's waitcnt pass does not see it, so the counted waits of the operand ring stay exact behind the rare
+// pass path (as a visible store it made the pieces behind every selection wait for more of the ring than they need: -3 % at configs[1]).
+// In hardware the store is one more (younger) entry of the in-order vmcnt queue: a ring wait can only wait LONGER for it, never shorter;
+// its readers (rq_prune_wave, the stream end) sit behind an s_waitcnt vmcnt(0) with a memory clobber.
+__device__ __forceinline__ void rq_append(uint64_t *p, uint64_t v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 // Exact prune of the calling wave's 32 queries whose append buffer passed MARK.  Out of line and cold: the scan keeps the query
@@ -95,10 +86,18 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
     uint32_t S, uint32_t G /* 32-row groups */, uint64_t *__restrict__ cand, uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all,
     uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, const uint32_t *__restrict__ gate) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
-    // operand ring: pieces in flight per wave.  A whole group at <= 128 dimensions; rows of 129 .. 256 dimensions (KS = 20 / 24 / 28 / 32: the
-    // queries take 80 .. 128 VGPRs, a ring of 16 spills at 32) keep 7 .. 10 pieces = 7 .. 10 KiB, ~4,000 cycles, ahead
-    constexpr int R = KS <= 16 ? KS : KS == 20 ? 10 : KS == 28 ? 7 : 8;
-    static_assert(KS % R == 0, "ring wrap");
+    // A loop iteration = one UNIT of GU groups = P pieces (GU = 1: one 32-row group); the operand ring holds R < P pieces (half a group up to
+    // 128 dimensions: 8 KiB, ~4,000 cycles ahead; 7 - 10 pieces beyond).  The loads are plain, compiler-visible loads: hipcc's own waitcnt pass orders every use, whatever it does to
+    // the registers.  (Round 6's first form issued and awaited them by inline asm tied to the ring registers -- 4 % faster at configs[1] --
+    // and was WRONG once in ~10^5 queries: hipcc carried a ring element through a v_mov AHEAD of its asm wait, reading a load in flight; a
+    // soak against the int8 route found it, tools/check_ring_regs.py shows the copies.)  Two things keep the compiler's form fast: the ring
+    // is SHORTER than the iteration (with R == P one element is carried through a copy at the loop head behind an s_waitcnt vmcnt(0): a
+    // drain of the ring per group, -9 %), and every load sits behind an opaque copy of its lane offset made at its place in the piece
+    // sequence (else all of them are hoisted to the top of the iteration into a second copy of the ring: 256 VGPRs, spills).
+    constexpr int GU = 1;   // (units of 2 / 4 groups with a ring of 16 were measured too: 460k against 474k QPS at configs[1], profiles/r6/c2_ring_ab.txt)
+    constexpr int P = GU * KS;
+    constexpr int R = KS == 8 ? 4 : KS == 20 ? 10 : KS == 28 ? 7 : 8;
+    static_assert(P % R == 0 && R < P, "ring wrap");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tau_f = reinterpret_cast<float *>(smem);              // exclusive bound: pass <=> key < tau
     uint32_t *cnt = reinterpret_cast<uint32_t *>(tau_f + T2);    // append slots handed out since the query's last prune
@@ -117,7 +116,9 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
     const uint32_t x = b & 7, jb = b >> 3;
     const uint32_t qt = jb % QT;
     const uint32_t s = (jb / QT) * 8 + x;
-    const uint32_t g0 = (uint32_t)(((uint64_t)s * G) / S), g1 = (uint32_t)(((uint64_t)(s + 1) * G) / S);  // my groups (ids ascend along a stream)
+    // my units (ids ascend along a stream); the mirror is padded to whole 256-row tiles = 8 groups, rows past N carry +inf norms
+    const uint32_t U = (G + GU - 1) / GU;
+    const uint32_t u0 = (uint32_t)(((uint64_t)s * U) / S), u1 = (uint32_t)(((uint64_t)(s + 1) * U) / S);
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
     uint64_t *kept = cand + (size_t)b * BLKV_ENTRIES;
     uint64_t *subs = kept + (size_t)T2 * KPMAX;
@@ -136,89 +137,91 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
     const unsigned char *qsrc = Qf + ((size_t)(qt * (T2 / 32) + wave) * KS) * 1024 + lane * 16;
     const uint32_t lane16 = (uint32_t)lane * 16;
     const uint32_t lds_state = (uint32_t)(size_t)(lptr_t)tau_f;
-    constexpr size_t gbytes = (size_t)KS * 1024;
+    constexpr size_t ubytes = (size_t)P * 1024;
     // a wave whose 32 queries are all past nq has nothing to select: it still runs (its registers are there), but never passes
     auto load_norm = [&](uint32_t g) -> float { return vnorm[(size_t)32 * g + fr]; };  // |v|^2 of row 32 g + fr (rows past N: +inf)
 
-    uint32_t g = g0;
-    // The group loop is entered once per launch and once more after every prune round of this wave: a prune is a CALL and nothing of
+    uint32_t u = u0;
+    // The unit loop is entered once per launch and once more after every prune round of this wave: a prune is a CALL and nothing of
     // the loop's register state lives across it (bf_bf16_stream.hip found hipcc spilling the query fragments around an inlined one).
-    while (g < g1) {
+    while (u < u1) {
         u32x4 B[KS];
 #pragma unroll
         for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
         const float thr = -tau_f[wave * 32 + fr];
-        u32x4 A[R];
+        u32x4 A[R];  // slot of piece p: R - 1 - p % R
         {
-            const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes);
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * ubytes);
 #pragma unroll
-            for (int j = 0; j < R; ++j) A[j] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + j * 1024);
+            for (int j = 0; j < R; ++j) A[R - 1 - j] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + j * 1024);
         }
         f32x16 init;  // start values of the group about to be multiplied: -|v|^2 / 2 of the register's row
         {
-            const float vn = load_norm(g);
+            const float vn = load_norm(u * GU);
 #pragma unroll
             for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
         }
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0), as an instruction the waitcnt pass sees: the ring is primed
         bool want_prune = false;
         do {
-            const uint32_t gn = min(g + 1, g1 - 1);  // (past the stream end: a harmless re-read of its last group)
-            // pieces J + R .. of this group (KS > R) and 0 .. of the next: the slot a piece frees is refilled a whole ring ahead
-            const gbytes_t cur = uniform_ptr(Vf + (size_t)g * gbytes + (size_t)R * 1024);
-            const gbytes_t nxt = uniform_ptr(Vf + (size_t)gn * gbytes);
-            const gbytes_t nrm = uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)32 * gn));
+            const uint32_t un = min(u + 1, u1 - 1);  // (past the stream end: a harmless re-read of its last unit)
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * ubytes + (size_t)R * 1024);  // pieces p + R of this unit ...
+            const gbytes_t nxt = uniform_ptr(Vf + (size_t)un * ubytes);                     // ... and 0 .. R - 1 of the next
             f32x16 acc = init;
-            float vn_next;
+            float vn_next = 0.0f;
             __builtin_amdgcn_sched_barrier(0);
-            // one piece = 4 MFMAs (256 matrix-pipe cycles), then the ring slot it freed is refilled.  Loads and their waits are inline asm
-            // tied to the ring registers (rq_load16 / rq_vm_wait): written as plain loads hipcc either hoists all of them to the top of the
-            // iteration into a second copy of the ring (256 VGPRs, spills) or rotates a ring slot through a v_mov behind an
-            // s_waitcnt vmcnt(0) at the loop head -- a drain of the whole ring per group.  Steady state: R + 1 loads (R pieces and
-            // the next group's norms) are younger than the piece about to be multiplied: s_waitcnt vmcnt(R + 1 - 1) ... see below.
-            static_for<KS>([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                constexpr int SL = J % R;
-                // slot SL was refilled R pieces ago: R - 1 younger pieces, + the norm load (issued behind piece 0's refill, once per group) when it
-                // falls inside that window: always with a ring of a whole group; with a shorter ring for pieces 1 .. R only
-                constexpr int W = (KS == R || (J >= 1 && J <= R)) ? R : R - 1;
-                rq_vm_wait<W>(A[SL]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].x), __uint_as_float(B[J].x), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].y), __uint_as_float(B[J].y), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].z), __uint_as_float(B[J].z), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(A[SL].w), __uint_as_float(B[J].w), acc, 0, 0, 0);
+            static_for<P>([&](auto pc) {
+                constexpr int PI = decltype(pc)::value;
+                constexpr int T = PI / KS, J = PI % KS;   // group of the unit, piece of the group
+                constexpr int SL = R - 1 - PI % R;
+                if constexpr (J == 0 && T > 0) acc = init;
+                const u32x4 a = A[SL];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(B[J].x), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(B[J].y), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(B[J].z), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(B[J].w), acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (J + R < KS) rq_load16(A[SL], lane16, cur + (size_t)J * 1024);
-                else rq_load16(A[SL], lane16, nxt + (size_t)(J + R - KS) * 1024);
-                if constexpr (J == 0) rq_load4(vn_next, fr * 4, nrm);  // (in ring order: consumed behind the last MFMA)
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            // start values of the next group while the last MFMAs drain (the norm load: KS - 1 pieces are younger)
-            rq_vm_wait_f<KS - 1>(vn_next);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn_next, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
-            __builtin_amdgcn_sched_barrier(0);
-            // selection of the finished group (32 rows x my 32 queries): the rare pass path appends to the queries' buffers
-            float m = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            if (__ballot(m > thr)) {
-                bool need = false;
-                const uint32_t q = (uint32_t)wave * 32 + fr;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (acc[r] > thr) {
-                        const uint32_t sl = atomicAdd(cnt + q, 1u);
-                        const uint32_t id = 32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
-                        if (sl < (uint32_t)RQ_CAP) subs[(size_t)q * RQ_CAP + sl] = ((uint64_t)f32_key(-acc[r]) << 32) | id;
-                        need |= sl == (uint32_t)RQ_HW;
-                    }
+                {   // the slot this piece freed is refilled R pieces ahead (an opaque copy of the lane offset, made HERE, pins the load's place)
+                    uint32_t off = lane16;
+                    asm volatile("" : "+v"(off));
+                    if constexpr (PI + R < P) A[SL] = *(const __attribute__((address_space(1))) u32x4 *)(cur + (size_t)PI * 1024 + off);
+                    else A[SL] = *(const __attribute__((address_space(1))) u32x4 *)(nxt + (size_t)(PI + R - P) * 1024 + off);
                 }
-                if (__ballot(need)) want_prune = true;  // (<= 32 more appends per query before the loop is left: RQ_CAP holds them)
-            }
-            ++g;
-        } while (g < g1 && !want_prune);
-        rq_vm_drain(A);  // loads still in flight land in the ring's registers: nothing behind this point may see them in flight
+                if constexpr (J == 0) {  // norms of the NEXT group (the next unit's first one behind this unit's last)
+                    uint32_t noff = fr * 4;
+                    asm volatile("" : "+v"(noff));
+                    const uint32_t gnx = T + 1 < GU ? u * GU + T + 1 : un * GU;
+                    vn_next = *(const __attribute__((address_space(1))) float *)(uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)32 * gnx)) + noff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (J == KS - 1) {
+                    // start values of the next group while the last MFMAs drain
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn_next, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // selection of the finished group (32 rows x my 32 queries): the rare pass path appends to the queries' buffers
+                    float m = acc[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                    if (__ballot(m > thr)) {
+                        bool need = false;
+                        const uint32_t q = (uint32_t)wave * 32 + fr;
+                        const uint32_t gi = u * GU + T;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if (acc[r] > thr) {
+                                const uint32_t sl = atomicAdd(cnt + q, 1u);
+                                const uint32_t id = 32 * gi + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
+                                if (sl < (uint32_t)RQ_CAP) rq_append(subs + (size_t)q * RQ_CAP + sl, ((uint64_t)f32_key(-acc[r]) << 32) | id);
+                                need |= sl == (uint32_t)RQ_HW;
+                            }
+                        }
+                        if (__ballot(need)) want_prune = true;  // (<= 32 GU more appends per query before the loop is left: RQ_CAP holds them)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            ++u;
+        } while (u < u1 && !want_prune);
         if (want_prune) rq_prune_wave<KPV>(kept, tau_g, kp, lds_state);
     }
 
