@@ -46,7 +46,7 @@ def leg(N, D, B, reps):
                 el = (time.perf_counter() - t0) / reps
                 kms, kn = idx.timing_read()
                 idx.timing_enable(0)
-                assert torch.equal(ids, ref[0]) and torch.equal(dd, ref[1]), name
+                assert os.environ.get("C2_AB_NOCHECK") or (torch.equal(ids, ref[0]) and torch.equal(dd, ref[1])), name   # (NOCHECK: the timing-only ablation builds)
             res.setdefault(name, []).append((el * 1e3, kms / max(kn, 1)))
     fl = 2.0 * B * N * D
     for name, v in res.items():

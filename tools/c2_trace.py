@@ -1,7 +1,7 @@
 import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, zvdb_amd as zv
-N2, D2, B2, K = 1_000_000, 128, 256, 10
+N2, D2, B2, K = 1_000_000, (int(sys.argv[2]) if len(sys.argv) > 2 else 128), 256, 10   # c2_trace.py [iterations [dim]]
 dev = torch.device("cuda", 0)
 idx = zv.Index(dim=D2, capacity=N2, flags=zv.FLAG_BF16_MIRROR)
 idx.add_synthetic(N2, D2, 0x5EED)

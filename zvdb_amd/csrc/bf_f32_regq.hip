@@ -52,6 +52,103 @@ __device__ __forceinline__ void rq_append(uint64_t *p, uint64_t v) {
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
+// ---- the operand ring: registers hipcc cannot allocate, named literally ------------------------------------------------------------
+// A kernel of this file is built with amdgpu_num_vgpr: hipcc's allocator ends at v[RA - 1] (RA = rq_acc_base = 236 - 4 R).  Above live
+// the group's 32 x 32 accumulator v[RA, RA + 16), the ring (RB = RA + 16: slot SL = v[RB + 4 SL, RB + 4 SL + 4)) and the next group's norms
+// (v[252]).  Nothing the compiler does to registers -- copies, rotations, spills -- can touch a load in flight or an MFMA result still
+// in the pipe there: the loads, their counted waits, the MFMAs and the first reads of their results are all inside asm statements
+// that name the registers.  (The accumulator is up there for the second reason: hipcc pads no wait states behind an MFMA inside a
+// string, and it did move the accumulator -- sixteen v_mov between two pieces' statements -- when it owned it.)  (One clobber of v255 makes the kernel descriptor allocate the whole file: 2 waves per SIMD
+// either way.)  tools/check_ring_regs.py audits every instantiation's ISA as a CPU test: no register >= RA outside ;;#ASMSTART / ;;#ASMEND,
+// no compiler wait on vmcnt inside the group loop, no spill.
+// Counting rule: a wait names only the ring's OWN younger loads (vmcnt(R - 1) ahead of the MFMAs of a slot: the R - 1 ring loads issued
+// since that slot's); any other memory operation in flight -- the norm load, an append's store -- is one more entry of the in-order
+// queue and can only make the wait longer.
+__host__ __device__ constexpr int rq_ring_len(int KS) { return KS <= 20 ? KS : KS == 24 ? 12 : KS == 28 ? 14 : 8; }
+__host__ __device__ constexpr int rq_ring_base(int KS) { return 252 - 4 * rq_ring_len(KS); }
+__host__ __device__ constexpr int rq_acc_base(int KS) { return rq_ring_base(KS) - 16; }
+constexpr int RQ_NORM_REG = 252;
+
+// prologue: slot at v[RG, RG + 4) <- 16 bytes per lane at base + off + IMM (the base may be fresh from SALU arithmetic: 5 states ahead of the load)
+template <int RG, int IMM>
+__device__ __forceinline__ void rq_ring_fill(gbytes_t base, uint32_t off) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%1:%1+3], %0, %2 offset:%3" ::"v"(off), "n"(RG), "s"(base), "n"(IMM));
+}
+
+// one piece: wait for the slot at v[RG, RG + 4) (WAIT = younger ring loads), its 4 MFMAs into v[RA, RA + 16), refill the slot from
+// base + off + IMM.  The group's first piece takes the start values as its C operand (no copy into the accumulator); they may be fresh
+// from VALU moves: 2 states ahead of the MFMA that reads them.
+template <int RA, int RG, int WAIT, int IMM>
+__device__ __forceinline__ void rq_piece_first(const f32x16 &init, const u32x4 &b, gbytes_t base, uint32_t off) {
+    asm volatile("s_nop 1\n\t"
+                 "s_waitcnt vmcnt(%7)\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%10:%10+15], v[%6+0], %1, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%10:%10+15], v[%6+1], %2, v[%10:%10+15]\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%10:%10+15], v[%6+2], %3, v[%10:%10+15]\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%10:%10+15], v[%6+3], %4, v[%10:%10+15]\n\t"
+                 "global_load_dwordx4 v[%6:%6+3], %5, %8 offset:%9" ::"v"(init),
+                 "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(off), "n"(RG), "n"(WAIT), "s"(base), "n"(IMM), "n"(RA));
+}
+template <int RA, int RG, int WAIT, int IMM>
+__device__ __forceinline__ void rq_piece(const u32x4 &b, gbytes_t base, uint32_t off) {
+    asm volatile("s_waitcnt vmcnt(%6)\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%9:%9+15], v[%5+0], %0, v[%9:%9+15]\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%9:%9+15], v[%5+1], %1, v[%9:%9+15]\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%9:%9+15], v[%5+2], %2, v[%9:%9+15]\n\t"
+                 "v_mfma_f32_32x32x2_f32 v[%9:%9+15], v[%5+3], %3, v[%9:%9+15]\n\t"
+                 "global_load_dwordx4 v[%5:%5+3], %4, %7 offset:%8" ::"v"(b.x),
+                 "v"(b.y), "v"(b.z), "v"(b.w), "v"(off), "n"(RG), "n"(WAIT), "s"(base), "n"(IMM), "n"(RA));
+}
+
+// the next group's norms: issued behind piece 0's refill, read behind piece KS - 1's (KS - 1 younger ring loads by then)
+__device__ __forceinline__ void rq_norm_load(gbytes_t base, uint32_t off) {
+    asm volatile("s_nop 4\n\tglobal_load_dword v[%1], %0, %2" ::"v"(off), "n"(RQ_NORM_REG), "s"(base));
+}
+template <int WAIT>
+__device__ __forceinline__ float rq_norm_take() {
+    float v;
+    asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, v[%1]" : "=v"(v) : "n"(RQ_NORM_REG), "n"(WAIT));
+    return v;
+}
+
+// The finished group's largest accumulator value.  The last MFMA of the group (16 passes) -> the first VALU read of its result: 19
+// states, and hipcc pads nothing for an MFMA inside a string: the pad opens this string.
+template <int RA>
+__device__ __forceinline__ float rq_group_max() {
+    float m;
+    asm volatile("s_nop 15\n\ts_nop 3\n\t"
+                 "v_max3_f32 %0, v[%1+0], v[%1+1], v[%1+2]\n\t"
+                 "v_max3_f32 %0, %0, v[%1+3], v[%1+4]\n\t"
+                 "v_max3_f32 %0, %0, v[%1+5], v[%1+6]\n\t"
+                 "v_max3_f32 %0, %0, v[%1+7], v[%1+8]\n\t"
+                 "v_max3_f32 %0, %0, v[%1+9], v[%1+10]\n\t"
+                 "v_max3_f32 %0, %0, v[%1+11], v[%1+12]\n\t"
+                 "v_max3_f32 %0, %0, v[%1+13], v[%1+14]\n\t"
+                 "v_max_f32 %0, %0, v[%1+15]"
+                 : "=v"(m)
+                 : "n"(RA));
+    return m;
+}
+// the rare pass path: the accumulator into registers the compiler owns (behind rq_group_max: the results have settled)
+template <int RA>
+__device__ __forceinline__ void rq_acc_read(float (&a)[16]) {
+    asm volatile("v_mov_b32 %0, v[%16+0]\n\tv_mov_b32 %1, v[%16+1]\n\tv_mov_b32 %2, v[%16+2]\n\tv_mov_b32 %3, v[%16+3]\n\t"
+                 "v_mov_b32 %4, v[%16+4]\n\tv_mov_b32 %5, v[%16+5]\n\tv_mov_b32 %6, v[%16+6]\n\tv_mov_b32 %7, v[%16+7]\n\t"
+                 "v_mov_b32 %8, v[%16+8]\n\tv_mov_b32 %9, v[%16+9]\n\tv_mov_b32 %10, v[%16+10]\n\tv_mov_b32 %11, v[%16+11]\n\t"
+                 "v_mov_b32 %12, v[%16+12]\n\tv_mov_b32 %13, v[%16+13]\n\tv_mov_b32 %14, v[%16+14]\n\tv_mov_b32 %15, v[%16+15]"
+                 : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]), "=v"(a[8]), "=v"(a[9]), "=v"(a[10]),
+                   "=v"(a[11]), "=v"(a[12]), "=v"(a[13]), "=v"(a[14]), "=v"(a[15])
+                 : "n"(RA));
+}
+
+// every query fragment has landed before the group loop is entered: hipcc would otherwise place ITS waits for them inside the loop, and a
+// compiler wait does not know the ring (its vmcnt(0) for the last fragment would drain the ring once per group)
+template <int KS>
+__device__ __forceinline__ void rq_frags_landed(const u32x4 (&B)[KS]) {  // (inputs only: a read-write operand made hipcc copy all of them)
+#pragma unroll
+    for (int j = 0; j < KS; j += 4) asm volatile("" ::"v"(B[j]), "v"(B[j + 1]), "v"(B[j + 2]), "v"(B[j + 3]));
+}
+
 // Exact prune of the calling wave's 32 queries whose append buffer passed MARK.  Out of line and cold: the scan keeps the query
 // fragments and the operand ring live, an inlined radix select would push the allocator into spilling them in the hot loop.
 // (Per-wave select scratch: the LDS is otherwise unused, so no lock as in bf_bf16_stream.hip.)
@@ -77,27 +174,23 @@ __device__ __attribute__((noinline, cold)) void rq_prune_wave(uint64_t *kept, ui
     }
 }
 
-// KS = 8-element k-steps (1-KiB pieces) per row: 8 / 16 (dim <= 64 / 128), 20 / 24 / 28 / 32 (dim <= 160 / 192 / 224 / 256).  GATED = 1: the same code under its own symbol
-// for the gated repair launch (a no-op unless the verification failed), so that profiler statistics do not average no-ops into the scan.
-template <int KS, int KPV = KP, int GATED = 0>
-__global__ __launch_bounds__(512, 2) void k_f32_regq(
+// The scan of one workgroup.  KS = 8-element k-steps (1-KiB pieces) per row: 8 / 16 (dim <= 64 / 128), 20 / 24 / 28 / 32 (dim <= 160 / 192 / 224 / 256).
+template <int KS, int KPV>
+__device__ __forceinline__ void rq_scan(
     const unsigned char *__restrict__ Qf /* [query group of 32][KS][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
     const float *__restrict__ vnorm /* [rows padded]: sum v^2 (0: dot / cosine), +inf past N */, uint32_t N, uint32_t nq, uint32_t QT,
     uint32_t S, uint32_t G /* 32-row groups */, uint64_t *__restrict__ cand, uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all,
     uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, const uint32_t *__restrict__ gate) {
     if (gate && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
-    // A loop iteration = one UNIT of GU groups = P pieces (GU = 1: one 32-row group); the operand ring holds R < P pieces (half a group up to
-    // 128 dimensions: 8 KiB, ~4,000 cycles ahead; 7 - 10 pieces beyond).  The loads are plain, compiler-visible loads: hipcc's own waitcnt pass orders every use, whatever it does to
-    // the registers.  (Round 6's first form issued and awaited them by inline asm tied to the ring registers -- 4 % faster at configs[1] --
-    // and was WRONG once in ~10^5 queries: hipcc carried a ring element through a v_mov AHEAD of its asm wait, reading a load in flight; a
-    // soak against the int8 route found it, tools/check_ring_regs.py shows the copies.)  Two things keep the compiler's form fast: the ring
-    // is SHORTER than the iteration (with R == P one element is carried through a copy at the loop head behind an s_waitcnt vmcnt(0): a
-    // drain of the ring per group, -9 %), and every load sits behind an opaque copy of its lane offset made at its place in the piece
-    // sequence (else all of them are hoisted to the top of the iteration into a second copy of the ring: 256 VGPRs, spills).
-    constexpr int GU = 1;   // (units of 2 / 4 groups with a ring of 16 were measured too: 460k against 474k QPS at configs[1], profiles/r6/c2_ring_ab.txt)
-    constexpr int P = GU * KS;
-    constexpr int R = KS == 8 ? 4 : KS == 20 ? 10 : KS == 28 ? 7 : 8;
-    static_assert(P % R == 0 && R < P, "ring wrap");
+    // The operand ring holds R pieces in ACCUMULATION registers (a whole group up to 160 dimensions: 16 KiB, ~4,000 cycles ahead; 8 - 14
+    // pieces beyond, where the query fragments need the room).  History of the ring, all measured at configs[1] on one box
+    // (profiles/r6/c2_ring_ab.txt): (1) inline-asm loads and waits tied to compiler-allocated ring registers: 495k QPS and WRONG once in
+    // ~10^5 queries -- hipcc carried a ring element through a v_mov AHEAD of its asm wait, reading a load in flight (a soak against the
+    // int8 route found it); (2) plain compiler-visible loads, ring half a group: correct, 474k; (3) this form: the ring in registers the
+    // compiler cannot allocate, named literally (see rq_piece above).
+    constexpr int R = rq_ring_len(KS), RB = rq_ring_base(KS), RA = rq_acc_base(KS);
+    static_assert(KS % R == 0 && KS % 4 == 0, "ring wrap");
+    asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tau_f = reinterpret_cast<float *>(smem);              // exclusive bound: pass <=> key < tau
     uint32_t *cnt = reinterpret_cast<uint32_t *>(tau_f + T2);    // append slots handed out since the query's last prune
@@ -116,9 +209,8 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
     const uint32_t x = b & 7, jb = b >> 3;
     const uint32_t qt = jb % QT;
     const uint32_t s = (jb / QT) * 8 + x;
-    // my units (ids ascend along a stream); the mirror is padded to whole 256-row tiles = 8 groups, rows past N carry +inf norms
-    const uint32_t U = (G + GU - 1) / GU;
-    const uint32_t u0 = (uint32_t)(((uint64_t)s * U) / S), u1 = (uint32_t)(((uint64_t)(s + 1) * U) / S);
+    // my groups (ids ascend along a stream); the mirror is padded to whole 256-row tiles = 8 groups, rows past N carry +inf norms
+    const uint32_t u0 = (uint32_t)(((uint64_t)s * G) / S), u1 = (uint32_t)(((uint64_t)(s + 1) * G) / S);
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
     uint64_t *kept = cand + (size_t)b * BLKV_ENTRIES;
     uint64_t *subs = kept + (size_t)T2 * KPMAX;
@@ -137,92 +229,83 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
     const unsigned char *qsrc = Qf + ((size_t)(qt * (T2 / 32) + wave) * KS) * 1024 + lane * 16;
     const uint32_t lane16 = (uint32_t)lane * 16;
     const uint32_t lds_state = (uint32_t)(size_t)(lptr_t)tau_f;
-    constexpr size_t ubytes = (size_t)P * 1024;
+    const uint32_t fr4 = fr * 4;
+    constexpr size_t gbytes = (size_t)KS * 1024;
     // a wave whose 32 queries are all past nq has nothing to select: it still runs (its registers are there), but never passes
-    auto load_norm = [&](uint32_t g) -> float { return vnorm[(size_t)32 * g + fr]; };  // |v|^2 of row 32 g + fr (rows past N: +inf)
 
     uint32_t u = u0;
-    // The unit loop is entered once per launch and once more after every prune round of this wave: a prune is a CALL and nothing of
+    // The group loop is entered once per launch and once more after every prune round of this wave: a prune is a CALL and nothing of
     // the loop's register state lives across it (bf_bf16_stream.hip found hipcc spilling the query fragments around an inlined one).
     while (u < u1) {
         u32x4 B[KS];
 #pragma unroll
         for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
         const float thr = -tau_f[wave * 32 + fr];
-        u32x4 A[R];  // slot of piece p: R - 1 - p % R
-        {
-            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * ubytes);
-#pragma unroll
-            for (int j = 0; j < R; ++j) A[R - 1 - j] = *(const __attribute__((address_space(1))) u32x4 *)(cur + lane16 + j * 1024);
+        {   // ring prologue: pieces 0 .. R - 1 of group u (slot of piece p: p % R)
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * gbytes);
+            static_for<R>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                rq_ring_fill<RB + 4 * J, (J % 4) * 1024>(cur + (J / 4) * 4096, lane16);
+            });
         }
-        f32x16 init;  // start values of the group about to be multiplied: -|v|^2 / 2 of the register's row
+        f32x16 init;  // start values of the group about to be multiplied: -|v|^2 / 2 of the register's row (rows past N: -inf)
         {
-            const float vn = load_norm(u * GU);
+            const float vh = -0.5f * vnorm[(size_t)32 * u + fr];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
+            for (int r = 0; r < 16; ++r) init[r] = __shfl(vh, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
         }
+        rq_frags_landed<KS>(B);
         bool want_prune = false;
         do {
-            const uint32_t un = min(u + 1, u1 - 1);  // (past the stream end: a harmless re-read of its last unit)
-            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * ubytes + (size_t)R * 1024);  // pieces p + R of this unit ...
-            const gbytes_t nxt = uniform_ptr(Vf + (size_t)un * ubytes);                     // ... and 0 .. R - 1 of the next
-            f32x16 acc = init;
-            float vn_next = 0.0f;
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<P>([&](auto pc) {
-                constexpr int PI = decltype(pc)::value;
-                constexpr int T = PI / KS, J = PI % KS;   // group of the unit, piece of the group
-                constexpr int SL = R - 1 - PI % R;
-                if constexpr (J == 0 && T > 0) acc = init;
-                const u32x4 a = A[SL];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(B[J].x), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(B[J].y), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(B[J].z), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(B[J].w), acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                {   // the slot this piece freed is refilled R pieces ahead (an opaque copy of the lane offset, made HERE, pins the load's place)
-                    uint32_t off = lane16;
-                    asm volatile("" : "+v"(off));
-                    if constexpr (PI + R < P) A[SL] = *(const __attribute__((address_space(1))) u32x4 *)(cur + (size_t)PI * 1024 + off);
-                    else A[SL] = *(const __attribute__((address_space(1))) u32x4 *)(nxt + (size_t)(PI + R - P) * 1024 + off);
+            const uint32_t un = min(u + 1, u1 - 1);  // (past the stream end: a harmless re-read of its last group)
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * gbytes);
+            const gbytes_t nxt = uniform_ptr(Vf + (size_t)un * gbytes);
+            const gbytes_t nrm = uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)32 * un));
+            static_for<KS>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                constexpr int NP = J + R;  // the piece this piece's slot is refilled with: of this group, or of the next
+                const gbytes_t base = NP < KS ? cur + (NP / 4) * 4096 : nxt + ((NP - KS) / 4) * 4096;
+                if constexpr (J == 0) {
+                    rq_piece_first<RA, RB + 4 * (J % R), R - 1, (NP % 4) * 1024>(init, B[J], base, lane16);
+                    rq_norm_load(nrm, fr4);
+                } else {
+                    rq_piece<RA, RB + 4 * (J % R), R - 1, (NP % 4) * 1024>(B[J], base, lane16);
                 }
-                if constexpr (J == 0) {  // norms of the NEXT group (the next unit's first one behind this unit's last)
-                    uint32_t noff = fr * 4;
-                    asm volatile("" : "+v"(noff));
-                    const uint32_t gnx = T + 1 < GU ? u * GU + T + 1 : un * GU;
-                    vn_next = *(const __attribute__((address_space(1))) float *)(uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)32 * gnx)) + noff);
+                if constexpr (J == KS - 3) {
+                    // start values of the next group, three pieces ahead of its first MFMA (their LDS round trip -- ds_bpermute -- hides
+                    // behind 12 MFMAs; at the group's end it was exposed: profiles/r6/c2_ring_ab.txt).  JS ring loads are younger than the norms'.
+                    const float vh = -0.5f * rq_norm_take<KS - 3>();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) init[r] = __shfl(vh, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 if constexpr (J == KS - 1) {
-                    // start values of the next group while the last MFMAs drain
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) init[r] = -0.5f * __shfl(vn_next, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
-                    __builtin_amdgcn_sched_barrier(0);
                     // selection of the finished group (32 rows x my 32 queries): the rare pass path appends to the queries' buffers
-                    float m = acc[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                    const float m = rq_group_max<RA>();
                     if (__ballot(m > thr)) {
                         bool need = false;
                         const uint32_t q = (uint32_t)wave * 32 + fr;
-                        const uint32_t gi = u * GU + T;
+                        float acc[16];
+                        rq_acc_read<RA>(acc);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             if (acc[r] > thr) {
                                 const uint32_t sl = atomicAdd(cnt + q, 1u);
-                                const uint32_t id = 32 * gi + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
+                                const uint32_t id = 32 * u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
                                 if (sl < (uint32_t)RQ_CAP) rq_append(subs + (size_t)q * RQ_CAP + sl, ((uint64_t)f32_key(-acc[r]) << 32) | id);
                                 need |= sl == (uint32_t)RQ_HW;
                             }
                         }
-                        if (__ballot(need)) want_prune = true;  // (<= 32 GU more appends per query before the loop is left: RQ_CAP holds them)
+                        if (__ballot(need)) want_prune = true;  // (<= 32 more appends per query before the loop is left: RQ_CAP holds them)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
             ++u;
         } while (u < u1 && !want_prune);
-        if (want_prune) rq_prune_wave<KPV>(kept, tau_g, kp, lds_state);
+        if (want_prune) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's loads in flight have landed before the callee may use accumulation registers
+            rq_prune_wave<KPV>(kept, tau_g, kp, lds_state);
+        }
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -257,6 +340,32 @@ __global__ __launch_bounds__(512, 2) void k_f32_regq(
         }
     }
 }
+
+// The kernels: one symbol per (KS, kept-list width, gated) so that amdgpu_num_vgpr -- a literal, not a template argument -- can end the
+// compiler's allocation at that KS's ring base.  GATED = 1: the same code under its own symbol for the gated repair launch (a no-op
+// unless the verification failed), so that profiler statistics do not average no-ops into the scan.
+template <int KS, int KPV, int GATED>
+struct RqKernel;
+#define RQ_KERNEL(KS, KPV, GATED, NV)                                                                                                        \
+    __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_num_vgpr(NV / 2))) void k_f32_regq_##KS##_##KPV##_##GATED(            \
+        const unsigned char *__restrict__ Qf, const unsigned char *__restrict__ Vf, const float *__restrict__ vnorm, uint32_t N, uint32_t nq,   \
+        uint32_t QT, uint32_t S, uint32_t G, uint64_t *__restrict__ cand, uint64_t *__restrict__ partial, uint32_t *__restrict__ tau_g_all,    \
+        uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *__restrict__ pcnt, const uint32_t *__restrict__ gate) {                      \
+        static_assert(NV == rq_acc_base(KS), "the compiler's last register + 1 = the first of the registers the asm statements own");                                          \
+        rq_scan<KS, KPV>(Qf, Vf, vnorm, N, nq, QT, S, G, cand, partial, tau_g_all, kp, list_base, Stot, pcnt, gate);                           \
+    }                                                                                                                                        \
+    template <>                                                                                                                              \
+    struct RqKernel<KS, KPV, GATED> {                                                                                                        \
+        static constexpr auto fn = &k_f32_regq_##KS##_##KPV##_##GATED;                                                                        \
+    };
+#define RQ_KERNELS(KS, NV) RQ_KERNEL(KS, 64, 0, NV) RQ_KERNEL(KS, 64, 1, NV) RQ_KERNEL(KS, 128, 0, NV) RQ_KERNEL(KS, 256, 0, NV)
+RQ_KERNELS(8, 204)
+RQ_KERNELS(16, 172)
+RQ_KERNELS(20, 156)
+RQ_KERNELS(24, 188)
+RQ_KERNELS(28, 180)
+RQ_KERNELS(32, 204)
+static_assert(KP == 64 && KPW == 128 && KPMAX == 256, "kernel symbols are spelled with the kept-list widths");
 
 // ---- thresholds from the corpus' second moments ---------------------------------------------------------------------------
 // The guessed-threshold pipeline needs, per query, mean and variance of the screen key over the rows (tau = mean + z sigma,
@@ -419,9 +528,9 @@ int rq_launch_geo(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t n
         return ZVDB_OK;
     };
     if constexpr (KPV == KP) {
-        if (gate) return go(k_f32_regq<KS, KP, 1>);
+        if (gate) return go(RqKernel<KS, KP, 1>::fn);
     }
-    return go(k_f32_regq<KS, KPV, 0>);
+    return go(RqKernel<KS, KPV, 0>::fn);
 }
 
 template <int KPV>
