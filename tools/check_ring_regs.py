@@ -7,7 +7,7 @@ blind) count inside the group loop.  This script compiles the TU to ISA and FAIL
   * inside the group loop: a compiler-emitted s_waitcnt with a vmcnt field (its vmcnt(0) for a late query fragment would drain the ring once
     per group), a compiler-emitted load or spill (outside the loop a spill is reported, not failed: k_f32_regq_28_256_0 parks 5 registers
     across the whole loop), a ring wait other than vmcnt(R - 1) / the norm's vmcnt(KS - 3), MFMAs != 4 x ring loads,
-    ring loads != KS;
+    ring loads != KS x groups per iteration;
   * a kernel descriptor that does not allocate the whole 256-register file.
 History (docs/design/k4_bruteforce.md, K4r): round 6's first ring was inline-asm loads and waits tied to COMPILER-allocated registers; hipcc
 copied a ring element AHEAD of its asm wait (v_mov_b64 in most instantiations) and a soak against the int8 route found one lost neighbour
@@ -20,8 +20,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def ring_len(ks):
-    return ks if ks <= 20 else {24: 12, 28: 14, 32: 8}[ks]
+def ring_len(ks):   # rq_ring_len / rq_unit_groups of bf_f32_regq.hip
+    return 16 if ks == 8 else ks if ks <= 20 else {24: 12, 28: 14, 32: 8}[ks]
+
+
+def unit_groups(ks):
+    return 2 if ks == 8 else 1
 
 
 def vregs(text):
@@ -97,7 +101,7 @@ def check(src=None, verbose=True):
         seg = [(l, kd) for l, kd in seg if l and not l.startswith(".")]
         nm = sum(l.startswith("v_mfma") for l, _ in seg)
         nl = sum(l.startswith("global_load_dwordx4") for l, _ in seg)
-        if nm != 4 * nl or nl != ks:
+        if nm != 4 * nl or nl != ks * unit_groups(ks):
             bad.append((tag, f"{nm} MFMAs, {nl} ring loads for KS = {ks}"))
         ring_waits = set()
         for l, kd in seg:

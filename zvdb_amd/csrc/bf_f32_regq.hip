@@ -64,7 +64,8 @@ __device__ __forceinline__ void rq_append(uint64_t *p, uint64_t v) {
 // Counting rule: a wait names only the ring's OWN younger loads (vmcnt(R - 1) ahead of the MFMAs of a slot: the R - 1 ring loads issued
 // since that slot's); any other memory operation in flight -- the norm load, an append's store -- is one more entry of the in-order
 // queue and can only make the wait longer.
-__host__ __device__ constexpr int rq_ring_len(int KS) { return KS <= 20 ? KS : KS == 24 ? 12 : KS == 28 ? 14 : 8; }
+__host__ __device__ constexpr int rq_unit_groups(int KS) { return KS == 8 ? 2 : 1; }   // groups per loop iteration (64 dimensions: two, the ring holds both)
+__host__ __device__ constexpr int rq_ring_len(int KS) { return KS == 8 ? 16 : KS <= 20 ? KS : KS == 24 ? 12 : KS == 28 ? 14 : 8; }
 __host__ __device__ constexpr int rq_ring_base(int KS) { return 252 - 4 * rq_ring_len(KS); }
 __host__ __device__ constexpr int rq_acc_base(int KS) { return rq_ring_base(KS) - 16; }
 constexpr int RQ_NORM_REG = 252;
@@ -189,7 +190,8 @@ __device__ __forceinline__ void rq_scan(
     // int8 route found it); (2) plain compiler-visible loads, ring half a group: correct, 474k; (3) this form: the ring in registers the
     // compiler cannot allocate, named literally (see rq_piece above).
     constexpr int R = rq_ring_len(KS), RB = rq_ring_base(KS), RA = rq_acc_base(KS);
-    static_assert(KS % R == 0 && KS % 4 == 0, "ring wrap");
+    constexpr int GU = rq_unit_groups(KS), P = GU * KS;   // a loop iteration = one UNIT of GU groups = P pieces; slot of piece p: p % R
+    static_assert(P % R == 0 && KS % 4 == 0, "ring wrap");
     asm volatile("" ::: "v255");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *tau_f = reinterpret_cast<float *>(smem);              // exclusive bound: pass <=> key < tau
@@ -209,8 +211,10 @@ __device__ __forceinline__ void rq_scan(
     const uint32_t x = b & 7, jb = b >> 3;
     const uint32_t qt = jb % QT;
     const uint32_t s = (jb / QT) * 8 + x;
-    // my groups (ids ascend along a stream); the mirror is padded to whole 256-row tiles = 8 groups, rows past N carry +inf norms
-    const uint32_t u0 = (uint32_t)(((uint64_t)s * G) / S), u1 = (uint32_t)(((uint64_t)(s + 1) * G) / S);
+    // my units (ids ascend along a stream); the mirror is padded to whole 256-row tiles = 8 groups, rows past N carry +inf norms (a unit's
+    // groups past G are there and pass nothing)
+    const uint32_t U = (G + GU - 1) / GU;
+    const uint32_t u0 = (uint32_t)(((uint64_t)s * U) / S), u1 = (uint32_t)(((uint64_t)(s + 1) * U) / S);
     uint32_t *tau_g = tau_g_all ? tau_g_all + (size_t)qt * T2 : nullptr;
     uint64_t *kept = cand + (size_t)b * BLKV_ENTRIES;
     uint64_t *subs = kept + (size_t)T2 * KPMAX;
@@ -230,7 +234,7 @@ __device__ __forceinline__ void rq_scan(
     const uint32_t lane16 = (uint32_t)lane * 16;
     const uint32_t lds_state = (uint32_t)(size_t)(lptr_t)tau_f;
     const uint32_t fr4 = fr * 4;
-    constexpr size_t gbytes = (size_t)KS * 1024;
+    constexpr size_t ubytes = (size_t)P * 1024;
     // a wave whose 32 queries are all past nq has nothing to select: it still runs (its registers are there), but never passes
 
     uint32_t u = u0;
@@ -241,8 +245,8 @@ __device__ __forceinline__ void rq_scan(
 #pragma unroll
         for (int j = 0; j < KS; ++j) B[j] = *reinterpret_cast<const u32x4 *>(qsrc + (size_t)j * 1024);
         const float thr = -tau_f[wave * 32 + fr];
-        {   // ring prologue: pieces 0 .. R - 1 of group u (slot of piece p: p % R)
-            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * gbytes);
+        {   // ring prologue: pieces 0 .. R - 1 of unit u
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * ubytes);
             static_for<R>([&](auto jc) {
                 constexpr int J = decltype(jc)::value;
                 rq_ring_fill<RB + 4 * J, (J % 4) * 1024>(cur + (J / 4) * 4096, lane16);
@@ -250,26 +254,29 @@ __device__ __forceinline__ void rq_scan(
         }
         f32x16 init;  // start values of the group about to be multiplied: -|v|^2 / 2 of the register's row (rows past N: -inf)
         {
-            const float vh = -0.5f * vnorm[(size_t)32 * u + fr];
+            const float vh = -0.5f * vnorm[(size_t)32 * GU * u + fr];
 #pragma unroll
             for (int r = 0; r < 16; ++r) init[r] = __shfl(vh, (r & 3) + 8 * (r >> 2) + 4 * (int)fh);
         }
         rq_frags_landed<KS>(B);
         bool want_prune = false;
         do {
-            const uint32_t un = min(u + 1, u1 - 1);  // (past the stream end: a harmless re-read of its last group)
-            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * gbytes);
-            const gbytes_t nxt = uniform_ptr(Vf + (size_t)un * gbytes);
-            const gbytes_t nrm = uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)32 * un));
-            static_for<KS>([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                constexpr int NP = J + R;  // the piece this piece's slot is refilled with: of this group, or of the next
-                const gbytes_t base = NP < KS ? cur + (NP / 4) * 4096 : nxt + ((NP - KS) / 4) * 4096;
+            const uint32_t un = min(u + 1, u1 - 1);  // (past the stream end: a harmless re-read of its last unit)
+            const gbytes_t cur = uniform_ptr(Vf + (size_t)u * ubytes);
+            const gbytes_t nxt = uniform_ptr(Vf + (size_t)un * ubytes);
+            static_for<P>([&](auto pc) {
+                constexpr int PI = decltype(pc)::value;
+                constexpr int T = PI / KS, J = PI % KS;   // group of the unit, piece of the group
+                constexpr int NP = PI + R;  // the piece this piece's slot is refilled with: of this unit, or of the next
+                const gbytes_t base = NP < P ? cur + (NP / 4) * 4096 : nxt + ((NP - P) / 4) * 4096;
+                const uint32_t g = u * GU + T;
                 if constexpr (J == 0) {
-                    rq_piece_first<RA, RB + 4 * (J % R), R - 1, (NP % 4) * 1024>(init, B[J], base, lane16);
-                    rq_norm_load(nrm, fr4);
+                    rq_piece_first<RA, RB + 4 * (PI % R), R - 1, (NP % 4) * 1024>(init, B[J], base, lane16);
+                    // the norms of the group after this one
+                    const uint32_t gn = T + 1 < GU ? g + 1 : un * GU;
+                    rq_norm_load(uniform_ptr(reinterpret_cast<const unsigned char *>(vnorm + (size_t)32 * gn)), fr4);
                 } else {
-                    rq_piece<RA, RB + 4 * (J % R), R - 1, (NP % 4) * 1024>(B[J], base, lane16);
+                    rq_piece<RA, RB + 4 * (PI % R), R - 1, (NP % 4) * 1024>(B[J], base, lane16);
                 }
                 if constexpr (J == KS - 3) {
                     // start values of the next group, three pieces ahead of its first MFMA (their LDS round trip -- ds_bpermute -- hides
@@ -290,12 +297,12 @@ __device__ __forceinline__ void rq_scan(
                         for (int r = 0; r < 16; ++r) {
                             if (acc[r] > thr) {
                                 const uint32_t sl = atomicAdd(cnt + q, 1u);
-                                const uint32_t id = 32 * u + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
+                                const uint32_t id = 32 * g + (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * fh;
                                 if (sl < (uint32_t)RQ_CAP) rq_append(subs + (size_t)q * RQ_CAP + sl, ((uint64_t)f32_key(-acc[r]) << 32) | id);
                                 need |= sl == (uint32_t)RQ_HW;
                             }
                         }
-                        if (__ballot(need)) want_prune = true;  // (<= 32 more appends per query before the loop is left: RQ_CAP holds them)
+                        if (__ballot(need)) want_prune = true;  // (<= 32 GU more appends per query before the loop is left: RQ_CAP holds them)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -359,7 +366,7 @@ struct RqKernel;
         static constexpr auto fn = &k_f32_regq_##KS##_##KPV##_##GATED;                                                                        \
     };
 #define RQ_KERNELS(KS, NV) RQ_KERNEL(KS, 64, 0, NV) RQ_KERNEL(KS, 64, 1, NV) RQ_KERNEL(KS, 128, 0, NV) RQ_KERNEL(KS, 256, 0, NV)
-RQ_KERNELS(8, 204)
+RQ_KERNELS(8, 172)
 RQ_KERNELS(16, 172)
 RQ_KERNELS(20, 156)
 RQ_KERNELS(24, 188)
