@@ -548,7 +548,7 @@ def c2_leg(zv, torch, dev, stream, k, modes=("f32",), steps=200):
         # batch's scan -- measured 353k QPS against 396k on one stream: two scans resident at once slow each other more than the
         # overlap saves; not reported)
         out[name] = {"qps": B2 * steps / el, "ms_per_batch": el / steps * 1e3,
-                     "roofline": {"bound": "mfma", "kernel": "k_f32_regq<16> (bf_f32_regq.hip: register-resident queries, fp32 MFMA)" if name == "f32" else KERNEL_NAMES[name],
+                     "roofline": {"bound": "mfma", "kernel": "k_f32_regq_16_64_0 (bf_f32_regq.hip: register-resident queries, fp32 MFMA)" if name == "f32" else KERNEL_NAMES[name],
                                   "region": "moments guess + packed queries (one launch) + ONE scan + verifying merge" if name == "f32" else None,
                                   "kernel_ms_avg": kms / kn, "timed_regions": kn, "achieved": ach, "peak": PEAK_TFLOPS[name],
                                   "unit": "TFLOP/s" if name != "i8" else "TOP/s", "frac": ach / PEAK_TFLOPS[name]}}

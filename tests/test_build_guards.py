@@ -14,3 +14,19 @@ def test_f32_regq_group_loop_keeps_its_shape_in_every_instantiation():
     spec.loader.exec_module(mod)
     seen, bad = mod.check(verbose=False)
     assert seen == 24 and not bad, bad[:5]
+
+
+import pytest
+
+
+@pytest.mark.parametrize("unit", ["bf_bf16_stream", "bf_i8_stream", "bf_fp4_stream", "bruteforce", "bf_f32_regq"])
+def test_no_compiler_copy_of_an_asm_read_in_flight(unit):
+    """tools/check_asm_reads.py: the screens' operand rings are inline-asm reads on compiler-allocated registers with separate tied waits;
+    hipcc may copy such a register before the data has landed (bf_f32_regq.hip's first ring: one lost neighbour in ~10^5 queries, and this
+    audit flags 16 copies in 8 kernels of that revision).  Every kernel of the unit: no copying instruction reads a register whose asm read is
+    still in flight.  (The headline scan is bf_bf16_stream; the empirical side is tools/soak_routes.py on the GPU.)"""
+    spec = importlib.util.spec_from_file_location("check_asm_reads", os.path.join(ROOT, "tools", "check_asm_reads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seen, bad = mod.check(unit, verbose=False)
+    assert seen >= 14 and not bad, bad[:5]
