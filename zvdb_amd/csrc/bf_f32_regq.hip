@@ -238,6 +238,9 @@ __device__ __forceinline__ void rq_scan(
     // a wave whose 32 queries are all past nq has nothing to select: it still runs (its registers are there), but never passes
 
     uint32_t u = u0;
+#ifdef ZVDB_ABL_RQ_NOLOOP   // (timing-only ablation: what a launch costs without its scan -- prologue + stream end: profiles/r6/c2_ring_ab.txt)
+    u = u1;
+#endif
     // The group loop is entered once per launch and once more after every prune round of this wave: a prune is a CALL and nothing of
     // the loop's register state lives across it (bf_bf16_stream.hip found hipcc spilling the query fragments around an inlined one).
     while (u < u1) {
@@ -328,7 +331,8 @@ __device__ __forceinline__ void rq_scan(
             uint64_t *dst = partial + ((size_t)qg * Stot + list_base + s) * KPV;
             for (uint32_t e = 0; e < nk; ++e) dst[e] = kept[(size_t)q * KPV + e];
             for (uint32_t e = 0; e < c; ++e) dst[nk + e] = subs[(size_t)q * RQ_CAP + e];
-            for (uint32_t e = nk + c; e < (uint32_t)KPV; ++e) dst[e] = ~0ull;
+            // (entries past the count are not written: every reader of a partial list stops at pcnt -- k_bf_merge_sel; filling them cost 62 scattered
+            //  8-byte stores per lane, most of the 25 us a launch took without its scan: profiles/r6/c2_ring_ab.txt)
             pcnt[(size_t)qg * Stot + list_base + s] = nk + c;
         }
         unsigned long long todo = __ballot(mine && !simple);
