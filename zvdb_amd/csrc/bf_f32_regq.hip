@@ -79,6 +79,13 @@ __device__ __forceinline__ void rq_ring_fill(gbytes_t base, uint32_t off) {
 // one piece: wait for the slot at v[RG, RG + 4) (WAIT = younger ring loads), its 4 MFMAs into v[RA, RA + 16), refill the slot from
 // base + off + IMM.  The group's first piece takes the start values as its C operand (no copy into the accumulator); they may be fresh
 // from VALU moves: 2 states ahead of the MFMA that reads them.
+#ifdef ZVDB_ABL_RQ_NOLOADS   // (timing-only ablation: the pieces without their refills -- what the MFMA stream alone achieves: profiles/r6/c2_ring_ab.txt)
+#define RQ_REFILL6 "s_nop 0"
+#define RQ_REFILL5 "s_nop 0"
+#else
+#define RQ_REFILL6 "global_load_dwordx4 v[%6:%6+3], %5, %8 offset:%9"
+#define RQ_REFILL5 "global_load_dwordx4 v[%5:%5+3], %4, %7 offset:%8"
+#endif
 template <int RA, int RG, int WAIT, int IMM>
 __device__ __forceinline__ void rq_piece_first(const f32x16 &init, const u32x4 &b, gbytes_t base, uint32_t off) {
     asm volatile("s_nop 1\n\t"
@@ -87,7 +94,7 @@ __device__ __forceinline__ void rq_piece_first(const f32x16 &init, const u32x4 &
                  "v_mfma_f32_32x32x2_f32 v[%10:%10+15], v[%6+1], %2, v[%10:%10+15]\n\t"
                  "v_mfma_f32_32x32x2_f32 v[%10:%10+15], v[%6+2], %3, v[%10:%10+15]\n\t"
                  "v_mfma_f32_32x32x2_f32 v[%10:%10+15], v[%6+3], %4, v[%10:%10+15]\n\t"
-                 "global_load_dwordx4 v[%6:%6+3], %5, %8 offset:%9" ::"v"(init),
+                 RQ_REFILL6 ::"v"(init),
                  "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(off), "n"(RG), "n"(WAIT), "s"(base), "n"(IMM), "n"(RA));
 }
 template <int RA, int RG, int WAIT, int IMM>
@@ -97,7 +104,7 @@ __device__ __forceinline__ void rq_piece(const u32x4 &b, gbytes_t base, uint32_t
                  "v_mfma_f32_32x32x2_f32 v[%9:%9+15], v[%5+1], %1, v[%9:%9+15]\n\t"
                  "v_mfma_f32_32x32x2_f32 v[%9:%9+15], v[%5+2], %2, v[%9:%9+15]\n\t"
                  "v_mfma_f32_32x32x2_f32 v[%9:%9+15], v[%5+3], %3, v[%9:%9+15]\n\t"
-                 "global_load_dwordx4 v[%5:%5+3], %4, %7 offset:%8" ::"v"(b.x),
+                 RQ_REFILL5 ::"v"(b.x),
                  "v"(b.y), "v"(b.z), "v"(b.w), "v"(off), "n"(RG), "n"(WAIT), "s"(base), "n"(IMM), "n"(RA));
 }
 
@@ -290,7 +297,12 @@ __device__ __forceinline__ void rq_scan(
                 }
                 if constexpr (J == KS - 1) {
                     // selection of the finished group (32 rows x my 32 queries): the rare pass path appends to the queries' buffers
+#ifndef ZVDB_ABL_RQ_NOLOADS
                     const float m = rq_group_max<RA>();
+#else
+                    float m = rq_group_max<RA>();
+                    m = fminf(m, -__builtin_inff());   // (the ablation multiplies stale rows: nothing may pass)
+#endif
                     if (__ballot(m > thr)) {
                         bool need = false;
                         const uint32_t q = (uint32_t)wave * 32 + fr;
