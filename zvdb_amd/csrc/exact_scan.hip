@@ -14,7 +14,8 @@
 //                  query into the result slots (no second launch).
 // The list's length is read on the device: with an empty list (the common case) the launch returns at once.
 // Cost when it runs (10M x 768 fp32 rows, profiles/r5/exact_scan_ab.txt): one pass over the rows per 32 listed queries; a list of <= 8
-// queries 7.9 ms (3.9 TB/s: the 128-byte pieces of a tile's rows are scattered reads for the memory), 16 queries 14.3 ms, 32 queries
+// queries 7.9 ms (3.9 TB/s.  NOT the memory: the same walk without arithmetic reads 7.0 TB/s whatever the piece size; the LDS reads of the queries' values cost
+// 12 - 33 % of a pass, and a scalar-load replacement was built and lost 2.4x to SMEM latency -- profiles/r6/exact_scan_ab.txt), 16 queries 14.3 ms, 32 queries
 // 26.4 ms = 0.82 ms per query (the arithmetic: 3 N dim operations per query; r4: 10 ms per 8 queries, one pass per 8).
 #include "common.h"
 #include "wave_select.h"
