@@ -58,7 +58,10 @@ if "A" in legs:
     q = bench.make_rows(zv, torch, g, N, D, True, dev, s, 4096)
     g.build_graph(M, 64, zv.BF_I8, 7)
     g.set_option(zv.OPT_EF_SEARCH_WIDTH, int(os.environ.get("EF_PROBE_WIDTH", "4")))
-    for B, ef in ((1024, 128), (1024, 256), (1024, 512), (4096, 128)):
+    cases = ((1024, 128), (1024, 256), (1024, 512), (4096, 128))
+    if os.environ.get("EF_PROBE_SWEEP"):   # the launch's fixed cost: kernel time against evaluations per query, small beams
+        cases = tuple((1024, ef) for ef in (10, 16, 24, 32, 48, 64, 96, 128))
+    for B, ef in cases:
         r = run(g, q, B, D, K, ef, 2)
         print(f"{tag:>10} A 1Mx768 bf16 rank12 bulk  batch {B:5d} ef {ef:4d}: kernel {r['kernel_ms']:.4f} ms  {r['qps']:9.0f} QPS  {r['TBps']:.3f} TB/s = {r['TBps'] / 8:.3f}  E {r['E']:.0f}  chk {r['checksum']}", flush=True)
     del g, q

@@ -182,7 +182,7 @@ __device__ __attribute__((noinline, cold)) void rq_prune_wave(uint64_t *kept, ui
     }
 }
 
-// The scan of one workgroup.  KS = 8-element k-steps (1-KiB pieces) per row: 8 / 16 (dim <= 64 / 128), 20 / 24 / 28 / 32 (dim <= 160 / 192 / 224 / 256).
+// The scan of one workgroup.  KS = 8-element k-steps (1-KiB pieces) per row: 8 / 12 / 16 (dim <= 64 / 96 / 128), 20 / 24 / 28 / 32 (dim <= 160 / 192 / 224 / 256).
 template <int KS, int KPV>
 __device__ __forceinline__ void rq_scan(
     const unsigned char *__restrict__ Qf /* [query group of 32][KS][64][16 B] */, const unsigned char *__restrict__ Vf /* same, rows */,
@@ -383,6 +383,7 @@ struct RqKernel;
     };
 #define RQ_KERNELS(KS, NV) RQ_KERNEL(KS, 64, 0, NV) RQ_KERNEL(KS, 64, 1, NV) RQ_KERNEL(KS, 128, 0, NV) RQ_KERNEL(KS, 256, 0, NV)
 RQ_KERNELS(8, 172)
+RQ_KERNELS(12, 188)
 RQ_KERNELS(16, 172)
 RQ_KERNELS(20, 156)
 RQ_KERNELS(24, 188)
@@ -561,6 +562,7 @@ int rq_launch(const zvdb_hip_index *h, const unsigned char *q_op, uint32_t nq, u
               uint32_t *tau_g, uint32_t kp, uint32_t list_base, uint32_t Stot, uint32_t *pcnt, const uint32_t *gate, hipStream_t s) {
     const uint32_t KS = f32s_ksteps(h->dim);
     if (KS == 8) return rq_launch_geo<8, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
+    if (KS == 12) return rq_launch_geo<12, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
     if (KS == 16) return rq_launch_geo<16, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
     if (KS == 20) return rq_launch_geo<20, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);
     if (KS == 24) return rq_launch_geo<24, KPV>(h, q_op, nq, QT, S, cand, partial, tau_g, kp, list_base, Stot, pcnt, gate, s);

@@ -500,6 +500,7 @@ int launch_i8_stream(const zvdb_hip_index *h, const unsigned char *q_op, uint32_
         else ZV_CHECK(go(k_i8_stream<2, 24, MOM, KPV>));
     } else if constexpr (MODE == 0) {
         if (KS == 8) ZV_CHECK(go(k_i8_stream<0, 8, MOM, KPV>));
+        else if (KS == 12) ZV_CHECK(go(k_i8_stream<0, 12, MOM, KPV>));
         else ZV_CHECK(go(k_i8_stream<0, 16, MOM, KPV>));
     } else {
         if (KS == 18) ZV_CHECK(go(k_i8_stream<3, 18, MOM, KPV>));
@@ -599,9 +600,9 @@ int launch_fp4s128_scan(const zvdb_hip_index *h, const unsigned char *q_op, uint
         return launch_i8_stream<3, false, KPW>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
     return launch_i8_stream<3, false>(h, q_op, nq, QT, S, nt, cand, partial, tau_g, kp, list_base, Stot, pcnt, 0u, gate, nullptr, s);
 }
-// ---- the same 128-query kernel with fp32 MFMAs on a fragment-order fp32 mirror: dim <= 128 (KS = 8, 16) -------------------------
+// ---- the same 128-query kernel with fp32 MFMAs on a fragment-order fp32 mirror: dim <= 128 (KS = 8, 12, 16: <= 64 / 96 / 128 dimensions) --------
 // (beyond 128 dimensions -- the register-query scan only, bf_f32_regq.hip -- whole 32-element steps: 20 / 24 / 28 / 32 pieces for <= 160 / 192 / 224 / 256)
-uint32_t f32s_ksteps(uint32_t dim) { return dim <= 64 ? 8u : dim <= 128 ? 16u : (dim + 31) / 32 * 4; }
+uint32_t f32s_ksteps(uint32_t dim) { return dim <= 64 ? 8u : dim <= 96 ? 12u : dim <= 128 ? 16u : (dim + 31) / 32 * 4; }
 bool f32s_eligible(const zvdb_hip_index *h) {
     const bool off = [] { const char *e = tuning("ZVDB_BF_F32_KERNEL"); return e && e[0] == 'v' && e[1] == '6'; }();
     return !off && h->dim > 4 && h->dim <= 128;
