@@ -1,4 +1,4 @@
-# soak: many different query batches through the fp32 register-query scan (bf_f32_regq.hip; thresholds from the rows' moments) on three row widths;
+# soak: many different query batches through the fp32 register-query scan (bf_f32_regq.hip; thresholds from the rows' moments) on four row widths (every ring geometry up to 256 dimensions but 28 / 32 pieces);
 # every batch compared with the certified int8 route bit for bit (both return the exact top-k), certificate counters printed at the end.
 # usage: python tools/soak_f32_regq.py [batches per shape]
 import os, sys, time
@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 s = torch.cuda.current_stream().cuda_stream
 bad = 0
 t0 = time.time()
-for N, D, B, K in ((2_000_000, 128, 300, 10), (1_000_000, 200, 1024, 32), (1_500_000, 64, 257, 100)):
+for N, D, B, K in ((2_000_000, 128, 300, 10), (1_000_000, 200, 1024, 32), (1_500_000, 64, 257, 100), (1_200_000, 96, 300, 10)):
     idx = zv.Index(dim=D, capacity=N)
     idx.add_synthetic(N, D, 0x5EED)
     wsb = max(idx.bruteforce_workspace(B, K, m) for m in (zv.BF_F32, zv.BF_I8))
