@@ -179,6 +179,7 @@ struct zvdb_hip_index {
     mutable size_t ef_net_list_words = 0, ef_net_table_words = 0;
     mutable hipEvent_t ef_event = nullptr;   // end of the last ef search that used the buffers above: the next one (any stream) waits for it
     mutable bool ef_event_set = false;
+    mutable hipStream_t ef_event_stream = nullptr;   // the stream that event was recorded on
     float guess_adapt = 0.0f;
     // bf16 stream scan: the rows are split over the 8 XCDs in proportion to the speed each one showed in earlier launches (their
     // clocks differ by a few per cent under the power limit).  Every workgroup leaves its duration in host-mapped memory; the

@@ -1305,6 +1305,16 @@ __global__ __launch_bounds__(64 * WPQ) void k_descend(const RT *__restrict__ row
     }
 }
 
+// A few words zeroed by a launch of our own instead of an 8-byte hipMemsetAsync (a blit kernel of the runtime's: the same 4 us, one library less in the path).
+__global__ void k_zero_words(uint32_t *p, uint32_t n) {
+    if (threadIdx.x < n) p[threadIdx.x] = 0;
+}
+static int zero_words(uint32_t *p, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, p, n);
+    ZV_HIP(hipGetLastError());
+    return ZVDB_OK;
+}
+
 int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
                    unsigned long long *d_stats, hipStream_t s) {
     if (nq == 0) return ZVDB_OK;
@@ -1326,12 +1336,16 @@ int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq,
 // ---- index-owned scratch of the ef search (all mutable members of the index; callers hold h->mu) -------------------------------
 static int ef_scratch_begin(const zvdb_hip_index *h, hipStream_t s) {
     if (!h->ef_event) ZV_HIP(hipEventCreateWithFlags(&h->ef_event, hipEventDisableTiming));
-    if (h->ef_event_set) ZV_HIP(hipStreamWaitEvent(s, h->ef_event, 0));
+    // (a search on the SAME stream as the last one is ordered behind it by the stream itself: no barrier packet for the stream's own event.
+    //  Measured with the change above: ef = 128 kernel-timed 0.671 -> 0.682 of HBM at batch 1,024, one box; the ~20-us hole rocprofv3 shows in
+    //  front of every call is the profiler's: host-timed calls are 13 us longer than their kernels, 8.5 of them the two small launches)
+    if (h->ef_event_set && h->ef_event_stream != s) ZV_HIP(hipStreamWaitEvent(s, h->ef_event, 0));
     return ZVDB_OK;
 }
 static int ef_scratch_end(const zvdb_hip_index *h, hipStream_t s) {
     ZV_HIP(hipEventRecord(h->ef_event, s));
     h->ef_event_set = true;
+    h->ef_event_stream = s;
     return ZVDB_OK;
 }
 // (re)allocation frees a buffer other streams may still be reading: wait for the whole device first (rare: sizes only grow)
@@ -1582,7 +1596,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             const char *dn_env = tuning("ZVDB_EF_DIRECT_NET");
             const bool direct_net = two_pass && !safe_global && (dn_env ? dn_env[0] == '1' : (seen != 0 && h->ef_hint_calls >= 16 && !tp_env));
             if (direct_net) {
-                ZV_HIP(hipMemsetAsync(h->ef_net_buf, 0, 8, s));  // list count + pop cursor
+                ZV_CHECK(zero_words(h->ef_net_buf, 2, s));  // list count + pop cursor
                 ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight, h->ef_net_buf));
                 ZV_CHECK(go_net());
             } else {
@@ -1590,7 +1604,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             if (safe_global) {
                 ZV_CHECK(go_global(two_pass ? kEfRetry : kEfSingle));
             } else {
-                ZV_HIP(hipMemsetAsync(h->ef_net_buf, 0, 8, s));  // list count + pop cursor
+                ZV_CHECK(zero_words(h->ef_net_buf, 2, s));  // list count + pop cursor
                 ZV_CHECK(go1(kern, wparam, hash_bits, two_pass ? kEfRetryMark : kEfTight, h->ef_net_buf));
                 ZV_CHECK(go_net());
             }
