@@ -483,7 +483,7 @@ def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16
     # beside it under "width<w>" (width 1 = the plain beam search, one node per step)
     for ef, width in [(e, w) for e in efs for w in widths]:
         g.set_option(zv.OPT_EF_SEARCH_WIDTH, width)
-        for _ in range(2):
+        for _ in range(12):   # (sub-millisecond launches: the clocks need tens of them -- tools/launch_distribution.sh; 2 warm launches + 5 timed read 4 - 6 % low)
             g.search_graph_dev(qg.data_ptr(), batch, dim, k, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
         st.zero_()
         g.search_graph_dev(qg.data_ptr(), batch, dim, k, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), stream)
@@ -493,6 +493,7 @@ def graph_leg(zv, torch, dev, stream, rows, dim, batch, k, efs, structured, bf16
         ev, pp = int(st[0].item()), int(st[1].item())
         g.timing_enable(True)
         t0 = time.perf_counter()
+        reps = max(reps, 20)
         for _ in range(reps):
             g.search_graph_dev(qg.data_ptr(), batch, dim, k, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, stream)
         torch.cuda.synchronize()
