@@ -180,6 +180,7 @@ struct zvdb_hip_index {
     mutable hipEvent_t ef_event = nullptr;   // end of the last ef search that used the buffers above: the next one (any stream) waits for it
     mutable bool ef_event_set = false;
     mutable hipStream_t ef_event_stream = nullptr;   // the stream that event was recorded on
+    mutable bool ef_net_dirty = false;               // a call is between its first LDS pass and its net launch (or failed there): the net's header words may be non-zero
     float guess_adapt = 0.0f;
     // bf16 stream scan: the rows are split over the 8 XCDs in proportion to the speed each one showed in earlier launches (their
     // clocks differ by a few per cent under the power limit).  Every workgroup leaves its duration in host-mapped memory; the

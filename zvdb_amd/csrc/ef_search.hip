@@ -268,7 +268,7 @@ struct EfDescend {
 };
 __device__ __forceinline__ void ef_mark_again(uint32_t *out_count, uint32_t qi, uint32_t *net_list) {  // (one lane)
     out_count[qi] = kEfAgain;
-    if (net_list) net_list[2 + atomicAdd(net_list, 1u)] = qi;
+    if (net_list) net_list[3 + atomicAdd(net_list, 1u)] = qi;
 }
 
 // one query of the LDS-beam search; hash_g: the query's visited table when GH (pre-zeroed), unused otherwise
@@ -542,8 +542,17 @@ __global__ __launch_bounds__(64) void k_search_ef(
                 uint32_t i = 0;
                 if (threadIdx.x == 0) i = atomicAdd(net_list + 1, 1u);
                 i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-                if (i >= total) return;
-                const uint32_t qi = net_list[2 + i];
+                if (i >= total) {
+                    // the list is empty: the LAST workgroup to find it so leaves the three header words zero for the next call (every other
+                    // workgroup has read its final cursor by then; the next call's kernels start behind this one) -- no zeroing launch per call
+                    if (threadIdx.x == 0 && atomicAdd(net_list + 2, 1u) == gridDim.x - 1) {
+                        __hip_atomic_store(net_list, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(net_list + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(net_list + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return;
+                }
+                const uint32_t qi = net_list[3 + i];
                 for (uint32_t j = threadIdx.x; j < (1u << hash_bits); j += kWave) table[j] = 0;
                 __threadfence();
                 __syncthreads();
@@ -1315,6 +1324,14 @@ static int zero_words(uint32_t *p, uint32_t n, hipStream_t s) {
     return ZVDB_OK;
 }
 
+// the net's header words are zero when a call begins: the previous call's net launch left them so -- unless that call failed between its
+// launches (dirty): then they are zeroed here
+static int ef_net_begin(const zvdb_hip_index *h, hipStream_t s) {
+    if (h->ef_net_dirty) ZV_CHECK(zero_words(h->ef_net_buf, 3, s));
+    h->ef_net_dirty = true;
+    return ZVDB_OK;
+}
+
 int launch_descend(const zvdb_hip_index *h, const float *d_queries, uint32_t nq, uint32_t top, uint32_t *d_entries,
                    unsigned long long *d_stats, hipStream_t s) {
     if (nq == 0) return ZVDB_OK;
@@ -1361,15 +1378,17 @@ static uint32_t ef_net_bits(const zvdb_hip_index *h, uint32_t ef) {
     const uint64_t N = std::max(h->count, h->cap);  // (from the capacity: rows added later must not make a reserved search reallocate)
     return bits_for(std::min<uint64_t>(std::max<uint64_t>(N, 1), std::max<uint64_t>((uint64_t)ef * h->gstride * 16, 65536)));
 }
-// the net's buffer: [list: 2 + nq words, padded to 256 B][kEfNetBlocks tables of 4 << bits bytes] -- 4 MiB at ef <= 256 / stride
+// the net's buffer: [list: 3 header words (count, pop cursor, workgroups done) + nq, padded to 256 B][kEfNetBlocks tables of 4 << bits bytes] -- 4 MiB at ef <= 256 / stride
 // 16, 32 MiB at ef = 1024 / stride 32 (before: 256 tables, up to 1 GiB, taken by the first search whether or not it needed them)
 static int ef_reserve_net(const zvdb_hip_index *h, uint32_t nq, uint32_t ef) {
-    const size_t list_words = round_up64((uint64_t)nq + 2, 64);
+    const size_t list_words = round_up64((uint64_t)nq + 3, 64);
     const size_t table_words = (size_t)kEfNetBlocks << ef_net_bits(h, ef);
     if (h->ef_net_list_words >= list_words && h->ef_net_table_words >= table_words) return ZVDB_OK;
     const size_t lw = std::max(list_words, h->ef_net_list_words), tw = std::max(table_words, h->ef_net_table_words);
     if (h->ef_net_buf) { ZV_HIP(hipDeviceSynchronize()); (void)hipFree(h->ef_net_buf); h->ef_net_buf = nullptr; h->ef_net_list_words = h->ef_net_table_words = 0; }
     ZV_HIP(hipMalloc(reinterpret_cast<void **>(&h->ef_net_buf), (lw + tw) * sizeof(uint32_t)));
+    ZV_HIP(hipMemset(h->ef_net_buf, 0, 16));   // the header words: zero from here on between calls (the net launch leaves them so)
+    h->ef_net_dirty = false;
     h->ef_net_list_words = lw;
     h->ef_net_table_words = tw;
     return ZVDB_OK;
@@ -1575,6 +1594,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
                                (uint32_t)N, d_queries, k, ef, entry, id_offset, d_ids, d_dist, d_count, d_stats, dim_pad, ef_net_bits(h, ef), efp, d_entries,
                                (uint32_t)kEfRetry, h->ef_hint_dev + bucket, h->ef_net_buf + h->ef_net_list_words, 0u, h->ef_net_buf, width, EfDescend{});
             ZV_HIP(hipGetLastError());
+            h->ef_net_dirty = false;   // (enqueued: it leaves the header words zero)
             return ZVDB_OK;
         };
         // Index-owned scratch (global visited tables, the net's list and tables) is shared by every ef search on this index whatever
@@ -1596,7 +1616,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             const char *dn_env = tuning("ZVDB_EF_DIRECT_NET");
             const bool direct_net = two_pass && !safe_global && (dn_env ? dn_env[0] == '1' : (seen != 0 && h->ef_hint_calls >= 16 && !tp_env));
             if (direct_net) {
-                ZV_CHECK(zero_words(h->ef_net_buf, 2, s));  // list count + pop cursor
+                ZV_CHECK(ef_net_begin(h, s));
                 ZV_CHECK(go1(kern, wparam, tight_bits, kEfTight, h->ef_net_buf));
                 ZV_CHECK(go_net());
             } else {
@@ -1604,7 +1624,7 @@ int launch_search_ef(const zvdb_hip_index *h, const float *d_queries, uint32_t n
             if (safe_global) {
                 ZV_CHECK(go_global(two_pass ? kEfRetry : kEfSingle));
             } else {
-                ZV_CHECK(zero_words(h->ef_net_buf, 2, s));  // list count + pop cursor
+                ZV_CHECK(ef_net_begin(h, s));
                 ZV_CHECK(go1(kern, wparam, hash_bits, two_pass ? kEfRetryMark : kEfTight, h->ef_net_buf));
                 ZV_CHECK(go_net());
             }
