@@ -25,14 +25,17 @@ legs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["A", "B"]
 M = 16
 
 
+ENTRY = 0 if os.environ.get("EF_PROBE_ENTRY") == "fixed" else zv.ENTRY_DESCEND   # EF_PROBE_ENTRY=fixed: every search starts at the graph's entry node (no descent)
+
+
 def run(g, q, B, D, K, ef, elt, reps=8):
     ids = torch.empty((B, K), dtype=torch.int64, device=dev); dd = torch.empty((B, K), dtype=torch.float32, device=dev); cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     st = torch.zeros(4, dtype=torch.int64, device=dev)
     g.search_graph_reserve(B, K, ef)
     for _ in range(3):
-        g.search_graph_dev(q.data_ptr(), B, D, K, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, s)
+        g.search_graph_dev(q.data_ptr(), B, D, K, ef, ENTRY, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, s)
     st.zero_()
-    g.search_graph_dev(q.data_ptr(), B, D, K, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), s)
+    g.search_graph_dev(q.data_ptr(), B, D, K, ef, ENTRY, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), st.data_ptr(), s)
     torch.cuda.synchronize()
     E, P = int(st[0].item()), int(st[1].item())
     best = None
@@ -40,7 +43,7 @@ def run(g, q, B, D, K, ef, elt, reps=8):
         g.timing_enable(True)
         t0 = time.perf_counter()
         for _ in range(reps):
-            g.search_graph_dev(q.data_ptr(), B, D, K, ef, zv.ENTRY_DESCEND, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, s)
+            g.search_graph_dev(q.data_ptr(), B, D, K, ef, ENTRY, 0, ids.data_ptr(), dd.data_ptr(), cnt.data_ptr(), 0, s)
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / reps
         kms, kn = g.timing_read()
