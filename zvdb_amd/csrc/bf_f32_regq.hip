@@ -9,8 +9,8 @@
 // instruction that takes ONE VGPR per operand: a wave's 32 queries x 128 dimensions are 64 VGPRs -- they stay in registers for the
 // whole launch; 8 waves = 256 queries per workgroup, one workgroup per CU, so a batch of 256 reads the corpus ONCE (the 128-query
 // kernel: twice, through the L2).  Every wave reads every row: a 32-row group is KS contiguous KiB of the fragment-order mirror
-// (rows_ff, shared with k_i8_stream<0>), one coalesced global_load_dwordx4 per 4 MFMAs (256 matrix-pipe cycles), prefetched half
-// a group ahead in a register ring; the 8 waves of a workgroup ask for the same lines (the first miss fills the L1 / L2, the rest
+// (rows_ff, shared with k_i8_stream<0>), one coalesced global_load_dwordx4 per 4 MFMAs (256 matrix-pipe cycles), prefetched a whole
+// group ahead (8 - 14 pieces beyond 160 dimensions) in a register ring that lives, with the accumulator, ABOVE the compiler's allocation limit; the 8 waves of a workgroup ask for the same lines (the first miss fills the L1 / L2, the rest
 // hit).  No wave reads what another wave wrote: NO barrier, NO LDS in the steady state -- SIMD partners drift apart and fill each
 // other's selection epilogues.  Work is split by 32-row GROUPS (31,250 at 1M rows: 122.07 per CU, a 0.8 % tail) instead of 256-row
 // tiles (15.26 per CU: 5 %).
